@@ -1,0 +1,105 @@
+"""Deterministic synthetic episode libraries for tests and bench.py (harness tool).
+
+Layout follows SURVEY.md §8(d): mono s16 at 11025 Hz, a unique tonal body per episode, one shared
+intro inside the opening search window (first 50 %, needle/src/audio/mod.rs:19) at an offset that
+is not a multiple of chromaprint's 1365-sample hop, one shared outro inside the ending window
+(last 25 %, mod.rs:24), episode-specific noise on top.  The sample generator is C
+(csrc/synth.c, no libm => bit-reproducible); this module only lays episodes out.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+RATE = 11025
+EPISODE_SEED = 0x6E6565646C65
+INTRO_SEED = 1
+OUTRO_SEED = 2
+
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libneedle_synth.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = ctypes.CDLL(path)
+        lib.needle_synth_episode.argtypes = [
+            ctypes.c_uint64, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_size_t,
+            ctypes.c_uint64, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        lib.needle_synth_episode.restype = None
+        _LIB = lib
+    return _LIB
+
+
+@dataclass
+class Episode:
+    index: int
+    pcm: np.ndarray          # int16 mono, full episode
+    intro_off: int           # samples
+    intro_len: int
+    outro_off: int
+    outro_len: int
+
+    @property
+    def duration_s(self) -> float:
+        return len(self.pcm) / RATE
+
+
+def episode_layout(k: int, total: int, intro_s: float, outro_s: float):
+    """Offsets of the shared segments in episode k (samples)."""
+    intro_len = int(intro_s * RATE)
+    outro_len = int(outro_s * RATE)
+    half = total // 2
+    # spread intro offsets over the opening window, never hop-aligned
+    room = max(half - intro_len, 1)
+    base = int((0.04 + 0.09 * (k % 5)) * room)
+    intro_off = min(base + 137 * k, max(room - 1, 0)) if intro_len else 0
+    tail_start = total - total // 4
+    room_t = max(total - tail_start - outro_len, 1)
+    base_t = int((0.10 + 0.15 * (k % 4)) * room_t)
+    outro_off = tail_start + min(base_t + 211 * (k % 16), max(room_t - 1, 0)) if outro_len else 0
+    return intro_off, intro_len, outro_off, outro_len
+
+
+def make_episode(k: int, seconds: float, intro_s: float, outro_s: float = 0.0,
+                 seed_base: int = EPISODE_SEED) -> Episode:
+    total = int(round(seconds * RATE))
+    intro_off, intro_len, outro_off, outro_len = episode_layout(k, total, intro_s, outro_s)
+    scratch = np.empty(total, dtype=np.float64)
+    out = np.empty(total, dtype=np.int16)
+    _lib().needle_synth_episode(
+        ctypes.c_uint64(seed_base ^ k), total, INTRO_SEED, intro_off, intro_len,
+        OUTRO_SEED, outro_off, outro_len, scratch.ctypes.data, out.ctypes.data)
+    return Episode(k, out, intro_off, intro_len, outro_off, outro_len)
+
+
+def make_library(n_episodes: int, seconds: float, intro_s: float, outro_s: float = 0.0,
+                 threads: int | None = None, seed_base: int = EPISODE_SEED) -> List[Episode]:
+    threads = threads or min(os.cpu_count() or 1, n_episodes, 16)
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        return list(pool.map(lambda k: make_episode(k, seconds, intro_s, outro_s, seed_base),
+                             range(n_episodes)))
+
+
+def write_wav(path: str, pcm: np.ndarray, channels: int = 1, rate: int = RATE) -> None:
+    """Minimal RIFF/WAVE PCM s16 writer (channels=2 duplicates the mono signal, L = R, which is
+    what the reference's resampler hands chromaprint for a mono source, analyzer.rs:183-185)."""
+    data = pcm if channels == 1 else np.repeat(pcm, channels)
+    data = np.ascontiguousarray(data, dtype="<i2")
+    nbytes = data.nbytes
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + (36 + nbytes).to_bytes(4, "little") + b"WAVE")
+        f.write(b"fmt " + (16).to_bytes(4, "little") + (1).to_bytes(2, "little")
+                + channels.to_bytes(2, "little") + rate.to_bytes(4, "little")
+                + (rate * channels * 2).to_bytes(4, "little") + (channels * 2).to_bytes(2, "little")
+                + (16).to_bytes(2, "little"))
+        f.write(b"data" + nbytes.to_bytes(4, "little"))
+        f.write(data.tobytes())
