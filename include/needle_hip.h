@@ -1,0 +1,193 @@
+/*
+ * needle_hip.h — additive, GPU-facing entry points of libneedle_capi.so (MI355X / gfx950).
+ *
+ * needle.h is the reference's C ABI verbatim; it only moves file paths.  The reference's hot path,
+ * however, runs *below* that surface, inside `Analyzer::process_frames` (chromaprint feed/finish,
+ * needle/src/audio/analyzer.rs:176-300) and `Comparator::longest_common_hash_match`
+ * (needle/src/audio/comparator.rs:157-250).  The functions here are the C-ABI form of exactly those
+ * two inner interfaces plus the in-memory calls the Rust API has and the C API lacks
+ * (`Comparator::run_with_frame_hashes`, comparator.rs:524; `FrameHashes` accessors, data.rs:143-168 —
+ * needle-capi/src/lib.rs:306-314 wraps FrameHashes as an opaque "TODO").  Plain pointers and sizes,
+ * no C++/torch types.  All functions return NeedleError; details of the last failure on the calling
+ * thread are available from needle_hip_last_error_message().
+ *
+ * Nothing here has a CPU fallback: without a usable HIP device the compute entry points fail with
+ * NeedleError_Unknown ("no HIP device").
+ */
+#ifndef NEEDLE_HIP_H
+#define NEEDLE_HIP_H
+
+#include "needle.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- device / diagnostics ------------------------------------------------------------------------ */
+enum NeedleError needle_hip_device_count(int *count);
+enum NeedleError needle_hip_set_device(int ordinal);
+enum NeedleError needle_hip_synchronize(void);
+const char *needle_hip_last_error_message(void);
+const char *needle_hip_version(void);
+
+/* Thin device-memory helpers so a host program (Rust/C/Python) needs no HIP headers. */
+enum NeedleError needle_hip_malloc(void **device_ptr, size_t bytes);
+enum NeedleError needle_hip_free(void *device_ptr);
+enum NeedleError needle_hip_memcpy_h2d(void *device_dst, const void *host_src, size_t bytes);
+enum NeedleError needle_hip_memcpy_d2h(void *host_dst, const void *device_src, size_t bytes);
+void needle_hip_host_free(void *ptr); /* frees arrays this library malloc'd for the caller */
+
+/* GPU timing of the last needle_hip_* compute call on this thread, measured with HIP events on the
+ * library's own stream (rocprofv3 sees the same kernels).  Names: "stft_chroma", "fir_norm",
+ * "classify", "hamming_runs".  Returns milliseconds, <0 if unknown. */
+double needle_hip_last_kernel_ms(const char *kernel);
+
+/* ---- fingerprint: the chromaprint Context replacement -------------------------------------------
+ * Replaces chromaprint::Context::{start,feed,finish,get_fingerprint_raw,get_delay,get_item_duration,
+ * sample_rate} as called from analyzer.rs:176,179,218,275,286,288-289,300.  Batched: many streams
+ * per call.  PCM is interleaved s16 at needle_hip_fingerprint_sample_rate() Hz, `channels` = 1 or 2
+ * (the reference always feeds 2, analyzer.rs:218; stereo is down-mixed (L+R)/2 with C truncation on
+ * the device).  `step` keeps raw items 0, step, 2*step, ... (analyzer.rs:293-304; step = 1 returns
+ * chromaprint's full raw fingerprint). */
+int needle_hip_fingerprint_sample_rate(void);      /* 11025 */
+int needle_hip_fingerprint_delay_ms(void);         /* 2600  (chromaprint_get_delay_ms) */
+int needle_hip_fingerprint_item_duration_ms(void); /* 123   (chromaprint_get_item_duration_ms) */
+size_t needle_hip_fingerprint_num_items(size_t samples_per_channel);
+size_t needle_hip_fingerprint_num_kept(size_t samples_per_channel, uint32_t step);
+
+/* Host buffers in, host buffers out (does H2D/D2H).  items[i] must hold num_kept(...) values. */
+enum NeedleError needle_hip_fingerprint_host(const int16_t *const *pcm, const size_t *num_values,
+                                             size_t num_streams, int channels, uint32_t step,
+                                             uint32_t *const *items);
+
+/* PCM already resident in HBM: stream i is d_pcm[pcm_offsets[i] .. +num_values[i]) (offsets in s16
+ * values, host arrays); kept items of stream i are written to d_items[item_offsets[i] ..].  Runs on
+ * the library stream; returns after the kernels are enqueued unless `sync` is true. */
+enum NeedleError needle_hip_fingerprint_device(const int16_t *d_pcm, const uint64_t *pcm_offsets,
+                                               const uint64_t *num_values, size_t num_streams,
+                                               int channels, uint32_t step, uint32_t *d_items,
+                                               const uint64_t *item_offsets, bool sync);
+
+/* Test hook: intermediate stages of one stream, copied to the host.  chroma [frames][12] (energy per
+ * pitch class per FFT frame), features [frames-4][12] (FIR-filtered, L2-normalised). NULLs allowed. */
+enum NeedleError needle_hip_fingerprint_debug(const int16_t *pcm, size_t num_values, int channels,
+                                              double *chroma, double *features);
+
+/* ---- search: the LCS-Hamming DP replacement -------------------------------------------------------
+ * Replaces Comparator::longest_common_hash_match's two table sweeps (comparator.rs:175-247).  For a
+ * problem (src, dst, min_len) it reports every maximal diagonal run of cells (i >= 1, j >= 1) with
+ * popcount(src[i] ^ dst[j]) <= threshold whose length L >= min_len, as (src_end = i, dst_end = j, L)
+ * of its last cell — exactly the cells the reference's reverse walk stops at (:196-200) with
+ * table[i][j] = L.  Order of the emitted runs is unspecified; the caller sorts. */
+typedef struct NeedleHipSeq {
+  uint32_t offset; /* first hash of the sequence inside the hash arena */
+  uint32_t len;
+} NeedleHipSeq;
+
+typedef struct NeedleHipProblem {
+  uint32_t src_seq;
+  uint32_t dst_seq;
+  uint32_t min_len; /* >= 1 */
+  uint32_t tag;     /* copied to NeedleHipRun.problem */
+} NeedleHipProblem;
+
+typedef struct NeedleHipRun {
+  uint32_t problem;
+  uint32_t src_end;
+  uint32_t dst_end;
+  uint32_t len;
+} NeedleHipRun;
+
+/* Hash arena resident in HBM; descriptors are host arrays.  Writes at most `capacity` runs to d_runs
+ * and the TOTAL number found to *d_count (device).  Synchronous when `sync`. */
+enum NeedleError needle_hip_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seqs,
+                                                size_t num_seqs, const NeedleHipProblem *problems,
+                                                size_t num_problems, uint32_t threshold,
+                                                NeedleHipRun *d_runs, uint32_t capacity,
+                                                uint32_t *d_count, bool sync);
+
+/* Host arrays in, malloc'd run list out (free with needle_hip_host_free). */
+enum NeedleError needle_hip_hamming_runs_host(const uint32_t *hashes, size_t num_hashes,
+                                              const NeedleHipSeq *seqs, size_t num_seqs,
+                                              const NeedleHipProblem *problems, size_t num_problems,
+                                              uint32_t threshold, NeedleHipRun **runs, size_t *num_runs);
+
+/* ---- FrameHashes (data.rs) ------------------------------------------------------------------------ */
+enum NeedleError needle_hip_frame_hashes_new(const uint32_t *opening_hashes, const uint64_t *opening_ts_ns,
+                                             size_t num_opening, const uint32_t *ending_hashes,
+                                             const uint64_t *ending_ts_ns, size_t num_ending,
+                                             uint64_t hash_duration_ns, const char *md5, FrameHashes **output);
+void needle_hip_frame_hashes_free(FrameHashes *frame_hashes);
+size_t needle_hip_frame_hashes_len(const FrameHashes *frame_hashes, bool ending);          /* data.rs:143,150 */
+enum NeedleError needle_hip_frame_hashes_copy(const FrameHashes *frame_hashes, bool ending, uint32_t *hashes,
+                                              uint64_t *ts_ns, size_t capacity);
+uint64_t needle_hip_frame_hashes_hash_duration_ns(const FrameHashes *frame_hashes);        /* data.rs:157 */
+const char *needle_hip_frame_hashes_md5(const FrameHashes *frame_hashes);                  /* data.rs:164 */
+enum NeedleError needle_hip_frame_hashes_read(const char *path, FrameHashes **output);     /* data.rs:104-115 */
+enum NeedleError needle_hip_frame_hashes_write(const FrameHashes *frame_hashes, const char *path);
+enum NeedleError needle_hip_header_md5(const char *path, char out[33]);                    /* util.rs:99-105 */
+
+/* ---- Analyzer at the PCM boundary -----------------------------------------------------------------
+ * Analyzer::run (analyzer.rs:425) with FFmpeg's half of process_frames already done by the caller:
+ * pcm[i] is the whole decoded stream of video i, interleaved s16 at `sample_rate` (must be 11025;
+ * resampling is the step before this path).  Applies the opening / ending search windows
+ * (analyzer.rs:378,390), fingerprints on the GPU, attaches timestamps (:293-318), stores the
+ * FrameHashes in the handle (retrieve with needle_audio_analyzer_get_frame_hashes) and persists
+ * <video>.needle.dat when `persist`. */
+enum NeedleError needle_hip_analyzer_run_pcm(struct NeedleAudioAnalyzer *analyzer, const int16_t *const *pcm,
+                                             const size_t *num_values, int channels, int sample_rate,
+                                             float hash_duration, bool persist);
+
+/* ---- Comparator in memory ------------------------------------------------------------------------- */
+typedef struct NeedleHipSearchResult {
+  bool has_result; /* false: the reference pushes no SearchResult for this video (comparator.rs:608-617) */
+  bool has_opening;
+  bool has_ending;
+  uint64_t opening_start_ns, opening_end_ns;
+  uint64_t ending_start_ns, ending_end_ns;
+} NeedleHipSearchResult;
+
+/* Comparator::run_with_frame_hashes (comparator.rs:524-629).  `results` has one slot per video. */
+enum NeedleError needle_hip_comparator_run_with_frame_hashes(const struct NeedleAudioComparator *comparator,
+                                                             const FrameHashes *const *frame_hashes,
+                                                             size_t num_videos, bool display,
+                                                             bool use_skip_files, bool write_skip_files,
+                                                             NeedleHipSearchResult *results);
+
+/* ---- Library: an HBM-resident analyze+search job, shardable across GPUs ----------------------------
+ * One object per process/GPU describing ALL videos of a job.  PCM of the videos this rank owns is
+ * uploaded once and stays in HBM; hashes live in a padded device arena [num_videos][stride] so a
+ * plain all-gather over contiguous video blocks fills the rows other ranks computed; pairs are
+ * addressed by their index in the reference's lexicographic pair list (comparator.rs:534-545). */
+typedef struct NeedleHipLibrary NeedleHipLibrary;
+
+enum NeedleError needle_hip_library_new(size_t num_videos, float opening_search_percentage, float hash_duration,
+                                        NeedleHipLibrary **output);
+void needle_hip_library_free(NeedleHipLibrary *library);
+/* Lengths (values per stream, all videos) are metadata every rank holds; pcm[i] may be NULL for
+ * videos this rank does not own.  Crops to the opening window and uploads. */
+enum NeedleError needle_hip_library_set_pcm(NeedleHipLibrary *library, const int16_t *const *pcm,
+                                            const size_t *num_values, int channels);
+/* Fingerprint videos [first, first+count) into their arena rows (GPU only, no host copy). */
+enum NeedleError needle_hip_library_analyze(NeedleHipLibrary *library, size_t first, size_t count, bool sync);
+/* Arena geometry: device pointer to u32[num_videos][stride]. */
+enum NeedleError needle_hip_library_hash_arena(NeedleHipLibrary *library, uint32_t **d_arena, size_t *stride);
+size_t needle_hip_library_num_pairs(const NeedleHipLibrary *library);
+/* Runs of pairs [first_pair, first_pair+num_pairs) into caller-provided device buffers
+ * (NeedleHipRun.problem = global pair index). */
+enum NeedleError needle_hip_library_search(NeedleHipLibrary *library, const struct NeedleAudioComparator *comparator,
+                                           size_t first_pair, size_t num_pairs, NeedleHipRun *d_runs,
+                                           uint32_t capacity, uint32_t *d_count, bool sync);
+/* Host epilogue over the complete run list (all pairs): D2H of the arena, duration validity,
+ * simhash32, BinaryHeap order, find_best_match.  `runs` is a host array. */
+enum NeedleError needle_hip_library_finalize(NeedleHipLibrary *library, const struct NeedleAudioComparator *comparator,
+                                             const NeedleHipRun *runs, size_t num_runs,
+                                             NeedleHipSearchResult *results);
+/* Copies one video's FrameHashes (opening only) out of the library after analyze (+gather). */
+enum NeedleError needle_hip_library_frame_hashes(NeedleHipLibrary *library, size_t index, FrameHashes **output);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* NEEDLE_HIP_H */

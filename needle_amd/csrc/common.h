@@ -1,0 +1,114 @@
+// Shared host-side declarations for libneedle_capi.so (MI355X-native needle analyze/search path).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/needle_hip.h"
+
+namespace needle {
+
+// ---- errors -------------------------------------------------------------------------------------------
+// Mirrors needle::Error (needle/src/lib.rs:117-149) closely enough to reproduce the mapping to
+// NeedleError done in needle-capi/src/lib.rs:121-134.
+struct Status {
+  NeedleError code = NeedleError_Ok;
+  std::string message;
+  bool ok() const { return code == NeedleError_Ok; }
+  static Status Ok() { return Status{}; }
+  static Status Make(NeedleError c, std::string m) { return Status{c, std::move(m)}; }
+};
+
+// Records the message for needle_hip_last_error_message() and, like lib.rs:124, prints
+// "needle error: ..." on stderr; returns the code.
+NeedleError report(const Status &s);
+void set_last_error(const std::string &m);
+const char *last_error();
+
+// ---- std::time::Duration, kept as total nanoseconds ----------------------------------------------------
+using ns_t = uint64_t;
+constexpr ns_t kNanosPerSec = 1000000000ull;
+
+ns_t duration_from_secs_f32(float s, bool *ok = nullptr);   // Duration::from_secs_f32 (round to nearest ns, ties even)
+ns_t duration_from_secs_f64(double s, bool *ok = nullptr);  // Duration::from_secs_f64
+float duration_as_secs_f32(ns_t d);                         // Duration::as_secs_f32
+double duration_as_secs_f64(ns_t d);
+ns_t duration_mul_f32(ns_t d, float rhs, bool *ok = nullptr);  // Duration::mul_f32
+
+// ---- FrameHashes (needle/src/audio/data.rs:15-26,74-80) -------------------------------------------------
+struct HashTs {
+  uint32_t hash;
+  ns_t ts;
+};
+
+struct FrameHashesData {
+  std::vector<HashTs> opening;
+  std::vector<HashTs> ending;
+  ns_t hash_duration = 0;
+  std::string md5;
+};
+
+Status frame_hashes_read(const std::string &path, FrameHashesData *out);         // data.rs:104-115
+Status frame_hashes_write(const std::string &path, const FrameHashesData &fh);   // analyzer.rs:414-417
+Status header_md5(const std::string &path, std::string *out);                    // util.rs:99-105
+std::string md5_hex(const uint8_t *data, size_t n);
+std::string with_extension(const std::string &path, const std::string &ext);     // Path::with_extension
+std::string format_time(ns_t t);                                                  // util.rs:8-12
+std::string format_f32_json(float v);                                             // serde_json/ryu f32
+
+// ---- chromaprint-facing constants -------------------------------------------------
+constexpr int kSampleRate = 11025;
+constexpr int kFrameSize = 4096;
+constexpr int kHop = 1365;
+constexpr int kBands = 12;
+constexpr int kFirTaps = 5;
+constexpr int kMaxFilterWidth = 16;
+constexpr int kItemLatency = (kFirTaps - 1) + (kMaxFilterWidth - 1);  // frames - items
+constexpr int kDelayMs = 2600;        // chromaprint_get_delay_ms
+constexpr int kItemDurationMs = 123;  // chromaprint_get_item_duration_ms
+
+inline size_t num_frames(size_t samples) { return samples < (size_t)kFrameSize ? 0 : (samples - kFrameSize) / kHop + 1; }
+inline size_t num_items(size_t samples) {
+  size_t f = num_frames(samples);
+  return f > (size_t)kItemLatency ? f - kItemLatency : 0;
+}
+inline size_t num_kept(size_t samples, uint32_t step) {
+  size_t n = num_items(samples);
+  return step ? (n + step - 1) / step : 0;
+}
+
+// analyzer.rs:293-318: timestamps of the kept items.  Returns false if step_by would be 0.
+bool step_for_hash_duration(ns_t hash_duration, uint32_t *step);
+void attach_timestamps(const uint32_t *kept, size_t n_kept, uint32_t step, bool has_seek, ns_t seek_to,
+                       std::vector<HashTs> *out);
+
+// ---- WAV (the only container this build decodes; FFmpeg is out of scope) ---------------------------------
+struct WavData {
+  int channels = 0;
+  int sample_rate = 0;
+  std::vector<int16_t> pcm;  // interleaved
+};
+Status wav_read(const std::string &path, WavData *out);
+
+// ---- GPU entry points used by the host classes (fingerprint.hip / search.hip) ----------------------------
+struct StreamSpan {
+  uint64_t pcm_off;     // offset into the PCM arena, in s16 values
+  uint64_t num_values;  // interleaved values
+  uint64_t item_off;    // offset into the item arena where kept items go
+};
+
+Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan> &streams, int channels,
+                              uint32_t step, uint32_t *d_items, bool sync, double *d_chroma_dbg = nullptr,
+                              double *d_feat_dbg = nullptr);
+Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
+                            int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items);
+Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
+                               const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
+                               NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync);
+Status gpu_hamming_runs_host(const uint32_t *hashes, size_t num_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
+                             const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
+                             std::vector<NeedleHipRun> *runs);
+
+}  // namespace needle

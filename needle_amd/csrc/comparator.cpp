@@ -1,0 +1,363 @@
+// needle::audio::Comparator (needle/src/audio/comparator.rs) with the O(n*m) table sweeps replaced by
+// the GPU diagonal scan (search.hip).  Everything that depends on order — the reverse table walk,
+// BinaryHeap pushes, candidate numbering, tie-breaks — is reproduced on the host from the run list.
+#include <algorithm>
+#include <cstdio>
+#include <fstream>
+#include <tuple>
+
+#include "needle_core.h"
+
+namespace needle {
+
+// chromaprint-rust simhash::simhash32: per bit, +1 for every set bit, -1 for every clear bit over the
+// slice; output bit set iff the tally is > 0.  Counting set bits is enough: 2*ones > n.
+uint32_t simhash32(const uint32_t *data, size_t n) {
+  uint32_t ones[32] = {0};
+  for (size_t i = 0; i < n; i++) {
+    uint32_t h = data[i];
+    while (h) {
+      ones[__builtin_ctz(h)]++;
+      h &= h - 1;
+    }
+  }
+  uint32_t out = 0;
+  for (int b = 0; b < 32; b++)
+    if (2 * (uint64_t)ones[b] > n) out |= 1u << b;
+  return out;
+}
+
+size_t pair_count(size_t n) { return n < 2 ? 0 : n * (n - 1) / 2; }
+
+void pair_at(size_t n, size_t index, size_t *pi, size_t *pj) {
+  // pairs (i, j), i < j, enumerated i-major (comparator.rs:537-545)
+  size_t i = 0;
+  while (index >= n - 1 - i) {
+    index -= n - 1 - i;
+    i++;
+  }
+  *pi = i;
+  *pj = i + 1 + index;
+}
+
+Comparator Comparator::from_files(std::vector<std::string> videos) {
+  Comparator c;
+  c.videos_ = std::move(videos);
+  return c;
+}
+
+Comparator Comparator::from_analyzer(const Analyzer &a) {
+  Comparator c;
+  c.videos_ = a.videos_;
+  return c;
+}
+
+uint32_t Comparator::min_run_length(const std::vector<HashTs> &seq, ns_t min_duration) {
+  // smallest L such that some end index i has ts[i] - ts[i-L] >= min_duration (the validity test of
+  // comparator.rs:212-217 with start index i-L, :206); 0 if no window ever qualifies.
+  if (seq.size() < 2) return 0;
+  if (min_duration == 0) return 1;
+  uint32_t best = 0;
+  size_t s = 0;
+  for (size_t i = 1; i < seq.size(); i++) {
+    while (s + 1 < i && seq[i].ts >= seq[s + 1].ts && seq[i].ts - seq[s + 1].ts >= min_duration) s++;
+    if (seq[i].ts >= seq[s].ts && seq[i].ts - seq[s].ts >= min_duration) {
+      const uint32_t len = (uint32_t)(i - s);
+      if (best == 0 || len < best) best = len;
+    }
+  }
+  return best;
+}
+
+namespace {
+
+// #[derive(Ord)] of ComparatorHeapEntry: lexicographic over the fields in declaration order
+// (comparator.rs:22-35); false < true for the four flags.
+auto entry_key(const HeapEntry &e) {
+  return std::make_tuple(e.score, e.src_start, e.src_end, e.dst_start, e.dst_end, e.src_match_hash,
+                         e.dst_match_hash, e.is_opening, !e.is_opening, e.is_opening, !e.is_opening,
+                         e.src_hash_duration, e.dst_hash_duration);
+}
+
+// std::collections::BinaryHeap::push: append, then sift the new element up while it is greater than
+// its parent.  `heap.into()` later returns this backing vector untouched (comparator.rs:249).
+void binary_heap_push(std::vector<HeapEntry> *heap, const HeapEntry &e) {
+  heap->push_back(e);
+  size_t pos = heap->size() - 1;
+  while (pos > 0) {
+    const size_t parent = (pos - 1) / 2;
+    if (entry_key((*heap)[pos]) <= entry_key((*heap)[parent])) break;
+    std::swap((*heap)[pos], (*heap)[parent]);
+    pos = parent;
+  }
+}
+
+struct Candidate {  // comparator.rs:410-432
+  ns_t start, end, hash_duration;
+  uint32_t match_hash;
+  bool is_opening;
+};
+
+Status read_skip_file_md5(const std::string &skip_path, std::string *md5) {
+  std::ifstream f(skip_path);
+  std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  const size_t key = text.find("\"md5\"");
+  if (key == std::string::npos) return Status::Make(NeedleError_Unknown, "serde_json error: skip file has no md5: " + skip_path);
+  const size_t q0 = text.find('"', text.find(':', key));
+  const size_t q1 = q0 == std::string::npos ? q0 : text.find('"', q0 + 1);
+  if (q1 == std::string::npos) return Status::Make(NeedleError_Unknown, "serde_json error: malformed skip file: " + skip_path);
+  *md5 = text.substr(q0 + 1, q1 - q0 - 1);
+  return Status::Ok();
+}
+
+}  // namespace
+
+void Comparator::entries_from_runs(std::vector<NeedleHipRun> runs, const std::vector<HashTs> &src,
+                                   const std::vector<HashTs> &dst, ns_t src_hash_duration, ns_t dst_hash_duration,
+                                   bool is_opening, std::vector<HeapEntry> *out) const {
+  out->clear();
+  // the reference walks i = n-1..1 and, inside, j = m-1..1 (:191-192): pushes happen in that order
+  std::sort(runs.begin(), runs.end(), [](const NeedleHipRun &a, const NeedleHipRun &b) {
+    return a.src_end != b.src_end ? a.src_end > b.src_end : a.dst_end > b.dst_end;
+  });
+  const ns_t min_duration = is_opening ? min_opening_duration_ : min_ending_duration_;
+  std::vector<uint32_t> tmp;
+  for (const NeedleHipRun &r : runs) {
+    const size_t i = r.src_end, j = r.dst_end, len = r.len;
+    if (len == 0 || len > i || len > j || i >= src.size() || j >= dst.size()) continue;  // cannot happen
+    const size_t si = i - len, sj = j - len;  // one BEFORE the first matched cell (:206-207)
+    const ns_t src_start = src[si].ts, src_end = src[i].ts, dst_start = dst[sj].ts, dst_end = dst[j].ts;
+    if (src_end < src_start || dst_end < dst_start) continue;  // the reference would panic on the subtraction
+    if (src_end - src_start < min_duration || dst_end - dst_start < min_duration) continue;  // :212-223
+    HeapEntry e;
+    e.score = len;
+    e.src_start = src_start;
+    e.src_end = src_end;
+    e.dst_start = dst_start;
+    e.dst_end = dst_end;
+    tmp.resize(len + 1);  // simhash over [start_idx ..= end_idx], L+1 hashes (:149-153,226-229)
+    for (size_t k = 0; k <= len; k++) tmp[k] = src[si + k].hash;
+    e.src_match_hash = simhash32(tmp.data(), len + 1);
+    for (size_t k = 0; k <= len; k++) tmp[k] = dst[sj + k].hash;
+    e.dst_match_hash = simhash32(tmp.data(), len + 1);
+    e.is_opening = is_opening;
+    e.src_hash_duration = src_hash_duration;
+    e.dst_hash_duration = dst_hash_duration;
+    binary_heap_push(out, e);
+  }
+}
+
+Status Comparator::best_matches(size_t num_videos, const std::vector<std::vector<HeapEntry>> &pair_entries,
+                                bool display, bool use_skip_files, bool write_skip_files,
+                                std::vector<VideoResult> *per_video) const {
+  per_video->assign(num_videos, {});
+  // info_map (:583-588): for every non-empty pair, (pair, as source) for i and (pair, as dest) for j
+  std::vector<std::vector<std::pair<size_t, bool>>> info_map(num_videos);
+  for (size_t p = 0; p < pair_entries.size(); p++) {
+    if (pair_entries[p].empty()) continue;  // :562
+    size_t i, j;
+    pair_at(num_videos, p, &i, &j);
+    info_map[i].push_back({p, true});
+    info_map[j].push_back({p, false});
+  }
+  const uint32_t bound = hash_match_threshold_ + hash_match_threshold_ / 2;  // :441
+  for (size_t v = 0; v < num_videos; v++) {
+    const std::string &path = v < videos_.size() ? videos_[v] : std::string();
+    if (display) std::printf("\n%s\n\n", path.c_str());  // :595-597
+    if (use_skip_files) {                                 // :600-605, check_skip_file :310-327
+      const std::string skip = with_extension(path, SKIP_FILE_NAME);
+      std::ifstream probe(skip);
+      if (probe) {
+        std::string md5, stored;
+        Status s = header_md5(path, &md5);
+        if (!s.ok()) return s;
+        s = read_skip_file_md5(skip, &stored);
+        if (!s.ok()) return s;
+        if (stored == md5) {
+          if (display) std::printf("Skipping due to existing skip file...\n");
+          continue;
+        }
+      }
+    }
+    // find_best_match (:405-515)
+    if (info_map[v].empty()) {
+      if (display) std::printf(include_endings_ ? "No opening or ending found.\n" : "No opening found.\n");
+      continue;
+    }
+    std::vector<Candidate> cand;
+    for (const auto &[p, is_source] : info_map[v]) {
+      for (int pass = 0; pass < 2; pass++) {  // openings first, then endings (:414-431)
+        for (const HeapEntry &e : pair_entries[p]) {
+          if (e.is_opening != (pass == 0)) continue;
+          if (is_source)
+            cand.push_back({e.src_start, e.src_end, e.src_hash_duration, e.src_match_hash, e.is_opening});
+          else
+            cand.push_back({e.dst_start, e.dst_end, e.dst_hash_duration, e.dst_match_hash, e.is_opening});
+        }
+      }
+    }
+    // distinct_matches (:434-454): symmetric relation, so the set size of i is its neighbour count
+    std::vector<uint32_t> links(cand.size(), 0);
+    for (size_t a = 0; a < cand.size(); a++)
+      for (size_t b = 0; b < cand.size(); b++)
+        if ((uint32_t)__builtin_popcount(cand[a].match_hash ^ cand[b].match_hash) < bound) links[a]++;
+
+    VideoResult &vr = (*per_video)[v];
+    vr.has_result = true;  // Some(best) even if neither side is found (:514)
+    for (int pass = 0; pass < 2; pass++) {
+      const bool want_opening = pass == 0;
+      if (!want_opening && !include_endings_) break;  // :486
+      bool have = false;
+      float best_score = 0.f;
+      size_t best_idx = 0;
+      for (size_t k = 0; k < cand.size(); k++) {
+        if (links[k] == 0 || cand[k].is_opening != want_opening) continue;
+        const float count = (float)(int64_t)links[k];
+        const float duration_secs = duration_as_secs_f32(cand[k].end - cand[k].start);
+        const float weighted = count * 0.3f + duration_secs * 0.7f;  // :469 (f32, no fused multiply-add)
+        const float score = -weighted;
+        // ascending sort of (score, index) and take the first (:473-475)
+        if (!have || score < best_score) {
+          have = true;
+          best_score = score;
+          best_idx = k;
+        }
+      }
+      if (!have) continue;
+      const Candidate &w = cand[best_idx];
+      if (w.end < time_padding_ || w.end - time_padding_ < w.hash_duration)  // Duration underflow panics upstream
+        return Status::Make(NeedleError_Unknown, "overflow when subtracting durations (time_padding / hash_duration exceed the match end)");
+      const ns_t start = w.start + time_padding_;                   // :479
+      const ns_t end = w.end - time_padding_ - w.hash_duration;     // :481
+      if (want_opening) {
+        vr.result.has_opening = true;
+        vr.result.opening_start = start;
+        vr.result.opening_end = end;
+      } else {
+        vr.result.has_ending = true;
+        vr.result.ending_start = start;
+        vr.result.ending_end = end;
+      }
+    }
+    if (display) {  // display_opening_ending_info (:356-381)
+      if (vr.result.has_opening)
+        std::printf("* Opening - \"%s\"-\"%s\"\n", format_time(vr.result.opening_start).c_str(),
+                    format_time(vr.result.opening_end).c_str());
+      else
+        std::printf("* Opening - N/A\n");
+      if (include_endings_) {
+        if (vr.result.has_ending)
+          std::printf("* Ending - \"%s\"-\"%s\"\n", format_time(vr.result.ending_start).c_str(),
+                      format_time(vr.result.ending_end).c_str());
+        else
+          std::printf("* Ending - N/A\n");
+      }
+    }
+    if (write_skip_files && (vr.result.has_opening || vr.result.has_ending)) {  // create_skip_file (:329-354)
+      std::string md5;
+      Status s = header_md5(path, &md5);
+      if (!s.ok()) return s;
+      std::string json = "{\"opening\":";
+      auto pair_text = [](ns_t a, ns_t b) {
+        return "[" + format_f32_json(duration_as_secs_f32(a)) + "," + format_f32_json(duration_as_secs_f32(b)) + "]";
+      };
+      json += vr.result.has_opening ? pair_text(vr.result.opening_start, vr.result.opening_end) : "null";
+      json += ",\"ending\":";
+      json += vr.result.has_ending ? pair_text(vr.result.ending_start, vr.result.ending_end) : "null";
+      json += ",\"md5\":\"" + md5 + "\"}";
+      std::ofstream f(with_extension(path, SKIP_FILE_NAME), std::ios::trunc);
+      if (!f) return Status::Make(NeedleError_IOError, "IO error: cannot create skip file for " + path);
+      f << json;
+    }
+  }
+  if (display) std::fflush(stdout);
+  return Status::Ok();
+}
+
+Status Comparator::run_with_frame_hashes(const std::vector<const FrameHashesData *> &fh, bool display,
+                                         bool use_skip_files, bool write_skip_files, bool /*threading*/,
+                                         std::vector<VideoResult> *per_video) const {
+  const size_t n = fh.size();
+  const size_t regions = include_endings_ ? 2 : 1;
+  // hash arena: [video][region] sequences back to back
+  std::vector<uint32_t> arena;
+  std::vector<NeedleHipSeq> seqs(n * regions);
+  std::vector<uint32_t> min_len(n * regions, 0);
+  for (size_t v = 0; v < n; v++) {
+    for (size_t r = 0; r < regions; r++) {
+      const std::vector<HashTs> &seq = r == 0 ? fh[v]->opening : fh[v]->ending;
+      seqs[v * regions + r] = NeedleHipSeq{(uint32_t)arena.size(), (uint32_t)seq.size()};
+      for (const HashTs &h : seq) arena.push_back(h.hash);
+      min_len[v * regions + r] = min_run_length(seq, r == 0 ? min_opening_duration_ : min_ending_duration_);
+    }
+  }
+  const size_t np = pair_count(n);
+  std::vector<NeedleHipProblem> problems;
+  for (size_t p = 0; p < np; p++) {
+    size_t i, j;
+    pair_at(n, p, &i, &j);
+    if (include_endings_ && (fh[i]->ending.empty() || fh[j]->ending.empty()))  // :271-273; the caller unwrap()s
+      return Status::Make(NeedleError_Unknown, "no ending hash data present");
+    for (size_t r = 0; r < regions; r++) {
+      const uint32_t a = min_len[i * regions + r], b = min_len[j * regions + r];
+      if (a == 0 || b == 0) continue;  // no run of this pair can satisfy the duration test
+      problems.push_back(NeedleHipProblem{(uint32_t)(i * regions + r), (uint32_t)(j * regions + r), std::max(a, b),
+                                          (uint32_t)(p * regions + r)});
+    }
+  }
+  std::vector<NeedleHipRun> runs;
+  // an empty problem list still goes through the device entry point: there is no CPU path to fall to
+  Status s = gpu_hamming_runs_host(arena.data(), arena.size(), seqs.data(), seqs.size(), problems.data(),
+                                   problems.size(), hash_match_threshold_, &runs);
+  if (!s.ok()) return s;
+  return results_from_runs(fh, runs, display, use_skip_files, write_skip_files, per_video);
+}
+
+Status Comparator::results_from_runs(const std::vector<const FrameHashesData *> &fh,
+                                     const std::vector<NeedleHipRun> &runs, bool display, bool use_skip_files,
+                                     bool write_skip_files, std::vector<VideoResult> *per_video) const {
+  const size_t n = fh.size();
+  const size_t regions = include_endings_ ? 2 : 1;
+  const size_t np = pair_count(n);
+  // bucket runs by (pair, region): NeedleHipRun.problem = pair * regions + region
+  std::vector<std::vector<NeedleHipRun>> buckets(np * regions);
+  for (const NeedleHipRun &r : runs)
+    if (r.problem < buckets.size()) buckets[r.problem].push_back(r);
+  std::vector<std::vector<HeapEntry>> pair_entries(np);
+  std::vector<HeapEntry> tmp;
+  for (size_t p = 0; p < np; p++) {
+    size_t i, j;
+    pair_at(n, p, &i, &j);
+    for (size_t r = 0; r < regions; r++) {  // entries.extend(opening); entries.extend(ending) (:262-281)
+      if (buckets[p * regions + r].empty()) continue;
+      entries_from_runs(std::move(buckets[p * regions + r]), r == 0 ? fh[i]->opening : fh[i]->ending,
+                        r == 0 ? fh[j]->opening : fh[j]->ending, fh[i]->hash_duration, fh[j]->hash_duration, r == 0,
+                        &tmp);
+      pair_entries[p].insert(pair_entries[p].end(), tmp.begin(), tmp.end());
+    }
+  }
+  return best_matches(n, pair_entries, display, use_skip_files, write_skip_files, per_video);
+}
+
+Status Comparator::run(bool analyze, bool display, bool use_skip_files, bool write_skip_files, bool threading,
+                       std::vector<VideoResult> *per_video) const {
+  std::vector<FrameHashesData> data(videos_.size());
+  if (!analyze) {
+    for (size_t v = 0; v < videos_.size(); v++) {  // FrameHashes::from_video(video, false), data.rs:124-128
+      Status s = frame_hashes_read(with_extension(videos_[v], FRAME_HASH_DATA_FILE_NAME), &data[v]);
+      if (!s.ok()) return s;
+    }
+  } else {
+    // data.rs:134-136: default Analyzer (no endings), force, 0.3 s, not persisted — here as one GPU batch
+    Analyzer a = Analyzer::from_files(videos_, false, true);
+    bool ok = true;
+    const ns_t hd = duration_from_secs_f32(DEFAULT_HASH_DURATION, &ok);
+    Status s = a.run(hd, false, threading, &data);
+    if (!s.ok()) return s;
+  }
+  std::vector<const FrameHashesData *> ptrs;
+  for (const FrameHashesData &d : data) ptrs.push_back(&d);
+  return run_with_frame_hashes(ptrs, display, use_skip_files, write_skip_files, threading, per_video);
+}
+
+}  // namespace needle

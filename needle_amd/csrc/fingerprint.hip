@@ -1,0 +1,402 @@
+// GPU fingerprinter: the chromaprint Context replacement behind
+// needle/src/audio/analyzer.rs:176-300 (start/feed/finish/get_fingerprint_raw), batched over streams.
+//
+//   stft_chroma : s16 PCM -> Hamming window -> 4096-pt real FFT (f64, LDS Stockham) -> |X|^2 over bins
+//                 10..1307 -> 12 pitch-class energies per frame            [frames][12] f64
+//   fir_norm    : 5-tap temporal FIR {.25,.75,1,.75,.25} + L2 normalise (zero if norm < 0.01)
+//                                                                          [frames-4][12] f64
+//   classify    : 16 Haar-like filters over a 16x12 window, log-ratio quantised to 2 bits, Gray coded,
+//                 packed MSB first -> u32 per kept item (items 0, step, 2*step, ...)
+//
+// HBM traffic that matters is the PCM read (2 B/sample, each sample touched by 3 overlapping frames:
+// re-reads are served by L2) and 96 B/frame of chroma; everything else stays on chip.
+#include "fp_core.h"
+#include "hipctx.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+namespace needle {
+
+using core::cd;
+
+namespace {
+
+struct FpStream {
+  uint64_t pcm_off;     // s16 values
+  uint64_t item_off;    // where this stream's kept items go in d_items
+  uint32_t frames;
+  uint32_t frame_base;  // prefix of frames
+  uint32_t fir_rows;    // frames - 4 (or 0)
+  uint32_t fir_base;
+  uint32_t kept;
+  uint32_t kept_base;
+};
+
+// ---- constant tables, generated on the host in double and uploaded once per device --------------------
+struct FpTables {
+  cd *tw = nullptr;                 // [4096] e^{-2 pi i k/4096}
+  double *window = nullptr;         // [4096] Hamming / 32767
+  uint16_t *class_bins = nullptr;   // [kNumBins] spectrum bins grouped by pitch class
+  uint32_t *class_start = nullptr;  // [13]
+  core::ClassifierThresholds *thr = nullptr;
+};
+
+std::mutex g_tab_mu;
+std::map<int, FpTables> g_tables;
+
+const double kThresholds[16][3] = {
+    {1.98215, 2.35817, 2.63523},          {-1.03809, -0.651211, -0.282167},  {-0.298702, 0.119262, 0.558497},
+    {-0.105439, 0.0153946, 0.135898},     {-0.142891, 0.0258736, 0.200632},  {-0.826319, -0.590612, -0.368214},
+    {-0.557409, -0.233035, 0.0534525},    {-0.0646826, 0.00620476, 0.0784847}, {-0.192387, -0.029699, 0.215855},
+    {-0.0397818, -0.00568076, 0.0292026}, {-0.53823, -0.369934, -0.190235},  {-0.124877, 0.0296483, 0.139239},
+    {-0.101475, 0.0225617, 0.231971},     {-0.0799915, -0.00729616, 0.063262}, {-0.272556, 0.019424, 0.302559},
+    {-0.164292, -0.0321188, 0.0846339},
+};
+
+Status get_tables(FpTables *out) {
+  int dev = 0;
+  NEEDLE_HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_tab_mu);
+  auto it = g_tables.find(dev);
+  if (it != g_tables.end()) {
+    *out = it->second;
+    return Status::Ok();
+  }
+  std::vector<cd> tw(4096);
+  for (int k = 0; k < 4096; k++) {
+    long double a = -2.0L * 3.14159265358979323846264338327950288L * k / 4096.0L;
+    tw[k] = cd{(double)cosl(a), (double)sinl(a)};
+  }
+  std::vector<double> window(4096);
+  for (int i = 0; i < 4096; i++)  // chromaprint PrepareHammingWindow(scale = 1/INT16_MAX)
+    window[i] = (1.0 / 32767.0) * (0.54 - 0.46 * std::cos(i * 2.0 * M_PI / (4096 - 1)));
+  // chromaprint Chroma::PrepareNotes: bin -> pitch class
+  std::vector<std::vector<uint16_t>> by_class(kBands);
+  for (int i = core::kMinBin; i < core::kMaxBin; i++) {
+    double freq = (double)i * kSampleRate / kFrameSize;
+    double octave = std::log(freq / (440.0 / 16.0)) / std::log(2.0);
+    double note = kBands * (octave - std::floor(octave));
+    by_class[(int)(signed char)note].push_back((uint16_t)i);
+  }
+  std::vector<uint16_t> bins;
+  std::vector<uint32_t> start(kBands + 1, 0);
+  for (int c = 0; c < kBands; c++) {
+    start[c] = (uint32_t)bins.size();
+    bins.insert(bins.end(), by_class[c].begin(), by_class[c].end());
+  }
+  start[kBands] = (uint32_t)bins.size();
+  core::ClassifierThresholds thr;
+  for (int i = 0; i < 16; i++)
+    for (int j = 0; j < 3; j++) thr.e[i][j] = std::exp(kThresholds[i][j]);
+
+  FpTables t;
+  NEEDLE_HIP_TRY(hipMalloc((void **)&t.tw, tw.size() * sizeof(cd)));
+  NEEDLE_HIP_TRY(hipMalloc((void **)&t.window, window.size() * sizeof(double)));
+  NEEDLE_HIP_TRY(hipMalloc((void **)&t.class_bins, bins.size() * sizeof(uint16_t)));
+  NEEDLE_HIP_TRY(hipMalloc((void **)&t.class_start, start.size() * sizeof(uint32_t)));
+  NEEDLE_HIP_TRY(hipMalloc((void **)&t.thr, sizeof(thr)));
+  NEEDLE_HIP_TRY(hipMemcpy(t.tw, tw.data(), tw.size() * sizeof(cd), hipMemcpyHostToDevice));
+  NEEDLE_HIP_TRY(hipMemcpy(t.window, window.data(), window.size() * sizeof(double), hipMemcpyHostToDevice));
+  NEEDLE_HIP_TRY(hipMemcpy(t.class_bins, bins.data(), bins.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  NEEDLE_HIP_TRY(hipMemcpy(t.class_start, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  NEEDLE_HIP_TRY(hipMemcpy(t.thr, &thr, sizeof(thr), hipMemcpyHostToDevice));
+  g_tables[dev] = t;
+  *out = t;
+  return Status::Ok();
+}
+
+// index of the stream whose [base, next base) range holds g; `base` is a field of FpStream
+template <uint32_t FpStream::*BASE>
+__device__ __forceinline__ int find_stream(const FpStream *streams, int n, uint32_t g) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (streams[mid].*BASE <= g) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// ---- kernel 1: one 256-thread workgroup per frame (grid-stride over frames) -----------------------------
+__global__ __launch_bounds__(256) void stft_chroma_kernel(const int16_t *__restrict__ pcm,
+                                                          const FpStream *__restrict__ streams, int num_streams,
+                                                          int channels, const cd *__restrict__ tw,
+                                                          const double *__restrict__ window,
+                                                          const uint16_t *__restrict__ class_bins,
+                                                          const uint32_t *__restrict__ class_start,
+                                                          double *__restrict__ chroma, uint32_t total_frames) {
+  __shared__ cd lds[core::kFftN];
+  const int t = threadIdx.x;
+  for (uint32_t g = blockIdx.x; g < total_frames; g += gridDim.x) {
+    const int si = find_stream<&FpStream::frame_base>(streams, num_streams, g);
+    const FpStream st = streams[si];
+    const uint32_t f = g - st.frame_base;
+    const int16_t *src = pcm + st.pcm_off + (uint64_t)f * kHop * channels;
+
+    // pass 0 inputs straight from global: z[m] = x[2m] + i x[2m+1], m = t + 256 k
+    cd r[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int m = t + 256 * k;
+      int s0, s1;
+      if (channels == 1) {
+        s0 = src[2 * m];
+        s1 = src[2 * m + 1];
+      } else {  // AudioProcessor::LoadStereo: (L + R) / 2, C truncation
+        s0 = ((int)src[4 * m] + (int)src[4 * m + 1]) / 2;
+        s1 = ((int)src[4 * m + 2] + (int)src[4 * m + 3]) / 2;
+      }
+      r[k] = cd{(double)s0 * window[2 * m], (double)s1 * window[2 * m + 1]};
+    }
+    core::pass_compute_write<0>(t, tw, lds, r);
+    __syncthreads();
+    core::pass_read<1>(t, lds, r);
+    __syncthreads();
+    core::pass_compute_write<1>(t, tw, lds, r);
+    __syncthreads();
+    core::pass_read<2>(t, lds, r);
+    __syncthreads();
+    core::pass_compute_write<2>(t, tw, lds, r);
+    __syncthreads();
+    core::pass3_inplace(t, lds);
+    __syncthreads();
+
+    // power of this thread's bins, then park them in LDS (aliasing the spectrum) for the class sums
+    double pw[core::kBinsPerThread];
+#pragma unroll
+    for (int i = 0; i < core::kBinsPerThread; i++) {
+      const int k = core::kMinBin + t + 256 * i;
+      pw[i] = (k < core::kMaxBin) ? core::bin_power(k, lds, tw) : 0.0;
+    }
+    __syncthreads();
+    double *plds = reinterpret_cast<double *>(lds);
+#pragma unroll
+    for (int i = 0; i < core::kBinsPerThread; i++) {
+      const int k = core::kMinBin + t + 256 * i;
+      if (k < core::kMaxBin) plds[k] = pw[i];
+    }
+    __syncthreads();
+
+    // 12 pitch classes x 16 lanes: strided partial sums, then a fixed-order 16-lane tree
+    if (t < kBands * 16) {
+      const int c = t >> 4, l = t & 15;
+      const uint32_t b0 = class_start[c], b1 = class_start[c + 1];
+      double acc = 0.0;
+      for (uint32_t b = b0 + l; b < b1; b += 16) acc += plds[class_bins[b]];
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 16);
+      if (l == 0) chroma[(uint64_t)g * kBands + c] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- kernel 2: temporal FIR + L2 normalise, one thread per output row -------------------------------------
+__global__ __launch_bounds__(256) void fir_norm_kernel(const double *__restrict__ chroma,
+                                                       const FpStream *__restrict__ streams, int num_streams,
+                                                       double *__restrict__ feat, uint32_t total_rows) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total_rows) return;
+  const int si = find_stream<&FpStream::fir_base>(streams, num_streams, g);
+  const FpStream st = streams[si];
+  const uint32_t r = g - st.fir_base;
+  const double *in = chroma + ((uint64_t)st.frame_base + r) * kBands;
+  const double coef[5] = {0.25, 0.75, 1.0, 0.75, 0.25};
+  double v[kBands];
+  double squares = 0.0;
+#pragma unroll
+  for (int c = 0; c < kBands; c++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) acc += in[j * kBands + c] * coef[j];
+    v[c] = acc;
+    squares += acc * acc;
+  }
+  const double norm = squares > 0.0 ? sqrt(squares) : 0.0;
+  double *out = feat + (uint64_t)g * kBands;
+  if (norm < 0.01) {
+#pragma unroll
+    for (int c = 0; c < kBands; c++) out[c] = 0.0;
+  } else {
+#pragma unroll
+    for (int c = 0; c < kBands; c++) out[c] = v[c] / norm;
+  }
+}
+
+// ---- kernel 3: 16 classifiers over a 16x12 window, one thread per kept item ----------------------------------
+__global__ __launch_bounds__(256) void classify_kernel(const double *__restrict__ feat,
+                                                       const FpStream *__restrict__ streams, int num_streams,
+                                                       const core::ClassifierThresholds *__restrict__ thr,
+                                                       uint32_t step, uint32_t *__restrict__ items,
+                                                       uint32_t total_kept) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total_kept) return;
+  const int si = find_stream<&FpStream::kept_base>(streams, num_streams, g);
+  const FpStream st = streams[si];
+  const uint32_t k = g - st.kept_base;
+  const uint32_t x = k * step;  // raw item index = first row of the window
+  const double *w = feat + ((uint64_t)st.fir_base + x) * kBands;
+  const uint32_t bits = core::classify_window(w, thr);
+  items[st.item_off + k] = bits;
+}
+
+// workspace reused across calls (per device)
+struct FpWorkspace {
+  DeviceBuffer<double> chroma, feat;
+  DeviceBuffer<FpStream> streams;
+  PinnedStage stage;
+};
+std::mutex g_ws_mu;
+std::map<int, FpWorkspace *> g_ws;
+
+FpWorkspace *workspace() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  auto it = g_ws.find(dev);
+  if (it != g_ws.end()) return it->second;
+  FpWorkspace *w = new FpWorkspace();
+  g_ws[dev] = w;
+  return w;
+}
+
+}  // namespace
+
+Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan> &spans, int channels,
+                              uint32_t step, uint32_t *d_items, bool sync, double *d_chroma_dbg,
+                              double *d_feat_dbg) {
+  if (channels != 1 && channels != 2)
+    return Status::Make(NeedleError_InvalidArgument, "fingerprint: channels must be 1 or 2");
+  if (step == 0) return Status::Make(NeedleError_InvalidArgument, "fingerprint: step must be >= 1");
+  Status s = ensure_device();
+  if (!s.ok()) return s;
+  FpTables tab;
+  s = get_tables(&tab);
+  if (!s.ok()) return s;
+  hipStream_t stream = library_stream();
+  FpWorkspace *ws = workspace();
+
+  // Streams are processed in chunks so the f64 chroma/feature workspaces stay bounded (96 B/frame each).
+  const uint64_t kMaxFramesPerChunk = 8u << 20;
+  size_t begin = 0;
+  while (begin < spans.size()) {
+    std::vector<FpStream> meta;
+    uint64_t frames = 0, rows = 0, kept = 0;
+    size_t end = begin;
+    while (end < spans.size()) {
+      const size_t samples = spans[end].num_values / (size_t)channels;
+      const uint64_t f = num_frames(samples);
+      if (!meta.empty() && frames + f > kMaxFramesPerChunk) break;
+      if (f > 0xFFFFFFF0ull) return Status::Make(NeedleError_InvalidArgument, "fingerprint: stream too long");
+      FpStream m;
+      m.pcm_off = spans[end].pcm_off;
+      m.item_off = spans[end].item_off;
+      m.frames = (uint32_t)f;
+      m.frame_base = (uint32_t)frames;
+      m.fir_rows = f >= (uint64_t)kFirTaps ? (uint32_t)(f - (kFirTaps - 1)) : 0;
+      m.fir_base = (uint32_t)rows;
+      m.kept = (uint32_t)num_kept(samples, step);
+      m.kept_base = (uint32_t)kept;
+      frames += m.frames;
+      rows += m.fir_rows;
+      kept += m.kept;
+      meta.push_back(m);
+      end++;
+    }
+    if (frames > 0) {
+      if (!(s = ws->streams.reserve(meta.size())).ok()) return s;
+      if (!(s = ws->chroma.reserve(frames * kBands)).ok()) return s;
+      if (!(s = ws->feat.reserve(std::max<uint64_t>(rows, 1) * kBands)).ok()) return s;
+      // descriptors go through a pinned staging buffer so the async copy never reads freed host memory
+      if (!(s = ws->stage.acquire(meta.size() * sizeof(FpStream))).ok()) return s;
+      std::memcpy(ws->stage.ptr, meta.data(), meta.size() * sizeof(FpStream));
+      NEEDLE_HIP_TRY(hipMemcpyAsync(ws->streams.ptr, ws->stage.ptr, meta.size() * sizeof(FpStream),
+                                    hipMemcpyHostToDevice, stream));
+      ws->stage.mark(stream);
+      const int n = (int)meta.size();
+      {
+        KernelTimer timer("stft_chroma");
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(frames, 256u * 64u);
+        hipLaunchKernelGGL(stft_chroma_kernel, dim3(grid), dim3(256), 0, stream, d_pcm, ws->streams.ptr, n,
+                           channels, tab.tw, tab.window, tab.class_bins, tab.class_start, ws->chroma.ptr,
+                           (uint32_t)frames);
+      }
+      if (rows > 0) {
+        KernelTimer timer("fir_norm");
+        hipLaunchKernelGGL(fir_norm_kernel, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, stream,
+                           ws->chroma.ptr, ws->streams.ptr, n, ws->feat.ptr, (uint32_t)rows);
+      }
+      if (kept > 0) {
+        KernelTimer timer("classify");
+        hipLaunchKernelGGL(classify_kernel, dim3((uint32_t)((kept + 255) / 256)), dim3(256), 0, stream,
+                           ws->feat.ptr, ws->streams.ptr, n, tab.thr, step, d_items, (uint32_t)kept);
+      }
+      NEEDLE_HIP_TRY(hipGetLastError());
+      if (d_chroma_dbg)
+        NEEDLE_HIP_TRY(hipMemcpyAsync(d_chroma_dbg, ws->chroma.ptr, frames * kBands * sizeof(double),
+                                      hipMemcpyDeviceToDevice, stream));
+      if (d_feat_dbg && rows)
+        NEEDLE_HIP_TRY(hipMemcpyAsync(d_feat_dbg, ws->feat.ptr, rows * kBands * sizeof(double),
+                                      hipMemcpyDeviceToDevice, stream));
+      // the next chunk reuses the workspaces and the descriptor buffer
+      if (end < spans.size()) NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+    }
+    begin = end;
+  }
+  if (sync) NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+  return Status::Ok();
+}
+
+Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
+                            int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items) {
+  Status s = ensure_device();
+  if (!s.ok()) return s;
+  if (channels != 1 && channels != 2)
+    return Status::Make(NeedleError_InvalidArgument, "fingerprint: channels must be 1 or 2");
+  if (step == 0) return Status::Make(NeedleError_InvalidArgument, "fingerprint: step must be >= 1");
+  const size_t n = pcm.size();
+  items->assign(n, {});
+  // Batches bounded by bytes so the device arena stays modest for huge libraries.
+  const uint64_t kMaxBatchValues = 1ull << 30;  // 2 GiB of s16
+  hipStream_t stream = library_stream();
+  size_t begin = 0;
+  while (begin < n) {
+    std::vector<StreamSpan> spans;
+    uint64_t values = 0, kept = 0;
+    size_t end = begin;
+    while (end < n) {
+      if (!spans.empty() && values + num_values[end] > kMaxBatchValues) break;
+      StreamSpan sp;
+      sp.pcm_off = values;
+      sp.num_values = num_values[end];
+      sp.item_off = kept;
+      values += (num_values[end] + 1) & ~(uint64_t)1;  // keep every stream 4-byte aligned in the arena
+      kept += num_kept(num_values[end] / (size_t)channels, step);
+      spans.push_back(sp);
+      end++;
+    }
+    DeviceBuffer<int16_t> d_pcm;
+    DeviceBuffer<uint32_t> d_items;
+    if (!(s = d_pcm.reserve(std::max<uint64_t>(values, 1))).ok()) return s;
+    if (!(s = d_items.reserve(std::max<uint64_t>(kept, 1))).ok()) return s;
+    for (size_t i = begin; i < end; i++)
+      if (num_values[i])
+        NEEDLE_HIP_TRY(hipMemcpyAsync(d_pcm.ptr + spans[i - begin].pcm_off, pcm[i], num_values[i] * sizeof(int16_t),
+                                      hipMemcpyHostToDevice, stream));
+    s = gpu_fingerprint_device(d_pcm.ptr, spans, channels, step, d_items.ptr, false);
+    if (!s.ok()) return s;
+    std::vector<uint32_t> host(std::max<uint64_t>(kept, 1));
+    NEEDLE_HIP_TRY(hipMemcpyAsync(host.data(), d_items.ptr, kept * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+    for (size_t i = begin; i < end; i++) {
+      const size_t k = num_kept(num_values[i] / (size_t)channels, step);
+      (*items)[i].assign(host.begin() + spans[i - begin].item_off, host.begin() + spans[i - begin].item_off + k);
+    }
+    begin = end;
+  }
+  return Status::Ok();
+}
+
+}  // namespace needle

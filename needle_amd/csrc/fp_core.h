@@ -1,0 +1,233 @@
+// Per-thread arithmetic of the fingerprint kernels, written once and shared by fingerprint.hip (device)
+// and tests/cpu_emu (a g++ build that steps the same per-thread code serially, phase by phase, to
+// validate indexing without a GPU; it is a test fixture, never a product path).
+//
+// STFT of one 4096-sample frame = 2048-point complex FFT of z[m] = x[2m] + i x[2m+1] (x = windowed
+// samples) followed by the real-input split.  The 2048-point transform is a Stockham autosort DIF in
+// four passes, radix 8,8,8,4, executed by 256 threads that each own one radix-8 butterfly per pass
+// (two radix-4 butterflies in the last), exchanging through one 32 KiB LDS buffer between passes.
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define NEEDLE_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define NEEDLE_HD inline
+#endif
+
+namespace needle {
+namespace core {
+
+struct cd {
+  double x, y;
+};
+
+NEEDLE_HD cd cadd(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
+NEEDLE_HD cd csub(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+NEEDLE_HD cd cmul(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+NEEDLE_HD cd mul_neg_i(cd a) { return cd{a.y, -a.x}; }
+
+constexpr int kFftN = 2048;      // complex points per frame
+constexpr int kThreads = 256;    // threads per frame
+constexpr int kMinBin = 10;      // max(1, round(4096*28/11025))
+constexpr int kMaxBin = 1308;    // min(2048, round(4096*3520/11025)), exclusive
+constexpr int kNumBins = kMaxBin - kMinBin;
+constexpr int kBinsPerThread = (kNumBins + kThreads - 1) / kThreads;  // 6
+
+// 8-point DFT, forward (e^{-2 pi i jk/8}), natural-order output, in place.
+NEEDLE_HD void fft8(cd *a) {
+  const double h = 0.70710678118654752440;
+  cd s0 = cadd(a[0], a[4]), d0 = csub(a[0], a[4]);
+  cd s1 = cadd(a[1], a[5]), t1 = csub(a[1], a[5]);
+  cd s2 = cadd(a[2], a[6]), t2 = csub(a[2], a[6]);
+  cd s3 = cadd(a[3], a[7]), t3 = csub(a[3], a[7]);
+  cd d1 = cd{(t1.x + t1.y) * h, (t1.y - t1.x) * h};
+  cd d2 = mul_neg_i(t2);
+  cd d3 = cd{(t3.y - t3.x) * h, -(t3.x + t3.y) * h};
+  {
+    cd e0 = cadd(s0, s2), e1 = csub(s0, s2), e2 = cadd(s1, s3), e3 = mul_neg_i(csub(s1, s3));
+    a[0] = cadd(e0, e2);
+    a[4] = csub(e0, e2);
+    a[2] = cadd(e1, e3);
+    a[6] = csub(e1, e3);
+  }
+  {
+    cd e0 = cadd(d0, d2), e1 = csub(d0, d2), e2 = cadd(d1, d3), e3 = mul_neg_i(csub(d1, d3));
+    a[1] = cadd(e0, e2);
+    a[5] = csub(e0, e2);
+    a[3] = cadd(e1, e3);
+    a[7] = csub(e1, e3);
+  }
+}
+
+NEEDLE_HD void fft4(cd *a) {
+  cd e0 = cadd(a[0], a[2]), e1 = csub(a[0], a[2]), e2 = cadd(a[1], a[3]), e3 = mul_neg_i(csub(a[1], a[3]));
+  a[0] = cadd(e0, e2);
+  a[2] = csub(e0, e2);
+  a[1] = cadd(e1, e3);
+  a[3] = csub(e1, e3);
+}
+
+// LDS index map (identity for now; the hook for a conflict-avoiding swizzle).
+NEEDLE_HD int lidx(int i) { return i; }
+
+// Stockham DIF pass geometry for N = 2048: pass P has sub-length n, stride s, radix R;
+// thread t owns (p, q) = (t / s, t % s); inputs x[q + s*(p + (n/R)*k)], outputs y[q + s*(R*p + j)]
+// multiplied by W_n^{p*j} = tw4096[p*j*(4096/n)].
+//   pass 0: n=2048 s=1   R=8      pass 1: n=256 s=8  R=8
+//   pass 2: n=32   s=64  R=8      pass 3: n=4   s=512 R=4 (two butterflies per thread, no twiddle)
+template <int PASS>
+struct PassGeom;
+template <>
+struct PassGeom<0> {
+  static constexpr int n = 2048, s = 1, R = 8;
+};
+template <>
+struct PassGeom<1> {
+  static constexpr int n = 256, s = 8, R = 8;
+};
+template <>
+struct PassGeom<2> {
+  static constexpr int n = 32, s = 64, R = 8;
+};
+
+template <int PASS>
+NEEDLE_HD void pass_read(int t, const cd *lds, cd *r) {
+  using G = PassGeom<PASS>;
+  const int p = t / G::s, q = t % G::s;
+#pragma unroll
+  for (int k = 0; k < 8; k++) r[k] = lds[lidx(q + G::s * (p + (G::n / 8) * k))];
+}
+
+// butterfly + twiddle + scatter to LDS
+template <int PASS>
+NEEDLE_HD void pass_compute_write(int t, const cd *tw4096, cd *lds, cd *r) {
+  using G = PassGeom<PASS>;
+  const int p = t / G::s, q = t % G::s;
+  fft8(r);
+  lds[lidx(q + G::s * (8 * p))] = r[0];
+#pragma unroll
+  for (int j = 1; j < 8; j++) {
+    cd w = tw4096[p * j * (4096 / G::n)];
+    lds[lidx(q + G::s * (8 * p + j))] = cmul(r[j], w);
+  }
+}
+
+// last pass: n = 4, s = 512: butterflies q = t and q = t + 256, in place in LDS (each thread touches
+// only its own eight slots, so no barrier is needed between its read and write).
+NEEDLE_HD void pass3_inplace(int t, cd *lds) {
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int q = t + 256 * h;
+    cd a[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) a[k] = lds[lidx(q + 512 * k)];
+    fft4(a);
+#pragma unroll
+    for (int j = 0; j < 4; j++) lds[lidx(q + 512 * j)] = a[j];
+  }
+}
+
+// Real-input split + power for bin k (kMinBin <= k < kMaxBin):
+//   E = (Z[k] + conj Z[N-k])/2, O = (Z[k] - conj Z[N-k])/(2i), X[k] = E + W_4096^k O, P = |X[k]|^2
+NEEDLE_HD double bin_power(int k, const cd *lds, const cd *tw4096) {
+  cd z = lds[lidx(k)], y = lds[lidx(kFftN - k)], w = tw4096[k];
+  double er = 0.5 * (z.x + y.x), ei = 0.5 * (z.y - y.y);
+  double orr = 0.5 * (z.y + y.y), oi = 0.5 * (y.x - z.x);
+  double xr = er + (w.x * orr - w.y * oi);
+  double xi = ei + (w.x * oi + w.y * orr);
+  return xr * xr + xi * xi;
+}
+
+// ---- classifiers (chromaprint kClassifiersTest2) ---------------------------------
+struct ClassifierDef {
+  int type, y, h, w;  // Filter(type, y, height, width)
+};
+
+constexpr ClassifierDef kClassifiers[16] = {
+    {0, 4, 3, 15}, {4, 4, 6, 15}, {1, 0, 4, 16}, {3, 8, 2, 12}, {3, 4, 4, 8}, {4, 0, 3, 5},
+    {1, 2, 2, 9},  {2, 7, 3, 4},  {2, 6, 2, 16}, {2, 1, 3, 2},  {5, 10, 1, 15}, {3, 6, 2, 10},
+    {2, 1, 1, 14}, {3, 5, 6, 4},  {1, 9, 2, 12}, {3, 4, 2, 14},
+};
+
+// Membership of image cell (row r = time offset within the 16-row window, column c = band) in the
+// classifier's "a" (+1) or "b" (-1) region, 0 if in neither.  Pure function of constants, so the
+// fully unrolled classify loop folds to straight-line adds.
+constexpr int cell_sign(const ClassifierDef &f, int r, int c) {
+  const int x = r, y = c;
+  if (x < 0 || x >= f.w || y < f.y || y >= f.y + f.h) return 0;
+  const int yy = y - f.y;
+  switch (f.type) {
+    case 0:
+      return 1;
+    case 1:  // a = high half in y, b = low half
+      return yy >= f.h / 2 ? 1 : -1;
+    case 2:  // a = later half in x, b = earlier half
+      return x >= f.w / 2 ? 1 : -1;
+    case 3: {  // a = (early x, high y) + (late x, low y)
+      const bool late = x >= f.w / 2, high = yy >= f.h / 2;
+      return (late != high) ? 1 : -1;
+    }
+    case 4: {  // a = middle third in y
+      const int h3 = f.h / 3;
+      return (yy >= h3 && yy < 2 * h3) ? 1 : -1;
+    }
+    default: {  // 5: a = middle third in x
+      const int w3 = f.w / 3;
+      return (x >= w3 && x < 2 * w3) ? 1 : -1;
+    }
+  }
+}
+
+// thresholds as exp(t): log((1+a)/(1+b)) < t  <=>  (1+a)/(1+b) < exp(t)
+struct ClassifierThresholds {
+  double e[16][3];
+};
+
+// Compile-time walk over the 16x12 window: cell (R, C) is added to accumulator a[I] / b[I] of every
+// classifier whose region holds it; all membership tests fold away.
+template <int R, int C, int I>
+struct CellStep {
+  static NEEDLE_HD void run(double v, double *a, double *b) {
+    constexpr int s = cell_sign(kClassifiers[I], R, C);
+    if (s > 0) a[I] += v;
+    if (s < 0) b[I] += v;
+    CellStep<R, C, I + 1>::run(v, a, b);
+  }
+};
+template <int R, int C>
+struct CellStep<R, C, 16> {
+  static NEEDLE_HD void run(double, double *, double *) {}
+};
+template <int R, int C>
+struct WindowStep {
+  static NEEDLE_HD void run(const double *w, double *a, double *b) {
+    CellStep<R, C, 0>::run(w[R * 12 + C], a, b);
+    WindowStep<(C == 11) ? R + 1 : R, (C == 11) ? 0 : C + 1>::run(w, a, b);
+  }
+};
+template <>
+struct WindowStep<16, 0> {
+  static NEEDLE_HD void run(const double *, double *, double *) {}
+};
+
+// One raw fingerprint item from 16 consecutive feature rows (w[16][12], row-major).
+NEEDLE_HD uint32_t classify_window(const double *w, const ClassifierThresholds *thr) {
+  double a[16], b[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) a[i] = b[i] = 0.0;
+  WindowStep<0, 0>::run(w, a, b);
+  uint32_t bits = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const double ratio = (1.0 + a[i]) / (1.0 + b[i]);
+    // Quantizer: v < t1 ? (v < t0 ? 0 : 1) : (v < t2 ? 2 : 3), on the exp() side of the monotone map
+    const unsigned q = ratio < thr->e[i][1] ? (ratio < thr->e[i][0] ? 0u : 1u) : (ratio < thr->e[i][2] ? 2u : 3u);
+    bits = (bits << 2) | (q ^ (q >> 1));  // Gray code {0,1,3,2}
+  }
+  return bits;
+}
+
+}  // namespace core
+}  // namespace needle

@@ -1,0 +1,87 @@
+// HIP plumbing shared by the kernel translation units: error mapping, the library stream, a tiny
+// device-buffer RAII type, and per-kernel HIP-event timers (what needle_hip_last_kernel_ms reports).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+
+#include "common.h"
+
+namespace needle {
+
+#define NEEDLE_HIP_TRY(expr)                                                                         \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess)                                                                            \
+      return Status::Make(NeedleError_Unknown, std::string("HIP error: ") + hipGetErrorString(_e) +  \
+                                                   " at " #expr);                                    \
+  } while (0)
+
+// Fails loudly (NeedleError_Unknown "no HIP device") when no GPU is usable: there is no CPU path.
+Status ensure_device();
+hipStream_t library_stream();
+
+template <typename T>
+struct DeviceBuffer {
+  T *ptr = nullptr;
+  size_t count = 0;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer &) = delete;
+  DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+  ~DeviceBuffer() { release(); }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+  }
+  // Grows (never shrinks) to hold n elements; contents are not preserved.
+  Status reserve(size_t n) {
+    if (n <= count) return Status::Ok();
+    release();
+    if (n == 0) return Status::Ok();
+    NEEDLE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T)));
+    count = n;
+    return Status::Ok();
+  }
+};
+
+// Pinned host staging for small descriptor uploads: acquire() waits until the previous async copy out
+// of the buffer has executed, mark() records that point on the stream.
+struct PinnedStage {
+  void *ptr = nullptr;
+  size_t cap = 0;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+  Status acquire(size_t bytes) {
+    if (pending) {
+      NEEDLE_HIP_TRY(hipEventSynchronize(done));
+      pending = false;
+    }
+    if (bytes > cap) {
+      if (ptr) (void)hipHostFree(ptr);
+      ptr = nullptr;
+      cap = 0;
+      size_t want = bytes < 4096 ? 4096 : bytes * 2;
+      NEEDLE_HIP_TRY(hipHostMalloc(&ptr, want, hipHostMallocDefault));
+      cap = want;
+    }
+    if (!done) NEEDLE_HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    return Status::Ok();
+  }
+  void mark(hipStream_t stream) {
+    if (hipEventRecord(done, stream) == hipSuccess) pending = true;
+  }
+};
+
+// Records start/stop events around a kernel launch on the library stream; elapsed time is read
+// lazily (after a sync) by needle_hip_last_kernel_ms.
+struct KernelTimer {
+  explicit KernelTimer(const char *name);
+  ~KernelTimer();
+  const char *name;
+};
+double kernel_ms(const std::string &name);
+
+}  // namespace needle

@@ -1,0 +1,368 @@
+// Host-side helpers of the needle path: std::time::Duration semantics, the bincode image of
+// FrameHashes (needle/src/audio/data.rs), header MD5 (needle/src/util.rs:99-105), serde_json-style f32
+// text, the step/timestamp rule of analyzer.rs:288-323 and a minimal RIFF/WAVE reader.
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "common.h"
+
+namespace needle {
+
+// ---- Duration ------------------------------------------------------------------------------------------
+// Duration::from_secs_f{32,64}: the exact binary value, rounded to the nearest nanosecond, ties to
+// even.  v = m * 2^e with an integer 53-bit m, so m * 1e9 (< 2^83) is exact in 128 bits.
+static bool exact_ns(double v, ns_t *out) {
+  if (!(v >= 0.0) || std::isinf(v)) return false;
+  if (v == 0.0) {
+    *out = 0;
+    return true;
+  }
+  int e = 0;
+  const double fr = std::frexp(v, &e);
+  const uint64_t m = (uint64_t)std::ldexp(fr, 53);
+  e -= 53;
+  unsigned __int128 num = (unsigned __int128)m * kNanosPerSec;
+  if (e >= 0) {
+    if (e > 10) return false;  // beyond u64 seconds
+    num <<= e;
+  } else {
+    const int k = -e;
+    if (k >= 126) {
+      *out = 0;
+      return true;
+    }
+    const unsigned __int128 q = num >> k;
+    const unsigned __int128 rem = num & ((((unsigned __int128)1) << k) - 1);
+    const unsigned __int128 half = ((unsigned __int128)1) << (k - 1);
+    num = q + ((rem > half || (rem == half && (q & 1))) ? 1 : 0);
+  }
+  if (num > (unsigned __int128)0xFFFFFFFFFFFFFFFFull) return false;
+  *out = (ns_t)num;
+  return true;
+}
+
+ns_t duration_from_secs_f32(float s, bool *ok) {
+  ns_t r = 0;
+  const bool good = exact_ns((double)s, &r);
+  if (ok) *ok = good;
+  return r;
+}
+
+ns_t duration_from_secs_f64(double s, bool *ok) {
+  ns_t r = 0;
+  const bool good = exact_ns(s, &r);
+  if (ok) *ok = good;
+  return r;
+}
+
+float duration_as_secs_f32(ns_t d) {
+  const float secs = (float)(d / kNanosPerSec);
+  const float frac = (float)(uint32_t)(d % kNanosPerSec) / 1000000000.0f;
+  return secs + frac;
+}
+
+double duration_as_secs_f64(ns_t d) {
+  return (double)(d / kNanosPerSec) + (double)(uint32_t)(d % kNanosPerSec) / 1000000000.0;
+}
+
+ns_t duration_mul_f32(ns_t d, float rhs, bool *ok) {
+  const float prod = rhs * duration_as_secs_f32(d);
+  return duration_from_secs_f32(prod, ok);
+}
+
+// ---- analyzer.rs:293-318 ---------------------------------------------------------------------------------
+bool step_for_hash_duration(ns_t hash_duration, uint32_t *step) {
+  const uint64_t hd_ms = hash_duration / 1000000ull;  // Duration::as_millis
+  const uint64_t st = hd_ms / (uint64_t)kItemDurationMs;
+  if (st == 0 || st > 0xFFFFFFFFull) return false;  // Iterator::step_by(0) panics upstream
+  *step = (uint32_t)st;
+  return true;
+}
+
+void attach_timestamps(const uint32_t *kept, size_t n_kept, uint32_t step, bool has_seek, ns_t seek_to,
+                       std::vector<HashTs> *out) {
+  const ns_t delay = (ns_t)kDelayMs * 1000000ull;
+  const ns_t item = (ns_t)kItemDurationMs * 1000000ull;
+  out->resize(n_kept);
+  for (size_t k = 0; k < n_kept; k++) {
+    const size_t i = k * (size_t)step;                       // raw item index
+    ns_t ts = delay + duration_mul_f32(item, (float)i);      // :309
+    if (has_seek) ts += seek_to;                             // :314-318
+    (*out)[k] = HashTs{kept[k], ts};
+  }
+}
+
+// ---- MD5 (RFC 1321) ---------------------------------------------------------------------------------------
+namespace {
+struct Md5 {
+  uint32_t a = 0x67452301u, b = 0xefcdab89u, c = 0x98badcfeu, d = 0x10325476u;
+  static uint32_t rotl(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
+  void block(const uint8_t *p) {
+    static const uint32_t K[64] = {
+        0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501,
+        0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
+        0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8,
+        0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
+        0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
+        0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
+        0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1,
+        0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+    static const int R[4][4] = {{7, 12, 17, 22}, {5, 9, 14, 20}, {4, 11, 16, 23}, {6, 10, 15, 21}};
+    uint32_t w[16];
+    for (int i = 0; i < 16; i++) std::memcpy(&w[i], p + 4 * i, 4);
+    uint32_t A = a, B = b, C = c, D = d;
+    for (int i = 0; i < 64; i++) {
+      uint32_t f;
+      int g;
+      switch (i >> 4) {
+        case 0: f = (B & C) | (~B & D); g = i; break;
+        case 1: f = (D & B) | (~D & C); g = (5 * i + 1) & 15; break;
+        case 2: f = B ^ C ^ D; g = (3 * i + 5) & 15; break;
+        default: f = C ^ (B | ~D); g = (7 * i) & 15; break;
+      }
+      const uint32_t tmp = D;
+      D = C;
+      C = B;
+      B = B + rotl(A + f + K[i] + w[g], R[i >> 4][i & 3]);
+      A = tmp;
+    }
+    a += A;
+    b += B;
+    c += C;
+    d += D;
+  }
+};
+}  // namespace
+
+std::string md5_hex(const uint8_t *data, size_t n) {
+  Md5 h;
+  size_t off = 0;
+  for (; off + 64 <= n; off += 64) h.block(data + off);
+  uint8_t tail[128] = {0};
+  const size_t rem = n - off;
+  std::memcpy(tail, data + off, rem);
+  tail[rem] = 0x80;
+  const size_t total = rem + 9 <= 64 ? 64 : 128;
+  const uint64_t bits = (uint64_t)n * 8;
+  std::memcpy(tail + total - 8, &bits, 8);
+  h.block(tail);
+  if (total == 128) h.block(tail + 64);
+  const uint32_t v[4] = {h.a, h.b, h.c, h.d};
+  char out[33];
+  for (int i = 0; i < 16; i++) std::snprintf(out + 2 * i, 3, "%02x", (v[i >> 2] >> (8 * (i & 3))) & 0xffu);
+  return std::string(out, 32);
+}
+
+Status header_md5(const std::string &path, std::string *out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return Status::Make(NeedleError_IOError, "IO error: cannot open " + path);
+  uint8_t buf[8 * 1024];
+  f.read(reinterpret_cast<char *>(buf), sizeof(buf));
+  if ((size_t)f.gcount() != sizeof(buf))  // read_exact -> UnexpectedEof
+    return Status::Make(NeedleError_IOError, "IO error: failed to fill whole buffer: " + path);
+  *out = md5_hex(buf, sizeof(buf));
+  return Status::Ok();
+}
+
+// ---- paths / text ---------------------------------------------------------------------------------------------
+std::string with_extension(const std::string &path, const std::string &ext) {
+  // std::path::Path::with_extension: replace what follows the last '.' of the file name (a leading
+  // dot does not start an extension), or append ".ext" if there is none.
+  const size_t slash = path.find_last_of('/');
+  const size_t name = slash == std::string::npos ? 0 : slash + 1;
+  const size_t dot = path.find_last_of('.');
+  std::string stem = path;
+  if (dot != std::string::npos && dot > name) stem = path.substr(0, dot);
+  return stem + "." + ext;
+}
+
+std::string format_time(ns_t t) {
+  const uint64_t secs = t / kNanosPerSec;
+  char buf[48];
+  std::snprintf(buf, sizeof(buf), "%02llu:%02llus", (unsigned long long)(secs / 60), (unsigned long long)(secs % 60));
+  return buf;
+}
+
+std::string format_f32_json(float v) {
+  // serde_json writes finite f32 with ryu: shortest digits that round-trip, printed plainly while
+  // the decimal point falls within 13 digits / 5 leading zeros, else d.ddde<exp>.
+  if (!std::isfinite(v)) return "null";
+  if (v == 0.0f) return std::signbit(v) ? "-0.0" : "0.0";
+  char sci[64];
+  auto res = std::to_chars(sci, sci + sizeof(sci), v, std::chars_format::scientific);
+  std::string s(sci, res.ptr);
+  std::string out;
+  size_t pos = 0;
+  if (s[0] == '-') {
+    out = "-";
+    pos = 1;
+  }
+  const size_t epos = s.find('e');
+  std::string digits;
+  for (size_t i = pos; i < epos; i++)
+    if (s[i] != '.') digits.push_back(s[i]);
+  const int exp10 = std::atoi(s.c_str() + epos + 1);
+  const int nd = (int)digits.size();
+  const int kk = exp10 + 1;   // position of the decimal point relative to the first digit
+  const int k = kk - nd;      // value = digits * 10^k
+  if (k >= 0 && kk <= 13) {
+    out += digits + std::string((size_t)k, '0') + ".0";
+  } else if (kk > 0 && kk <= 13) {
+    out += digits.substr(0, (size_t)kk) + "." + digits.substr((size_t)kk);
+  } else if (kk > -6 && kk <= 0) {
+    out += "0." + std::string((size_t)(-kk), '0') + digits;
+  } else if (nd == 1) {
+    out += digits + "e" + std::to_string(kk - 1);
+  } else {
+    out += digits.substr(0, 1) + "." + digits.substr(1) + "e" + std::to_string(kk - 1);
+  }
+  return out;
+}
+
+// ---- bincode image of FrameHashes -------------------------------------------------------
+namespace {
+struct Writer {
+  std::string buf;
+  template <typename T>
+  void put(T v) {
+    buf.append(reinterpret_cast<const char *>(&v), sizeof(T));
+  }
+  void duration(ns_t d) {
+    put<uint64_t>(d / kNanosPerSec);
+    put<uint32_t>((uint32_t)(d % kNanosPerSec));
+  }
+  void hashes(const std::vector<HashTs> &v) {
+    put<uint64_t>(v.size());
+    for (const HashTs &h : v) {
+      put<uint32_t>(h.hash);
+      duration(h.ts);
+    }
+  }
+};
+
+struct Reader {
+  const std::string &buf;
+  size_t off = 0;
+  bool bad = false;
+  explicit Reader(const std::string &b) : buf(b) {}
+  template <typename T>
+  T get() {
+    T v{};
+    if (bad || buf.size() - off < sizeof(T)) {
+      bad = true;
+      return v;
+    }
+    std::memcpy(&v, buf.data() + off, sizeof(T));
+    off += sizeof(T);
+    return v;
+  }
+  ns_t duration() {
+    const uint64_t secs = get<uint64_t>();
+    const uint32_t nanos = get<uint32_t>();
+    // serde's Duration visitor checks secs + nanos/1e9 for overflow, then Duration::new carries
+    if (secs > (0xFFFFFFFFFFFFFFFFull - nanos) / kNanosPerSec) {
+      bad = true;
+      return 0;
+    }
+    return secs * kNanosPerSec + nanos;
+  }
+  void hashes(std::vector<HashTs> *v) {
+    const uint64_t len = get<uint64_t>();
+    if (bad || len > (buf.size() - off) / 16) {
+      bad = true;
+      return;
+    }
+    v->resize((size_t)len);
+    for (uint64_t i = 0; i < len && !bad; i++) {
+      (*v)[i].hash = get<uint32_t>();
+      (*v)[i].ts = duration();
+    }
+  }
+};
+}  // namespace
+
+Status frame_hashes_write(const std::string &path, const FrameHashesData &fh) {
+  Writer w;
+  w.put<uint32_t>(0);  // FrameHashesVersion::V1 — bincode writes the variant INDEX, data.rs:16-18
+  w.put<uint32_t>(0);  // FrameHashesData::V1, data.rs:61-66
+  w.hashes(fh.opening);
+  w.hashes(fh.ending);
+  w.duration(fh.hash_duration);
+  w.put<uint64_t>(fh.md5.size());
+  w.buf.append(fh.md5);
+  std::ofstream f(path, std::ios::binary | std::ios::trunc);
+  if (!f) return Status::Make(NeedleError_IOError, "IO error: cannot create " + path);
+  f.write(w.buf.data(), (std::streamsize)w.buf.size());
+  if (!f) return Status::Make(NeedleError_IOError, "IO error: short write to " + path);
+  return Status::Ok();
+}
+
+Status frame_hashes_read(const std::string &path, FrameHashesData *out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f)  // data.rs:106-108
+    return Status::Make(NeedleError_FrameHashDataNotFound, "frame hash data not found at: \"" + path + "\"");
+  std::string buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  Reader r(buf);
+  const uint32_t version = r.get<uint32_t>();
+  if (!r.bad && version != 0) r.bad = true;  // unknown variant index is a bincode error
+  const uint32_t tag = r.get<uint32_t>();
+  if (!r.bad && tag != 0) r.bad = true;
+  FrameHashesData fh;
+  if (!r.bad) r.hashes(&fh.opening);
+  if (!r.bad) r.hashes(&fh.ending);
+  fh.hash_duration = r.duration();
+  const uint64_t len = r.get<uint64_t>();
+  if (!r.bad && len > buf.size() - r.off) r.bad = true;
+  if (r.bad)  // needle::Error::BincodeError -> InvalidFrameHashData, needle-capi/src/lib.rs:128
+    return Status::Make(NeedleError_InvalidFrameHashData, "bincode error: malformed frame hash data in " + path);
+  fh.md5.assign(buf.data() + r.off, (size_t)len);
+  // is_version_valid (data.rs:96-101): with one variant on each side, index 0/0 always agrees;
+  // kept as an explicit check for future versions.
+  if (version != tag) return Status::Make(NeedleError_FrameHashDataInvalidVersion, "invalid frame hash data version");
+  *out = std::move(fh);
+  return Status::Ok();
+}
+
+// ---- RIFF/WAVE PCM s16 --------------------------------------------------------------------------------------------
+Status wav_read(const std::string &path, WavData *out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return Status::Make(NeedleError_IOError, "IO error: cannot open " + path);
+  std::string buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  auto u32 = [&](size_t o) { uint32_t v; std::memcpy(&v, buf.data() + o, 4); return v; };
+  auto u16 = [&](size_t o) { uint16_t v; std::memcpy(&v, buf.data() + o, 2); return v; };
+  if (buf.size() < 12 || buf.compare(0, 4, "RIFF") != 0 || buf.compare(8, 4, "WAVE") != 0)
+    return Status::Make(NeedleError_Unknown, "unsupported media (only RIFF/WAVE PCM s16 is decoded here; "
+                                             "FFmpeg decode is outside this build): " + path);
+  size_t off = 12;
+  bool have_fmt = false;
+  int format = 0, bits = 0;
+  while (off + 8 <= buf.size()) {
+    const std::string id = buf.substr(off, 4);
+    const size_t len = u32(off + 4);
+    const size_t body = off + 8;
+    if (id == "fmt " && body + 16 <= buf.size()) {
+      format = u16(body);
+      out->channels = u16(body + 2);
+      out->sample_rate = (int)u32(body + 4);
+      bits = u16(body + 14);
+      if (format == 0xFFFE && len >= 26) format = u16(body + 24);  // WAVE_FORMAT_EXTENSIBLE sub-format
+      have_fmt = true;
+    } else if (id == "data") {
+      if (!have_fmt) break;
+      if (format != 1 || bits != 16 || out->channels < 1 || out->channels > 2)
+        return Status::Make(NeedleError_Unknown, "unsupported WAV encoding (need PCM s16, 1-2 channels): " + path);
+      const size_t avail = std::min(len, buf.size() - body);
+      const size_t values = avail / 2;
+      out->pcm.resize(values - values % (size_t)out->channels);
+      std::memcpy(out->pcm.data(), buf.data() + body, out->pcm.size() * 2);
+      return Status::Ok();
+    }
+    off = body + len + (len & 1);
+  }
+  return Status::Make(NeedleError_Unknown, "malformed WAV (no fmt/data chunk): " + path);
+}
+
+}  // namespace needle

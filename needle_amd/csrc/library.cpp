@@ -1,0 +1,256 @@
+// NeedleHipLibrary: an HBM-resident analyze+search job (include/needle_hip.h, last section).
+//
+// The reference's library path is Analyzer::run -> Comparator::run_with_frame_hashes
+// (needle/src/audio/analyzer.rs:425, comparator.rs:524): analyze every video, then search every pair.
+// Here the PCM of the videos a rank owns stays in HBM, hashes are written straight into a padded device
+// arena u32[num_videos][stride] (row v = kept hashes of video v's opening window), the pair search reads
+// that arena in place, and only the short run list and — for simhash32 in the epilogue — the arena
+// itself cross PCIe.  Rows computed by other ranks are filled by the caller with one all-gather over
+// contiguous row blocks (RCCL over xGMI); pairs are sharded by index in the lexicographic pair list.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "hipctx.h"
+#include "needle_core.h"
+
+struct FrameHashes;
+struct NeedleAudioComparator;
+
+namespace needle {
+const Comparator &comparator_of(const NeedleAudioComparator *c);
+FrameHashes *make_frame_hashes(FrameHashesData &&d);
+void fill_c_result(const VideoResult &v, NeedleHipSearchResult *r);
+}  // namespace needle
+
+using namespace needle;
+
+struct NeedleHipLibrary {
+  size_t n = 0;
+  float opening_pct = DEFAULT_OPENING_SEARCH_PERCENTAGE;
+  ns_t hash_duration = 0;
+  uint32_t step = 0;
+  int channels = 1;
+  bool have_pcm = false;
+  std::vector<size_t> window_values;  // interleaved values of each video's opening window
+  std::vector<uint32_t> kept;         // kept hashes per video
+  std::vector<uint64_t> pcm_off;      // offset into d_pcm (values); ~0 when this rank does not hold the PCM
+  size_t stride = 0;
+  DeviceBuffer<int16_t> d_pcm;
+  DeviceBuffer<uint32_t> d_arena;
+  std::vector<std::vector<HashTs>> ts_cache;  // timestamps by kept length (identical for equal lengths)
+  std::vector<uint32_t> min_len;              // per video, for the comparator's opening duration
+
+  const std::vector<HashTs> &timestamps(uint32_t k) {
+    if (ts_cache.size() <= k) ts_cache.resize(k + 1);
+    if (ts_cache[k].empty() && k) {
+      std::vector<uint32_t> zeros(k, 0);
+      attach_timestamps(zeros.data(), k, step, false, 0, &ts_cache[k]);
+    }
+    return ts_cache[k];
+  }
+};
+
+namespace {
+template <typename F>
+NeedleError guarded(F &&f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc &) {
+    return report(Status::Make(NeedleError_Unknown, "out of memory"));
+  } catch (...) {
+    return report(Status::Make(NeedleError_Unknown, "internal error"));
+  }
+}
+}  // namespace
+
+extern "C" {
+
+enum NeedleError needle_hip_library_new(size_t num_videos, float opening_search_percentage, float hash_duration,
+                                        NeedleHipLibrary **output) {
+  if (!output) return NeedleError_NullArgument;
+  if (num_videos == 0) return NeedleError_InvalidArgument;
+  if (!(hash_duration > 0.0f)) return NeedleError_AnalyzerInvalidHashDuration;
+  return guarded([&]() -> NeedleError {
+    bool ok = true;
+    const ns_t hd = duration_from_secs_f32(hash_duration, &ok);
+    uint32_t step = 0;
+    if (!ok || !step_for_hash_duration(hd, &step)) return NeedleError_AnalyzerInvalidHashDuration;
+    auto *lib = new NeedleHipLibrary();
+    lib->n = num_videos;
+    lib->opening_pct = opening_search_percentage;
+    lib->hash_duration = hd;
+    lib->step = step;
+    *output = lib;
+    return NeedleError_Ok;
+  });
+}
+
+void needle_hip_library_free(NeedleHipLibrary *library) { delete library; }
+
+enum NeedleError needle_hip_library_set_pcm(NeedleHipLibrary *lib, const int16_t *const *pcm, const size_t *num_values,
+                                            int channels) {
+  if (!lib || !pcm || !num_values) return NeedleError_NullArgument;
+  if (channels != 1 && channels != 2) return NeedleError_InvalidArgument;
+  return guarded([&]() -> NeedleError {
+    Status s = ensure_device();
+    if (!s.ok()) return report(s);
+    lib->channels = channels;
+    lib->window_values.assign(lib->n, 0);
+    lib->kept.assign(lib->n, 0);
+    lib->pcm_off.assign(lib->n, ~0ull);
+    uint64_t total = 0;
+    uint32_t max_kept = 0;
+    for (size_t v = 0; v < lib->n; v++) {
+      const size_t samples = num_values[v] / (size_t)channels;
+      size_t open_samples = 0, end_first = 0;
+      ns_t seek = 0;
+      s = Analyzer::windows(samples, kSampleRate, lib->opening_pct, DEFAULT_ENDING_SEARCH_PERCENTAGE, &open_samples,
+                            &end_first, &seek);
+      if (!s.ok()) return report(s);
+      lib->window_values[v] = open_samples * (size_t)channels;
+      lib->kept[v] = (uint32_t)num_kept(open_samples, lib->step);
+      max_kept = std::max(max_kept, lib->kept[v]);
+      if (pcm[v]) {
+        lib->pcm_off[v] = total;
+        total += (lib->window_values[v] + 1) & ~(uint64_t)1;
+      }
+    }
+    lib->stride = ((size_t)max_kept + 63) & ~(size_t)63;  // rows start 256-byte aligned
+    if (lib->stride == 0) lib->stride = 64;
+    if (!(s = lib->d_pcm.reserve(std::max<uint64_t>(total, 1))).ok()) return report(s);
+    if (!(s = lib->d_arena.reserve(lib->n * lib->stride)).ok()) return report(s);
+    hipStream_t stream = library_stream();
+    if (hipMemsetAsync(lib->d_arena.ptr, 0, lib->n * lib->stride * sizeof(uint32_t), stream) != hipSuccess)
+      return report(Status::Make(NeedleError_Unknown, "hipMemset failed"));
+    for (size_t v = 0; v < lib->n; v++) {
+      if (!pcm[v] || !lib->window_values[v]) continue;
+      if (hipMemcpyAsync(lib->d_pcm.ptr + lib->pcm_off[v], pcm[v], lib->window_values[v] * sizeof(int16_t),
+                         hipMemcpyHostToDevice, stream) != hipSuccess)
+        return report(Status::Make(NeedleError_Unknown, "PCM upload failed"));
+    }
+    if (hipStreamSynchronize(stream) != hipSuccess) return report(Status::Make(NeedleError_Unknown, "PCM upload failed"));
+    lib->have_pcm = true;
+    lib->min_len.clear();
+    return NeedleError_Ok;
+  });
+}
+
+enum NeedleError needle_hip_library_analyze(NeedleHipLibrary *lib, size_t first, size_t count, bool sync) {
+  if (!lib) return NeedleError_NullArgument;
+  if (!lib->have_pcm || first > lib->n || count > lib->n - first) return NeedleError_InvalidArgument;
+  return guarded([&]() -> NeedleError {
+    std::vector<StreamSpan> spans;
+    for (size_t v = first; v < first + count; v++) {
+      if (lib->pcm_off[v] == ~0ull)
+        return report(Status::Make(NeedleError_InvalidArgument, "video " + std::to_string(v) + " has no PCM on this rank"));
+      spans.push_back(StreamSpan{lib->pcm_off[v], lib->window_values[v], (uint64_t)v * lib->stride});
+    }
+    Status s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->d_arena.ptr, sync);
+    return s.ok() ? NeedleError_Ok : report(s);
+  });
+}
+
+enum NeedleError needle_hip_library_hash_arena(NeedleHipLibrary *lib, uint32_t **d_arena, size_t *stride) {
+  if (!lib || !d_arena || !stride) return NeedleError_NullArgument;
+  if (!lib->have_pcm) return NeedleError_InvalidArgument;
+  *d_arena = lib->d_arena.ptr;
+  *stride = lib->stride;
+  return NeedleError_Ok;
+}
+
+size_t needle_hip_library_num_pairs(const NeedleHipLibrary *lib) { return lib ? pair_count(lib->n) : 0; }
+
+enum NeedleError needle_hip_library_search(NeedleHipLibrary *lib, const struct NeedleAudioComparator *comparator,
+                                           size_t first_pair, size_t num_pairs, NeedleHipRun *d_runs,
+                                           uint32_t capacity, uint32_t *d_count, bool sync) {
+  if (!lib || !comparator || !d_runs || !d_count) return NeedleError_NullArgument;
+  const size_t np = pair_count(lib->n);
+  if (!lib->have_pcm || first_pair > np || num_pairs > np - first_pair) return NeedleError_InvalidArgument;
+  return guarded([&]() -> NeedleError {
+    const Comparator &cmp = comparator_of(comparator);
+    if (cmp.include_endings())
+      return report(Status::Make(NeedleError_Unknown, "no ending hash data present"));  // library = default Analyzer
+    // per-video minimum run length for the opening duration test (same for equal kept lengths)
+    std::vector<NeedleHipSeq> seqs(lib->n);
+    lib->min_len.assign(lib->n, 0);
+    for (size_t v = 0; v < lib->n; v++) {
+      seqs[v] = NeedleHipSeq{(uint32_t)(v * lib->stride), lib->kept[v]};
+      lib->min_len[v] = cmp.min_run_length_for(lib->timestamps(lib->kept[v]), true);
+    }
+    std::vector<NeedleHipProblem> problems;
+    problems.reserve(num_pairs);
+    for (size_t p = first_pair; p < first_pair + num_pairs; p++) {
+      size_t i, j;
+      pair_at(lib->n, p, &i, &j);
+      const uint32_t a = lib->min_len[i], b = lib->min_len[j];
+      if (a == 0 || b == 0) continue;
+      problems.push_back(NeedleHipProblem{(uint32_t)i, (uint32_t)j, std::max(a, b), (uint32_t)p});
+    }
+    Status s = gpu_hamming_runs_device(lib->d_arena.ptr, seqs.data(), seqs.size(), problems.data(), problems.size(),
+                                       cmp.hash_match_threshold(), d_runs, capacity, d_count, sync);
+    return s.ok() ? NeedleError_Ok : report(s);
+  });
+}
+
+static NeedleError library_frame_hashes(NeedleHipLibrary *lib, std::vector<FrameHashesData> *out) {
+  std::vector<uint32_t> host(lib->n * lib->stride);
+  hipStream_t stream = library_stream();
+  if (hipMemcpyAsync(host.data(), lib->d_arena.ptr, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) !=
+          hipSuccess ||
+      hipStreamSynchronize(stream) != hipSuccess)
+    return report(Status::Make(NeedleError_Unknown, "hash arena download failed"));
+  out->assign(lib->n, {});
+  for (size_t v = 0; v < lib->n; v++) {
+    FrameHashesData &fh = (*out)[v];
+    fh.opening = lib->timestamps(lib->kept[v]);
+    for (uint32_t k = 0; k < lib->kept[v]; k++) fh.opening[k].hash = host[v * lib->stride + k];
+    fh.hash_duration = lib->hash_duration;
+  }
+  return NeedleError_Ok;
+}
+
+enum NeedleError needle_hip_library_finalize(NeedleHipLibrary *lib, const struct NeedleAudioComparator *comparator,
+                                             const NeedleHipRun *runs, size_t num_runs,
+                                             NeedleHipSearchResult *results) {
+  if (!lib || !comparator || (!runs && num_runs) || !results) return NeedleError_NullArgument;
+  if (!lib->have_pcm) return NeedleError_InvalidArgument;
+  return guarded([&]() -> NeedleError {
+    const Comparator &cmp = comparator_of(comparator);
+    std::vector<FrameHashesData> data;
+    NeedleError e = library_frame_hashes(lib, &data);
+    if (e != NeedleError_Ok) return e;
+    std::vector<const FrameHashesData *> fh;
+    for (const FrameHashesData &d : data) fh.push_back(&d);
+    std::vector<NeedleHipRun> run_vec(runs, runs + num_runs);
+    std::vector<VideoResult> res;
+    Status s = cmp.results_from_runs(fh, run_vec, false, false, false, &res);
+    if (!s.ok()) return report(s);
+    for (size_t v = 0; v < lib->n; v++) fill_c_result(res[v], &results[v]);
+    return NeedleError_Ok;
+  });
+}
+
+enum NeedleError needle_hip_library_frame_hashes(NeedleHipLibrary *lib, size_t index, FrameHashes **output) {
+  if (!lib || !output) return NeedleError_NullArgument;
+  if (!lib->have_pcm || index >= lib->n) return NeedleError_InvalidArgument;
+  return guarded([&]() -> NeedleError {
+    std::vector<uint32_t> host(lib->kept[index]);
+    hipStream_t stream = library_stream();
+    if (!host.empty() &&
+        (hipMemcpyAsync(host.data(), lib->d_arena.ptr + index * lib->stride, host.size() * sizeof(uint32_t),
+                        hipMemcpyDeviceToHost, stream) != hipSuccess ||
+         hipStreamSynchronize(stream) != hipSuccess))
+      return report(Status::Make(NeedleError_Unknown, "hash arena download failed"));
+    FrameHashesData fh;
+    fh.opening = lib->timestamps(lib->kept[index]);
+    for (size_t k = 0; k < host.size(); k++) fh.opening[k].hash = host[k];
+    fh.hash_duration = lib->hash_duration;
+    *output = make_frame_hashes(std::move(fh));
+    return NeedleError_Ok;
+  });
+}
+
+}  // extern "C"

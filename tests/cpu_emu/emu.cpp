@@ -1,0 +1,153 @@
+// TEST FIXTURE — steps the per-thread code of the fingerprint / search kernels (needle_amd/csrc/fp_core.h,
+// the loop body of search.hip) serially on the CPU, phase by phase with the barriers where the kernel has
+// them, so indexing mistakes are caught in the CPU test-suite before any GPU time is spent.
+// It is built by tests/conftest.py with g++ into tests/cpu_emu/libemu.so and is not part of, nor
+// reachable from, libneedle_capi.so.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../needle_amd/csrc/fp_core.h"
+
+using namespace needle::core;
+
+namespace {
+struct Tables {
+  std::vector<cd> tw;
+  std::vector<double> window;
+  std::vector<uint16_t> class_bins;
+  uint32_t class_start[13];
+  ClassifierThresholds thr;
+};
+
+const double kThr[16][3] = {
+    {1.98215, 2.35817, 2.63523},          {-1.03809, -0.651211, -0.282167},  {-0.298702, 0.119262, 0.558497},
+    {-0.105439, 0.0153946, 0.135898},     {-0.142891, 0.0258736, 0.200632},  {-0.826319, -0.590612, -0.368214},
+    {-0.557409, -0.233035, 0.0534525},    {-0.0646826, 0.00620476, 0.0784847}, {-0.192387, -0.029699, 0.215855},
+    {-0.0397818, -0.00568076, 0.0292026}, {-0.53823, -0.369934, -0.190235},  {-0.124877, 0.0296483, 0.139239},
+    {-0.101475, 0.0225617, 0.231971},     {-0.0799915, -0.00729616, 0.063262}, {-0.272556, 0.019424, 0.302559},
+    {-0.164292, -0.0321188, 0.0846339},
+};
+
+const Tables &tables() {
+  static Tables t;
+  if (!t.tw.empty()) return t;
+  t.tw.resize(4096);
+  for (int k = 0; k < 4096; k++) {
+    long double a = -2.0L * 3.14159265358979323846264338327950288L * k / 4096.0L;
+    t.tw[k] = cd{(double)cosl(a), (double)sinl(a)};
+  }
+  t.window.resize(4096);
+  for (int i = 0; i < 4096; i++) t.window[i] = (1.0 / 32767.0) * (0.54 - 0.46 * std::cos(i * 2.0 * M_PI / 4095));
+  std::vector<std::vector<uint16_t>> by(12);
+  for (int i = kMinBin; i < kMaxBin; i++) {
+    double freq = (double)i * 11025 / 4096;
+    double octave = std::log(freq / (440.0 / 16.0)) / std::log(2.0);
+    double note = 12 * (octave - std::floor(octave));
+    by[(int)(signed char)note].push_back((uint16_t)i);
+  }
+  for (int c = 0; c < 12; c++) {
+    t.class_start[c] = (uint32_t)t.class_bins.size();
+    t.class_bins.insert(t.class_bins.end(), by[c].begin(), by[c].end());
+  }
+  t.class_start[12] = (uint32_t)t.class_bins.size();
+  for (int i = 0; i < 16; i++)
+    for (int j = 0; j < 3; j++) t.thr.e[i][j] = std::exp(kThr[i][j]);
+  return t;
+}
+}  // namespace
+
+extern "C" {
+
+// stft_chroma_kernel, one frame: 256 emulated threads, phases separated exactly where the kernel syncs.
+void emu_stft_chroma(const int16_t *src, int channels, double *chroma12) {
+  const Tables &T = tables();
+  std::vector<cd> lds(kFftN);
+  std::vector<cd> regs(256 * 8);
+  for (int t = 0; t < 256; t++) {
+    cd *r = &regs[t * 8];
+    for (int k = 0; k < 8; k++) {
+      const int m = t + 256 * k;
+      int s0, s1;
+      if (channels == 1) {
+        s0 = src[2 * m];
+        s1 = src[2 * m + 1];
+      } else {
+        s0 = ((int)src[4 * m] + (int)src[4 * m + 1]) / 2;
+        s1 = ((int)src[4 * m + 2] + (int)src[4 * m + 3]) / 2;
+      }
+      r[k] = cd{(double)s0 * T.window[2 * m], (double)s1 * T.window[2 * m + 1]};
+    }
+  }
+  for (int t = 0; t < 256; t++) pass_compute_write<0>(t, T.tw.data(), lds.data(), &regs[t * 8]);
+  for (int t = 0; t < 256; t++) pass_read<1>(t, lds.data(), &regs[t * 8]);
+  for (int t = 0; t < 256; t++) pass_compute_write<1>(t, T.tw.data(), lds.data(), &regs[t * 8]);
+  for (int t = 0; t < 256; t++) pass_read<2>(t, lds.data(), &regs[t * 8]);
+  for (int t = 0; t < 256; t++) pass_compute_write<2>(t, T.tw.data(), lds.data(), &regs[t * 8]);
+  for (int t = 0; t < 256; t++) pass3_inplace(t, lds.data());
+  std::vector<double> pw(256 * kBinsPerThread, 0.0);
+  for (int t = 0; t < 256; t++)
+    for (int i = 0; i < kBinsPerThread; i++) {
+      const int k = kMinBin + t + 256 * i;
+      pw[t * kBinsPerThread + i] = k < kMaxBin ? bin_power(k, lds.data(), T.tw.data()) : 0.0;
+    }
+  double *plds = reinterpret_cast<double *>(lds.data());
+  for (int t = 0; t < 256; t++)
+    for (int i = 0; i < kBinsPerThread; i++) {
+      const int k = kMinBin + t + 256 * i;
+      if (k < kMaxBin) plds[k] = pw[t * kBinsPerThread + i];
+    }
+  for (int c = 0; c < 12; c++) {
+    double lane[16];
+    for (int l = 0; l < 16; l++) {
+      double acc = 0.0;
+      for (uint32_t b = T.class_start[c] + l; b < T.class_start[c + 1]; b += 16) acc += plds[T.class_bins[b]];
+      lane[l] = acc;
+    }
+    for (int off = 8; off >= 1; off >>= 1) {  // __shfl_xor tree: every lane adds its partner
+      double nxt[16];
+      for (int l = 0; l < 16; l++) nxt[l] = lane[l] + lane[l ^ off];
+      std::memcpy(lane, nxt, sizeof(lane));
+    }
+    chroma12[c] = lane[0];
+  }
+}
+
+// classify_kernel, one item: 16 feature rows in, raw u32 out
+uint32_t emu_classify(const double *window16x12) { return classify_window(window16x12, &tables().thr); }
+
+// hamming_runs_kernel, one problem: every diagonal walked exactly as a lane does it
+struct EmuRun {
+  uint32_t src_end, dst_end, len;
+};
+size_t emu_hamming_runs(const uint32_t *s, int n, const uint32_t *t, int m, uint32_t threshold, uint32_t min_len,
+                        EmuRun *out, size_t cap) {
+  size_t count = 0;
+  if (n < 2 || m < 2) return 0;
+  const int num_diags = n + m - 3;
+  for (int dd = 0; dd < num_diags; dd++) {
+    const int d = dd - (n - 2);
+    const int i_lo = d < 0 ? 1 - d : 1;
+    const int i_hi = (n - 1) < (m - 1 - d) ? (n - 1) : (m - 1 - d);
+    uint32_t run = 0;
+    for (int i = i_lo; i <= i_hi; i++) {
+      const bool match = (uint32_t)__builtin_popcount(s[i] ^ t[i + d]) <= threshold;
+      if (match) {
+        run++;
+      } else {
+        if (run >= min_len) {
+          if (count < cap) out[count] = EmuRun{(uint32_t)(i - 1), (uint32_t)(i - 1 + d), run};
+          count++;
+        }
+        run = 0;
+      }
+    }
+    if (run >= min_len) {
+      if (count < cap) out[count] = EmuRun{(uint32_t)i_hi, (uint32_t)(i_hi + d), run};
+      count++;
+    }
+  }
+  return count;
+}
+}

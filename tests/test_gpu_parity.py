@@ -1,0 +1,311 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the
+CPU oracle on the same seeded inputs.  Integer stages must be bit-exact; the f64 fingerprint stages must
+yield bit-identical u32 hashes (north_star) with intermediate features within 1e-11 relative."""
+import os
+
+import numpy as np
+import pytest
+
+from needle_amd import capi, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+NS = O.NS
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert capi.device_count() > 0, "GPU tests need a HIP device (the product has no CPU fallback)"
+
+
+@pytest.fixture(scope="module")
+def lib3():
+    """BASELINE.json configs[0]: 3 synthetic 90 s episodes with a shared 20 s intro."""
+    return synth.make_library(3, 90.0, 20.0)
+
+
+def _rand_hashes(rng, n):
+    return rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+
+
+# ---- fingerprint (stft_chroma + fir_norm + classify) ---------------------------------------------------------
+def test_fingerprint_hashes_bit_exact_vs_oracle(lib3):
+    pcms = [e.pcm[: len(e.pcm) // 2] for e in lib3]
+    got = capi.fingerprint(pcms, channels=1, step=1)
+    for g, p in zip(got, pcms):
+        want = O.fingerprint(p)
+        assert len(g) == len(want) == 342
+        assert g.tolist() == want.tolist()
+
+
+def test_fingerprint_intermediates_close_and_margin(lib3):
+    pcm = lib3[0].pcm[: 30 * 11025]
+    chroma, feats = capi.fingerprint_debug(pcm)
+    _, o_chroma, o_feats, margin = O.fingerprint(pcm, debug=True)
+    assert chroma.shape == o_chroma.shape and feats.shape == o_feats.shape
+    rel = np.max(np.abs(chroma - o_chroma) / np.maximum(np.abs(o_chroma), 1e-300))
+    assert rel < 1e-11, rel
+    assert np.max(np.abs(feats - o_feats)) < 1e-11
+    # every quantiser decision of the oracle sits farther from its threshold than the stages differ
+    assert margin > 1e-9
+
+
+def test_fingerprint_step_and_stereo(lib3):
+    pcm = lib3[1].pcm[: 40 * 11025]
+    full = O.fingerprint(pcm)
+    kept = capi.fingerprint([pcm], step=2)[0]
+    assert kept.tolist() == full[::2].tolist()
+    kept3 = capi.fingerprint([pcm], step=3)[0]
+    assert kept3.tolist() == full[::3].tolist()
+    stereo = capi.fingerprint([np.repeat(pcm, 2)], channels=2, step=1)[0]   # L = R (analyzer.rs:183-185,218)
+    assert stereo.tolist() == full.tolist()
+    lr = np.zeros(2 * len(pcm), dtype=np.int16)
+    lr[0::2] = pcm
+    lr[1::2] = np.roll(pcm, 3)
+    assert capi.fingerprint([lr], channels=2)[0].tolist() == O.fingerprint(lr, channels=2).tolist()
+
+
+def test_fingerprint_edge_lengths():
+    rng = np.random.default_rng(5)
+    lens = [0, 1, 4095, 4096, 4096 + 18 * 1365, 4096 + 19 * 1365, 4096 + 19 * 1365 + 1364, 4096 + 40 * 1365 + 7]
+    pcms = [(rng.standard_normal(n) * 3000).astype(np.int16) for n in lens]
+    got = capi.fingerprint(pcms, step=1)
+    for g, p in zip(got, pcms):
+        want = O.fingerprint(p)
+        assert len(g) == len(want) == O.num_items(len(p))
+        assert g.tolist() == want.tolist()
+    # digital silence and full-scale square wave
+    silence = np.zeros(4096 + 30 * 1365, np.int16)
+    assert capi.fingerprint([silence])[0].tolist() == O.fingerprint(silence).tolist()
+    loud = np.where((np.arange(4096 + 30 * 1365) // 25) % 2 == 0, 32767, -32768).astype(np.int16)
+    assert capi.fingerprint([loud])[0].tolist() == O.fingerprint(loud).tolist()
+
+
+def test_fingerprint_ragged_batch_matches_single_calls(lib3):
+    pcms = [lib3[0].pcm[: 7 * 11025], lib3[1].pcm[: 3 * 11025 + 1], np.zeros(10, np.int16), lib3[2].pcm[: 20 * 11025]]
+    batch = capi.fingerprint(pcms, step=2)
+    for b, p in zip(batch, pcms):
+        assert b.tolist() == O.fingerprint(p)[::2].tolist()
+
+
+# ---- search (hamming_runs) ------------------------------------------------------------------------------------
+def _oracle_runs(src, dst, thr, min_len):
+    cmp = O.Comparator(hash_match_threshold=thr, min_opening_duration=0)
+    ents = O.longest_common_hash_match(cmp, [(int(h), i) for i, h in enumerate(src)],
+                                       [(int(h), i) for i, h in enumerate(dst)], 0, 0)
+    return sorted((e["src_end_idx"], e["dst_end_idx"], e["score"]) for e in ents if e["score"] >= min_len)
+
+
+def _gpu_runs(seqs, problems, thr):
+    r = capi.hamming_runs(seqs, problems, thr)
+    out = {}
+    for x in r:
+        out.setdefault(int(x["problem"]), []).append((int(x["src_end"]), int(x["dst_end"]), int(x["len"])))
+    return {k: sorted(v) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("n,m", [(171, 171), (2897, 2897), (5441, 2715), (2, 2), (2, 300), (300, 2), (65, 257)])
+def test_hamming_runs_equal_reference_dp(n, m):
+    """Sizes from SURVEY.md §8 (90 s / 24 min / 45 min windows) plus degenerate shapes; random hashes with
+    planted near-duplicate runs, min_len = 1 so EVERY maximal run must be reported (runs at table edges,
+    single cells, rows/cols 0 excluded, comparator.rs:179-200)."""
+    rng = np.random.default_rng(n * 131 + m)
+    src, dst = _rand_hashes(rng, n), _rand_hashes(rng, m)
+    if n > 150 and m > 150:
+        for (a, b, L) in [(10, 40, 90), (n - 60, m - 60, 60), (0, 0, 30), (100, 5, 45)]:
+            L = min(L, n - a, m - b)
+            noise = (np.uint32(1) << rng.integers(0, 32, L).astype(np.uint32)) * (rng.random(L) < 0.6)
+            dst[b:b + L] = src[a:a + L] ^ noise
+    thr = 10 if n > 2000 else 12
+    min_len = 3 if n * m > 4_000_000 else 1     # keep the big cases' run lists (2.5 % random matches) short
+    got = _gpu_runs([src, dst], [(0, 1, min_len)], thr).get(0, [])
+    assert got == _oracle_runs(src, dst, thr, min_len)
+
+
+def test_hamming_runs_thresholds_and_min_len():
+    rng = np.random.default_rng(9)
+    src, dst = _rand_hashes(rng, 120), _rand_hashes(rng, 140)
+    dst[20:70] = src[30:80]
+    for thr in [0, 1, 31, 32, 40, 65535]:      # >= 32 matches every cell with i,j >= 1
+        assert _gpu_runs([src, dst], [(0, 1, 1)], thr).get(0, []) == _oracle_runs(src, dst, thr, 1)
+    for min_len in [2, 49, 50, 51, 1000]:
+        assert _gpu_runs([src, dst], [(0, 1, min_len)], 10).get(0, []) == _oracle_runs(src, dst, 10, min_len)
+
+
+def test_hamming_runs_many_problems_in_one_launch():
+    rng = np.random.default_rng(10)
+    seqs = [_rand_hashes(rng, int(k)) for k in rng.integers(2, 400, 9)]
+    seqs.append(np.zeros(0, np.uint32))
+    seqs.append(_rand_hashes(rng, 1))
+    for k in range(0, 8, 2):
+        L = min(len(seqs[k]), len(seqs[k + 1])) // 2
+        seqs[k + 1][:L] = seqs[k][-L:]
+    problems = [(a, b, 1 + (a + b) % 3) for a in range(len(seqs)) for b in range(len(seqs)) if a != b]
+    got = _gpu_runs(seqs, problems, 11)
+    for p, (a, b, ml) in enumerate(problems):
+        assert got.get(p, []) == _oracle_runs(seqs[a], seqs[b], 11, ml), (p, a, b)
+
+
+# ---- Analyzer / Comparator through the C ABI ---------------------------------------------------------------------
+def _same_results(got, want):
+    g = [None if r is None else (r.opening, r.ending) for r in got]
+    w = [None if r is None else (r.opening, r.ending) for r in want]
+    assert g == w
+
+
+def test_config1_analyze_search_matches_oracle(lib3, tmp_path):
+    """configs[0]: 3 x 90 s, shared 20 s intro; default min_opening_duration (20 s) finds nothing
+    (SURVEY.md §7.6), 10 s finds the intro in every episode; both must equal the reference path."""
+    paths = [str(tmp_path / f"ep{k}.wav") for k in range(3)]
+    fhs = capi.Analyzer.from_files(paths).run_pcm([e.pcm for e in lib3])
+    hd = O.duration_from_secs_f32(0.3)
+    ref = O.analyze_batch([e.pcm[: len(e.pcm) // 2] for e in lib3], 1, hd)
+    for got, want in zip(fhs, ref):
+        h, ts = got.opening_data()
+        assert h.tolist() == [x for x, _ in want.opening]
+        assert ts.tolist() == [t for _, t in want.opening]
+        assert got.hash_duration() == 300_000_012 and len(got.ending_data()[0]) == 0
+    for min_s in (20, 10, 0):
+        res = capi.Comparator.from_files(paths).with_min_opening_duration(min_s).run_with_frame_hashes(fhs)
+        want = O.run_with_frame_hashes(O.Comparator(min_opening_duration=min_s * NS), ref)
+        _same_results(res, want)
+    res10 = capi.Comparator.from_files(paths).with_min_opening_duration(10).run_with_frame_hashes(fhs)
+    for r, e in zip(res10, lib3):
+        assert r is not None and r.opening is not None
+        # the reference stamps a hash with the END of its 2.6 s analysis span (delay 2600 ms, analyzer.rs:288,309)
+        # and runs its clock at 123/123.81: detected times trail the planted intro by at most that span
+        start, end = r.opening[0] / 1e9, r.opening[1] / 1e9
+        assert e.intro_off / 11025 <= start <= e.intro_off / 11025 + 2.7
+        assert abs(end - (e.intro_off + e.intro_len) / 11025) < 2.7
+
+
+def test_endings_and_parameters_match_oracle(tmp_path):
+    eps = synth.make_library(4, 120.0, 25.0, 22.0)
+    paths = [str(tmp_path / f"e{k}.wav") for k in range(4)]
+    an = capi.Analyzer.from_files(paths).with_include_endings(True).with_opening_search_percentage(0.4) \
+        .with_ending_search_percentage(0.35)
+    fhs = an.run_pcm([e.pcm for e in eps])
+    hd = O.duration_from_secs_f32(0.3)
+    ref = []
+    for e, f in zip(eps, fhs):
+        total = len(e.pcm)
+        dur = O.duration_from_secs_f64(total * (1.0 / 11025.0))
+        n_open = O.duration_mul_f32(dur, 0.4) * 11025 // NS
+        seek = O.duration_mul_f32(dur, float(np.float32(1.0) - np.float32(0.35)))
+        first = seek * 11025 // NS
+        o = O.step_and_timestamp(O.fingerprint(e.pcm[:n_open]), hd)
+        en = O.step_and_timestamp(O.fingerprint(e.pcm[first:]), hd, seek_to_ns=seek)
+        ref.append(O.FrameHashes(o, en, hd))
+        assert f.opening_data()[0].tolist() == [h for h, _ in o] and f.opening_data()[1].tolist() == [t for _, t in o]
+        assert f.ending_data()[0].tolist() == [h for h, _ in en] and f.ending_data()[1].tolist() == [t for _, t in en]
+    for kw in [dict(include_endings=True, min_opening_duration=12, min_ending_duration=12),
+               dict(include_endings=True, min_opening_duration=12, min_ending_duration=12, time_padding=1.5),
+               dict(include_endings=False, min_opening_duration=15, hash_match_threshold=6),
+               dict(include_endings=True, min_opening_duration=5, min_ending_duration=30, hash_match_threshold=14)]:
+        c = capi.Comparator(paths, **kw)
+        got = c.run_with_frame_hashes(fhs)
+        ocmp = O.Comparator(include_endings=kw.get("include_endings", False),
+                            hash_match_threshold=kw.get("hash_match_threshold", 10),
+                            min_opening_duration=kw.get("min_opening_duration", 20) * NS,
+                            min_ending_duration=kw.get("min_ending_duration", 20) * NS,
+                            time_padding=O.duration_from_secs_f32(kw.get("time_padding", 0.0)))
+        _same_results(got, O.run_with_frame_hashes(ocmp, ref))
+    # include_endings without ending data is the reference's FrameHashDataNoEnding error
+    fh_no_end = capi.Analyzer.from_files(paths).run_pcm([e.pcm for e in eps])
+    with pytest.raises(capi.NeedleError):
+        capi.Comparator(paths, include_endings=True).run_with_frame_hashes(fh_no_end)
+
+
+def test_file_based_c_abi_roundtrip(lib3, tmp_path, capfd):
+    """The unmodified needle-capi call sequence on WAV files: analyze with persist (.needle.dat), search from
+    disk with display + skip files, then the cached / skip-file paths (analyzer.rs:338-348, comparator.rs:600-605)."""
+    paths = []
+    for k, e in enumerate(lib3):
+        p = str(tmp_path / f"show-ep{k}.wav")
+        synth.write_wav(p, e.pcm, channels=2)            # stereo L = R like the reference's resampler output
+        paths.append(p)
+    an = capi.Analyzer.from_files(paths)
+    fhs = an.run(0.3, persist=True)
+    hd = O.duration_from_secs_f32(0.3)
+    ref = O.analyze_batch([e.pcm[: len(e.pcm) // 2] for e in lib3], 1, hd)
+    for p, got, want in zip(paths, fhs, ref):
+        assert got.opening_data()[0].tolist() == [h for h, _ in want.opening]
+        assert got.md5() == O.header_md5(p)
+        rc, disk = O.frame_hashes_read(p[:-4] + ".needle.dat")     # our file, read by the oracle's bincode reader
+        assert rc == 0 and disk.opening == want.opening and disk.md5 == got.md5() and disk.hash_duration == hd
+    capfd.readouterr()
+    an2 = capi.Analyzer.from_files(paths)
+    an2.run(0.3, persist=False)                           # cached: "Skipping analysis for ..." (analyzer.rs:344)
+    out = capfd.readouterr().out
+    assert out.count("Skipping analysis for") == 3
+    c = capi.Comparator(paths, min_opening_duration=10)
+    c.run(analyze=False, display=True, write_skip_files=True)
+    out = capfd.readouterr().out
+    want = O.run_with_frame_hashes(O.Comparator(min_opening_duration=10 * NS), ref)
+    for p, w in zip(paths, want):
+        assert f"\n{p}\n" in out
+        line = f'* Opening - "{O.format_time(w.opening[0])}"-"{O.format_time(w.opening[1])}"'
+        assert line in out
+        skip = open(p[:-4] + ".needle.skip.json").read()
+        assert skip == O.skip_file_json(w, O.header_md5(p))
+    c.run(analyze=False, display=True, use_skip_files=True)
+    assert capfd.readouterr().out.count("Skipping due to existing skip file...") == 3
+    # analyze-in-place variant of search (comparator.rs:650-654 -> data.rs:134-136)
+    for p in paths:
+        os.remove(p[:-4] + ".needle.dat")
+    c.run(analyze=True, display=True)
+    out = capfd.readouterr().out
+    assert all(f'* Opening - "{O.format_time(w.opening[0])}"' in out for w in want)
+    with pytest.raises(capi.NeedleError) as ei:
+        c.run(analyze=False)
+    assert ei.value.name == "FrameHashDataNotFound"
+
+
+# ---- library-scale parity at BASELINE.json's full size ----------------------------------------------------------
+@pytest.fixture(scope="module")
+def lib28():
+    """configs[1]: 28 episodes x 24 min, 90 s shared intro."""
+    return synth.make_library(28, 24 * 60.0, 90.0)
+
+
+def test_config2_full_size_parity(lib28):
+    n = len(lib28)
+    threads = min(os.cpu_count() or 1, 16)
+    hd = O.duration_from_secs_f32(0.3)
+    windows = [e.pcm[: len(e.pcm) // 2] for e in lib28]
+    ref = O.analyze_batch(windows, 1, hd, threads=threads)
+    lib = capi.Library(n)
+    lib.set_pcm([e.pcm for e in lib28], [len(e.pcm) for e in lib28])
+    lib.analyze()
+    for v in range(n):
+        h, ts = lib.frame_hashes(v).opening_data()
+        assert len(h) == 2897
+        assert h.tolist() == [x for x, _ in ref[v].opening], f"episode {v}"
+        assert ts.tolist() == [t for _, t in ref[v].opening]
+    cmp = capi.Comparator([f"ep{k}.wav" for k in range(n)])
+    cmp.handle()
+    cap = 1 << 16
+    d_runs, d_count = capi.DeviceBuffer(cap * 16), capi.DeviceBuffer(4)
+    lib.search(cmp, 0, lib.num_pairs(), d_runs.ptr, cap, d_count.ptr)
+    count = int(d_count.to_host(np.uint32, 1)[0])
+    assert 0 < count <= cap
+    runs = d_runs.to_host(capi.RUN_DTYPE, count)
+    got = lib.finalize(cmp, runs)
+    want = O.run_with_frame_hashes(O.Comparator(), ref, threads=threads)
+    _same_results(got, want)
+    for r, e in zip(got, lib28):
+        assert r is not None and r.opening is not None
+        start, end = r.opening[0] / 1e9, r.opening[1] / 1e9
+        # within the reference's own systematic offset (2.6 s span, 0.65 % slow clock) of the planted intro
+        assert e.intro_off / 11025 - 0.25 <= start <= e.intro_off / 11025 + 3.0
+        assert abs(end - (e.intro_off + e.intro_len) / 11025) < 3.0
+    # sharded search (two "ranks" splitting the pair list) gives the same run set
+    half = lib.num_pairs() // 2
+    parts = []
+    for first, cnt in [(0, half), (half, lib.num_pairs() - half)]:
+        lib.search(cmp, first, cnt, d_runs.ptr, cap, d_count.ptr)
+        c = int(d_count.to_host(np.uint32, 1)[0])
+        parts.append(d_runs.to_host(capi.RUN_DTYPE, c))
+    merged = np.concatenate(parts)
+    assert sorted(map(tuple, merged.tolist())) == sorted(map(tuple, runs.tolist()))
+    _same_results(lib.finalize(cmp, merged), want)
