@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on MI355X.
+
+metric  : episode-pairs/sec (analyze+search) = N(N-1)/2 / wall(analyze N episodes + search all pairs +
+          per-video best match), N = 28 synthetic 24-min episodes (BASELINE.json configs[1]).
+step    : one complete pass of the hot path over the library: fingerprint every episode's opening window
+          (stft_chroma, fir_norm, classify kernels), scan every pair (hamming_runs kernel), copy the run list
+          and the hash arena back, run the order-sensitive host epilogue (duration validity, simhash32,
+          BinaryHeap order, find_best_match).  PCM is resident in HBM before the timed region starts.
+N > 1   : one process per GPU (torch.distributed, backend nccl = RCCL).  The SAME 28-episode job is sharded:
+          episodes in contiguous blocks, one all-gather of hash rows, pairs in contiguous ranges, one
+          all-gather of run lists, epilogue on rank 0 ("strong" scaling, BASELINE.json configs[3]).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed live with HIP events on the
+library's stream; `cpu_baseline` times the oracle (the C restatement of the reference's CPU path, full
+DP table per pair, one task per episode / pair over all host cores) on rank 0 at N = 1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+RATE = 11025
+
+
+def algorithmic_bytes(kernel: str, windows, kept, n_pairs: int, n_runs: int) -> float:
+    """analyze 2*S + 4*H per episode; search 4*(n+m) + 12*R per pair (R runs of 3 u32)."""
+    if kernel == "hamming_runs":
+        n = sum(kept) / max(len(kept), 1)
+        return n_pairs * 4.0 * 2.0 * n + 12.0 * n_runs
+    return float(sum(2 * s + 4 * h for s, h in zip(windows, kept)))
+
+
+def cpu_baseline(eps, results_gpu, hashes_gpu):
+    """The oracle on the host cores (rank 0, N = 1 only): same episodes, same pairs, reference cost
+    structure.  Bounded: the whole 28-episode job when the core count makes it ~<= 30 s, else a prefix of
+    the pair list, scaled.  Also cross-checks the GPU's hashes and results against it."""
+    from oracle import oracle as O
+    threads = max(1, len(os.sched_getaffinity(0)))
+    hd = O.duration_from_secs_f32(0.3)
+    windows = [e.pcm[: len(e.pcm) // 2] for e in eps]
+    t0 = time.perf_counter()
+    fhs = O.analyze_batch(windows, 1, hd, threads=threads)
+    t_analyze = time.perf_counter() - t0
+    n = len(eps)
+    pairs_total = n * (n - 1) // 2
+    # ~0.1 core-seconds per 24-min pair: keep the search leg under ~25 s of wall
+    est_pair_s = 0.1 * (len(fhs[0].opening) / 2897.0) ** 2
+    budget_pairs = int(25.0 * threads / max(est_pair_s, 1e-6))
+    k = n
+    while k > 2 and k * (k - 1) // 2 > budget_pairs:
+        k -= 1
+    t0 = time.perf_counter()
+    res = O.run_with_frame_hashes(O.Comparator(), fhs[:k], threads=threads)
+    t_search = time.perf_counter() - t0
+    sample_pairs = k * (k - 1) // 2
+    t_search_full = t_search * pairs_total / max(sample_pairs, 1)
+    value = pairs_total / (t_analyze + t_search_full)
+    parity = all(hashes_gpu[v].tolist() == [h for h, _ in fhs[v].opening] for v in range(n))
+    if k == n:
+        got = [None if r is None else (r.opening, r.ending) for r in results_gpu]
+        want = [None if r is None else (r.opening, r.ending) for r in res]
+        parity = parity and got == want
+    return {
+        "value": round(value, 3), "unit": "episode-pairs/s", "cores": threads, "kind": "port",
+        "sample": f"oracle (C restatement of analyzer.rs/comparator.rs + chromaprint, not the Rust binary): "
+                  f"analyze all {n} episodes in {t_analyze:.2f} s, search {sample_pairs}/{pairs_total} pairs in "
+                  f"{t_search:.2f} s (scaled to all pairs), {threads} threads",
+        "analyze_s": round(t_analyze, 3), "search_s_scaled": round(t_search_full, 3),
+        "gpu_matches_oracle": bool(parity),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--episodes", type=int, default=28)
+    ap.add_argument("--minutes", type=float, default=24.0)
+    ap.add_argument("--intro-seconds", type=float, default=90.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even at N=1")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1 or args.force_dist
+
+    torch = dist = None
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch  # noqa: F811  (loads its HIP runtime first; libneedle_capi.so binds to the same one)
+        import torch.distributed as dist  # noqa: F811
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from needle_amd import capi, synth
+    from needle_amd import dist as ndist
+
+    if capi.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the needle path has no CPU fallback")
+    capi.set_device(local_rank if distributed else 0)
+
+    n = args.episodes
+    eps = synth.make_library(n, args.minutes * 60.0, args.intro_seconds)
+    first, count = ndist.shard(n, world, rank)
+    lib = capi.Library(n)
+    lib.set_pcm([e.pcm if first <= k < first + count else None for k, e in enumerate(eps)],
+                [len(e.pcm) for e in eps])
+    cmp = capi.Comparator([f"episode-{k:04d}.wav" for k in range(n)])
+    cmp.handle()
+    n_pairs = lib.num_pairs()
+    cap = 1 << 16
+    windows = [len(e.pcm) // 2 for e in eps]
+    kept = [capi.lib().needle_hip_fingerprint_num_kept(w, 2) for w in windows]
+
+    kernel_names = ["stft_chroma", "fir_norm", "classify", "hamming_runs"]
+    kernel_ms = {k: 0.0 for k in kernel_names}
+    state = {"runs": 0, "results": None}
+
+    if not distributed:
+        d_runs, d_count = capi.DeviceBuffer(cap * 16), capi.DeviceBuffer(4)
+
+        def step(collect):
+            lib.analyze(0, n, sync=False)
+            lib.search(cmp, 0, n_pairs, d_runs.ptr, cap, d_count.ptr, sync=False)
+            found = int(d_count.to_host(np.uint32, 1)[0])            # D2H on the library stream: waits for the kernels
+            if found > cap:
+                raise SystemExit("run list overflow")
+            runs = d_runs.to_host(capi.RUN_DTYPE, found)
+            state["results"] = lib.finalize(cmp, runs)
+            state["runs"] = found
+            if collect:
+                for k in kernel_names:
+                    kernel_ms[k] += capi.last_kernel_ms(k)
+
+        def barrier():
+            capi.synchronize()
+    else:
+        b = ndist.block(n, world)
+        _, stride = lib.hash_arena()
+        arena = torch.zeros((b * world, stride), dtype=torch.int32, device="cuda")
+        lib.use_hash_arena(arena.data_ptr(), b * world, stride)
+        t_runs = torch.zeros((cap, 4), dtype=torch.int32, device="cuda")
+        t_count = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+        def sync():
+            capi.synchronize()
+            torch.cuda.synchronize()
+
+        def search_pairs(pfirst, pcount):
+            lib.search(cmp, pfirst, pcount, t_runs.data_ptr(), cap, t_count.data_ptr(), sync=True)
+            found = int(t_count.item())
+            if found > cap:
+                raise SystemExit("run list overflow")
+            state["runs"] = found
+            return t_runs[:found]
+
+        def finalize(runs_np):
+            runs = np.ascontiguousarray(runs_np.astype(np.int32)).view(capi.RUN_DTYPE).reshape(-1)
+            return lib.finalize(cmp, runs)
+
+        def step(collect):
+            state["results"] = ndist.run_job(n, world, rank, arena, lambda f, c: lib.analyze(f, c, sync=False),
+                                             search_pairs, finalize, sync)
+            if collect:
+                for k in kernel_names:
+                    kernel_ms[k] += max(capi.last_kernel_ms(k), 0.0)
+
+        def barrier():
+            sync()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1000.0 * elapsed / args.steps
+        value = n_pairs / (elapsed / args.steps)
+        avg = {k: kernel_ms[k] / args.steps for k in kernel_names}
+        dominant = max(avg, key=avg.get)
+        # per-launch work of THIS rank's launch of the dominant kernel
+        if dominant == "hamming_runs":
+            _, pcount = ndist.shard(n_pairs, world, 0)
+            abytes = algorithmic_bytes(dominant, windows, kept, pcount, state["runs"])
+        else:
+            f0, c0 = ndist.shard(n, world, 0)
+            abytes = algorithmic_bytes(dominant, windows[f0:f0 + c0], kept[f0:f0 + c0], 0, 0)
+        achieved = abytes / (avg[dominant] * 1e-3) / 1e9 if avg[dominant] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes/launch from rocprofv3 PMC passes
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dominant)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "episode-pairs/sec (analyze+search)", "value": round(value, 2), "unit": "episode-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{n} episodes x {args.minutes:g} min synthetic mono s16 PCM @ 11025 Hz, "
+                                   f"{args.intro_seconds:g} s shared intro, opening window 50 %, hash 0.3 s, "
+                                   f"threshold 10, min opening 20 s; analyze+search, {n_pairs} pairs "
+                                   f"(BASELINE.json configs[1]; configs[3] sharding when n_gpus > 1)",
+                       "episodes": n, "pairs": n_pairs, "hashes_per_episode": kept[0],
+                       "parallelism": "1 gpu" if world == 1 else f"{world} ranks: episode blocks + pair ranges, "
+                                                                "2 all-gathers (RCCL)"},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(abytes),
+                         "avg_launch_ms": round(avg[dominant], 5)},
+            "kernel_ms_per_step": {k: round(v, 5) for k, v in avg.items()},
+            "runs_per_step": state["runs"],
+            "detected": sum(1 for r in state["results"] if r is not None and r.opening is not None),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            hashes = [lib.frame_hashes(v).opening_data()[0] for v in range(n)]
+            out["cpu_baseline"] = cpu_baseline(eps, state["results"], hashes)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

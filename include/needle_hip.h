@@ -172,6 +172,11 @@ enum NeedleError needle_hip_library_set_pcm(NeedleHipLibrary *library, const int
 enum NeedleError needle_hip_library_analyze(NeedleHipLibrary *library, size_t first, size_t count, bool sync);
 /* Arena geometry: device pointer to u32[num_videos][stride]. */
 enum NeedleError needle_hip_library_hash_arena(NeedleHipLibrary *library, uint32_t **d_arena, size_t *stride);
+/* Adopt caller-owned device memory u32[rows][stride] (rows >= num_videos, stride >= the library's) as the
+ * arena, e.g. a buffer a collective library allocated so rows can be all-gathered in place.  Call after
+ * set_pcm and before analyze; the caller keeps the memory alive and zero-initialised. */
+enum NeedleError needle_hip_library_use_hash_arena(NeedleHipLibrary *library, uint32_t *d_arena, size_t rows,
+                                                   size_t stride);
 size_t needle_hip_library_num_pairs(const NeedleHipLibrary *library);
 /* Runs of pairs [first_pair, first_pair+num_pairs) into caller-provided device buffers
  * (NeedleHipRun.problem = global pair index). */

@@ -76,7 +76,7 @@ NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_frame_hashes_read", "needle_hip_frame_hashes_write", "needle_hip_header_md5",
     "needle_hip_analyzer_run_pcm", "needle_hip_comparator_run_with_frame_hashes", "needle_hip_library_new",
     "needle_hip_library_free", "needle_hip_library_set_pcm", "needle_hip_library_analyze",
-    "needle_hip_library_hash_arena", "needle_hip_library_num_pairs", "needle_hip_library_search",
+    "needle_hip_library_hash_arena", "needle_hip_library_use_hash_arena", "needle_hip_library_num_pairs", "needle_hip_library_search",
     "needle_hip_library_finalize", "needle_hip_library_frame_hashes"]
 
 _LIB = None
@@ -159,6 +159,7 @@ def lib():
     L.needle_hip_library_set_pcm.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.c_int]
     L.needle_hip_library_analyze.argtypes = [vp, sz, sz, b]
     L.needle_hip_library_hash_arena.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    L.needle_hip_library_use_hash_arena.argtypes = [vp, vp, sz, sz]
     L.needle_hip_library_num_pairs.argtypes = [vp]
     L.needle_hip_library_num_pairs.restype = sz
     L.needle_hip_library_search.argtypes = [vp, vp, sz, sz, vp, u32, vp, b]
@@ -500,6 +501,9 @@ class Library:
         stride = C.c_size_t(0)
         check(lib().needle_hip_library_hash_arena(self._h, C.byref(ptr), C.byref(stride)))
         return ptr.value, stride.value
+
+    def use_hash_arena(self, d_ptr: int, rows: int, stride: int) -> None:
+        check(lib().needle_hip_library_use_hash_arena(self._h, d_ptr, rows, stride))
 
     def num_pairs(self) -> int:
         return lib().needle_hip_library_num_pairs(self._h)

@@ -120,6 +120,7 @@ Status Analyzer::run(ns_t hash_duration, bool persist, bool /*threading*/, std::
         if (!s.ok()) return s;  // the reference unwrap()s the deserialisation
         if (existing.md5 == md5s[i]) {
           std::printf("Skipping analysis for %s...\n", videos_[i].c_str());
+          std::fflush(stdout);  // println! is line buffered
           (*out)[i] = std::move(existing);
           cached[i] = 1;
           continue;

@@ -40,6 +40,7 @@ struct NeedleHipLibrary {
   size_t stride = 0;
   DeviceBuffer<int16_t> d_pcm;
   DeviceBuffer<uint32_t> d_arena;
+  uint32_t *arena = nullptr;  // d_arena.ptr, or caller-owned memory adopted with needle_hip_library_use_hash_arena
   std::vector<std::vector<HashTs>> ts_cache;  // timestamps by kept length (identical for equal lengths)
   std::vector<uint32_t> min_len;              // per video, for the comparator's opening duration
 
@@ -123,7 +124,8 @@ enum NeedleError needle_hip_library_set_pcm(NeedleHipLibrary *lib, const int16_t
     if (!(s = lib->d_pcm.reserve(std::max<uint64_t>(total, 1))).ok()) return report(s);
     if (!(s = lib->d_arena.reserve(lib->n * lib->stride)).ok()) return report(s);
     hipStream_t stream = library_stream();
-    if (hipMemsetAsync(lib->d_arena.ptr, 0, lib->n * lib->stride * sizeof(uint32_t), stream) != hipSuccess)
+    lib->arena = lib->d_arena.ptr;
+    if (hipMemsetAsync(lib->arena, 0, lib->n * lib->stride * sizeof(uint32_t), stream) != hipSuccess)
       return report(Status::Make(NeedleError_Unknown, "hipMemset failed"));
     for (size_t v = 0; v < lib->n; v++) {
       if (!pcm[v] || !lib->window_values[v]) continue;
@@ -148,7 +150,7 @@ enum NeedleError needle_hip_library_analyze(NeedleHipLibrary *lib, size_t first,
         return report(Status::Make(NeedleError_InvalidArgument, "video " + std::to_string(v) + " has no PCM on this rank"));
       spans.push_back(StreamSpan{lib->pcm_off[v], lib->window_values[v], (uint64_t)v * lib->stride});
     }
-    Status s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->d_arena.ptr, sync);
+    Status s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->arena, sync);
     return s.ok() ? NeedleError_Ok : report(s);
   });
 }
@@ -156,8 +158,17 @@ enum NeedleError needle_hip_library_analyze(NeedleHipLibrary *lib, size_t first,
 enum NeedleError needle_hip_library_hash_arena(NeedleHipLibrary *lib, uint32_t **d_arena, size_t *stride) {
   if (!lib || !d_arena || !stride) return NeedleError_NullArgument;
   if (!lib->have_pcm) return NeedleError_InvalidArgument;
-  *d_arena = lib->d_arena.ptr;
+  *d_arena = lib->arena;
   *stride = lib->stride;
+  return NeedleError_Ok;
+}
+
+enum NeedleError needle_hip_library_use_hash_arena(NeedleHipLibrary *lib, uint32_t *d_arena, size_t rows, size_t stride) {
+  if (!lib || !d_arena) return NeedleError_NullArgument;
+  if (!lib->have_pcm || rows < lib->n || stride < lib->stride) return NeedleError_InvalidArgument;
+  lib->arena = d_arena;
+  lib->stride = stride;
+  lib->d_arena.release();
   return NeedleError_Ok;
 }
 
@@ -189,7 +200,7 @@ enum NeedleError needle_hip_library_search(NeedleHipLibrary *lib, const struct N
       if (a == 0 || b == 0) continue;
       problems.push_back(NeedleHipProblem{(uint32_t)i, (uint32_t)j, std::max(a, b), (uint32_t)p});
     }
-    Status s = gpu_hamming_runs_device(lib->d_arena.ptr, seqs.data(), seqs.size(), problems.data(), problems.size(),
+    Status s = gpu_hamming_runs_device(lib->arena, seqs.data(), seqs.size(), problems.data(), problems.size(),
                                        cmp.hash_match_threshold(), d_runs, capacity, d_count, sync);
     return s.ok() ? NeedleError_Ok : report(s);
   });
@@ -198,7 +209,7 @@ enum NeedleError needle_hip_library_search(NeedleHipLibrary *lib, const struct N
 static NeedleError library_frame_hashes(NeedleHipLibrary *lib, std::vector<FrameHashesData> *out) {
   std::vector<uint32_t> host(lib->n * lib->stride);
   hipStream_t stream = library_stream();
-  if (hipMemcpyAsync(host.data(), lib->d_arena.ptr, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) !=
+  if (hipMemcpyAsync(host.data(), lib->arena, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) !=
           hipSuccess ||
       hipStreamSynchronize(stream) != hipSuccess)
     return report(Status::Make(NeedleError_Unknown, "hash arena download failed"));
@@ -240,7 +251,7 @@ enum NeedleError needle_hip_library_frame_hashes(NeedleHipLibrary *lib, size_t i
     std::vector<uint32_t> host(lib->kept[index]);
     hipStream_t stream = library_stream();
     if (!host.empty() &&
-        (hipMemcpyAsync(host.data(), lib->d_arena.ptr + index * lib->stride, host.size() * sizeof(uint32_t),
+        (hipMemcpyAsync(host.data(), lib->arena + index * lib->stride, host.size() * sizeof(uint32_t),
                         hipMemcpyDeviceToHost, stream) != hipSuccess ||
          hipStreamSynchronize(stream) != hipSuccess))
       return report(Status::Make(NeedleError_Unknown, "hash arena download failed"));

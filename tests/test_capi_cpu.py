@@ -1,0 +1,226 @@
+"""CPU-side tests of the drop-in boundary: libneedle_capi.so loads, exports every symbol the headers
+declare, reproduces the reference's constructor/argument behaviour (needle-capi/src/lib.rs), and its
+host-only pieces (FrameHashes files, header MD5, file discovery) agree with the oracle.  No compute entry
+point is called with a GPU here; where one is called it must fail loudly because there is no CPU path."""
+import ctypes as C
+import os
+import re
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from needle_amd import capi, synth
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(needle_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    for header, listed in [("needle.h", capi.NEEDLE_H_SYMBOLS), ("needle_hip.h", capi.NEEDLE_HIP_H_SYMBOLS)]:
+        declared = _declared(header)
+        assert declared == sorted(listed), f"{header} and capi.py disagree"
+        for sym in declared:
+            assert hasattr(L, sym), f"{sym} declared in {header} but not exported"
+    assert len(capi.NEEDLE_H_SYMBOLS) == 13   # needle-capi/needle.h:146-248
+
+
+def test_error_enum_and_strings():
+    """repr(C) values 0..11 and the exact strings of needle_error_to_str (lib.rs:58-85,138-199)."""
+    want = ["No error", "Invalid UTF-8 string", "Input argument is NULL",
+            "One or more input arguments were invalid (usually zero)", "Frame hash data not found on disk",
+            "Frame hash data has an invalid version.", "Invalid frame hash data read from disk",
+            "Comparator requires at least 2 video paths", "Analyzer hash period must be greater than 0",
+            "Analyzer hash duration must be greater than 3 seconds", "I/O error",
+            "Unknown error occurred; please re-run with logging enabled"]
+    assert [capi.error_to_str(i) for i in range(12)] == want
+    header = open(os.path.join(ROOT, "include", "needle.h")).read()
+    names = re.findall(r"NeedleError_(\w+)", header.split("typedef enum NeedleError")[1].split("} NeedleError;")[0])
+    assert names == capi.ERROR_NAMES
+
+
+def _cpaths(paths):
+    arr = (C.c_char_p * len(paths))(*[p if isinstance(p, bytes) else p.encode() for p in paths])
+    return C.cast(arr, C.POINTER(C.c_char_p)), arr
+
+
+def test_analyzer_constructors_like_reference_tests():
+    """needle-capi/src/lib.rs:681-703: _new_default on a path that need not exist -> Ok, non-null; free."""
+    L = capi.lib()
+    ptr, keep = _cpaths(["/tmp/abcd.mkv"])
+    out = C.c_void_p()
+    assert L.needle_audio_analyzer_new_default(ptr, 1, C.byref(out)) == 0 and out.value
+    fh = C.c_void_p()
+    assert L.needle_audio_analyzer_get_frame_hashes(out, 0, C.byref(fh)) == 3     # nothing run yet: InvalidArgument
+    assert L.needle_audio_analyzer_get_frame_hashes(None, 0, C.byref(fh)) == 2
+    assert L.needle_audio_analyzer_run(out, 0.0, False, True) == 9               # hash_duration <= 0 (lib.rs:474)
+    assert L.needle_audio_analyzer_run(None, 0.3, False, True) == 2
+    L.needle_audio_analyzer_free(out)
+    L.needle_audio_analyzer_free(None)
+    assert L.needle_audio_analyzer_new_default(None, 1, C.byref(out)) == 2        # NullArgument (lib.rs:383)
+    assert L.needle_audio_analyzer_new_default(ptr, 1, None) == 2
+    bad, keep2 = _cpaths([b"/tmp/\xff\xfe.mkv"])
+    assert L.needle_audio_analyzer_new_default(bad, 1, C.byref(out)) == 1         # InvalidUtf8String (lib.rs:297)
+    nullelem = (C.c_char_p * 1)(None)
+    assert L.needle_audio_analyzer_new_default(C.cast(nullelem, C.POINTER(C.c_char_p)), 1, C.byref(out)) == 2
+
+
+def test_comparator_constructors_like_reference_tests():
+    """lib.rs:705-739 plus the minimum-paths rule (lib.rs:569-571)."""
+    L = capi.lib()
+    ptr, keep = _cpaths(["/tmp/abcd.mkv", "/tmp/efgh.mp4"])
+    out = C.c_void_p()
+    assert L.needle_audio_comparator_new(ptr, 2, False, 10, 10, 10, 0.0, C.byref(out)) == 0 and out.value
+    L.needle_audio_comparator_free(out)
+    out = C.c_void_p()
+    assert L.needle_audio_comparator_new_default(ptr, 2, C.byref(out)) == 0 and out.value
+    assert L.needle_audio_comparator_run(None, True, True, False, False, True) == 2
+    # search without analyze and without .needle.dat files: FrameHashDataNotFound (data.rs:106-108)
+    assert L.needle_audio_comparator_run(out, False, False, False, False, True) == 4
+    L.needle_audio_comparator_free(out)
+    L.needle_audio_comparator_free(None)
+    assert L.needle_audio_comparator_new_default(ptr, 1, C.byref(out)) == 7       # ComparatorMinimumPaths
+    assert L.needle_audio_comparator_new_default(None, 2, C.byref(out)) == 2
+
+
+def test_print_paths(capfd):
+    L = capi.lib()
+    ptr, keep = _cpaths(["/tmp/a b.mkv", "/tmp/é.mp4"])
+    out = C.c_void_p()
+    assert L.needle_audio_analyzer_new_default(ptr, 2, C.byref(out)) == 0
+    L.needle_audio_analyzer_print_paths(out)
+    L.needle_audio_analyzer_free(out)
+    assert capfd.readouterr().out == "/tmp/a b.mkv\n/tmp/é.mp4\n"
+
+
+def test_find_video_files(tmp_path):
+    """lib.rs:208-281 / util.rs:60-96: existing paths only, one directory level, *.needle.dat excluded.
+    Decodable media in this build = RIFF/WAVE (FFmpeg is out of scope)."""
+    L = capi.lib()
+    e = synth.make_episode(0, 2.0, 0.0)
+    d = tmp_path / "show"
+    d.mkdir()
+    synth.write_wav(str(d / "b.wav"), e.pcm)
+    synth.write_wav(str(d / "a.wav"), e.pcm)
+    (d / "notes.txt").write_text("not media")
+    (d / "a.needle.dat").write_bytes(b"RIFF0000WAVE")
+    (d / "sub").mkdir()
+    synth.write_wav(str(d / "sub" / "deep.wav"), e.pcm)
+    single = tmp_path / "single.wav"
+    synth.write_wav(str(single), e.pcm, channels=2)
+    ptr, keep = _cpaths([str(d), str(single)])
+    videos = C.POINTER(C.c_char_p)()
+    n = C.c_size_t(0)
+    for full in (False, True):
+        assert L.needle_util_find_video_files(ptr, 2, full, True, C.byref(videos), C.byref(n)) == 0
+        got = [videos[i].decode() for i in range(n.value)]
+        assert got == [str(d / "a.wav"), str(d / "b.wav"), str(single)]
+        L.needle_util_video_files_free(videos, n)
+    L.needle_util_video_files_free(None, 0)
+    assert L.needle_util_find_video_files(ptr, 0, False, True, C.byref(videos), C.byref(n)) == 3
+    assert L.needle_util_find_video_files(None, 1, False, True, C.byref(videos), C.byref(n)) == 2
+    missing, k2 = _cpaths([str(tmp_path / "nope")])
+    assert L.needle_util_find_video_files(missing, 1, False, True, C.byref(videos), C.byref(n)) == 11  # PathNotFound -> Unknown
+
+
+def test_frame_hashes_file_is_bincode_compatible(tmp_path):
+    """Files written through the C ABI are byte-identical to the oracle's (= the reference's bincode layout,
+    SURVEY.md Appendix B) and each side reads the other's."""
+    opening = [(0xDEADBEEF, 2_600_000_000), (7, 2_846_000_007), (0, 3_092_000_014)]
+    ending = [(9, 1_082_600_000_000)]
+    md5 = "759c6a520c5ce70359fdff38c4be6b98"
+    ours = str(tmp_path / "ours.needle.dat")
+    theirs = str(tmp_path / "theirs.needle.dat")
+    fh = capi.FrameHashes.new(opening, ending, 300_000_012, md5)
+    fh.write(ours)
+    assert O.frame_hashes_write(theirs, O.FrameHashes(opening, ending, 300_000_012, md5)) == 0
+    assert open(ours, "rb").read() == open(theirs, "rb").read()
+    back = capi.FrameHashes.from_path(theirs)
+    assert list(zip(*[a.tolist() for a in back.opening_data()])) == opening
+    assert list(zip(*[a.tolist() for a in back.ending_data()])) == ending
+    assert back.hash_duration() == 300_000_012 and back.md5() == md5
+    rc, o = O.frame_hashes_read(ours)
+    assert rc == 0 and o.opening == opening and o.ending == ending
+    # error mapping (lib.rs:126-128)
+    with pytest.raises(capi.NeedleError) as e:
+        capi.FrameHashes.from_path(str(tmp_path / "missing.needle.dat"))
+    assert e.value.name == "FrameHashDataNotFound"
+    raw = open(ours, "rb").read()
+    for blob in (raw[:-3], raw[:20], struct.pack("<I", 5) + raw[4:], raw[:4] + struct.pack("<I", 1) + raw[8:]):
+        open(ours, "wb").write(blob)
+        with pytest.raises(capi.NeedleError) as e:
+            capi.FrameHashes.from_path(ours)
+        assert e.value.name == "InvalidFrameHashData"
+
+
+def test_header_md5_golden_and_short_file(tmp_path):
+    head = open(os.path.join(HERE, "golden", "sample-5s.header8k.bin"), "rb").read()
+    p = tmp_path / "v.mp4"
+    p.write_bytes(head + b"x" * 100)
+    assert capi.header_md5(str(p)) == "759c6a520c5ce70359fdff38c4be6b98"   # reference snapshot :43
+    p.write_bytes(head[:100])
+    with pytest.raises(capi.NeedleError) as e:
+        capi.header_md5(str(p))
+    assert e.value.name == "IOError"
+
+
+def test_fingerprint_constants_match_oracle():
+    L = capi.lib()
+    assert L.needle_hip_fingerprint_sample_rate() == 11025
+    assert L.needle_hip_fingerprint_delay_ms() == O.delay_ms() == 2600
+    assert L.needle_hip_fingerprint_item_duration_ms() == O.item_duration_ms() == 123
+    for s in [0, 4095, 4096, 30000, 496125, 7938000, 14883750]:
+        assert L.needle_hip_fingerprint_num_items(s) == O.num_items(s)
+        assert L.needle_hip_fingerprint_num_kept(s, 2) == (O.num_items(s) + 1) // 2
+
+
+def test_compute_entry_points_fail_loudly_without_a_gpu(has_gpu):
+    """There is no CPU fallback: on a box without a HIP device every compute call returns an error."""
+    if has_gpu:
+        pytest.skip("a GPU is present; covered by the -m gpu parity tests")
+    pcm = np.zeros(20000, np.int16)
+    with pytest.raises(capi.NeedleError) as e:
+        capi.fingerprint([pcm])
+    assert e.value.name == "Unknown" and "no HIP device" in str(e.value)
+    with pytest.raises(capi.NeedleError):
+        capi.hamming_runs([np.arange(10, dtype=np.uint32), np.arange(10, dtype=np.uint32)], [(0, 1, 1)], 10)
+    fhs = [capi.FrameHashes.new([(i, 2_600_000_000 + i * 246_000_000) for i in range(100)], [], 300_000_012)
+           for _ in range(2)]
+    with pytest.raises(capi.NeedleError):
+        capi.Comparator(["a.wav", "b.wav"]).run_with_frame_hashes(fhs)
+    with pytest.raises(capi.NeedleError):
+        capi.Analyzer(["a.wav"]).run_pcm([pcm])
+    with pytest.raises(capi.NeedleError):
+        capi.set_device(0)
+
+
+def test_c_program_links_against_header_and_library(tmp_path):
+    """An ordinary C consumer of needle.h (same call sequence as the reference's examples, which CI only
+    compiles: .github/workflows/test.yml:39-40) builds with -Wall -Werror and runs."""
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.run(["gcc", "-Wall", "-Werror", "-std=c11", os.path.join(HERE, "c_abi", "abi_smoke.c"),
+                    "-I", os.path.join(ROOT, "include"), "-L", os.path.dirname(capi.LIB_PATH), "-lneedle_capi",
+                    "-Wl,-rpath," + os.path.dirname(capi.LIB_PATH), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "abi smoke ok" in out
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/needle-capi/examples"), reason="reference tree not present")
+def test_reference_examples_compile_unchanged(tmp_path):
+    """needle-capi/examples/*.c compile and link, unmodified and in place, against OUR header and library
+    (the reference's own ABI gate; nothing is copied into the repo)."""
+    for name in ("analyzer", "comparator", "full"):
+        src = f"/root/reference/needle-capi/examples/{name}.c"
+        subprocess.run(["gcc", src, "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-L",
+                        os.path.dirname(capi.LIB_PATH), "-lneedle_capi", "-o", str(tmp_path / f"{name}.out")],
+                       check=True)
