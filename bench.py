@@ -105,7 +105,7 @@ def main() -> None:
         import torch  # noqa: F811  (loads its HIP runtime first; libneedle_capi.so binds to the same one)
         import torch.distributed as dist  # noqa: F811
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from needle_amd import capi, synth
     from needle_amd import dist as ndist

@@ -5,6 +5,7 @@
  */
 #include "ora_needle.h"
 
+#include <malloc.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -339,7 +340,14 @@ void ora_frame_hashes_free(ora_frame_hashes *fh) {
  * ================================================================================================ */
 static int g_threads = 1;
 
-void ora_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+void ora_set_threads(int n) {
+  g_threads = n < 1 ? 1 : n;
+  /* The per-pair table is 2898 separate 23 KiB rows (comparator.rs:175).  With glibc's default trim
+   * threshold every pair returns that memory to the kernel and faults it back in, which serialises many
+   * threads on the mm lock; keep freed heap mapped so the CPU baseline measures the algorithm. */
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  mallopt(M_TOP_PAD, 64 << 20);
+}
 int ora_get_threads(void) { return g_threads; }
 
 /* analyzer.rs:425-455 restated at the PCM boundary: one episode per task (rayon par_iter :440-444),

@@ -296,8 +296,9 @@ def test_config2_full_size_parity(lib28):
     for r, e in zip(got, lib28):
         assert r is not None and r.opening is not None
         start, end = r.opening[0] / 1e9, r.opening[1] / 1e9
-        # within the reference's own systematic offset (2.6 s span, 0.65 % slow clock) of the planted intro
-        assert e.intro_off / 11025 - 0.25 <= start <= e.intro_off / 11025 + 3.0
+        # ground truth: the reference's own result sits within one analysis span (2.7 s: a hash covers 2.6 s of
+        # audio and tolerates 10 differing bits, so runs begin/end up to a span away from the planted edges)
+        assert abs(start - e.intro_off / 11025) < 3.0
         assert abs(end - (e.intro_off + e.intro_len) / 11025) < 3.0
     # sharded search (two "ranks" splitting the pair list) gives the same run set
     half = lib.num_pairs() // 2
