@@ -127,12 +127,12 @@ def main() -> None:
     windows = [len(e.pcm) // 2 for e in eps]
     kept = [capi.lib().needle_hip_fingerprint_num_kept(w, 2) for w in windows]
 
-    kernel_names = ["stft_chroma", "fir_norm", "classify", "hamming_runs"]
+    kernel_names = ["stft_chroma", "fir_norm", "classify", "hamming_runs", "simhash_runs"]
     kernel_ms = {k: 0.0 for k in kernel_names}
     state = {"runs": 0, "results": None}
 
     if not distributed:
-        d_runs, d_count = capi.DeviceBuffer(cap * 16), capi.DeviceBuffer(4)
+        d_runs, d_count = capi.DeviceBuffer(cap * capi.RUN_DTYPE.itemsize), capi.DeviceBuffer(4)
 
         def step(collect):
             lib.analyze(0, n, sync=False)
@@ -154,7 +154,7 @@ def main() -> None:
         _, stride = lib.hash_arena()
         arena = torch.zeros((b * world, stride), dtype=torch.int32, device="cuda")
         lib.use_hash_arena(arena.data_ptr(), b * world, stride)
-        t_runs = torch.zeros((cap, 4), dtype=torch.int32, device="cuda")
+        t_runs = torch.zeros((cap, capi.RUN_WORDS), dtype=torch.int32, device="cuda")
         t_count = torch.zeros(1, dtype=torch.int32, device="cuda")
 
         def sync():

@@ -78,7 +78,8 @@ enum NeedleError needle_hip_fingerprint_debug(const int16_t *pcm, size_t num_val
  * problem (src, dst, min_len) it reports every maximal diagonal run of cells (i >= 1, j >= 1) with
  * popcount(src[i] ^ dst[j]) <= threshold whose length L >= min_len, as (src_end = i, dst_end = j, L)
  * of its last cell — exactly the cells the reference's reverse walk stops at (:196-200) with
- * table[i][j] = L.  Order of the emitted runs is unspecified; the caller sorts. */
+ * table[i][j] = L — together with the two chromaprint simhashes the reference computes for such a run
+ * (:226-229).  Order of the emitted runs is unspecified; the caller sorts. */
 typedef struct NeedleHipSeq {
   uint32_t offset; /* first hash of the sequence inside the hash arena */
   uint32_t len;
@@ -96,6 +97,8 @@ typedef struct NeedleHipRun {
   uint32_t src_end;
   uint32_t dst_end;
   uint32_t len;
+  uint32_t src_match_hash; /* simhash32 of src[src_end-len ..= src_end], L+1 hashes (comparator.rs:149-153,226-229) */
+  uint32_t dst_match_hash; /* simhash32 of dst[dst_end-len ..= dst_end] */
 } NeedleHipRun;
 
 /* Hash arena resident in HBM; descriptors are host arrays.  Writes at most `capacity` runs to d_runs

@@ -46,7 +46,8 @@ class Problem(C.Structure):
 
 
 class Run(C.Structure):
-    _fields_ = [("problem", C.c_uint32), ("src_end", C.c_uint32), ("dst_end", C.c_uint32), ("len", C.c_uint32)]
+    _fields_ = [("problem", C.c_uint32), ("src_end", C.c_uint32), ("dst_end", C.c_uint32), ("len", C.c_uint32),
+                ("src_match_hash", C.c_uint32), ("dst_match_hash", C.c_uint32)]
 
 
 class CSearchResult(C.Structure):
@@ -55,7 +56,9 @@ class CSearchResult(C.Structure):
                 ("ending_start_ns", C.c_uint64), ("ending_end_ns", C.c_uint64)]
 
 
-RUN_DTYPE = np.dtype([("problem", "<u4"), ("src_end", "<u4"), ("dst_end", "<u4"), ("len", "<u4")])
+RUN_DTYPE = np.dtype([("problem", "<u4"), ("src_end", "<u4"), ("dst_end", "<u4"), ("len", "<u4"),
+                      ("src_match_hash", "<u4"), ("dst_match_hash", "<u4")])
+RUN_WORDS = 6
 
 # Every symbol include/needle.h and include/needle_hip.h declare (tests check the library exports all).
 NEEDLE_H_SYMBOLS = [

@@ -121,7 +121,6 @@ void Comparator::entries_from_runs(std::vector<NeedleHipRun> runs, const std::ve
     return a.src_end != b.src_end ? a.src_end > b.src_end : a.dst_end > b.dst_end;
   });
   const ns_t min_duration = is_opening ? min_opening_duration_ : min_ending_duration_;
-  std::vector<uint32_t> tmp;
   for (const NeedleHipRun &r : runs) {
     const size_t i = r.src_end, j = r.dst_end, len = r.len;
     if (len == 0 || len > i || len > j || i >= src.size() || j >= dst.size()) continue;  // cannot happen
@@ -135,11 +134,9 @@ void Comparator::entries_from_runs(std::vector<NeedleHipRun> runs, const std::ve
     e.src_end = src_end;
     e.dst_start = dst_start;
     e.dst_end = dst_end;
-    tmp.resize(len + 1);  // simhash over [start_idx ..= end_idx], L+1 hashes (:149-153,226-229)
-    for (size_t k = 0; k <= len; k++) tmp[k] = src[si + k].hash;
-    e.src_match_hash = simhash32(tmp.data(), len + 1);
-    for (size_t k = 0; k <= len; k++) tmp[k] = dst[sj + k].hash;
-    e.dst_match_hash = simhash32(tmp.data(), len + 1);
+    // simhash32 over [start_idx ..= end_idx] (L+1 hashes, :149-153,226-229) arrives with the run
+    e.src_match_hash = r.src_match_hash;
+    e.dst_match_hash = r.dst_match_hash;
     e.is_opening = is_opening;
     e.src_hash_duration = src_hash_duration;
     e.dst_hash_duration = dst_hash_duration;

@@ -206,23 +206,6 @@ enum NeedleError needle_hip_library_search(NeedleHipLibrary *lib, const struct N
   });
 }
 
-static NeedleError library_frame_hashes(NeedleHipLibrary *lib, std::vector<FrameHashesData> *out) {
-  std::vector<uint32_t> host(lib->n * lib->stride);
-  hipStream_t stream = library_stream();
-  if (hipMemcpyAsync(host.data(), lib->arena, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream) !=
-          hipSuccess ||
-      hipStreamSynchronize(stream) != hipSuccess)
-    return report(Status::Make(NeedleError_Unknown, "hash arena download failed"));
-  out->assign(lib->n, {});
-  for (size_t v = 0; v < lib->n; v++) {
-    FrameHashesData &fh = (*out)[v];
-    fh.opening = lib->timestamps(lib->kept[v]);
-    for (uint32_t k = 0; k < lib->kept[v]; k++) fh.opening[k].hash = host[v * lib->stride + k];
-    fh.hash_duration = lib->hash_duration;
-  }
-  return NeedleError_Ok;
-}
-
 enum NeedleError needle_hip_library_finalize(NeedleHipLibrary *lib, const struct NeedleAudioComparator *comparator,
                                              const NeedleHipRun *runs, size_t num_runs,
                                              NeedleHipSearchResult *results) {
@@ -230,9 +213,12 @@ enum NeedleError needle_hip_library_finalize(NeedleHipLibrary *lib, const struct
   if (!lib->have_pcm) return NeedleError_InvalidArgument;
   return guarded([&]() -> NeedleError {
     const Comparator &cmp = comparator_of(comparator);
-    std::vector<FrameHashesData> data;
-    NeedleError e = library_frame_hashes(lib, &data);
-    if (e != NeedleError_Ok) return e;
+    // the epilogue needs timestamps only: the runs carry their simhashes, so the hash arena stays in HBM
+    std::vector<FrameHashesData> data(lib->n);
+    for (size_t v = 0; v < lib->n; v++) {
+      data[v].opening = lib->timestamps(lib->kept[v]);
+      data[v].hash_duration = lib->hash_duration;
+    }
     std::vector<const FrameHashesData *> fh;
     for (const FrameHashesData &d : data) fh.push_back(&d);
     std::vector<NeedleHipRun> run_vec(runs, runs + num_runs);

@@ -13,6 +13,7 @@
 #include "hipctx.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -21,6 +22,8 @@ namespace needle {
 namespace {
 
 constexpr int kDiagsPerBlock = 256;
+constexpr int kBandR = 7, kBandU = 3;          // band kernel: 7 diagonals per lane, checkpoint every 21 rows
+constexpr int kBandB = 64 * kBandR;
 
 struct SearchProblem {
   uint32_t src_off, n;  // hash arena offset + length of the source sequence
@@ -66,14 +69,160 @@ __global__ __launch_bounds__(256) void hamming_runs_kernel(const uint32_t *__res
     } else {
       if (run >= min_len) {  // run ended at the previous cell
         const uint32_t slot = atomicAdd(count, 1u);
-        if (slot < capacity) runs[slot] = NeedleHipRun{pr.tag, (uint32_t)(i - 1), (uint32_t)(i - 1 + d), run};
+        if (slot < capacity) runs[slot] = NeedleHipRun{(uint32_t)lo, (uint32_t)(i - 1), (uint32_t)(i - 1 + d), run, 0u, 0u};
       }
       run = 0;
     }
   }
   if (run >= min_len) {  // run reaches the table edge (i == n-1 or j == m-1, comparator.rs:197)
     const uint32_t slot = atomicAdd(count, 1u);
-    if (slot < capacity) runs[slot] = NeedleHipRun{pr.tag, (uint32_t)i_hi, (uint32_t)(i_hi + d), run};
+    if (slot < capacity) runs[slot] = NeedleHipRun{(uint32_t)lo, (uint32_t)i_hi, (uint32_t)(i_hi + d), run, 0u, 0u};
+  }
+}
+
+// ---- fast path: register-window band scan ------------------------------------------------------------------
+// One wave owns a band of B = 64*R consecutive diagonals, lane l the R diagonals d_l + r (d_l = D0 + l*R).
+// At row i the lane holds the window W[r] = dst[i + d_l + r] in registers; moving to row i+1 the window
+// slides by one element, so with the row loop unrolled R-fold the registers are simply renamed and ONE new
+// element per lane per row comes from LDS (lane stride R dwords: conflict-free for odd R).  src[i] is
+// wave-uniform and comes through the scalar cache.  Per cell that leaves xor, popcount, compare, and one
+// select that keeps Z[r] = the last row at which diagonal r mismatched (run length = row - Z[r]).
+//
+// No per-cell bounds masking: the band is a parallelogram, so near the table edges some cells lie outside
+// rows/cols [1, n-1] x [1, m-1]; they are computed on zero padding (or on row/col 0) and can only EXTEND a
+// run backwards.  Exactness is restored where runs are reported: every K rows (a "checkpoint") a lane whose
+// current run is >= min_len - K + 1 walks forward from the checkpoint with explicit bounds to find the true
+// end of the run, clamps the start to the valid range, and emits it iff it is the last checkpoint inside
+// the run (so each maximal run with L >= min_len >= K is emitted exactly once).
+template <int R, int U>
+__global__ __launch_bounds__(256) void hamming_runs_band_kernel(const uint32_t *__restrict__ hashes,
+                                                                const SearchProblem *__restrict__ problems,
+                                                                int num_problems, uint32_t threshold,
+                                                                NeedleHipRun *__restrict__ runs, uint32_t capacity,
+                                                                uint32_t *__restrict__ count) {
+  constexpr int K = R * U;   // rows per checkpoint
+  constexpr int B = 64 * R;  // diagonals per wave
+  extern __shared__ uint32_t lds[];
+  int lo = 0, hi = num_problems - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (problems[mid].block_base <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SearchProblem pr = problems[lo];
+  const int n = (int)pr.n, m = (int)pr.m;
+  const uint32_t *__restrict__ src = hashes + pr.src_off;
+  const uint32_t *__restrict__ dst = hashes + pr.dst_off;
+  // dst staged with B zero-padded slots on both sides: lds[B + j] = dst[j]
+  for (int k = threadIdx.x; k < m + 2 * B; k += blockDim.x) {
+    const int j = k - B;
+    lds[k] = (j >= 0 && j < m) ? dst[j] : 0u;
+  }
+  __syncthreads();
+
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  const int band = (int)(blockIdx.x - pr.block_base) * 4 + wave;
+  const int D0 = band * B - (n - 2);  // first diagonal of the band
+  if (D0 > m - 2) return;
+  const int i_start = max(1, 2 - D0 - B);   // first row on which some diagonal of the band has j >= 1
+  const int i_end = min(n - 1, m - 1 - D0); // last row on which some diagonal of the band has j <= m-1
+  if (i_start > i_end) return;
+  const int d_l = D0 + lane * R;
+  const int min_len = (int)pr.min_len;
+  const int flag_len = min_len - K + 1;     // >= 1: the host only selects this kernel when min_len >= K
+
+  uint32_t W[R];
+  int Z[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    W[r] = lds[B + i_start + d_l + r];
+    Z[r] = i_start - 1;
+  }
+
+  auto checkpoint = [&](int c) {
+    // c = row just processed.  Lanes with a long enough current run resolve it exactly.
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (c - Z[r] >= flag_len) {
+        const int d = d_l + r;
+        const int ilo = d < 0 ? 1 - d : 1;
+        const int ihi = min(n - 1, m - 1 - d);
+        if (c >= ilo && c <= ihi) {
+          const int a = max(Z[r] + 1, ilo);  // first matched row of the real run
+          const int limit = min(ihi, c + K);
+          int e = c + 1;
+          while (e <= limit && (uint32_t)__popc(src[e] ^ lds[B + e + d]) <= threshold) e++;
+          const bool reaches_next_checkpoint = (e > limit) && (limit == c + K);
+          if (!reaches_next_checkpoint) {
+            const int b = e - 1;
+            const int len = b - a + 1;
+            if (len >= min_len) {
+              const uint32_t slot = atomicAdd(count, 1u);
+              if (slot < capacity) runs[slot] = NeedleHipRun{(uint32_t)lo, (uint32_t)b, (uint32_t)(b + d), (uint32_t)len, 0u, 0u};
+            }
+          }
+        }
+      }
+    }
+  };
+
+  int i = i_start;
+  for (; i + K - 1 <= i_end; i += K) {
+    const uint32_t *__restrict__ nxt = lds + (B + i + d_l + R);  // element entering the window after row i
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+      const int row = i + s;
+      const uint32_t sv = src[row];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const uint32_t c = (uint32_t)__popc(sv ^ W[(r + s) % R]);
+        Z[r] = (c <= threshold) ? Z[r] : row;
+        if (r == 0) W[s % R] = nxt[s];  // slot of the consumed oldest element takes the newest
+      }
+    }
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < R; r++) any |= (i + K - 1 - Z[r] >= flag_len);
+    if (__any(any)) checkpoint(i + K - 1);
+  }
+  // remainder (< K rows), rolled: window kept in order W[0..R-1] again (K is a multiple of R)
+  for (; i <= i_end; i++) {
+    const uint32_t sv = src[i];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const uint32_t c = (uint32_t)__popc(sv ^ W[r]);
+      Z[r] = (c <= threshold) ? Z[r] : i;
+    }
+#pragma unroll
+    for (int r = 0; r + 1 < R; r++) W[r] = W[r + 1];
+    W[R - 1] = lds[B + i + d_l + R];
+  }
+}
+
+// ---- simhash of every emitted run (comparator.rs:149-153,226-229) -----------------------------------------------
+// The scan kernels leave NeedleHipRun.problem = index of the problem descriptor; this pass computes
+// chromaprint's simhash32 over the L+1 hashes [end-len ..= end] of both sequences and replaces the index by
+// the caller's tag.  One wave per run: lanes 0-31 count bit `lane` over the source slice, lanes 32-63 over
+// the destination slice; bit set iff ones > zeros (a tie leaves it clear), collected with one ballot.
+__global__ __launch_bounds__(256) void simhash_runs_kernel(const uint32_t *__restrict__ hashes,
+                                                           const SearchProblem *__restrict__ problems,
+                                                           NeedleHipRun *__restrict__ runs, uint32_t capacity,
+                                                           const uint32_t *__restrict__ count) {
+  const uint32_t total = min(*count, capacity);
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63, bit = lane & 31;
+  for (uint32_t k = wave; k < total; k += waves) {
+    const NeedleHipRun r = runs[k];
+    const SearchProblem pr = problems[r.problem];
+    const uint32_t *base = lane < 32 ? hashes + pr.src_off + (r.src_end - r.len) : hashes + pr.dst_off + (r.dst_end - r.len);
+    uint32_t ones = 0;
+    for (uint32_t q = 0; q <= r.len; q++) ones += (base[q] >> bit) & 1u;
+    const unsigned long long mask = __ballot(2u * ones > r.len + 1u);
+    if (lane == 0) {
+      runs[k].problem = pr.tag;
+      runs[k].src_match_hash = (uint32_t)mask;
+      runs[k].dst_match_hash = (uint32_t)(mask >> 32);
+    }
   }
 }
 
@@ -132,10 +281,31 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
     meta.push_back(m);
   }
   if (blocks > 0x7FFFFFFFull) return Status::Make(NeedleError_InvalidArgument, "hamming_runs: too many problems for one launch");
-  if (max_lds > 160 * 1024)
-    return Status::Make(NeedleError_InvalidArgument,
-                        "hamming_runs: a sequence pair exceeds the 160 KiB LDS staging limit (40960 hashes)");
   if (!meta.empty()) {
+    // The band kernel needs min_len >= its checkpoint spacing for every problem; otherwise (tiny minimum
+    // durations) the general one-lane-per-diagonal kernel handles the launch.
+    uint32_t smallest = 0xFFFFFFFFu;
+    size_t max_m = 0;
+    for (const SearchProblem &m : meta) {
+      smallest = std::min(smallest, m.min_len);
+      max_m = std::max<size_t>(max_m, m.m);
+    }
+    const bool fast = smallest >= (uint32_t)(kBandR * kBandU) && !getenv("NEEDLE_HIP_GENERIC_SEARCH");
+    size_t lds_bytes = max_lds;
+    if (fast) {
+      uint64_t fb = 0;
+      for (SearchProblem &m : meta) {
+        m.block_base = (uint32_t)fb;
+        const uint64_t diags = (uint64_t)m.n + m.m - 3;
+        const uint64_t bands = (diags + kBandB - 1) / kBandB;
+        fb += (bands + 3) / 4;
+      }
+      blocks = fb;
+      lds_bytes = (max_m + 2 * kBandB) * sizeof(uint32_t);
+    }
+    if (lds_bytes > 160 * 1024)
+      return Status::Make(NeedleError_InvalidArgument,
+                          "hamming_runs: a sequence pair exceeds the 160 KiB LDS staging limit (~40000 hashes)");
     SearchWorkspace *ws = workspace();
     if (!(s = ws->problems.reserve(meta.size())).ok()) return s;
     if (!(s = ws->stage.acquire(meta.size() * sizeof(SearchProblem))).ok()) return s;
@@ -143,15 +313,26 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
     NEEDLE_HIP_TRY(hipMemcpyAsync(ws->problems.ptr, ws->stage.ptr, meta.size() * sizeof(SearchProblem),
                                   hipMemcpyHostToDevice, stream));
     ws->stage.mark(stream);
-    if (max_lds > 64 * 1024 && !g_lds_attr_set) {
+    if (lds_bytes > 64 * 1024 && !g_lds_attr_set) {
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_band_kernel<kBandR, kBandU>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       g_lds_attr_set = true;
     }
     {
       KernelTimer timer("hamming_runs");
-      hipLaunchKernelGGL(hamming_runs_kernel, dim3((uint32_t)blocks), dim3(256), max_lds, stream, d_hashes,
-                         ws->problems.ptr, (int)meta.size(), threshold, d_runs, capacity, d_count);
+      if (fast)
+        hipLaunchKernelGGL((hamming_runs_band_kernel<kBandR, kBandU>), dim3((uint32_t)blocks), dim3(256), lds_bytes,
+                           stream, d_hashes, ws->problems.ptr, (int)meta.size(), threshold, d_runs, capacity, d_count);
+      else
+        hipLaunchKernelGGL(hamming_runs_kernel, dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
+                           ws->problems.ptr, (int)meta.size(), threshold, d_runs, capacity, d_count);
+    }
+    {
+      KernelTimer timer("simhash_runs");
+      hipLaunchKernelGGL(simhash_runs_kernel, dim3(256), dim3(256), 0, stream, d_hashes, ws->problems.ptr, d_runs,
+                         capacity, d_count);
     }
     NEEDLE_HIP_TRY(hipGetLastError());
   }

@@ -52,7 +52,7 @@ def gather_rows(arena, world: int, rank: int):
 
 
 def gather_runs(local_runs, world: int):
-    """All-gather variable-length run lists.  `local_runs` is a torch tensor [k, 4] (u32 stored as int32) on the
+    """All-gather variable-length run lists.  `local_runs` is a torch tensor [k, words] (u32 stored as int32) on the
     collective's device.  Returns the concatenation over ranks, in rank order, on the same device."""
     import torch
     import torch.distributed as dist
@@ -63,9 +63,10 @@ def gather_runs(local_runs, world: int):
     dist.all_gather_into_tensor(counts, count)
     counts = counts.cpu().tolist()
     width = max(max(counts), 1)
-    padded = torch.zeros((width, 4), dtype=local_runs.dtype, device=local_runs.device)
+    cols = local_runs.shape[1]
+    padded = torch.zeros((width, cols), dtype=local_runs.dtype, device=local_runs.device)
     padded[: local_runs.shape[0]] = local_runs
-    out = torch.zeros((world * width, 4), dtype=local_runs.dtype, device=local_runs.device)
+    out = torch.zeros((world * width, cols), dtype=local_runs.dtype, device=local_runs.device)
     dist.all_gather_into_tensor(out, padded)
     return torch.cat([out[r * width: r * width + counts[r]] for r in range(world)], dim=0)
 

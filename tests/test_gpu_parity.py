@@ -93,14 +93,16 @@ def _oracle_runs(src, dst, thr, min_len):
     cmp = O.Comparator(hash_match_threshold=thr, min_opening_duration=0)
     ents = O.longest_common_hash_match(cmp, [(int(h), i) for i, h in enumerate(src)],
                                        [(int(h), i) for i, h in enumerate(dst)], 0, 0)
-    return sorted((e["src_end_idx"], e["dst_end_idx"], e["score"]) for e in ents if e["score"] >= min_len)
+    return sorted((e["src_end_idx"], e["dst_end_idx"], e["score"], e["src_match_hash"], e["dst_match_hash"])
+                  for e in ents if e["score"] >= min_len)
 
 
 def _gpu_runs(seqs, problems, thr):
     r = capi.hamming_runs(seqs, problems, thr)
     out = {}
     for x in r:
-        out.setdefault(int(x["problem"]), []).append((int(x["src_end"]), int(x["dst_end"]), int(x["len"])))
+        out.setdefault(int(x["problem"]), []).append((int(x["src_end"]), int(x["dst_end"]), int(x["len"]),
+                                                      int(x["src_match_hash"]), int(x["dst_match_hash"])))
     return {k: sorted(v) for k, v in out.items()}
 
 
@@ -120,6 +122,49 @@ def test_hamming_runs_equal_reference_dp(n, m):
     min_len = 3 if n * m > 4_000_000 else 1     # keep the big cases' run lists (2.5 % random matches) short
     got = _gpu_runs([src, dst], [(0, 1, min_len)], thr).get(0, [])
     assert got == _oracle_runs(src, dst, thr, min_len)
+
+
+@pytest.mark.parametrize("n,m,min_len", [(2897, 2897, 82), (5441, 2715, 41), (2715, 5441, 21), (500, 449, 21),
+                                         (449, 460, 25), (30, 3000, 21), (3000, 30, 21), (22, 22, 21), (2, 2, 21)])
+def test_band_kernel_equals_reference_dp(n, m, min_len):
+    """min_len >= 21 selects the register-window band kernel.  Planted runs sit on every kind of edge: starting
+    at row/col 1, ending at n-1 / m-1, crossing checkpoint rows, exactly min_len and min_len-1 long, and
+    preceded by matches in row/col 0 (which the reference never counts, comparator.rs:179-180)."""
+    rng = np.random.default_rng(n * 7 + m * 3 + min_len)
+    src, dst = _rand_hashes(rng, n), _rand_hashes(rng, m)
+
+    def plant(a, b, L):
+        L = min(L, n - a, m - b)
+        if L > 0:
+            noise = (np.uint32(1) << rng.integers(0, 32, L).astype(np.uint32)) * (rng.random(L) < 0.5)
+            dst[b:b + L] = src[a:a + L] ^ noise
+    for (a, b, L) in [(0, 0, min_len + 5), (n - min_len - 3, m - min_len - 3, min_len + 3), (0, m // 2, min_len),
+                      (n // 2, 0, min_len + 1), (n // 3, m // 3, min_len - 1), (n // 4, m // 2 + 7, 3 * min_len),
+                      (1, m - min_len - 1, min_len + 1), (n - min_len - 1, 1, min_len + 1)]:
+        if a >= 0 and b >= 0:
+            plant(a, b, L)
+    thr = 10
+    got = _gpu_runs([src, dst], [(0, 1, min_len)], thr).get(0, [])
+    want = _oracle_runs(src, dst, thr, min_len)
+    assert got == want
+    if n > 400 and m > 400:
+        assert len(want) >= 4
+
+
+def test_band_kernel_all_cells_match_and_many_problems():
+    rng = np.random.default_rng(77)
+    # threshold >= 32: every cell with i, j >= 1 matches; each diagonal is one run as long as the diagonal
+    src, dst = _rand_hashes(rng, 300), _rand_hashes(rng, 260)
+    for thr in (32, 65535):
+        assert _gpu_runs([src, dst], [(0, 1, 30)], thr).get(0, []) == _oracle_runs(src, dst, thr, 30)
+    seqs = [_rand_hashes(rng, int(k)) for k in rng.integers(40, 900, 8)]
+    for k in range(0, 8, 2):
+        L = min(len(seqs[k]), len(seqs[k + 1])) - 3
+        seqs[k + 1][2:2 + L] = seqs[k][1:1 + L]
+    problems = [(a, b, 21 + (a * 5 + b) % 40) for a in range(8) for b in range(8) if a != b]
+    got = _gpu_runs(seqs, problems, 9)
+    for p, (a, b, ml) in enumerate(problems):
+        assert got.get(p, []) == _oracle_runs(seqs[a], seqs[b], 9, ml), (p, a, b)
 
 
 def test_hamming_runs_thresholds_and_min_len():
@@ -285,7 +330,7 @@ def test_config2_full_size_parity(lib28):
     cmp = capi.Comparator([f"ep{k}.wav" for k in range(n)])
     cmp.handle()
     cap = 1 << 16
-    d_runs, d_count = capi.DeviceBuffer(cap * 16), capi.DeviceBuffer(4)
+    d_runs, d_count = capi.DeviceBuffer(cap * capi.RUN_DTYPE.itemsize), capi.DeviceBuffer(4)
     lib.search(cmp, 0, lib.num_pairs(), d_runs.ptr, cap, d_count.ptr)
     count = int(d_count.to_host(np.uint32, 1)[0])
     assert 0 < count <= cap
