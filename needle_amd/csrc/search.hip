@@ -24,6 +24,7 @@ namespace {
 constexpr int kDiagsPerBlock = 256;
 constexpr int kBandR = 7, kBandU = 3;          // band kernel: 7 diagonals per lane, checkpoint every 21 rows
 constexpr int kBandB = 64 * kBandR;
+constexpr int kSampleW = 8;                     // sampled kernel: rows per aligned window
 
 struct SearchProblem {
   uint32_t src_off, n;  // hash arena offset + length of the source sequence
@@ -199,6 +200,130 @@ __global__ __launch_bounds__(256) void hamming_runs_band_kernel(const uint32_t *
   }
 }
 
+// ---- sampled path: aligned-window candidates + exact cooperative resolution ------------------------------------
+// A maximal run of L >= min_len cells on a diagonal covers at least one ALIGNED window of W rows out of every
+// P = min_len - W + 1 rows (windows at rows [1 + kP, 1 + kP + W)): any W + P - 1 = min_len consecutive rows
+// contain one.  So only W of every P rows are evaluated — for each (diagonal, window) the AND of its W cell
+// tests — and a diagonal/window whose W cells all match is a candidate.  Candidates are rare; each one is
+// resolved exactly by the whole wave: 64 cells at a time are tested forwards and backwards from the window
+// with explicit bounds, giving the true maximal run [a, b]; it is emitted by the LAST aligned window it
+// covers, so exactly once, and only if b - a + 1 >= min_len.  Nothing is approximated: the output equals
+// the reference's table walk (comparator.rs:191-247) for every run long enough to matter.
+//
+// Per evaluated cell: v_xor, v_bcnt, v_cmp (+ one scalar AND of lane masks); at the default 20 s minimum
+// (min_len 82, W 8, P 75) that is 3 VALU on 10.7 % of the cells instead of 4 VALU on all of them.
+template <int R, int W>
+__global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_t *__restrict__ hashes,
+                                                                   const SearchProblem *__restrict__ problems,
+                                                                   int num_problems, uint32_t threshold,
+                                                                   NeedleHipRun *__restrict__ runs,
+                                                                   uint32_t capacity, uint32_t *__restrict__ count) {
+  constexpr int B = 64 * R;
+  extern __shared__ uint32_t lds[];
+  int lo = 0, hi = num_problems - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (problems[mid].block_base <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SearchProblem pr = problems[lo];
+  const int n = (int)pr.n, m = (int)pr.m;
+  const uint32_t *__restrict__ src = hashes + pr.src_off;
+  const uint32_t *__restrict__ dst = hashes + pr.dst_off;
+  // LDS: dst with B zero slots on both sides (ldst[B + j] = dst[j]), then src (lsrc[i] = src[i])
+  uint32_t *ldst = lds, *lsrc = lds + (m + 2 * B);
+  for (int k = threadIdx.x; k < m + 2 * B; k += blockDim.x) {
+    const int j = k - B;
+    ldst[k] = (j >= 0 && j < m) ? dst[j] : 0u;
+  }
+  for (int k = threadIdx.x; k < n; k += blockDim.x) lsrc[k] = src[k];
+  __syncthreads();
+
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  const int band = (int)(blockIdx.x - pr.block_base) * 4 + wave;
+  const int D0 = band * B - (n - 2);
+  if (D0 > m - 2) return;
+  const int i_start = max(1, 2 - D0 - B);
+  const int i_end = min(n - 1, m - 1 - D0);
+  const int min_len = (int)pr.min_len;
+  const int P = min_len - W + 1;  // >= W: the host selects this kernel only when min_len >= 2W - 1
+  const int d_l = D0 + lane * R;
+
+  // first aligned window (rows 1 + kP ...) that starts at or after i_start
+  int k0 = (i_start - 1 + P - 1) / P;
+  for (int w0 = 1 + k0 * P; w0 + W - 1 <= i_end; w0 += P) {
+    // the W + R - 1 destination hashes this lane's R diagonals meet in rows w0 .. w0+W-1
+    uint32_t E[W + R - 1];
+#pragma unroll
+    for (int q = 0; q < W + R - 1; q++) E[q] = ldst[B + w0 + d_l + q];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) ok[r] = true;
+#pragma unroll
+    for (int s = 0; s < W; s++) {
+      const uint32_t sv = src[w0 + s];
+#pragma unroll
+      for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv ^ E[s + r]) <= threshold);
+    }
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < R; r++) any |= ok[r];
+    if (!__any(any)) continue;
+
+    // ---- candidates: resolved one at a time by the whole wave ----
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      unsigned long long cand = __ballot(ok[r]);
+      while (cand) {
+        const int src_lane = __ffsll((long long)cand) - 1;
+        cand &= cand - 1;
+        const int d = D0 + src_lane * R + r;       // wave-uniform
+        const int ilo = d < 0 ? 1 - d : 1;
+        const int ihi = min(n - 1, m - 1 - d);
+        if (w0 < ilo || w0 + W - 1 > ihi) continue;  // window not inside the table on this diagonal
+        // forwards from the window: first mismatching row after it (or ihi + 1)
+        int e = w0 + W;
+        bool ended = false;
+        const int fwd_limit = min(ihi, w0 + P + W - 1);  // last row of the NEXT aligned window
+        while (e <= fwd_limit) {
+          const int row = e + lane;
+          const bool bad = row <= fwd_limit && (uint32_t)__popc(lsrc[row] ^ ldst[B + row + d]) > threshold;
+          const unsigned long long mm = __ballot(bad);
+          if (mm) {
+            e += __ffsll((long long)mm) - 1;
+            ended = true;
+            break;
+          }
+          e += 64;
+        }
+        if (!ended) {
+          if (fwd_limit == w0 + P + W - 1) continue;  // the run also covers the next window: it reports the run
+          e = ihi + 1;                                  // the run reaches the table edge (comparator.rs:197)
+        }
+        const int b = e - 1;
+        // backwards from the window: last mismatching row before it (or ilo - 1)
+        int a = ilo;
+        int q = w0 - 1;
+        while (q >= ilo) {
+          const int row = q - lane;
+          const bool bad = row >= ilo && (uint32_t)__popc(lsrc[row] ^ ldst[B + row + d]) > threshold;
+          const unsigned long long mm = __ballot(bad);
+          if (mm) {
+            a = q - (__ffsll((long long)mm) - 1) + 1;
+            break;
+          }
+          q -= 64;
+        }
+        const int len = b - a + 1;
+        if (len >= min_len && lane == 0) {
+          const uint32_t slot = atomicAdd(count, 1u);
+          if (slot < capacity) runs[slot] = NeedleHipRun{(uint32_t)lo, (uint32_t)b, (uint32_t)(b + d), (uint32_t)len, 0u, 0u};
+        }
+      }
+    }
+  }
+}
+
 // ---- simhash of every emitted run (comparator.rs:149-153,226-229) -----------------------------------------------
 // The scan kernels leave NeedleHipRun.problem = index of the problem descriptor; this pass computes
 // chromaprint's simhash32 over the L+1 hashes [end-len ..= end] of both sequences and replaces the index by
@@ -290,18 +415,22 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
       smallest = std::min(smallest, m.min_len);
       max_m = std::max<size_t>(max_m, m.m);
     }
-    const bool fast = smallest >= (uint32_t)(kBandR * kBandU) && !getenv("NEEDLE_HIP_GENERIC_SEARCH");
+    const bool generic_only = getenv("NEEDLE_HIP_GENERIC_SEARCH") != nullptr;
+    const bool sampled = !generic_only && smallest >= (uint32_t)(2 * kSampleW - 1 + 8) && !getenv("NEEDLE_HIP_BAND_SEARCH");
+    const bool fast = !generic_only && !sampled && smallest >= (uint32_t)(kBandR * kBandU);
     size_t lds_bytes = max_lds;
-    if (fast) {
+    if (fast || sampled) {
       uint64_t fb = 0;
+      size_t need = 0;
       for (SearchProblem &m : meta) {
         m.block_base = (uint32_t)fb;
         const uint64_t diags = (uint64_t)m.n + m.m - 3;
         const uint64_t bands = (diags + kBandB - 1) / kBandB;
         fb += (bands + 3) / 4;
+        need = std::max<size_t>(need, (size_t)m.m + 2 * kBandB + (sampled ? m.n : 0));
       }
       blocks = fb;
-      lds_bytes = (max_m + 2 * kBandB) * sizeof(uint32_t);
+      lds_bytes = need * sizeof(uint32_t);
     }
     if (lds_bytes > 160 * 1024)
       return Status::Make(NeedleError_InvalidArgument,
@@ -318,11 +447,17 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_band_kernel<kBandR, kBandU>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_sampled_kernel<kBandR, kSampleW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       g_lds_attr_set = true;
     }
     {
       KernelTimer timer("hamming_runs");
-      if (fast)
+      if (sampled)
+        hipLaunchKernelGGL((hamming_runs_sampled_kernel<kBandR, kSampleW>), dim3((uint32_t)blocks), dim3(256),
+                           lds_bytes, stream, d_hashes, ws->problems.ptr, (int)meta.size(), threshold, d_runs,
+                           capacity, d_count);
+      else if (fast)
         hipLaunchKernelGGL((hamming_runs_band_kernel<kBandR, kBandU>), dim3((uint32_t)blocks), dim3(256), lds_bytes,
                            stream, d_hashes, ws->problems.ptr, (int)meta.size(), threshold, d_runs, capacity, d_count);
       else
