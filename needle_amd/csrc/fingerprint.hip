@@ -33,11 +33,15 @@ struct FpStream {
   uint32_t fir_base;
   uint32_t kept;
   uint32_t kept_base;
+  uint32_t pair_base;   // prefix of ceil(frames / 2): the STFT kernel transforms two frames per FFT
+  uint32_t pad;
 };
 
 // ---- constant tables, generated on the host in double and uploaded once per device --------------------
 struct FpTables {
   cd *tw = nullptr;                 // [4096] e^{-2 pi i k/4096}
+  cd *tw0 = nullptr;                // [15][256] W_4096^{t j}      pass-0 twiddles, lane-contiguous
+  cd *tw1 = nullptr;                // [15][16]  W_4096^{16 p j}   pass-1 twiddles
   double *window = nullptr;         // [4096] Hamming / 32767
   uint16_t *class_bins = nullptr;   // [kNumBins] spectrum bins grouped by pitch class
   uint32_t *class_start = nullptr;  // [13]
@@ -92,7 +96,16 @@ Status get_tables(FpTables *out) {
   for (int i = 0; i < 16; i++)
     for (int j = 0; j < 3; j++) thr.e[i][j] = std::exp(kThresholds[i][j]);
 
+  std::vector<cd> tw0(15 * 256), tw1(15 * 16);
+  for (int j = 1; j < 16; j++) {
+    for (int q = 0; q < 256; q++) tw0[(j - 1) * 256 + q] = tw[(q * j) & 4095];
+    for (int q = 0; q < 16; q++) tw1[(j - 1) * 16 + q] = tw[(16 * q * j) & 4095];
+  }
   FpTables t;
+  NEEDLE_HIP_TRY(hipMalloc((void **)&t.tw0, tw0.size() * sizeof(cd)));
+  NEEDLE_HIP_TRY(hipMalloc((void **)&t.tw1, tw1.size() * sizeof(cd)));
+  NEEDLE_HIP_TRY(hipMemcpy(t.tw0, tw0.data(), tw0.size() * sizeof(cd), hipMemcpyHostToDevice));
+  NEEDLE_HIP_TRY(hipMemcpy(t.tw1, tw1.data(), tw1.size() * sizeof(cd), hipMemcpyHostToDevice));
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.tw, tw.size() * sizeof(cd)));
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.window, window.size() * sizeof(double)));
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.class_bins, bins.size() * sizeof(uint16_t)));
@@ -119,75 +132,88 @@ __device__ __forceinline__ int find_stream(const FpStream *streams, int n, uint3
   return lo;
 }
 
-// ---- kernel 1: one 256-thread workgroup per frame (grid-stride over frames) -----------------------------
-__global__ __launch_bounds__(256) void stft_chroma_kernel(const int16_t *__restrict__ pcm,
-                                                          const FpStream *__restrict__ streams, int num_streams,
-                                                          int channels, const cd *__restrict__ tw,
-                                                          const double *__restrict__ window,
-                                                          const uint16_t *__restrict__ class_bins,
-                                                          const uint32_t *__restrict__ class_start,
-                                                          double *__restrict__ chroma, uint32_t total_frames) {
-  __shared__ cd lds[core::kFftN];
+// ---- kernel 1: one 256-thread workgroup per PAIR of consecutive frames ---------------------------------------
+// z = frameA + i*frameB through one 4096-point complex FFT (fp_core.h, radix 16 x 3, padded LDS), split into
+// the two real spectra, |X|^2 over bins 10..1307 folded into 12 pitch classes per frame.  A workgroup walks
+// kPairsPerBlock CONSECUTIVE pairs of one region of the batch, so the 3x overlap between neighbouring frames
+// (hop 1365 of 4096) is re-read from this XCD's L2 rather than from HBM.
+constexpr int kPairsPerBlock = 16;
+
+__global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__restrict__ pcm,
+                                                             const FpStream *__restrict__ streams, int num_streams,
+                                                             int channels, const cd *__restrict__ tw0,
+                                                             const cd *__restrict__ tw1,
+                                                             const double *__restrict__ window,
+                                                             const uint16_t *__restrict__ class_bins,
+                                                             const uint32_t *__restrict__ class_start,
+                                                             double *__restrict__ chroma, uint32_t total_pairs) {
+  extern __shared__ cd lds[];  // core::kLds2Slots complex slots
   const int t = threadIdx.x;
-  for (uint32_t g = blockIdx.x; g < total_frames; g += gridDim.x) {
-    const int si = find_stream<&FpStream::frame_base>(streams, num_streams, g);
+  const uint32_t first = blockIdx.x * kPairsPerBlock;
+  const uint32_t last = min(total_pairs, first + kPairsPerBlock);
+  for (uint32_t g = first; g < last; g++) {
+    const int si = find_stream<&FpStream::pair_base>(streams, num_streams, g);
     const FpStream st = streams[si];
-    const uint32_t f = g - st.frame_base;
-    const int16_t *src = pcm + st.pcm_off + (uint64_t)f * kHop * channels;
+    const uint32_t fa = 2 * (g - st.pair_base);
+    const bool has_b = fa + 1 < st.frames;
+    const int16_t *src_a = pcm + st.pcm_off + (uint64_t)fa * kHop * channels;
+    const int16_t *src_b = src_a + kHop * channels;
 
-    // pass 0 inputs straight from global: z[m] = x[2m] + i x[2m+1], m = t + 256 k
-    cd r[8];
+    cd r[16];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int m = t + 256 * k;
-      int s0, s1;
+    for (int k = 0; k < 16; k++) {
+      const int n = t + 256 * k;
+      int sa, sb = 0;
       if (channels == 1) {
-        s0 = src[2 * m];
-        s1 = src[2 * m + 1];
+        sa = src_a[n];
+        if (has_b) sb = src_b[n];
       } else {  // AudioProcessor::LoadStereo: (L + R) / 2, C truncation
-        s0 = ((int)src[4 * m] + (int)src[4 * m + 1]) / 2;
-        s1 = ((int)src[4 * m + 2] + (int)src[4 * m + 3]) / 2;
+        sa = ((int)src_a[2 * n] + (int)src_a[2 * n + 1]) / 2;
+        if (has_b) sb = ((int)src_b[2 * n] + (int)src_b[2 * n + 1]) / 2;
       }
-      r[k] = cd{(double)s0 * window[2 * m], (double)s1 * window[2 * m + 1]};
+      const double w = window[n];
+      r[k] = cd{(double)sa * w, (double)sb * w};
     }
-    core::pass_compute_write<0>(t, tw, lds, r);
+    core::pass16_compute_write<0>(t, tw0, lds, r);
     __syncthreads();
-    core::pass_read<1>(t, lds, r);
+    core::pass16_read(t, lds, r);
     __syncthreads();
-    core::pass_compute_write<1>(t, tw, lds, r);
+    core::pass16_compute_write<1>(t, tw1, lds, r);
     __syncthreads();
-    core::pass_read<2>(t, lds, r);
+    core::pass16_read(t, lds, r);
     __syncthreads();
-    core::pass_compute_write<2>(t, tw, lds, r);
-    __syncthreads();
-    core::pass3_inplace(t, lds);
+    core::pass16_compute_write<2>(t, nullptr, lds, r);
     __syncthreads();
 
-    // power of this thread's bins, then park them in LDS (aliasing the spectrum) for the class sums
-    double pw[core::kBinsPerThread];
+    double pa[core::kBinsPerThread], pb[core::kBinsPerThread];
 #pragma unroll
     for (int i = 0; i < core::kBinsPerThread; i++) {
       const int k = core::kMinBin + t + 256 * i;
-      pw[i] = (k < core::kMaxBin) ? core::bin_power(k, lds, tw) : 0.0;
+      pa[i] = pb[i] = 0.0;
+      if (k < core::kMaxBin) core::bin_power2(k, lds, &pa[i], &pb[i]);
     }
     __syncthreads();
-    double *plds = reinterpret_cast<double *>(lds);
+    double *plds = reinterpret_cast<double *>(lds);  // frame A powers at [k], frame B at [2048 + k]
 #pragma unroll
     for (int i = 0; i < core::kBinsPerThread; i++) {
       const int k = core::kMinBin + t + 256 * i;
-      if (k < core::kMaxBin) plds[k] = pw[i];
+      if (k < core::kMaxBin) {
+        plds[k] = pa[i];
+        plds[2048 + k] = pb[i];
+      }
     }
     __syncthreads();
-
-    // 12 pitch classes x 16 lanes: strided partial sums, then a fixed-order 16-lane tree
-    if (t < kBands * 16) {
-      const int c = t >> 4, l = t & 15;
+    // 2 frames x 12 pitch classes x 8 lanes: strided partial sums, then a fixed-order 8-lane tree
+    if (t < 2 * kBands * 8) {
+      const int grp = t >> 3, l = t & 7;
+      const int which = grp >= kBands ? 1 : 0, c = grp - which * kBands;
       const uint32_t b0 = class_start[c], b1 = class_start[c + 1];
+      const double *pw = plds + which * 2048;
       double acc = 0.0;
-      for (uint32_t b = b0 + l; b < b1; b += 16) acc += plds[class_bins[b]];
+      for (uint32_t b = b0 + l; b < b1; b += 8) acc += pw[class_bins[b]];
 #pragma unroll
-      for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 16);
-      if (l == 0) chroma[(uint64_t)g * kBands + c] = acc;
+      for (int off = 4; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 8);
+      if (l == 0 && (which == 0 || has_b)) chroma[((uint64_t)st.frame_base + fa + which) * kBands + c] = acc;
     }
     __syncthreads();
   }
@@ -247,6 +273,7 @@ struct FpWorkspace {
   DeviceBuffer<double> chroma, feat;
   DeviceBuffer<FpStream> streams;
   PinnedStage stage;
+  bool lds_attr_set = false;  // the STFT kernel's 68 KiB of dynamic LDS needs an explicit opt-in
 };
 std::mutex g_ws_mu;
 std::map<int, FpWorkspace *> g_ws;
@@ -283,7 +310,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
   size_t begin = 0;
   while (begin < spans.size()) {
     std::vector<FpStream> meta;
-    uint64_t frames = 0, rows = 0, kept = 0;
+    uint64_t frames = 0, rows = 0, kept = 0, pairs = 0;
     size_t end = begin;
     while (end < spans.size()) {
       const size_t samples = spans[end].num_values / (size_t)channels;
@@ -299,6 +326,9 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       m.fir_base = (uint32_t)rows;
       m.kept = (uint32_t)num_kept(samples, step);
       m.kept_base = (uint32_t)kept;
+      m.pair_base = (uint32_t)pairs;
+      m.pad = 0;
+      pairs += (m.frames + 1) / 2;
       frames += m.frames;
       rows += m.fir_rows;
       kept += m.kept;
@@ -316,12 +346,18 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
                                     hipMemcpyHostToDevice, stream));
       ws->stage.mark(stream);
       const int n = (int)meta.size();
+      if (!ws->lds_attr_set) {
+        NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_chroma_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(core::kLds2Slots * sizeof(cd))));
+        ws->lds_attr_set = true;
+      }
       {
         KernelTimer timer("stft_chroma");
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(frames, 256u * 64u);
-        hipLaunchKernelGGL(stft_chroma_kernel, dim3(grid), dim3(256), 0, stream, d_pcm, ws->streams.ptr, n,
-                           channels, tab.tw, tab.window, tab.class_bins, tab.class_start, ws->chroma.ptr,
-                           (uint32_t)frames);
+        const uint32_t grid = (uint32_t)((pairs + kPairsPerBlock - 1) / kPairsPerBlock);
+        hipLaunchKernelGGL(stft_chroma_kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm,
+                           ws->streams.ptr, n, channels, tab.tw0, tab.tw1, tab.window, tab.class_bins,
+                           tab.class_start, ws->chroma.ptr, (uint32_t)pairs);
       }
       if (rows > 0) {
         KernelTimer timer("fir_norm");

@@ -140,6 +140,89 @@ NEEDLE_HD double bin_power(int k, const cd *lds, const cd *tw4096) {
   return xr * xr + xi * xi;
 }
 
+// ================================================================================================
+// v2 transform: TWO real frames per 4096-point complex FFT (z = frameA + i*frameB), radix 16,16,16.
+// 256 threads own one radix-16 butterfly per pass; every pass reads x[t + 256 k] (k = 0..15) and writes
+//   pass 0: y[16 t + j]            * W_4096^{t j}
+//   pass 1: y[q + 256 p + 16 j]    * W_4096^{16 p j}      (p = t / 16, q = t % 16)
+//   pass 2: y[t + 256 j]
+// through one LDS buffer whose index is padded by one slot per 16 (pidx) so that the stride-16 scatter of
+// pass 0 and every 16-lane group of the other accesses are bank-conflict free for 16-byte elements.
+// The split X_A = (Z[k] + conj Z[N-k])/2, X_B = (Z[k] - conj Z[N-k])/(2i) needs no twiddles.
+// ================================================================================================
+constexpr int kFft2N = 4096;
+constexpr int kLds2Slots = kFft2N + kFft2N / 16;  // padded complex slots
+
+NEEDLE_HD int pidx(int i) { return i + (i >> 4); }
+
+NEEDLE_HD void bfly4(cd &a0, cd &a1, cd &a2, cd &a3) {
+  cd e0 = cadd(a0, a2), e1 = csub(a0, a2), e2 = cadd(a1, a3), e3 = mul_neg_i(csub(a1, a3));
+  a0 = cadd(e0, e2);
+  a1 = cadd(e1, e3);
+  a2 = csub(e0, e2);
+  a3 = csub(e1, e3);
+}
+
+// 16-point forward DFT in place.  Output X[k], k = k1 + 4 k2, is left in a[4 k1 + k2]; out16(j) gives the
+// register holding X[j].
+NEEDLE_HD int out16(int j) { return 4 * (j & 3) + (j >> 2); }
+
+NEEDLE_HD void fft16(cd *a) {
+  const double c = 0.92387953251128673848, s = 0.38268343236508977173, h = 0.70710678118654752440;
+  // step 1: 4-point DFTs over n1 for each n2 (x[4 n1 + n2]); result y[n2][k1] -> a[4 k1 + n2]
+#pragma unroll
+  for (int n2 = 0; n2 < 4; n2++) bfly4(a[n2], a[4 + n2], a[8 + n2], a[12 + n2]);
+  // step 2: twiddles W_16^{n2 k1}
+  {
+    cd v;
+    v = a[4 * 1 + 1]; a[4 * 1 + 1] = cd{v.x * c + v.y * s, v.y * c - v.x * s};            // W^1 = (c, -s)
+    v = a[4 * 2 + 1]; a[4 * 2 + 1] = cd{(v.x + v.y) * h, (v.y - v.x) * h};                // W^2 = (h, -h)
+    v = a[4 * 3 + 1]; a[4 * 3 + 1] = cd{v.x * s + v.y * c, v.y * s - v.x * c};            // W^3 = (s, -c)
+    v = a[4 * 1 + 2]; a[4 * 1 + 2] = cd{(v.x + v.y) * h, (v.y - v.x) * h};                // W^2
+    v = a[4 * 2 + 2]; a[4 * 2 + 2] = cd{v.y, -v.x};                                        // W^4 = -i
+    v = a[4 * 3 + 2]; a[4 * 3 + 2] = cd{(v.y - v.x) * h, -(v.x + v.y) * h};               // W^6 = (-h, -h)
+    v = a[4 * 1 + 3]; a[4 * 1 + 3] = cd{v.x * s + v.y * c, v.y * s - v.x * c};            // W^3
+    v = a[4 * 2 + 3]; a[4 * 2 + 3] = cd{(v.y - v.x) * h, -(v.x + v.y) * h};               // W^6
+    v = a[4 * 3 + 3]; a[4 * 3 + 3] = cd{-(v.x * c) - v.y * s, v.x * s - v.y * c};          // W^9 = (-c, s)
+  }
+  // step 3: 4-point DFTs over n2 for each k1
+#pragma unroll
+  for (int k1 = 0; k1 < 4; k1++) bfly4(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);
+}
+
+NEEDLE_HD void pass16_read(int t, const cd *lds, cd *r) {
+#pragma unroll
+  for (int k = 0; k < 16; k++) r[k] = lds[pidx(t + 256 * k)];
+}
+
+// tw: this pass's table laid out [j-1][column] so that lanes read consecutive entries
+template <int PASS>
+NEEDLE_HD void pass16_compute_write(int t, const cd *tw, cd *lds, cd *r) {
+  fft16(r);
+  if (PASS == 0) {
+    lds[pidx(16 * t)] = r[out16(0)];
+#pragma unroll
+    for (int j = 1; j < 16; j++) lds[pidx(16 * t + j)] = cmul(r[out16(j)], tw[(j - 1) * 256 + t]);
+  } else if (PASS == 1) {
+    const int p = t >> 4, q = t & 15;
+    lds[pidx(q + 256 * p)] = r[out16(0)];
+#pragma unroll
+    for (int j = 1; j < 16; j++) lds[pidx(q + 256 * p + 16 * j)] = cmul(r[out16(j)], tw[(j - 1) * 16 + p]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; j++) lds[pidx(t + 256 * j)] = r[out16(j)];
+  }
+}
+
+// powers of bin k for the two frames packed in Z (kMinBin <= k < kMaxBin)
+NEEDLE_HD void bin_power2(int k, const cd *lds, double *pa, double *pb) {
+  const cd z = lds[pidx(k)], y = lds[pidx(kFft2N - k)];
+  const double ar = z.x + y.x, ai = z.y - y.y;  // 2 X_A
+  const double br = z.y + y.y, bi = y.x - z.x;  // 2 X_B
+  *pa = 0.25 * (ar * ar + ai * ai);
+  *pb = 0.25 * (br * br + bi * bi);
+}
+
 // ---- classifiers (chromaprint kClassifiersTest2) ---------------------------------
 struct ClassifierDef {
   int type, y, h, w;  // Filter(type, y, height, width)

@@ -19,6 +19,7 @@ struct Tables {
   std::vector<uint16_t> class_bins;
   uint32_t class_start[13];
   ClassifierThresholds thr;
+  std::vector<cd> tw0, tw1;  // v2: [15][256] W_4096^{t j}, [15][16] W_4096^{16 p j}
 };
 
 const double kThr[16][3] = {
@@ -54,6 +55,12 @@ const Tables &tables() {
   t.class_start[12] = (uint32_t)t.class_bins.size();
   for (int i = 0; i < 16; i++)
     for (int j = 0; j < 3; j++) t.thr.e[i][j] = std::exp(kThr[i][j]);
+  t.tw0.resize(15 * 256);
+  t.tw1.resize(15 * 16);
+  for (int j = 1; j < 16; j++) {
+    for (int q = 0; q < 256; q++) t.tw0[(j - 1) * 256 + q] = t.tw[(q * j) & 4095];
+    for (int q = 0; q < 16; q++) t.tw1[(j - 1) * 16 + q] = t.tw[(16 * q * j) & 4095];
+  }
   return t;
 }
 }  // namespace
@@ -111,6 +118,53 @@ void emu_stft_chroma(const int16_t *src, int channels, double *chroma12) {
       std::memcpy(lane, nxt, sizeof(lane));
     }
     chroma12[c] = lane[0];
+  }
+}
+
+// stft_chroma2_kernel, one frame pair (frame B may be NULL): radix-16 x3 on z = A + iB, padded LDS slots
+void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, double *chroma_a, double *chroma_b) {
+  const Tables &T = tables();
+  std::vector<cd> lds(kLds2Slots);
+  std::vector<cd> regs(256 * 16);
+  auto sample = [&](const int16_t *src, int n) -> int {
+    if (!src) return 0;
+    if (channels == 1) return src[n];
+    return ((int)src[2 * n] + (int)src[2 * n + 1]) / 2;
+  };
+  for (int t = 0; t < 256; t++)
+    for (int k = 0; k < 16; k++) {
+      const int n = t + 256 * k;
+      regs[t * 16 + k] = cd{(double)sample(fa, n) * T.window[n], (double)sample(fb, n) * T.window[n]};
+    }
+  for (int t = 0; t < 256; t++) pass16_compute_write<0>(t, T.tw0.data(), lds.data(), &regs[t * 16]);
+  for (int t = 0; t < 256; t++) pass16_read(t, lds.data(), &regs[t * 16]);
+  for (int t = 0; t < 256; t++) pass16_compute_write<1>(t, T.tw1.data(), lds.data(), &regs[t * 16]);
+  for (int t = 0; t < 256; t++) pass16_read(t, lds.data(), &regs[t * 16]);
+  for (int t = 0; t < 256; t++) pass16_compute_write<2>(t, nullptr, lds.data(), &regs[t * 16]);
+  std::vector<double> pa(2048, 0.0), pb(2048, 0.0);
+  for (int t = 0; t < 256; t++)
+    for (int i = 0; i < kBinsPerThread; i++) {
+      const int k = kMinBin + t + 256 * i;
+      if (k < kMaxBin) bin_power2(k, lds.data(), &pa[k], &pb[k]);
+    }
+  for (int which = 0; which < 2; which++) {
+    const std::vector<double> &pw = which ? pb : pa;
+    double *out = which ? chroma_b : chroma_a;
+    if (!out) continue;
+    for (int c = 0; c < 12; c++) {
+      double lane[8];
+      for (int l = 0; l < 8; l++) {
+        double acc = 0.0;
+        for (uint32_t b = T.class_start[c] + l; b < T.class_start[c + 1]; b += 8) acc += pw[T.class_bins[b]];
+        lane[l] = acc;
+      }
+      for (int off = 4; off >= 1; off >>= 1) {
+        double nxt[8];
+        for (int l = 0; l < 8; l++) nxt[l] = lane[l] + lane[l ^ off];
+        std::memcpy(lane, nxt, sizeof(lane));
+      }
+      out[c] = lane[0];
+    }
   }
 }
 
