@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -40,8 +41,7 @@ struct FpStream {
 // ---- constant tables, generated on the host in double and uploaded once per device --------------------
 struct FpTables {
   cd *tw = nullptr;                 // [4096] e^{-2 pi i k/4096}
-  cd *tw0 = nullptr;                // [15][256] W_4096^{t j}      pass-0 twiddles, lane-contiguous
-  cd *tw1 = nullptr;                // [15][16]  W_4096^{16 p j}   pass-1 twiddles
+  uint16_t *bin_slot = nullptr;     // [kNumBins] position of bin (kMinBin + i) in the class-sorted order
   double *window = nullptr;         // [4096] Hamming / 32767
   uint16_t *class_bins = nullptr;   // [kNumBins] spectrum bins grouped by pitch class
   uint32_t *class_start = nullptr;  // [13]
@@ -96,16 +96,11 @@ Status get_tables(FpTables *out) {
   for (int i = 0; i < 16; i++)
     for (int j = 0; j < 3; j++) thr.e[i][j] = std::exp(kThresholds[i][j]);
 
-  std::vector<cd> tw0(15 * 256), tw1(15 * 16);
-  for (int j = 1; j < 16; j++) {
-    for (int q = 0; q < 256; q++) tw0[(j - 1) * 256 + q] = tw[(q * j) & 4095];
-    for (int q = 0; q < 16; q++) tw1[(j - 1) * 16 + q] = tw[(16 * q * j) & 4095];
-  }
+  std::vector<uint16_t> bin_slot(core::kNumBins);
+  for (size_t pos = 0; pos < bins.size(); pos++) bin_slot[bins[pos] - core::kMinBin] = (uint16_t)pos;
   FpTables t;
-  NEEDLE_HIP_TRY(hipMalloc((void **)&t.tw0, tw0.size() * sizeof(cd)));
-  NEEDLE_HIP_TRY(hipMalloc((void **)&t.tw1, tw1.size() * sizeof(cd)));
-  NEEDLE_HIP_TRY(hipMemcpy(t.tw0, tw0.data(), tw0.size() * sizeof(cd), hipMemcpyHostToDevice));
-  NEEDLE_HIP_TRY(hipMemcpy(t.tw1, tw1.data(), tw1.size() * sizeof(cd), hipMemcpyHostToDevice));
+  NEEDLE_HIP_TRY(hipMalloc((void **)&t.bin_slot, bin_slot.size() * sizeof(uint16_t)));
+  NEEDLE_HIP_TRY(hipMemcpy(t.bin_slot, bin_slot.data(), bin_slot.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.tw, tw.size() * sizeof(cd)));
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.window, window.size() * sizeof(double)));
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.class_bins, bins.size() * sizeof(uint16_t)));
@@ -139,50 +134,64 @@ __device__ __forceinline__ int find_stream(const FpStream *streams, int n, uint3
 // (hop 1365 of 4096) is re-read from this XCD's L2 rather than from HBM.
 constexpr int kPairsPerBlock = 16;
 
-__global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__restrict__ pcm,
+template <int CH, bool WIN_IN_REGS>
+__global__ __launch_bounds__(256, WIN_IN_REGS ? 1 : 2) void stft_chroma_kernel(const int16_t *__restrict__ pcm,
                                                              const FpStream *__restrict__ streams, int num_streams,
-                                                             int channels, const cd *__restrict__ tw0,
-                                                             const cd *__restrict__ tw1,
+                                                             const cd *__restrict__ tw,
                                                              const double *__restrict__ window,
-                                                             const uint16_t *__restrict__ class_bins,
+                                                             const uint16_t *__restrict__ bin_slot,
                                                              const uint32_t *__restrict__ class_start,
                                                              double *__restrict__ chroma, uint32_t total_pairs) {
   extern __shared__ cd lds[];  // core::kLds2Slots complex slots
   const int t = threadIdx.x;
   const uint32_t first = blockIdx.x * kPairsPerBlock;
   const uint32_t last = min(total_pairs, first + kPairsPerBlock);
+  // loop-invariant per-thread constants, held in registers across the block's pairs
+  const cd base0 = tw[t], base1 = tw[16 * (t >> 4)];  // W_4096^t, W_4096^{16 p}
+  double win[WIN_IN_REGS ? 16 : 1];
+  if (WIN_IN_REGS) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) win[WIN_IN_REGS ? k : 0] = window[t + 256 * k];
+  }
+  int slot[core::kBinsPerThread];  // where this thread's bins go in the class-sorted power array
+#pragma unroll
+  for (int i = 0; i < core::kBinsPerThread; i++) {
+    const int k = t + 256 * i;
+    slot[i] = k < core::kNumBins ? (int)bin_slot[k] : -1;
+  }
   for (uint32_t g = first; g < last; g++) {
     const int si = find_stream<&FpStream::pair_base>(streams, num_streams, g);
     const FpStream st = streams[si];
     const uint32_t fa = 2 * (g - st.pair_base);
     const bool has_b = fa + 1 < st.frames;
-    const int16_t *src_a = pcm + st.pcm_off + (uint64_t)fa * kHop * channels;
-    const int16_t *src_b = src_a + kHop * channels;
+    const int16_t *src_a = pcm + st.pcm_off + (uint64_t)fa * kHop * CH;
+    const int16_t *src_b = has_b ? src_a + kHop * CH : src_a;  // no frame B: read A again, weight 0 (branch-free)
+    const double keep_b = has_b ? 1.0 : 0.0;
 
     cd r[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int n = t + 256 * k;
-      int sa, sb = 0;
-      if (channels == 1) {
+      int sa, sb;
+      if (CH == 1) {
         sa = src_a[n];
-        if (has_b) sb = src_b[n];
+        sb = src_b[n];
       } else {  // AudioProcessor::LoadStereo: (L + R) / 2, C truncation
         sa = ((int)src_a[2 * n] + (int)src_a[2 * n + 1]) / 2;
-        if (has_b) sb = ((int)src_b[2 * n] + (int)src_b[2 * n + 1]) / 2;
+        sb = ((int)src_b[2 * n] + (int)src_b[2 * n + 1]) / 2;
       }
-      const double w = window[n];
-      r[k] = cd{(double)sa * w, (double)sb * w};
+      const double w = WIN_IN_REGS ? win[WIN_IN_REGS ? k : 0] : window[n];
+      r[k] = cd{(double)sa * w, (double)sb * (w * keep_b)};
     }
-    core::pass16_compute_write<0>(t, tw0, lds, r);
+    core::pass16_compute_write<0>(t, base0, lds, r);
     __syncthreads();
     core::pass16_read(t, lds, r);
     __syncthreads();
-    core::pass16_compute_write<1>(t, tw1, lds, r);
+    core::pass16_compute_write<1>(t, base1, lds, r);
     __syncthreads();
     core::pass16_read(t, lds, r);
     __syncthreads();
-    core::pass16_compute_write<2>(t, nullptr, lds, r);
+    core::pass16_compute_write<2>(t, base1, lds, r);
     __syncthreads();
 
     double pa[core::kBinsPerThread], pb[core::kBinsPerThread];
@@ -193,24 +202,24 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
       if (k < core::kMaxBin) core::bin_power2(k, lds, &pa[i], &pb[i]);
     }
     __syncthreads();
-    double *plds = reinterpret_cast<double *>(lds);  // frame A powers at [k], frame B at [2048 + k]
+    double *plds = reinterpret_cast<double *>(lds);  // class-sorted powers: frame A at [slot], frame B at [2048 + slot]
 #pragma unroll
     for (int i = 0; i < core::kBinsPerThread; i++) {
-      const int k = core::kMinBin + t + 256 * i;
-      if (k < core::kMaxBin) {
-        plds[k] = pa[i];
-        plds[2048 + k] = pb[i];
+      if (slot[i] >= 0) {
+        plds[slot[i]] = pa[i];
+        plds[2048 + slot[i]] = pb[i];
       }
     }
     __syncthreads();
-    // 2 frames x 12 pitch classes x 8 lanes: strided partial sums, then a fixed-order 8-lane tree
+    // 2 frames x 12 pitch classes x 8 lanes: each class is a contiguous slice; strided partial sums, then a
+    // fixed-order 8-lane tree
     if (t < 2 * kBands * 8) {
       const int grp = t >> 3, l = t & 7;
       const int which = grp >= kBands ? 1 : 0, c = grp - which * kBands;
       const uint32_t b0 = class_start[c], b1 = class_start[c + 1];
       const double *pw = plds + which * 2048;
       double acc = 0.0;
-      for (uint32_t b = b0 + l; b < b1; b += 8) acc += pw[class_bins[b]];
+      for (uint32_t b = b0 + l; b < b1; b += 8) acc += pw[b];
 #pragma unroll
       for (int off = 4; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 8);
       if (l == 0 && (which == 0 || has_b)) chroma[((uint64_t)st.frame_base + fa + which) * kBands + c] = acc;
@@ -347,17 +356,29 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       ws->stage.mark(stream);
       const int n = (int)meta.size();
       if (!ws->lds_attr_set) {
-        NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(stft_chroma_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(core::kLds2Slots * sizeof(cd))));
+        const void *variants[4] = {reinterpret_cast<const void *>(stft_chroma_kernel<1, false>),
+                                   reinterpret_cast<const void *>(stft_chroma_kernel<2, false>),
+                                   reinterpret_cast<const void *>(stft_chroma_kernel<1, true>),
+                                   reinterpret_cast<const void *>(stft_chroma_kernel<2, true>)};
+        for (const void *fn : variants)
+          NEEDLE_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(core::kLds2Slots * sizeof(cd))));
         ws->lds_attr_set = true;
       }
       {
         KernelTimer timer("stft_chroma");
         const uint32_t grid = (uint32_t)((pairs + kPairsPerBlock - 1) / kPairsPerBlock);
-        hipLaunchKernelGGL(stft_chroma_kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm,
-                           ws->streams.ptr, n, channels, tab.tw0, tab.tw1, tab.window, tab.class_bins,
-                           tab.class_start, ws->chroma.ptr, (uint32_t)pairs);
+        const bool occ1 = getenv("NEEDLE_STFT_OCC1") != nullptr;
+        auto launch = [&](auto kernel) {
+          hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm,
+                             ws->streams.ptr, n, tab.tw, tab.window, tab.bin_slot, tab.class_start, ws->chroma.ptr,
+                             (uint32_t)pairs);
+        };
+        if (channels == 1) {
+          if (occ1) launch(stft_chroma_kernel<1, true>); else launch(stft_chroma_kernel<1, false>);
+        } else {
+          if (occ1) launch(stft_chroma_kernel<2, true>); else launch(stft_chroma_kernel<2, false>);
+        }
       }
       if (rows > 0) {
         KernelTimer timer("fir_norm");

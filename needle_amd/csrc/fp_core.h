@@ -19,13 +19,17 @@
 namespace needle {
 namespace core {
 
-struct cd {
+struct cd {  // 8-byte aligned on purpose: LDS traffic as paired 64-bit accesses measured faster than b128 here
   double x, y;
 };
 
 NEEDLE_HD cd cadd(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
 NEEDLE_HD cd csub(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
 NEEDLE_HD cd cmul(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// complex multiply with explicit fused multiply-adds (2 mul + 2 fma): same on host (fma()) and device
+NEEDLE_HD cd cmulf(cd a, cd b) {
+  return cd{__builtin_fma(a.x, b.x, -(a.y * b.y)), __builtin_fma(a.x, b.y, a.y * b.x)};
+}
 NEEDLE_HD cd mul_neg_i(cd a) { return cd{a.y, -a.x}; }
 
 constexpr int kFftN = 2048;      // complex points per frame
@@ -195,22 +199,26 @@ NEEDLE_HD void pass16_read(int t, const cd *lds, cd *r) {
   for (int k = 0; k < 16; k++) r[k] = lds[pidx(t + 256 * k)];
 }
 
-// tw: this pass's table laid out [j-1][column] so that lanes read consecutive entries
+// Twiddles W^j (j = 1..15) of one butterfly come from its base W = W_4096^{t} (pass 0) or W_4096^{16 p}
+// (pass 1) by the running product w_j = w_{j-1} * W: the base is a loop-invariant register pair, so there is
+// no per-pair table traffic and only one extra complex value is live at a time.
 template <int PASS>
-NEEDLE_HD void pass16_compute_write(int t, const cd *tw, cd *lds, cd *r) {
+NEEDLE_HD void pass16_compute_write(int t, cd base, cd *lds, cd *r) {
   fft16(r);
-  if (PASS == 0) {
-    lds[pidx(16 * t)] = r[out16(0)];
-#pragma unroll
-    for (int j = 1; j < 16; j++) lds[pidx(16 * t + j)] = cmul(r[out16(j)], tw[(j - 1) * 256 + t]);
-  } else if (PASS == 1) {
-    const int p = t >> 4, q = t & 15;
-    lds[pidx(q + 256 * p)] = r[out16(0)];
-#pragma unroll
-    for (int j = 1; j < 16; j++) lds[pidx(q + 256 * p + 16 * j)] = cmul(r[out16(j)], tw[(j - 1) * 16 + p]);
-  } else {
+  if (PASS == 2) {
 #pragma unroll
     for (int j = 0; j < 16; j++) lds[pidx(t + 256 * j)] = r[out16(j)];
+    return;
+  }
+  // output j goes to slot o0 + j * stride (before padding)
+  const int o0 = PASS == 0 ? 16 * t : (t & 15) + 256 * (t >> 4);
+  constexpr int stride = PASS == 0 ? 1 : 16;
+  lds[pidx(o0)] = r[out16(0)];
+  cd w = base;
+#pragma unroll
+  for (int j = 1; j < 16; j++) {
+    lds[pidx(o0 + j * stride)] = cmulf(r[out16(j)], w);
+    if (j < 15) w = cmulf(w, base);
   }
 }
 

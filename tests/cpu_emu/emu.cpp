@@ -136,11 +136,11 @@ void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, do
       const int n = t + 256 * k;
       regs[t * 16 + k] = cd{(double)sample(fa, n) * T.window[n], (double)sample(fb, n) * T.window[n]};
     }
-  for (int t = 0; t < 256; t++) pass16_compute_write<0>(t, T.tw0.data(), lds.data(), &regs[t * 16]);
+  for (int t = 0; t < 256; t++) pass16_compute_write<0>(t, T.tw[t], lds.data(), &regs[t * 16]);
   for (int t = 0; t < 256; t++) pass16_read(t, lds.data(), &regs[t * 16]);
-  for (int t = 0; t < 256; t++) pass16_compute_write<1>(t, T.tw1.data(), lds.data(), &regs[t * 16]);
+  for (int t = 0; t < 256; t++) pass16_compute_write<1>(t, T.tw[16 * (t >> 4)], lds.data(), &regs[t * 16]);
   for (int t = 0; t < 256; t++) pass16_read(t, lds.data(), &regs[t * 16]);
-  for (int t = 0; t < 256; t++) pass16_compute_write<2>(t, nullptr, lds.data(), &regs[t * 16]);
+  for (int t = 0; t < 256; t++) pass16_compute_write<2>(t, T.tw[0], lds.data(), &regs[t * 16]);
   std::vector<double> pa(2048, 0.0), pb(2048, 0.0);
   for (int t = 0; t < 256; t++)
     for (int i = 0; i < kBinsPerThread; i++) {
