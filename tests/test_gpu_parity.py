@@ -373,3 +373,18 @@ def test_config2_full_size_parity(lib28):
     merged = np.concatenate(parts)
     assert sorted(map(tuple, merged.tolist())) == sorted(map(tuple, runs.tolist()))
     _same_results(lib.finalize(cmp, merged), want)
+
+
+def test_gpu_reproduces_committed_golden_vectors(lib3, tmp_path):
+    """tests/golden/config1.json (oracle outputs for the seeded configs[0] library) through the C ABI."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config1.json")))
+    paths = [str(tmp_path / f"g{k}.wav") for k in range(3)]
+    fhs = capi.Analyzer.from_files(paths).run_pcm([e.pcm for e in lib3])
+    for f, want in zip(fhs, g["opening"]):
+        h, ts = f.opening_data()
+        assert [[int(a), int(b)] for a, b in zip(h, ts)] == want
+    assert capi.fingerprint([lib3[0].pcm[: len(lib3[0].pcm) // 2]])[0].tolist() == g["raw_items_first_episode"]
+    for min_s, want in g["results"].items():
+        res = capi.Comparator(paths, min_opening_duration=int(min_s)).run_with_frame_hashes(fhs)
+        assert [None if r is None else list(r.opening) if r.opening else [] for r in res] == want

@@ -301,3 +301,17 @@ def test_skip_file_json_and_format_time():
     assert O.skip_file_json(O.SearchResult(None, None), "x") == ""      # comparator.rs:336-338: nothing written
     assert O.format_time(43 * NS) == "00:43s" and O.format_time(132_900_000_000) == "02:12s"
     assert O.format_time(3_723 * NS) == "62:03s"
+
+
+# ---- committed golden vectors (tests/golden/make_golden.py) ---------------------------------------------------
+def test_oracle_reproduces_committed_golden_vectors():
+    from needle_amd import synth
+    g = json.load(open(os.path.join(HERE, "golden", "config1.json")))
+    eps = synth.make_library(3, 90.0, 20.0)
+    assert [int(e.pcm.astype("int64").sum()) for e in eps] == g["pcm_crc"], "synthetic generator drifted"
+    fhs = O.analyze_batch([e.pcm[: len(e.pcm) // 2] for e in eps], 1, g["hash_duration_ns"])
+    assert [[[h, t] for h, t in f.opening] for f in fhs] == g["opening"]
+    assert O.fingerprint(eps[0].pcm[: len(eps[0].pcm) // 2]).tolist() == g["raw_items_first_episode"]
+    for min_s, want in g["results"].items():
+        res = O.run_with_frame_hashes(O.Comparator(min_opening_duration=int(min_s) * NS), fhs)
+        assert [None if r is None else list(r.opening) if r.opening else [] for r in res] == want
