@@ -388,3 +388,60 @@ def test_gpu_reproduces_committed_golden_vectors(lib3, tmp_path):
     for min_s, want in g["results"].items():
         res = capi.Comparator(paths, min_opening_duration=int(min_s)).run_with_frame_hashes(fhs)
         assert [None if r is None else list(r.opening) if r.opening else [] for r in res] == want
+
+
+def test_config3_search_only_from_needle_dat_files(tmp_path, capfd):
+    """BASELINE.json configs[2] at reduced count: precomputed .needle.dat files (written by the ORACLE's bincode
+    writer, 24-min-sized: 2897 opening + 1443 ending hashes), search-only through needle_audio_comparator_run
+    with endings, display and skip files; every printed line and skip file must equal the reference path."""
+    n = 24
+    rng = np.random.default_rng(2024)
+    hd = O.duration_from_secs_f32(0.3)
+    intro = _rand_hashes(rng, 360)
+    outro = _rand_hashes(rng, 250)
+    fhs, paths = [], []
+    for v in range(n):
+        op = _rand_hashes(rng, 2897)
+        en = _rand_hashes(rng, 1443)
+        if v % 6 != 5:                                    # every sixth episode has no intro / outro
+            a = 40 + 37 * (v % 7)
+            op[a:a + 360] = intro ^ ((np.uint32(1) << rng.integers(0, 32, 360).astype(np.uint32)) * (rng.random(360) < 0.7))
+            b = 300 + 29 * (v % 5)
+            en[b:b + 250] = outro ^ ((np.uint32(1) << rng.integers(0, 32, 250).astype(np.uint32)) * (rng.random(250) < 0.7))
+        o = O.step_and_timestamp(np.repeat(op, 2)[: 2 * len(op)], hd)[: len(op)]
+        o = [(int(h), t) for h, (_, t) in zip(op, o)]
+        e = [(int(h), t + 1080 * NS) for h, (_, t) in zip(en, O.step_and_timestamp(np.repeat(en, 2), hd))]
+        p = tmp_path / f"library-ep{v:02d}.wav"
+        p.write_bytes(bytes(range(256)) * 32 + bytes([v]) * 64)          # >= 8 KiB so the header MD5 exists
+        f = O.FrameHashes(o, e, hd, O.header_md5(str(p)))
+        assert O.frame_hashes_write(str(p)[:-4] + ".needle.dat", f) == 0
+        fhs.append(f)
+        paths.append(str(p))
+    cmp = capi.Comparator(paths, include_endings=True, min_opening_duration=30, min_ending_duration=25)
+    cmp.run(analyze=False, display=True, write_skip_files=True)
+    out = capfd.readouterr().out
+    want = O.run_with_frame_hashes(O.Comparator(include_endings=True, min_opening_duration=30 * NS,
+                                                min_ending_duration=25 * NS), fhs, threads=min(os.cpu_count() or 1, 16))
+    blocks = out.split("\n\n")
+    expected = []
+    for p, w in zip(paths, want):
+        expected.append(f"\n{p}\n")
+        if w is None:
+            expected.append("No opening or ending found.")
+        else:
+            o = f'* Opening - "{O.format_time(w.opening[0])}"-"{O.format_time(w.opening[1])}"' if w.opening else "* Opening - N/A"
+            e = f'* Ending - "{O.format_time(w.ending[0])}"-"{O.format_time(w.ending[1])}"' if w.ending else "* Ending - N/A"
+            expected.append(o + "\n" + e)
+    assert out == "\n".join(expected) + "\n", blocks[:3]
+    found = 0
+    for p, w in zip(paths, want):
+        skip = p[:-4] + ".needle.skip.json"
+        if w is None or (w.opening is None and w.ending is None):
+            assert not os.path.exists(skip)
+        else:
+            assert open(skip).read() == O.skip_file_json(w, O.header_md5(p))
+            found += 1
+    assert found >= 18
+    # in-memory call returns the same per-video results
+    got = cmp.run_with_frame_hashes([capi.FrameHashes.from_path(p[:-4] + ".needle.dat") for p in paths])
+    _same_results(got, want)
