@@ -153,12 +153,6 @@ __global__ __launch_bounds__(256, WIN_IN_REGS ? 1 : 2) void stft_chroma_kernel(c
 #pragma unroll
     for (int k = 0; k < 16; k++) win[WIN_IN_REGS ? k : 0] = window[t + 256 * k];
   }
-  int slot[core::kBinsPerThread];  // where this thread's bins go in the class-sorted power array
-#pragma unroll
-  for (int i = 0; i < core::kBinsPerThread; i++) {
-    const int k = t + 256 * i;
-    slot[i] = k < core::kNumBins ? (int)bin_slot[k] : -1;
-  }
   for (uint32_t g = first; g < last; g++) {
     const int si = find_stream<&FpStream::pair_base>(streams, num_streams, g);
     const FpStream st = streams[si];
@@ -168,6 +162,8 @@ __global__ __launch_bounds__(256, WIN_IN_REGS ? 1 : 2) void stft_chroma_kernel(c
     const int16_t *src_b = has_b ? src_a + kHop * CH : src_a;  // no frame B: read A again, weight 0 (branch-free)
     const double keep_b = has_b ? 1.0 : 0.0;
 
+    const double *wptr = window;
+    if (!WIN_IN_REGS) asm volatile("" : "+s"(wptr));  // hoisted, the 16 window values would be spilled to scratch
     cd r[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -180,7 +176,7 @@ __global__ __launch_bounds__(256, WIN_IN_REGS ? 1 : 2) void stft_chroma_kernel(c
         sa = ((int)src_a[2 * n] + (int)src_a[2 * n + 1]) / 2;
         sb = ((int)src_b[2 * n] + (int)src_b[2 * n + 1]) / 2;
       }
-      const double w = WIN_IN_REGS ? win[WIN_IN_REGS ? k : 0] : window[n];
+      const double w = WIN_IN_REGS ? win[WIN_IN_REGS ? k : 0] : wptr[n];
       r[k] = cd{(double)sa * w, (double)sb * (w * keep_b)};
     }
     core::pass16_compute_write<0>(t, base0, lds, r);
@@ -203,11 +199,15 @@ __global__ __launch_bounds__(256, WIN_IN_REGS ? 1 : 2) void stft_chroma_kernel(c
     }
     __syncthreads();
     double *plds = reinterpret_cast<double *>(lds);  // class-sorted powers: frame A at [slot], frame B at [2048 + slot]
+    const uint16_t *slot_tab = bin_slot;
+    asm volatile("" : "+s"(slot_tab));  // keep these small table loads here rather than hoisted + spilled
 #pragma unroll
     for (int i = 0; i < core::kBinsPerThread; i++) {
-      if (slot[i] >= 0) {
-        plds[slot[i]] = pa[i];
-        plds[2048 + slot[i]] = pb[i];
+      const int k = t + 256 * i;
+      if (k < core::kNumBins) {
+        const int slot = slot_tab[k];
+        plds[slot] = pa[i];
+        plds[2048 + slot] = pb[i];
       }
     }
     __syncthreads();
