@@ -134,15 +134,25 @@ def main() -> None:
     if not distributed:
         d_runs, d_count = capi.DeviceBuffer(cap * capi.RUN_DTYPE.itemsize), capi.DeviceBuffer(4)
 
+        host_ms = {"enqueue": 0.0, "wait_count": 0.0, "copy_runs": 0.0, "epilogue": 0.0}
+
         def step(collect):
+            t0 = time.perf_counter()
             lib.analyze(0, n, sync=False)
             lib.search(cmp, 0, n_pairs, d_runs.ptr, cap, d_count.ptr, sync=False)
+            t1 = time.perf_counter()
             found = int(d_count.to_host(np.uint32, 1)[0])            # D2H on the library stream: waits for the kernels
             if found > cap:
                 raise SystemExit("run list overflow")
+            t2 = time.perf_counter()
             runs = d_runs.to_host(capi.RUN_DTYPE, found)
+            t3 = time.perf_counter()
             state["results"] = lib.finalize(cmp, runs)
+            t4 = time.perf_counter()
             state["runs"] = found
+            if collect:
+                for key, dt in (("enqueue", t1 - t0), ("wait_count", t2 - t1), ("copy_runs", t3 - t2), ("epilogue", t4 - t3)):
+                    host_ms[key] += 1e3 * dt
             if collect:
                 for k in kernel_names:
                     kernel_ms[k] += capi.last_kernel_ms(k)
@@ -235,6 +245,7 @@ def main() -> None:
                          "algorithmic_bytes_per_launch": int(abytes),
                          "avg_launch_ms": round(avg[dominant], 5)},
             "kernel_ms_per_step": {k: round(v, 5) for k, v in avg.items()},
+            "host_ms_per_step": ({k: round(v / args.steps, 4) for k, v in host_ms.items()} if not distributed else None),
             "runs_per_step": state["runs"],
             "detected": sum(1 for r in state["results"] if r is not None and r.opening is not None),
         }

@@ -112,16 +112,14 @@ Status read_skip_file_md5(const std::string &skip_path, std::string *md5) {
 
 }  // namespace
 
-void Comparator::entries_from_runs(std::vector<NeedleHipRun> runs, const std::vector<HashTs> &src,
+void Comparator::entries_from_runs(const NeedleHipRun *runs, size_t num_runs, const std::vector<HashTs> &src,
                                    const std::vector<HashTs> &dst, ns_t src_hash_duration, ns_t dst_hash_duration,
                                    bool is_opening, std::vector<HeapEntry> *out) const {
   out->clear();
-  // the reference walks i = n-1..1 and, inside, j = m-1..1 (:191-192): pushes happen in that order
-  std::sort(runs.begin(), runs.end(), [](const NeedleHipRun &a, const NeedleHipRun &b) {
-    return a.src_end != b.src_end ? a.src_end > b.src_end : a.dst_end > b.dst_end;
-  });
+  // `runs` is already in the order the reference pushes: i = n-1..1 and, inside, j = m-1..1 (:191-192)
   const ns_t min_duration = is_opening ? min_opening_duration_ : min_ending_duration_;
-  for (const NeedleHipRun &r : runs) {
+  for (size_t q = 0; q < num_runs; q++) {
+    const NeedleHipRun &r = runs[q];
     const size_t i = r.src_end, j = r.dst_end, len = r.len;
     if (len == 0 || len > i || len > j || i >= src.size() || j >= dst.size()) continue;  // cannot happen
     const size_t si = i - len, sj = j - len;  // one BEFORE the first matched cell (:206-207)
@@ -316,22 +314,30 @@ Status Comparator::results_from_runs(const std::vector<const FrameHashesData *> 
   const size_t n = fh.size();
   const size_t regions = include_endings_ ? 2 : 1;
   const size_t np = pair_count(n);
-  // bucket runs by (pair, region): NeedleHipRun.problem = pair * regions + region
-  std::vector<std::vector<NeedleHipRun>> buckets(np * regions);
-  for (const NeedleHipRun &r : runs)
-    if (r.problem < buckets.size()) buckets[r.problem].push_back(r);
+  // one sort puts the runs of each (pair, region) together (NeedleHipRun.problem = pair * regions + region) and,
+  // inside a group, in the reference's reverse table-walk order: src_end descending, then dst_end descending
+  std::vector<NeedleHipRun> sorted(runs.begin(), runs.end());
+  std::sort(sorted.begin(), sorted.end(), [](const NeedleHipRun &a, const NeedleHipRun &b) {
+    if (a.problem != b.problem) return a.problem < b.problem;
+    return a.src_end != b.src_end ? a.src_end > b.src_end : a.dst_end > b.dst_end;
+  });
   std::vector<std::vector<HeapEntry>> pair_entries(np);
   std::vector<HeapEntry> tmp;
-  for (size_t p = 0; p < np; p++) {
-    size_t i, j;
-    pair_at(n, p, &i, &j);
-    for (size_t r = 0; r < regions; r++) {  // entries.extend(opening); entries.extend(ending) (:262-281)
-      if (buckets[p * regions + r].empty()) continue;
-      entries_from_runs(std::move(buckets[p * regions + r]), r == 0 ? fh[i]->opening : fh[i]->ending,
+  for (size_t lo = 0; lo < sorted.size();) {
+    size_t hi = lo;
+    while (hi < sorted.size() && sorted[hi].problem == sorted[lo].problem) hi++;
+    const size_t problem = sorted[lo].problem;
+    if (problem < np * regions) {
+      const size_t p = problem / regions, r = problem % regions;
+      size_t i, j;
+      pair_at(n, p, &i, &j);
+      entries_from_runs(&sorted[lo], hi - lo, r == 0 ? fh[i]->opening : fh[i]->ending,
                         r == 0 ? fh[j]->opening : fh[j]->ending, fh[i]->hash_duration, fh[j]->hash_duration, r == 0,
                         &tmp);
+      // entries.extend(opening); entries.extend(ending) (:262-281): region 0 sorts before region 1
       pair_entries[p].insert(pair_entries[p].end(), tmp.begin(), tmp.end());
     }
+    lo = hi;
   }
   return best_matches(n, pair_entries, display, use_skip_files, write_skip_files, per_video);
 }

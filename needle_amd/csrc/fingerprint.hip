@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 namespace needle {
 
@@ -134,8 +135,19 @@ __device__ __forceinline__ int find_stream(const FpStream *streams, int n, uint3
 // (hop 1365 of 4096) is re-read from this XCD's L2 rather than from HBM.
 constexpr int kPairsPerBlock = 16;
 
-template <int CH, bool WIN_IN_REGS>
-__global__ __launch_bounds__(256, WIN_IN_REGS ? 1 : 2) void stft_chroma_kernel(const int16_t *__restrict__ pcm,
+// LDS-only workgroup barrier: waits for this wave's LDS traffic, not for its outstanding global loads
+// (__syncthreads() would also drain vmcnt and with it the prefetch of the next pair's PCM).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct PairSrc {
+  const int16_t *a, *b;  // first value of frame A / frame B (B = A when the stream has an odd frame count)
+  double keep_b;         // 1.0, or 0.0 when there is no frame B
+  uint64_t row;          // chroma row of frame A
+  bool has_b;
+};
+
+template <int CH>
+__global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__restrict__ pcm,
                                                              const FpStream *__restrict__ streams, int num_streams,
                                                              const cd *__restrict__ tw,
                                                              const double *__restrict__ window,
@@ -143,52 +155,69 @@ __global__ __launch_bounds__(256, WIN_IN_REGS ? 1 : 2) void stft_chroma_kernel(c
                                                              const uint32_t *__restrict__ class_start,
                                                              double *__restrict__ chroma, uint32_t total_pairs) {
   extern __shared__ cd lds[];  // core::kLds2Slots complex slots
+  using raw_t = typename std::conditional<CH == 1, int16_t, int>::type;  // one sample, or one packed L|R pair
   const int t = threadIdx.x;
   const uint32_t first = blockIdx.x * kPairsPerBlock;
   const uint32_t last = min(total_pairs, first + kPairsPerBlock);
-  // loop-invariant per-thread constants, held in registers across the block's pairs
-  const cd base0 = tw[t], base1 = tw[16 * (t >> 4)];  // W_4096^t, W_4096^{16 p}
-  double win[WIN_IN_REGS ? 16 : 1];
-  if (WIN_IN_REGS) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) win[WIN_IN_REGS ? k : 0] = window[t + 256 * k];
-  }
-  for (uint32_t g = first; g < last; g++) {
+  if (first >= last) return;
+  const cd base0 = tw[t], base1 = tw[16 * (t >> 4)];  // W_4096^t, W_4096^{16 p}: loop-invariant twiddle bases
+
+  auto locate = [&](uint32_t g) {
     const int si = find_stream<&FpStream::pair_base>(streams, num_streams, g);
     const FpStream st = streams[si];
     const uint32_t fa = 2 * (g - st.pair_base);
-    const bool has_b = fa + 1 < st.frames;
-    const int16_t *src_a = pcm + st.pcm_off + (uint64_t)fa * kHop * CH;
-    const int16_t *src_b = has_b ? src_a + kHop * CH : src_a;  // no frame B: read A again, weight 0 (branch-free)
-    const double keep_b = has_b ? 1.0 : 0.0;
+    PairSrc p;
+    p.has_b = fa + 1 < st.frames;
+    p.a = pcm + st.pcm_off + (uint64_t)fa * kHop * CH;
+    p.b = p.has_b ? p.a + kHop * CH : p.a;  // no frame B: read A again, weight 0 (branch-free)
+    p.keep_b = p.has_b ? 1.0 : 0.0;
+    p.row = (uint64_t)st.frame_base + fa;
+    return p;
+  };
+  raw_t ra[16], rb[16];
+  auto issue_loads = [&](const PairSrc &p) {
+    const raw_t *qa = reinterpret_cast<const raw_t *>(p.a), *qb = reinterpret_cast<const raw_t *>(p.b);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      ra[k] = qa[t + 256 * k];
+      rb[k] = qb[t + 256 * k];
+    }
+  };
+  PairSrc cur = locate(first);
+  issue_loads(cur);
 
+  for (uint32_t g = first; g < last; g++) {
+    // window: loaded here every pair (hoisted out of the loop the 16 values would be spilled to scratch)
     const double *wptr = window;
-    if (!WIN_IN_REGS) asm volatile("" : "+s"(wptr));  // hoisted, the 16 window values would be spilled to scratch
+    asm volatile("" : "+s"(wptr));
     cd r[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      const int n = t + 256 * k;
       int sa, sb;
       if (CH == 1) {
-        sa = src_a[n];
-        sb = src_b[n];
+        sa = ra[k];
+        sb = rb[k];
       } else {  // AudioProcessor::LoadStereo: (L + R) / 2, C truncation
-        sa = ((int)src_a[2 * n] + (int)src_a[2 * n + 1]) / 2;
-        sb = ((int)src_b[2 * n] + (int)src_b[2 * n + 1]) / 2;
+        sa = ((int)(int16_t)ra[k] + (ra[k] >> 16)) / 2;
+        sb = ((int)(int16_t)rb[k] + (rb[k] >> 16)) / 2;
       }
-      const double w = WIN_IN_REGS ? win[WIN_IN_REGS ? k : 0] : wptr[n];
-      r[k] = cd{(double)sa * w, (double)sb * (w * keep_b)};
+      const double w = wptr[t + 256 * k];
+      r[k] = cd{(double)sa * w, (double)sb * (w * cur.keep_b)};
     }
     core::pass16_compute_write<0>(t, base0, lds, r);
-    __syncthreads();
+    lds_barrier();
     core::pass16_read(t, lds, r);
-    __syncthreads();
+    lds_barrier();
     core::pass16_compute_write<1>(t, base1, lds, r);
-    __syncthreads();
+    lds_barrier();
     core::pass16_read(t, lds, r);
-    __syncthreads();
+    lds_barrier();
     core::pass16_compute_write<2>(t, base1, lds, r);
-    __syncthreads();
+    lds_barrier();
+
+    // the next pair's PCM is fetched while this pair's spectrum is folded (last pair: harmless re-read)
+    const PairSrc nxt = locate(min(g + 1, last - 1));
+    issue_loads(nxt);
 
     double pa[core::kBinsPerThread], pb[core::kBinsPerThread];
 #pragma unroll
@@ -197,7 +226,7 @@ __global__ __launch_bounds__(256, WIN_IN_REGS ? 1 : 2) void stft_chroma_kernel(c
       pa[i] = pb[i] = 0.0;
       if (k < core::kMaxBin) core::bin_power2(k, lds, &pa[i], &pb[i]);
     }
-    __syncthreads();
+    lds_barrier();
     double *plds = reinterpret_cast<double *>(lds);  // class-sorted powers: frame A at [slot], frame B at [2048 + slot]
     const uint16_t *slot_tab = bin_slot;
     asm volatile("" : "+s"(slot_tab));  // keep these small table loads here rather than hoisted + spilled
@@ -210,7 +239,7 @@ __global__ __launch_bounds__(256, WIN_IN_REGS ? 1 : 2) void stft_chroma_kernel(c
         plds[2048 + slot] = pb[i];
       }
     }
-    __syncthreads();
+    lds_barrier();
     // 2 frames x 12 pitch classes x 8 lanes: each class is a contiguous slice; strided partial sums, then a
     // fixed-order 8-lane tree
     if (t < 2 * kBands * 8) {
@@ -222,9 +251,10 @@ __global__ __launch_bounds__(256, WIN_IN_REGS ? 1 : 2) void stft_chroma_kernel(c
       for (uint32_t b = b0 + l; b < b1; b += 8) acc += pw[b];
 #pragma unroll
       for (int off = 4; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 8);
-      if (l == 0 && (which == 0 || has_b)) chroma[((uint64_t)st.frame_base + fa + which) * kBands + c] = acc;
+      if (l == 0 && (which == 0 || cur.has_b)) chroma[(cur.row + which) * kBands + c] = acc;
     }
-    __syncthreads();
+    lds_barrier();
+    cur = nxt;
   }
 }
 
@@ -356,10 +386,8 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       ws->stage.mark(stream);
       const int n = (int)meta.size();
       if (!ws->lds_attr_set) {
-        const void *variants[4] = {reinterpret_cast<const void *>(stft_chroma_kernel<1, false>),
-                                   reinterpret_cast<const void *>(stft_chroma_kernel<2, false>),
-                                   reinterpret_cast<const void *>(stft_chroma_kernel<1, true>),
-                                   reinterpret_cast<const void *>(stft_chroma_kernel<2, true>)};
+        const void *variants[2] = {reinterpret_cast<const void *>(stft_chroma_kernel<1>),
+                                   reinterpret_cast<const void *>(stft_chroma_kernel<2>)};
         for (const void *fn : variants)
           NEEDLE_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)(core::kLds2Slots * sizeof(cd))));
@@ -368,17 +396,12 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       {
         KernelTimer timer("stft_chroma");
         const uint32_t grid = (uint32_t)((pairs + kPairsPerBlock - 1) / kPairsPerBlock);
-        const bool occ1 = getenv("NEEDLE_STFT_OCC1") != nullptr;
         auto launch = [&](auto kernel) {
           hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm,
                              ws->streams.ptr, n, tab.tw, tab.window, tab.bin_slot, tab.class_start, ws->chroma.ptr,
                              (uint32_t)pairs);
         };
-        if (channels == 1) {
-          if (occ1) launch(stft_chroma_kernel<1, true>); else launch(stft_chroma_kernel<1, false>);
-        } else {
-          if (occ1) launch(stft_chroma_kernel<2, true>); else launch(stft_chroma_kernel<2, false>);
-        }
+        if (channels == 1) launch(stft_chroma_kernel<1>); else launch(stft_chroma_kernel<2>);
       }
       if (rows > 0) {
         KernelTimer timer("fir_norm");

@@ -194,9 +194,20 @@ NEEDLE_HD void fft16(cd *a) {
   for (int k1 = 0; k1 < 4; k1++) bfly4(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);
 }
 
+// One complex slot as a single 128-bit LDS read (slots are 16-byte aligned); stores stay paired 64-bit.
+NEEDLE_HD cd lds_get(const cd *lds, int slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef double v2d __attribute__((ext_vector_type(2), aligned(16)));
+  const v2d v = *reinterpret_cast<const v2d *>(lds + slot);
+  return cd{v.x, v.y};
+#else
+  return lds[slot];
+#endif
+}
+
 NEEDLE_HD void pass16_read(int t, const cd *lds, cd *r) {
 #pragma unroll
-  for (int k = 0; k < 16; k++) r[k] = lds[pidx(t + 256 * k)];
+  for (int k = 0; k < 16; k++) r[k] = lds_get(lds, pidx(t + 256 * k));
 }
 
 // Twiddles W^j (j = 1..15) of one butterfly come from its base W = W_4096^{t} (pass 0) or W_4096^{16 p}
@@ -224,7 +235,7 @@ NEEDLE_HD void pass16_compute_write(int t, cd base, cd *lds, cd *r) {
 
 // powers of bin k for the two frames packed in Z (kMinBin <= k < kMaxBin)
 NEEDLE_HD void bin_power2(int k, const cd *lds, double *pa, double *pb) {
-  const cd z = lds[pidx(k)], y = lds[pidx(kFft2N - k)];
+  const cd z = lds_get(lds, pidx(k)), y = lds_get(lds, pidx(kFft2N - k));
   const double ar = z.x + y.x, ai = z.y - y.y;  // 2 X_A
   const double br = z.y + y.y, bi = y.x - z.x;  // 2 X_B
   *pa = 0.25 * (ar * ar + ai * ai);

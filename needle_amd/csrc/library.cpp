@@ -42,7 +42,9 @@ struct NeedleHipLibrary {
   DeviceBuffer<uint32_t> d_arena;
   uint32_t *arena = nullptr;  // d_arena.ptr, or caller-owned memory adopted with needle_hip_library_use_hash_arena
   std::vector<std::vector<HashTs>> ts_cache;  // timestamps by kept length (identical for equal lengths)
-  std::vector<uint32_t> min_len;              // per video, for the comparator's opening duration
+  std::vector<uint32_t> min_len;              // per video, for the comparator's opening duration ...
+  ns_t min_len_for = ~0ull;                   // ... this one (recomputed only when it changes)
+  std::vector<FrameHashesData> shells;        // per-video timestamps for the epilogue (hashes stay in HBM)
 
   const std::vector<HashTs> &timestamps(uint32_t k) {
     if (ts_cache.size() <= k) ts_cache.resize(k + 1);
@@ -136,6 +138,7 @@ enum NeedleError needle_hip_library_set_pcm(NeedleHipLibrary *lib, const int16_t
     if (hipStreamSynchronize(stream) != hipSuccess) return report(Status::Make(NeedleError_Unknown, "PCM upload failed"));
     lib->have_pcm = true;
     lib->min_len.clear();
+    lib->shells.clear();
     return NeedleError_Ok;
   });
 }
@@ -186,10 +189,14 @@ enum NeedleError needle_hip_library_search(NeedleHipLibrary *lib, const struct N
       return report(Status::Make(NeedleError_Unknown, "no ending hash data present"));  // library = default Analyzer
     // per-video minimum run length for the opening duration test (same for equal kept lengths)
     std::vector<NeedleHipSeq> seqs(lib->n);
-    lib->min_len.assign(lib->n, 0);
-    for (size_t v = 0; v < lib->n; v++) {
-      seqs[v] = NeedleHipSeq{(uint32_t)(v * lib->stride), lib->kept[v]};
-      lib->min_len[v] = cmp.min_run_length_for(lib->timestamps(lib->kept[v]), true);
+    for (size_t v = 0; v < lib->n; v++) seqs[v] = NeedleHipSeq{(uint32_t)(v * lib->stride), lib->kept[v]};
+    if (lib->min_len.size() != lib->n || lib->min_len_for != cmp.min_opening_duration()) {
+      lib->min_len.assign(lib->n, 0);
+      for (size_t v = 0; v < lib->n; v++)
+        lib->min_len[v] = v > 0 && lib->kept[v] == lib->kept[v - 1]
+                              ? lib->min_len[v - 1]
+                              : cmp.min_run_length_for(lib->timestamps(lib->kept[v]), true);
+      lib->min_len_for = cmp.min_opening_duration();
     }
     std::vector<NeedleHipProblem> problems;
     problems.reserve(num_pairs);
@@ -214,13 +221,15 @@ enum NeedleError needle_hip_library_finalize(NeedleHipLibrary *lib, const struct
   return guarded([&]() -> NeedleError {
     const Comparator &cmp = comparator_of(comparator);
     // the epilogue needs timestamps only: the runs carry their simhashes, so the hash arena stays in HBM
-    std::vector<FrameHashesData> data(lib->n);
-    for (size_t v = 0; v < lib->n; v++) {
-      data[v].opening = lib->timestamps(lib->kept[v]);
-      data[v].hash_duration = lib->hash_duration;
+    if (lib->shells.size() != lib->n) {
+      lib->shells.assign(lib->n, {});
+      for (size_t v = 0; v < lib->n; v++) {
+        lib->shells[v].opening = lib->timestamps(lib->kept[v]);
+        lib->shells[v].hash_duration = lib->hash_duration;
+      }
     }
     std::vector<const FrameHashesData *> fh;
-    for (const FrameHashesData &d : data) fh.push_back(&d);
+    for (const FrameHashesData &d : lib->shells) fh.push_back(&d);
     std::vector<NeedleHipRun> run_vec(runs, runs + num_runs);
     std::vector<VideoResult> res;
     Status s = cmp.results_from_runs(fh, run_vec, false, false, false, &res);

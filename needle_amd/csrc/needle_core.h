@@ -116,9 +116,10 @@ class Comparator {
   }
   // Turns the GPU's raw runs of ONE sequence pair into the reference's Vec<ComparatorHeapEntry>
   // (:191-249): reverse-walk order, duration validity, simhash32, BinaryHeap array order.
-  void entries_from_runs(std::vector<NeedleHipRun> runs, const std::vector<HashTs> &src,
+  void entries_from_runs(const NeedleHipRun *runs, size_t num_runs, const std::vector<HashTs> &src,
                          const std::vector<HashTs> &dst, ns_t src_hash_duration, ns_t dst_hash_duration,
                          bool is_opening, std::vector<HeapEntry> *out) const;
+  ns_t min_opening_duration() const { return min_opening_duration_; }
   // Run list of ALL pairs (NeedleHipRun.problem = pair_index * regions + region) -> per-video results.
   Status results_from_runs(const std::vector<const FrameHashesData *> &frame_hashes,
                            const std::vector<NeedleHipRun> &runs, bool display, bool use_skip_files,
