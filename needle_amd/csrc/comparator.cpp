@@ -193,9 +193,14 @@ Status Comparator::best_matches(size_t num_videos, const std::vector<std::vector
     }
     // distinct_matches (:434-454): symmetric relation, so the set size of i is its neighbour count
     std::vector<uint32_t> links(cand.size(), 0);
-    for (size_t a = 0; a < cand.size(); a++)
-      for (size_t b = 0; b < cand.size(); b++)
-        if ((uint32_t)__builtin_popcount(cand[a].match_hash ^ cand[b].match_hash) < bound) links[a]++;
+    for (size_t a = 0; a < cand.size(); a++) {
+      if (bound > 0) links[a]++;  // dist(a, a) = 0 < bound
+      for (size_t b = a + 1; b < cand.size(); b++)
+        if ((uint32_t)__builtin_popcount(cand[a].match_hash ^ cand[b].match_hash) < bound) {
+          links[a]++;
+          links[b]++;
+        }
+    }
 
     VideoResult &vr = (*per_video)[v];
     vr.has_result = true;  // Some(best) even if neither side is found (:514)

@@ -10,6 +10,9 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -232,7 +235,11 @@ enum NeedleError needle_hip_library_finalize(NeedleHipLibrary *lib, const struct
     for (const FrameHashesData &d : lib->shells) fh.push_back(&d);
     std::vector<NeedleHipRun> run_vec(runs, runs + num_runs);
     std::vector<VideoResult> res;
+    const auto t0 = std::chrono::steady_clock::now();
     Status s = cmp.results_from_runs(fh, run_vec, false, false, false, &res);
+    if (getenv("NEEDLE_HIP_TRACE"))
+      std::fprintf(stderr, "[needle_hip] epilogue %zu runs: %.1f us\n", num_runs,
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     if (!s.ok()) return report(s);
     for (size_t v = 0; v < lib->n; v++) fill_c_result(res[v], &results[v]);
     return NeedleError_Ok;

@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 KERNELS = {"stft_chroma": "stft_chroma_kernel", "fir_norm": "fir_norm_kernel", "classify": "classify_kernel",
-           "hamming_runs_band": "hamming_runs_band_kernel", "hamming_runs": "hamming_runs_kernel",
+           "hamming_runs_sampled": "hamming_runs_sampled_kernel", "hamming_runs_band": "hamming_runs_band_kernel", "hamming_runs": "hamming_runs_kernel",
            "simhash_runs": "simhash_runs_kernel"}
 
 
