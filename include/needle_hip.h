@@ -159,7 +159,7 @@ enum NeedleError needle_hip_comparator_run_with_frame_hashes(const struct Needle
 
 /* ---- Library: an HBM-resident analyze+search job, shardable across GPUs ----------------------------
  * One object per process/GPU describing ALL videos of a job.  PCM of the videos this rank owns is
- * uploaded once and stays in HBM; hashes live in a padded device arena [num_videos][stride] so a
+ * uploaded once and stays in HBM; hashes live in a padded device arena [video * rows_per_video][stride] so a
  * plain all-gather over contiguous video blocks fills the rows other ranks computed; pairs are
  * addressed by their index in the reference's lexicographic pair list (comparator.rs:534-545). */
 typedef struct NeedleHipLibrary NeedleHipLibrary;
@@ -167,15 +167,19 @@ typedef struct NeedleHipLibrary NeedleHipLibrary;
 enum NeedleError needle_hip_library_new(size_t num_videos, float opening_search_percentage, float hash_duration,
                                         NeedleHipLibrary **output);
 void needle_hip_library_free(NeedleHipLibrary *library);
+/* Analyzer::with_include_endings + with_ending_search_percentage (analyzer.rs:130-139): also fingerprint the
+ * last `ending_search_percentage` of every video.  Call before set_pcm; the arena then has two rows per video. */
+enum NeedleError needle_hip_library_include_endings(NeedleHipLibrary *library, float ending_search_percentage);
+size_t needle_hip_library_rows_per_video(const NeedleHipLibrary *library);
 /* Lengths (values per stream, all videos) are metadata every rank holds; pcm[i] may be NULL for
  * videos this rank does not own.  Crops to the opening window and uploads. */
 enum NeedleError needle_hip_library_set_pcm(NeedleHipLibrary *library, const int16_t *const *pcm,
                                             const size_t *num_values, int channels);
 /* Fingerprint videos [first, first+count) into their arena rows (GPU only, no host copy). */
 enum NeedleError needle_hip_library_analyze(NeedleHipLibrary *library, size_t first, size_t count, bool sync);
-/* Arena geometry: device pointer to u32[num_videos][stride]. */
+/* Arena geometry: device pointer to u32[num_videos * rows_per_video][stride]. */
 enum NeedleError needle_hip_library_hash_arena(NeedleHipLibrary *library, uint32_t **d_arena, size_t *stride);
-/* Adopt caller-owned device memory u32[rows][stride] (rows >= num_videos, stride >= the library's) as the
+/* Adopt caller-owned device memory u32[rows][stride] (rows >= num_videos * rows_per_video, stride >= the library's) as the
  * arena, e.g. a buffer a collective library allocated so rows can be all-gathered in place.  Call after
  * set_pcm and before analyze; the caller keeps the memory alive and zero-initialised. */
 enum NeedleError needle_hip_library_use_hash_arena(NeedleHipLibrary *library, uint32_t *d_arena, size_t rows,
@@ -191,7 +195,7 @@ enum NeedleError needle_hip_library_search(NeedleHipLibrary *library, const stru
 enum NeedleError needle_hip_library_finalize(NeedleHipLibrary *library, const struct NeedleAudioComparator *comparator,
                                              const NeedleHipRun *runs, size_t num_runs,
                                              NeedleHipSearchResult *results);
-/* Copies one video's FrameHashes (opening only) out of the library after analyze (+gather). */
+/* Copies one video's FrameHashes out of the library after analyze (+gather). */
 enum NeedleError needle_hip_library_frame_hashes(NeedleHipLibrary *library, size_t index, FrameHashes **output);
 
 #ifdef __cplusplus

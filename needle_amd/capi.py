@@ -78,7 +78,8 @@ NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_frame_hashes_copy", "needle_hip_frame_hashes_hash_duration_ns", "needle_hip_frame_hashes_md5",
     "needle_hip_frame_hashes_read", "needle_hip_frame_hashes_write", "needle_hip_header_md5",
     "needle_hip_analyzer_run_pcm", "needle_hip_comparator_run_with_frame_hashes", "needle_hip_library_new",
-    "needle_hip_library_free", "needle_hip_library_set_pcm", "needle_hip_library_analyze",
+    "needle_hip_library_free", "needle_hip_library_include_endings", "needle_hip_library_rows_per_video",
+    "needle_hip_library_set_pcm", "needle_hip_library_analyze",
     "needle_hip_library_hash_arena", "needle_hip_library_use_hash_arena", "needle_hip_library_num_pairs", "needle_hip_library_search",
     "needle_hip_library_finalize", "needle_hip_library_frame_hashes"]
 
@@ -159,6 +160,9 @@ def lib():
     L.needle_hip_library_new.argtypes = [sz, f32, f32, C.POINTER(vp)]
     L.needle_hip_library_free.argtypes = [vp]
     L.needle_hip_library_free.restype = None
+    L.needle_hip_library_include_endings.argtypes = [vp, f32]
+    L.needle_hip_library_rows_per_video.argtypes = [vp]
+    L.needle_hip_library_rows_per_video.restype = sz
     L.needle_hip_library_set_pcm.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.c_int]
     L.needle_hip_library_analyze.argtypes = [vp, sz, sz, b]
     L.needle_hip_library_hash_arena.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
@@ -489,6 +493,13 @@ class Library:
         check(lib().needle_hip_library_new(num_videos, opening_search_percentage, hash_duration, C.byref(out)))
         self._h = out
         self.n = num_videos
+
+    def include_endings(self, ending_search_percentage: float = DEFAULT_ENDING_SEARCH_PERCENTAGE) -> "Library":
+        check(lib().needle_hip_library_include_endings(self._h, ending_search_percentage))
+        return self
+
+    def rows_per_video(self) -> int:
+        return lib().needle_hip_library_rows_per_video(self._h)
 
     def set_pcm(self, pcm: Sequence[Optional[np.ndarray]], num_values: Sequence[int], channels: int = 1) -> None:
         arrs = [None if p is None else np.ascontiguousarray(p, dtype=np.int16) for p in pcm]

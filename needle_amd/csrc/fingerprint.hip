@@ -333,6 +333,7 @@ FpWorkspace *workspace() {
 Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan> &spans, int channels,
                               uint32_t step, uint32_t *d_items, bool sync, double *d_chroma_dbg,
                               double *d_feat_dbg) {
+  std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   if (channels != 1 && channels != 2)
     return Status::Make(NeedleError_InvalidArgument, "fingerprint: channels must be 1 or 2");
   if (step == 0) return Status::Make(NeedleError_InvalidArgument, "fingerprint: step must be >= 1");
@@ -431,6 +432,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
 
 Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
                             int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items) {
+  std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   Status s = ensure_device();
   if (!s.ok()) return s;
   if (channels != 1 && channels != 2)

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 
 #include "common.h"
@@ -18,6 +19,10 @@ namespace needle {
       return Status::Make(NeedleError_Unknown, std::string("HIP error: ") + hipGetErrorString(_e) +  \
                                                    " at " #expr);                                    \
   } while (0)
+
+// The device workspaces (chroma/feature buffers, descriptor staging) are shared per device, so GPU entry points
+// are serialised; host threads (e.g. a rayon pool calling chromaprint_finish) may call in concurrently.
+std::recursive_mutex &gpu_mutex();
 
 // Fails loudly (NeedleError_Unknown "no HIP device") when no GPU is usable: there is no CPU path.
 Status ensure_device();

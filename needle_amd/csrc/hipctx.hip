@@ -23,6 +23,11 @@ std::string timer_key(const char *name) {
 }
 }  // namespace
 
+std::recursive_mutex &gpu_mutex() {
+  static std::recursive_mutex mu;
+  return mu;
+}
+
 void set_last_error(const std::string &m) { g_last_error = m; }
 const char *last_error() { return g_last_error.c_str(); }
 

@@ -3,10 +3,11 @@
 // The reference's library path is Analyzer::run -> Comparator::run_with_frame_hashes
 // (needle/src/audio/analyzer.rs:425, comparator.rs:524): analyze every video, then search every pair.
 // Here the PCM of the videos a rank owns stays in HBM, hashes are written straight into a padded device
-// arena u32[num_videos][stride] (row v = kept hashes of video v's opening window), the pair search reads
-// that arena in place, and only the short run list and — for simhash32 in the epilogue — the arena
-// itself cross PCIe.  Rows computed by other ranks are filled by the caller with one all-gather over
-// contiguous row blocks (RCCL over xGMI); pairs are sharded by index in the lexicographic pair list.
+// arena u32[rows][stride] (one row per video and search window: row v*R = opening, v*R+1 = ending when
+// endings are enabled), the pair search reads that arena in place, and only the short run list crosses
+// PCIe — the runs carry their simhashes, so the host epilogue needs timestamps only.  Rows computed by
+// other ranks are filled by the caller with one all-gather over contiguous row blocks (RCCL over xGMI);
+// pairs are sharded by index in the lexicographic pair list.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -30,24 +31,36 @@ void fill_c_result(const VideoResult &v, NeedleHipSearchResult *r);
 
 using namespace needle;
 
+namespace {
+struct Window {              // one search window of one video
+  size_t values = 0;         // interleaved s16 values
+  uint64_t pcm_off = ~0ull;  // offset into d_pcm; ~0 when this rank does not hold the PCM
+  uint32_t kept = 0;         // hashes kept (every step-th raw item)
+  ns_t seek = 0;             // added to every timestamp (ending window, analyzer.rs:314-318)
+};
+}  // namespace
+
 struct NeedleHipLibrary {
   size_t n = 0;
   float opening_pct = DEFAULT_OPENING_SEARCH_PERCENTAGE;
+  float ending_pct = DEFAULT_ENDING_SEARCH_PERCENTAGE;
+  bool endings = false;
   ns_t hash_duration = 0;
   uint32_t step = 0;
   int channels = 1;
   bool have_pcm = false;
-  std::vector<size_t> window_values;  // interleaved values of each video's opening window
-  std::vector<uint32_t> kept;         // kept hashes per video
-  std::vector<uint64_t> pcm_off;      // offset into d_pcm (values); ~0 when this rank does not hold the PCM
+  std::vector<Window> win;  // [video * regions() + region]
   size_t stride = 0;
   DeviceBuffer<int16_t> d_pcm;
   DeviceBuffer<uint32_t> d_arena;
   uint32_t *arena = nullptr;  // d_arena.ptr, or caller-owned memory adopted with needle_hip_library_use_hash_arena
-  std::vector<std::vector<HashTs>> ts_cache;  // timestamps by kept length (identical for equal lengths)
-  std::vector<uint32_t> min_len;              // per video, for the comparator's opening duration ...
-  ns_t min_len_for = ~0ull;                   // ... this one (recomputed only when it changes)
+  std::vector<std::vector<HashTs>> ts_cache;  // un-seeked timestamps by kept length
+  std::vector<uint32_t> min_len;              // per row, for the durations below
+  ns_t min_len_for[2] = {~0ull, ~0ull};
   std::vector<FrameHashesData> shells;        // per-video timestamps for the epilogue (hashes stay in HBM)
+
+  size_t regions() const { return endings ? 2 : 1; }
+  size_t rows() const { return n * regions(); }
 
   const std::vector<HashTs> &timestamps(uint32_t k) {
     if (ts_cache.size() <= k) ts_cache.resize(k + 1);
@@ -56,6 +69,12 @@ struct NeedleHipLibrary {
       attach_timestamps(zeros.data(), k, step, false, 0, &ts_cache[k]);
     }
     return ts_cache[k];
+  }
+  std::vector<HashTs> window_timestamps(const Window &w) {
+    std::vector<HashTs> ts = timestamps(w.kept);
+    if (w.seek)
+      for (HashTs &h : ts) h.ts += w.seek;
+    return ts;
   }
 };
 
@@ -96,6 +115,14 @@ enum NeedleError needle_hip_library_new(size_t num_videos, float opening_search_
 
 void needle_hip_library_free(NeedleHipLibrary *library) { delete library; }
 
+enum NeedleError needle_hip_library_include_endings(NeedleHipLibrary *lib, float ending_search_percentage) {
+  if (!lib) return NeedleError_NullArgument;
+  if (lib->have_pcm) return NeedleError_InvalidArgument;  // must precede set_pcm
+  lib->endings = true;
+  lib->ending_pct = ending_search_percentage;
+  return NeedleError_Ok;
+}
+
 enum NeedleError needle_hip_library_set_pcm(NeedleHipLibrary *lib, const int16_t *const *pcm, const size_t *num_values,
                                             int channels) {
   if (!lib || !pcm || !num_values) return NeedleError_NullArgument;
@@ -104,39 +131,47 @@ enum NeedleError needle_hip_library_set_pcm(NeedleHipLibrary *lib, const int16_t
     Status s = ensure_device();
     if (!s.ok()) return report(s);
     lib->channels = channels;
-    lib->window_values.assign(lib->n, 0);
-    lib->kept.assign(lib->n, 0);
-    lib->pcm_off.assign(lib->n, ~0ull);
+    const size_t R = lib->regions();
+    lib->win.assign(lib->rows(), Window{});
     uint64_t total = 0;
     uint32_t max_kept = 0;
+    std::vector<size_t> first_sample(lib->rows(), 0);
     for (size_t v = 0; v < lib->n; v++) {
       const size_t samples = num_values[v] / (size_t)channels;
       size_t open_samples = 0, end_first = 0;
       ns_t seek = 0;
-      s = Analyzer::windows(samples, kSampleRate, lib->opening_pct, DEFAULT_ENDING_SEARCH_PERCENTAGE, &open_samples,
-                            &end_first, &seek);
+      s = Analyzer::windows(samples, kSampleRate, lib->opening_pct, lib->ending_pct, &open_samples, &end_first, &seek);
       if (!s.ok()) return report(s);
-      lib->window_values[v] = open_samples * (size_t)channels;
-      lib->kept[v] = (uint32_t)num_kept(open_samples, lib->step);
-      max_kept = std::max(max_kept, lib->kept[v]);
-      if (pcm[v]) {
-        lib->pcm_off[v] = total;
-        total += (lib->window_values[v] + 1) & ~(uint64_t)1;
+      for (size_t r = 0; r < R; r++) {
+        Window &w = lib->win[v * R + r];
+        const size_t count = r == 0 ? open_samples : samples - end_first;
+        first_sample[v * R + r] = r == 0 ? 0 : end_first;
+        w.values = count * (size_t)channels;
+        w.kept = (uint32_t)num_kept(count, lib->step);
+        w.seek = r == 0 ? 0 : seek;
+        max_kept = std::max(max_kept, w.kept);
+        if (pcm[v]) {
+          w.pcm_off = total;
+          total += (w.values + 1) & ~(uint64_t)1;
+        }
       }
     }
     lib->stride = ((size_t)max_kept + 63) & ~(size_t)63;  // rows start 256-byte aligned
     if (lib->stride == 0) lib->stride = 64;
     if (!(s = lib->d_pcm.reserve(std::max<uint64_t>(total, 1))).ok()) return report(s);
-    if (!(s = lib->d_arena.reserve(lib->n * lib->stride)).ok()) return report(s);
+    if (!(s = lib->d_arena.reserve(lib->rows() * lib->stride)).ok()) return report(s);
     hipStream_t stream = library_stream();
     lib->arena = lib->d_arena.ptr;
-    if (hipMemsetAsync(lib->arena, 0, lib->n * lib->stride * sizeof(uint32_t), stream) != hipSuccess)
+    if (hipMemsetAsync(lib->arena, 0, lib->rows() * lib->stride * sizeof(uint32_t), stream) != hipSuccess)
       return report(Status::Make(NeedleError_Unknown, "hipMemset failed"));
     for (size_t v = 0; v < lib->n; v++) {
-      if (!pcm[v] || !lib->window_values[v]) continue;
-      if (hipMemcpyAsync(lib->d_pcm.ptr + lib->pcm_off[v], pcm[v], lib->window_values[v] * sizeof(int16_t),
-                         hipMemcpyHostToDevice, stream) != hipSuccess)
-        return report(Status::Make(NeedleError_Unknown, "PCM upload failed"));
+      for (size_t r = 0; r < R; r++) {
+        const Window &w = lib->win[v * R + r];
+        if (!pcm[v] || !w.values) continue;
+        if (hipMemcpyAsync(lib->d_pcm.ptr + w.pcm_off, pcm[v] + first_sample[v * R + r] * (size_t)channels,
+                           w.values * sizeof(int16_t), hipMemcpyHostToDevice, stream) != hipSuccess)
+          return report(Status::Make(NeedleError_Unknown, "PCM upload failed"));
+      }
     }
     if (hipStreamSynchronize(stream) != hipSuccess) return report(Status::Make(NeedleError_Unknown, "PCM upload failed"));
     lib->have_pcm = true;
@@ -151,10 +186,12 @@ enum NeedleError needle_hip_library_analyze(NeedleHipLibrary *lib, size_t first,
   if (!lib->have_pcm || first > lib->n || count > lib->n - first) return NeedleError_InvalidArgument;
   return guarded([&]() -> NeedleError {
     std::vector<StreamSpan> spans;
-    for (size_t v = first; v < first + count; v++) {
-      if (lib->pcm_off[v] == ~0ull)
-        return report(Status::Make(NeedleError_InvalidArgument, "video " + std::to_string(v) + " has no PCM on this rank"));
-      spans.push_back(StreamSpan{lib->pcm_off[v], lib->window_values[v], (uint64_t)v * lib->stride});
+    const size_t R = lib->regions();
+    for (size_t row = first * R; row < (first + count) * R; row++) {
+      const Window &w = lib->win[row];
+      if (w.pcm_off == ~0ull)
+        return report(Status::Make(NeedleError_InvalidArgument, "video " + std::to_string(row / R) + " has no PCM on this rank"));
+      spans.push_back(StreamSpan{w.pcm_off, w.values, (uint64_t)row * lib->stride});
     }
     Status s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->arena, sync);
     return s.ok() ? NeedleError_Ok : report(s);
@@ -169,9 +206,11 @@ enum NeedleError needle_hip_library_hash_arena(NeedleHipLibrary *lib, uint32_t *
   return NeedleError_Ok;
 }
 
+size_t needle_hip_library_rows_per_video(const NeedleHipLibrary *lib) { return lib ? lib->regions() : 0; }
+
 enum NeedleError needle_hip_library_use_hash_arena(NeedleHipLibrary *lib, uint32_t *d_arena, size_t rows, size_t stride) {
   if (!lib || !d_arena) return NeedleError_NullArgument;
-  if (!lib->have_pcm || rows < lib->n || stride < lib->stride) return NeedleError_InvalidArgument;
+  if (!lib->have_pcm || rows < lib->rows() || stride < lib->stride) return NeedleError_InvalidArgument;
   lib->arena = d_arena;
   lib->stride = stride;
   lib->d_arena.release();
@@ -188,27 +227,39 @@ enum NeedleError needle_hip_library_search(NeedleHipLibrary *lib, const struct N
   if (!lib->have_pcm || first_pair > np || num_pairs > np - first_pair) return NeedleError_InvalidArgument;
   return guarded([&]() -> NeedleError {
     const Comparator &cmp = comparator_of(comparator);
-    if (cmp.include_endings())
-      return report(Status::Make(NeedleError_Unknown, "no ending hash data present"));  // library = default Analyzer
-    // per-video minimum run length for the opening duration test (same for equal kept lengths)
-    std::vector<NeedleHipSeq> seqs(lib->n);
-    for (size_t v = 0; v < lib->n; v++) seqs[v] = NeedleHipSeq{(uint32_t)(v * lib->stride), lib->kept[v]};
-    if (lib->min_len.size() != lib->n || lib->min_len_for != cmp.min_opening_duration()) {
-      lib->min_len.assign(lib->n, 0);
-      for (size_t v = 0; v < lib->n; v++)
-        lib->min_len[v] = v > 0 && lib->kept[v] == lib->kept[v - 1]
-                              ? lib->min_len[v - 1]
-                              : cmp.min_run_length_for(lib->timestamps(lib->kept[v]), true);
-      lib->min_len_for = cmp.min_opening_duration();
+    if (cmp.include_endings() && !lib->endings)  // comparator.rs:271-273
+      return report(Status::Make(NeedleError_Unknown, "no ending hash data present"));
+    const size_t R = lib->regions(), Rc = cmp.include_endings() ? 2 : 1;
+    std::vector<NeedleHipSeq> seqs(lib->rows());
+    for (size_t row = 0; row < lib->rows(); row++)
+      seqs[row] = NeedleHipSeq{(uint32_t)(row * lib->stride), lib->win[row].kept};
+    // per-row minimum run length for the duration tests (it depends on the kept length only: the seek offset
+    // of an ending window cancels in ts[i] - ts[i-L])
+    if (lib->min_len.size() != lib->rows() || lib->min_len_for[0] != cmp.min_opening_duration() ||
+        lib->min_len_for[1] != cmp.min_ending_duration()) {
+      lib->min_len.assign(lib->rows(), 0);
+      for (size_t row = 0; row < lib->rows(); row++) {
+        const bool opening = row % R == 0;
+        lib->min_len[row] = row >= R && lib->win[row].kept == lib->win[row - R].kept
+                                ? lib->min_len[row - R]
+                                : cmp.min_run_length_for(lib->timestamps(lib->win[row].kept), opening);
+      }
+      lib->min_len_for[0] = cmp.min_opening_duration();
+      lib->min_len_for[1] = cmp.min_ending_duration();
     }
     std::vector<NeedleHipProblem> problems;
-    problems.reserve(num_pairs);
+    problems.reserve(num_pairs * Rc);
     for (size_t p = first_pair; p < first_pair + num_pairs; p++) {
       size_t i, j;
       pair_at(lib->n, p, &i, &j);
-      const uint32_t a = lib->min_len[i], b = lib->min_len[j];
-      if (a == 0 || b == 0) continue;
-      problems.push_back(NeedleHipProblem{(uint32_t)i, (uint32_t)j, std::max(a, b), (uint32_t)p});
+      for (size_t r = 0; r < Rc; r++) {
+        if (r == 1 && (lib->win[i * R + 1].kept == 0 || lib->win[j * R + 1].kept == 0))  // comparator.rs:271-273
+          return report(Status::Make(NeedleError_Unknown, "no ending hash data present"));
+        const uint32_t a = lib->min_len[i * R + r], b = lib->min_len[j * R + r];
+        if (a == 0 || b == 0) continue;
+        problems.push_back(NeedleHipProblem{(uint32_t)(i * R + r), (uint32_t)(j * R + r), std::max(a, b),
+                                            (uint32_t)(p * Rc + r)});
+      }
     }
     Status s = gpu_hamming_runs_device(lib->arena, seqs.data(), seqs.size(), problems.data(), problems.size(),
                                        cmp.hash_match_threshold(), d_runs, capacity, d_count, sync);
@@ -226,8 +277,10 @@ enum NeedleError needle_hip_library_finalize(NeedleHipLibrary *lib, const struct
     // the epilogue needs timestamps only: the runs carry their simhashes, so the hash arena stays in HBM
     if (lib->shells.size() != lib->n) {
       lib->shells.assign(lib->n, {});
+      const size_t R = lib->regions();
       for (size_t v = 0; v < lib->n; v++) {
-        lib->shells[v].opening = lib->timestamps(lib->kept[v]);
+        lib->shells[v].opening = lib->window_timestamps(lib->win[v * R]);
+        if (lib->endings) lib->shells[v].ending = lib->window_timestamps(lib->win[v * R + 1]);
         lib->shells[v].hash_duration = lib->hash_duration;
       }
     }
@@ -250,16 +303,21 @@ enum NeedleError needle_hip_library_frame_hashes(NeedleHipLibrary *lib, size_t i
   if (!lib || !output) return NeedleError_NullArgument;
   if (!lib->have_pcm || index >= lib->n) return NeedleError_InvalidArgument;
   return guarded([&]() -> NeedleError {
-    std::vector<uint32_t> host(lib->kept[index]);
-    hipStream_t stream = library_stream();
-    if (!host.empty() &&
-        (hipMemcpyAsync(host.data(), lib->arena + index * lib->stride, host.size() * sizeof(uint32_t),
-                        hipMemcpyDeviceToHost, stream) != hipSuccess ||
-         hipStreamSynchronize(stream) != hipSuccess))
-      return report(Status::Make(NeedleError_Unknown, "hash arena download failed"));
+    const size_t R = lib->regions();
     FrameHashesData fh;
-    fh.opening = lib->timestamps(lib->kept[index]);
-    for (size_t k = 0; k < host.size(); k++) fh.opening[k].hash = host[k];
+    hipStream_t stream = library_stream();
+    for (size_t r = 0; r < R; r++) {
+      const Window &w = lib->win[index * R + r];
+      std::vector<uint32_t> host(w.kept);
+      if (!host.empty() &&
+          (hipMemcpyAsync(host.data(), lib->arena + (index * R + r) * lib->stride, host.size() * sizeof(uint32_t),
+                          hipMemcpyDeviceToHost, stream) != hipSuccess ||
+           hipStreamSynchronize(stream) != hipSuccess))
+        return report(Status::Make(NeedleError_Unknown, "hash arena download failed"));
+      std::vector<HashTs> ts = lib->window_timestamps(w);
+      for (size_t k = 0; k < host.size(); k++) ts[k].hash = host[k];
+      (r == 0 ? fh.opening : fh.ending) = std::move(ts);
+    }
     fh.hash_duration = lib->hash_duration;
     *output = make_frame_hashes(std::move(fh));
     return NeedleError_Ok;

@@ -120,6 +120,7 @@ class Comparator {
                          const std::vector<HashTs> &dst, ns_t src_hash_duration, ns_t dst_hash_duration,
                          bool is_opening, std::vector<HeapEntry> *out) const;
   ns_t min_opening_duration() const { return min_opening_duration_; }
+  ns_t min_ending_duration() const { return min_ending_duration_; }
   // Run list of ALL pairs (NeedleHipRun.problem = pair_index * regions + region) -> per-video results.
   Status results_from_runs(const std::vector<const FrameHashesData *> &frame_hashes,
                            const std::vector<NeedleHipRun> &runs, bool display, bool use_skip_files,

@@ -224,3 +224,54 @@ def test_reference_examples_compile_unchanged(tmp_path):
         subprocess.run(["gcc", src, "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-L",
                         os.path.dirname(capi.LIB_PATH), "-lneedle_capi", "-o", str(tmp_path / f"{name}.out")],
                        check=True)
+
+
+# ---- libchromaprint-compatible entry points (include/needle_chromaprint.h) ---------------------------------------
+def _chromaprint_lib():
+    L = C.CDLL(os.path.join(os.path.dirname(capi.LIB_PATH), "libneedle_chromaprint.so"))
+    L.chromaprint_new.restype = C.c_void_p
+    L.chromaprint_new.argtypes = [C.c_int]
+    L.chromaprint_get_version.restype = C.c_char_p
+    for fn in ("chromaprint_free", "chromaprint_dealloc"):
+        getattr(L, fn).argtypes = [C.c_void_p]
+        getattr(L, fn).restype = None
+    for fn in ("chromaprint_get_sample_rate", "chromaprint_get_item_duration", "chromaprint_get_item_duration_ms",
+               "chromaprint_get_delay", "chromaprint_get_delay_ms", "chromaprint_finish", "chromaprint_get_num_channels",
+               "chromaprint_get_algorithm", "chromaprint_clear_fingerprint"):
+        getattr(L, fn).argtypes = [C.c_void_p]
+    L.chromaprint_start.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.chromaprint_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.chromaprint_get_raw_fingerprint.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int)]
+    L.chromaprint_get_raw_fingerprint_size.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    return L
+
+
+def test_chromaprint_compat_exports_and_constants(has_gpu):
+    """The libchromaprint calls needle makes (analyzer.rs:176,179,218,275,286,288-289,300) exist with
+    libchromaprint's names, 1/0 return convention and the constants chromaprint reports for its default algorithm."""
+    L = _chromaprint_lib()
+    text = open(os.path.join(ROOT, "include", "needle_chromaprint.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for sym in sorted(set(re.findall(r"\b(chromaprint_[a-z_]+)\s*\(", text))):
+        assert hasattr(L, sym), sym
+    assert L.chromaprint_new(0) is None and L.chromaprint_new(3) is None      # only TEST2 (the default)
+    ctx = L.chromaprint_new(1)
+    assert ctx
+    assert L.chromaprint_get_sample_rate(ctx) == 11025 and L.chromaprint_get_num_channels(ctx) == 1
+    assert (L.chromaprint_get_item_duration(ctx), L.chromaprint_get_item_duration_ms(ctx)) == (1365, 123)
+    assert (L.chromaprint_get_delay(ctx), L.chromaprint_get_delay_ms(ctx)) == (28666, 2600)
+    assert L.chromaprint_get_delay_ms(ctx) == O.delay_ms() and L.chromaprint_get_item_duration_ms(ctx) == O.item_duration_ms()
+    pcm = np.zeros(30000, np.int16)
+    assert L.chromaprint_feed(ctx, pcm.ctypes.data, 100) == 0                   # not started
+    assert L.chromaprint_start(ctx, 44100, 2) == 0                              # no resampler: needle feeds 11025 Hz
+    assert L.chromaprint_start(ctx, 11025, 6) == 0
+    assert L.chromaprint_start(ctx, 11025, 2) == 1
+    assert L.chromaprint_feed(ctx, pcm.ctypes.data, 101) == 0                   # not a multiple of the channel count
+    assert L.chromaprint_feed(ctx, pcm.ctypes.data, 30000) == 1
+    n = C.c_int(-1)
+    assert L.chromaprint_get_raw_fingerprint_size(ctx, C.byref(n)) == 0         # before finish
+    if not has_gpu:
+        assert L.chromaprint_finish(ctx) == 0                                   # no device, no CPU fallback
+    L.chromaprint_free(ctx)
+    L.chromaprint_free(None)
+    L.chromaprint_dealloc(None)

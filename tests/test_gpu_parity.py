@@ -445,3 +445,78 @@ def test_config3_search_only_from_needle_dat_files(tmp_path, capfd):
     # in-memory call returns the same per-video results
     got = cmp.run_with_frame_hashes([capi.FrameHashes.from_path(p[:-4] + ".needle.dat") for p in paths])
     _same_results(got, want)
+
+
+def test_chromaprint_compat_streaming_equals_oracle(lib3):
+    """libchromaprint's streaming calls as needle issues them (start(rate, 2); feed per resampled frame; finish;
+    get_raw_fingerprint) give the oracle's raw fingerprint, whatever the feed chunking."""
+    import ctypes as C
+    from .test_capi_cpu import _chromaprint_lib
+    L = _chromaprint_lib()
+    pcm = np.ascontiguousarray(lib3[2].pcm[: 50 * 11025])
+    want = O.fingerprint(pcm)
+    stereo = np.ascontiguousarray(np.repeat(pcm, 2))
+    for channels, data, chunk in [(1, pcm, 4096), (2, stereo, 2 * 1152), (2, stereo, 2 * 7), (1, pcm, len(pcm))]:
+        ctx = L.chromaprint_new(1)
+        assert L.chromaprint_start(ctx, L.chromaprint_get_sample_rate(ctx), channels) == 1
+        step = chunk if chunk > 64 else 2 * 50001                              # tiny chunks only for the head
+        off = 0
+        first = True
+        while off < len(data):
+            size = min(chunk if first else step, len(data) - off)
+            assert L.chromaprint_feed(ctx, data[off:].ctypes.data, size) == 1
+            off += size
+            first = False
+        assert L.chromaprint_finish(ctx) == 1
+        fp = C.POINTER(C.c_uint32)()
+        n = C.c_int(0)
+        assert L.chromaprint_get_raw_fingerprint(ctx, C.byref(fp), C.byref(n)) == 1
+        assert [fp[i] for i in range(n.value)] == want.tolist()
+        L.chromaprint_dealloc(fp)
+        L.chromaprint_free(ctx)
+
+
+def test_library_with_endings_matches_oracle():
+    """The HBM-resident Library with both search windows (Analyzer.with_include_endings) and a comparator that
+    asks for endings: hashes, timestamps (seek offset included) and results equal the reference path."""
+    eps = synth.make_library(6, 150.0, 30.0, 28.0)
+    hd = O.duration_from_secs_f32(0.3)
+    lib = capi.Library(len(eps)).include_endings(0.25)
+    assert lib.rows_per_video() == 2
+    lib.set_pcm([e.pcm for e in eps], [len(e.pcm) for e in eps])
+    lib.analyze()
+    ref = []
+    for v, e in enumerate(eps):
+        dur = O.duration_from_secs_f64(len(e.pcm) * (1.0 / 11025.0))
+        n_open = O.duration_mul_f32(dur, 0.5) * 11025 // NS
+        seek = O.duration_mul_f32(dur, float(np.float32(1.0) - np.float32(0.25)))
+        first = seek * 11025 // NS
+        o = O.step_and_timestamp(O.fingerprint(e.pcm[:n_open]), hd)
+        en = O.step_and_timestamp(O.fingerprint(e.pcm[first:]), hd, seek_to_ns=seek)
+        ref.append(O.FrameHashes(o, en, hd))
+        f = lib.frame_hashes(v)
+        assert [list(x) for x in zip(*[a.tolist() for a in f.opening_data()])] == [list(x) for x in o]
+        assert [list(x) for x in zip(*[a.tolist() for a in f.ending_data()])] == [list(x) for x in en]
+    for kw in (dict(include_endings=True, min_opening_duration=20, min_ending_duration=15),
+               dict(include_endings=False, min_opening_duration=25)):
+        cmp = capi.Comparator([f"e{k}.wav" for k in range(len(eps))], **kw)
+        cmp.handle()
+        cap = 1 << 14
+        d_runs, d_count = capi.DeviceBuffer(cap * capi.RUN_DTYPE.itemsize), capi.DeviceBuffer(4)
+        lib.search(cmp, 0, lib.num_pairs(), d_runs.ptr, cap, d_count.ptr)
+        runs = d_runs.to_host(capi.RUN_DTYPE, int(d_count.to_host(np.uint32, 1)[0]))
+        got = lib.finalize(cmp, runs)
+        want = O.run_with_frame_hashes(O.Comparator(include_endings=kw["include_endings"],
+                                                    min_opening_duration=kw["min_opening_duration"] * NS,
+                                                    min_ending_duration=kw.get("min_ending_duration", 20) * NS), ref)
+        _same_results(got, want)
+        if kw["include_endings"]:
+            assert all(r is not None and r.opening is not None and r.ending is not None for r in got)
+    # a comparator that wants endings on a library analysed without them is the reference's NoEnding error
+    plain = capi.Library(2)
+    plain.set_pcm([eps[0].pcm, eps[1].pcm], [len(eps[0].pcm), len(eps[1].pcm)])
+    plain.analyze()
+    c2 = capi.Comparator(["a.wav", "b.wav"], include_endings=True)
+    c2.handle()
+    with pytest.raises(capi.NeedleError):
+        plain.search(c2, 0, 1, d_runs.ptr, cap, d_count.ptr)
