@@ -172,15 +172,12 @@ def main() -> None:
             torch.cuda.synchronize()
 
         def search_pairs(pfirst, pcount):
-            lib.search(cmp, pfirst, pcount, t_runs.data_ptr(), cap, t_count.data_ptr(), sync=True)
-            found = int(t_count.item())
-            if found > cap:
-                raise SystemExit("run list overflow")
-            state["runs"] = found
-            return t_runs[:found]
+            lib.search(cmp, pfirst, pcount, t_runs.data_ptr(), cap, t_count.data_ptr(), sync=False)
+            return t_runs, t_count          # gathered with one fixed-size collective (ndist.gather_runs_slab)
 
         def finalize(runs_np):
             runs = np.ascontiguousarray(runs_np.astype(np.int32)).view(capi.RUN_DTYPE).reshape(-1)
+            state["runs"] = len(runs)
             return lib.finalize(cmp, runs)
 
         def step(collect):

@@ -71,12 +71,37 @@ def gather_runs(local_runs, world: int):
     return torch.cat([out[r * width: r * width + counts[r]] for r in range(world)], dim=0)
 
 
+def gather_runs_slab(run_buffer, count_tensor, world: int, slab: int = 512):
+    """Latency-lean variant for short run lists: ONE fixed-size all-gather and no host round trip before it.
+    `run_buffer` [capacity, words] and `count_tensor` [1] (int32, total runs found, may exceed the slab) live on
+    the collective's device.  Each rank contributes a slab of 1 + `slab` rows whose row 0 carries its count.
+    Returns (runs ndarray [total, words], complete): `complete` is False when some rank found more than `slab`
+    runs, in which case the caller falls back to gather_runs."""
+    import torch
+    import torch.distributed as dist
+    cols = run_buffer.shape[1]
+    mine = torch.zeros((1 + slab, cols), dtype=run_buffer.dtype, device=run_buffer.device)
+    mine[0, 0] = count_tensor[0]
+    mine[1:] = run_buffer[:slab]
+    if world == 1:
+        out = mine.unsqueeze(0)
+    else:
+        out = torch.empty((world, 1 + slab, cols), dtype=run_buffer.dtype, device=run_buffer.device)
+        dist.all_gather_into_tensor(out.view(world * (1 + slab), cols), mine)
+    host = out.cpu().numpy()
+    counts = [int(host[r, 0, 0]) for r in range(world)]
+    complete = all(c <= slab for c in counts)
+    runs = np.concatenate([host[r, 1:1 + min(counts[r], slab)] for r in range(world)], axis=0)
+    return runs, complete
+
+
 def run_job(n_videos: int, world: int, rank: int, arena, analyze_rows: Callable[[int, int], None],
             search_pairs: Callable[[int, int], "object"], finalize: Callable[[np.ndarray], "object"],
-            sync: Callable[[], None]):
+            sync: Callable[[], None], slab: int = 512):
     """One analyze+search pass.  analyze_rows(first, count) fills this rank's arena rows; search_pairs(first,
-    count) returns this rank's runs as a torch tensor [k, 4]; finalize(runs ndarray) builds the per-video
-    results (rank 0 only; other ranks get None).  sync() orders the compute stream against the collective."""
+    count) returns this rank's runs, either as a torch tensor [k, words] or as a (run_buffer, count_tensor) pair
+    of device tensors for the single-collective slab gather; finalize(runs ndarray) builds the per-video results
+    (rank 0 only; other ranks get None).  sync() orders the compute stream against the collective."""
     first, count = shard(n_videos, world, rank)
     if count:
         analyze_rows(first, count)
@@ -86,7 +111,13 @@ def run_job(n_videos: int, world: int, rank: int, arena, analyze_rows: Callable[
     pfirst, pcount = shard(pair_count(n_videos), world, rank)
     local = search_pairs(pfirst, pcount)
     sync()
-    merged = gather_runs(local, world)
+    if isinstance(local, tuple):
+        run_buffer, count_tensor = local
+        runs, complete = gather_runs_slab(run_buffer, count_tensor, world, slab)
+        if not complete:  # a rank overflowed its slab: exact two-step gather
+            runs = gather_runs(run_buffer[: int(count_tensor.item())], world).cpu().numpy()
+    else:
+        runs = gather_runs(local, world).cpu().numpy()
     if rank != 0:
         return None
-    return finalize(merged.cpu().numpy())
+    return finalize(runs)

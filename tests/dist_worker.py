@@ -63,9 +63,15 @@ def main():
             t = np.ascontiguousarray(rows[j, :kept[j]])
             k = emu.emu_hamming_runs(s.ctypes.data, len(s), t.ctypes.data, len(t), 10, 20, buf, 4096)
             found += [(p, buf[x].src_end, buf[x].dst_end, buf[x].len) for x in range(k)]
-        return torch.tensor(found, dtype=torch.int32).reshape(-1, 4)
+        runs = torch.tensor(found, dtype=torch.int32).reshape(-1, 4)
+        if os.environ.get("NEEDLE_TEST_SLAB"):      # exercise the single-collective path too
+            buf = torch.zeros((4096, 4), dtype=torch.int32)
+            buf[: len(runs)] = runs
+            return buf, torch.tensor([len(runs)], dtype=torch.int32)
+        return runs
 
-    res = ndist.run_job(n, world, rank, arena, analyze_rows, search_pairs, lambda runs: runs.tolist(), lambda: None)
+    res = ndist.run_job(n, world, rank, arena, analyze_rows, search_pairs, lambda runs: runs.tolist(), lambda: None,
+                        slab=int(os.environ.get("NEEDLE_TEST_SLAB", "512")))
     ok_arena = bool(np.array_equal(arena.numpy().view(np.uint32)[:n], truth))
     with open(f"{out_path}.{rank}", "w") as f:
         json.dump({"rank": rank, "arena_complete": ok_arena, "runs": res}, f)

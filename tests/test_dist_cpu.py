@@ -21,12 +21,14 @@ def _free_port():
     return port
 
 
-def _launch(world, n, out):
+def _launch(world, n, out, slab=0):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        if slab:
+            env["NEEDLE_TEST_SLAB"] = str(slab)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), out, str(n)], env=env))
     for p in procs:
         assert p.wait(timeout=300) == 0
@@ -52,3 +54,7 @@ def test_gloo_job_equals_single_process(tmp_path, world, n):
     assert multi[0]["runs"] is not None and all(m["runs"] is None for m in multi[1:])
     assert len(single["runs"]) >= n * (n - 1) // 2           # every pair shares the planted intro
     assert sorted(map(tuple, multi[0]["runs"])) == sorted(map(tuple, single["runs"]))
+    # the single-collective slab gather agrees, both when every rank fits its slab and when one overflows
+    for slab in (512, 4):
+        got = _launch(world, n, str(tmp_path / f"s{world}_{slab}"), slab=slab)
+        assert sorted(map(tuple, got[0]["runs"])) == sorted(map(tuple, single["runs"]))
