@@ -37,7 +37,8 @@ enum NeedleError needle_hip_memcpy_h2d(void *device_dst, const void *host_src, s
 enum NeedleError needle_hip_memcpy_d2h(void *host_dst, const void *device_src, size_t bytes);
 void needle_hip_host_free(void *ptr); /* frees arrays this library malloc'd for the caller */
 
-/* GPU timing of the last needle_hip_* compute call on this thread, measured with HIP events on the
+/* GPU timing of the most recent COMPLETED launch of a kernel (it never waits behind queued work unless no
+ * launch has finished yet), measured with HIP events on the
  * library's own stream (rocprofv3 sees the same kernels).  Names: "stft_chroma", "fir_norm",
  * "classify", "hamming_runs".  Returns milliseconds, <0 if unknown. */
 double needle_hip_last_kernel_ms(const char *kernel);
@@ -190,6 +191,16 @@ size_t needle_hip_library_num_pairs(const NeedleHipLibrary *library);
 enum NeedleError needle_hip_library_search(NeedleHipLibrary *library, const struct NeedleAudioComparator *comparator,
                                            size_t first_pair, size_t num_pairs, NeedleHipRun *d_runs,
                                            uint32_t capacity, uint32_t *d_count, bool sync);
+/* Asynchronous download of a run list for pipelining jobs: _begin enqueues (on the library stream, behind the
+ * search that fills them) the copy of *d_count and of the first max_runs runs into pinned host memory of
+ * `slot` (0 or 1) and returns at once; _end waits for that copy only and hands back a pointer into the pinned
+ * buffer (valid until the slot's next _begin).  *num_runs is the TOTAL found: if it exceeds max_runs the list
+ * is truncated and the caller must fetch it synchronously.  Lets the host epilogue of job k overlap the
+ * kernels of job k+1. */
+enum NeedleError needle_hip_library_fetch_runs_begin(NeedleHipLibrary *library, int slot, const NeedleHipRun *d_runs,
+                                                     const uint32_t *d_count, uint32_t max_runs);
+enum NeedleError needle_hip_library_fetch_runs_end(NeedleHipLibrary *library, int slot, const NeedleHipRun **runs,
+                                                   uint32_t *num_runs);
 /* Host epilogue over the complete run list (all pairs): D2H of the arena, duration validity,
  * simhash32, BinaryHeap order, find_best_match.  `runs` is a host array. */
 enum NeedleError needle_hip_library_finalize(NeedleHipLibrary *library, const struct NeedleAudioComparator *comparator,

@@ -81,6 +81,7 @@ NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_library_free", "needle_hip_library_include_endings", "needle_hip_library_rows_per_video",
     "needle_hip_library_set_pcm", "needle_hip_library_analyze",
     "needle_hip_library_hash_arena", "needle_hip_library_use_hash_arena", "needle_hip_library_num_pairs", "needle_hip_library_search",
+    "needle_hip_library_fetch_runs_begin", "needle_hip_library_fetch_runs_end",
     "needle_hip_library_finalize", "needle_hip_library_frame_hashes"]
 
 _LIB = None
@@ -170,6 +171,8 @@ def lib():
     L.needle_hip_library_num_pairs.argtypes = [vp]
     L.needle_hip_library_num_pairs.restype = sz
     L.needle_hip_library_search.argtypes = [vp, vp, sz, sz, vp, u32, vp, b]
+    L.needle_hip_library_fetch_runs_begin.argtypes = [vp, C.c_int, vp, vp, u32]
+    L.needle_hip_library_fetch_runs_end.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(u32)]
     L.needle_hip_library_finalize.argtypes = [vp, vp, vp, sz, C.POINTER(CSearchResult)]
     L.needle_hip_library_frame_hashes.argtypes = [vp, sz, C.POINTER(vp)]
     _LIB = L
@@ -526,6 +529,20 @@ class Library:
                d_count: int, sync: bool = True) -> None:
         check(lib().needle_hip_library_search(self._h, comparator._h or comparator.handle(), first_pair, num_pairs,
                                               d_runs, capacity, d_count, sync))
+
+    def fetch_runs_begin(self, slot: int, d_runs: int, d_count: int, max_runs: int) -> None:
+        check(lib().needle_hip_library_fetch_runs_begin(self._h, slot, d_runs, d_count, max_runs))
+
+    def fetch_runs_end(self, slot: int, max_runs: int) -> Tuple[np.ndarray, int]:
+        """(runs actually downloaded, total found).  The array is a copy, so the slot can be reused."""
+        ptr = C.c_void_p()
+        total = C.c_uint32(0)
+        check(lib().needle_hip_library_fetch_runs_end(self._h, slot, C.byref(ptr), C.byref(total)))
+        k = min(total.value, max_runs)
+        out = np.zeros(k, dtype=RUN_DTYPE)
+        if k:
+            C.memmove(out.ctypes.data, ptr.value, k * RUN_DTYPE.itemsize)
+        return out, total.value
 
     def finalize(self, comparator: Comparator, runs: np.ndarray) -> List[Optional[SearchResult]]:
         runs = np.ascontiguousarray(runs, dtype=RUN_DTYPE)

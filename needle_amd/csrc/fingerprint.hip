@@ -133,7 +133,7 @@ __device__ __forceinline__ int find_stream(const FpStream *streams, int n, uint3
 // the two real spectra, |X|^2 over bins 10..1307 folded into 12 pitch classes per frame.  A workgroup walks
 // kPairsPerBlock CONSECUTIVE pairs of one region of the batch, so the 3x overlap between neighbouring frames
 // (hop 1365 of 4096) is re-read from this XCD's L2 rather than from HBM.
-constexpr int kPairsPerBlock = 16;
+constexpr int kPairsPerBlock = 16;  // default; NEEDLE_STFT_PAIRS overrides for tuning
 
 // LDS-only workgroup barrier: waits for this wave's LDS traffic, not for its outstanding global loads
 // (__syncthreads() would also drain vmcnt and with it the prefetch of the next pair's PCM).
@@ -153,12 +153,13 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
                                                              const double *__restrict__ window,
                                                              const uint16_t *__restrict__ bin_slot,
                                                              const uint32_t *__restrict__ class_start,
-                                                             double *__restrict__ chroma, uint32_t total_pairs) {
+                                                             double *__restrict__ chroma, uint32_t total_pairs,
+                                                             uint32_t pairs_per_block) {
   extern __shared__ cd lds[];  // core::kLds2Slots complex slots
   using raw_t = typename std::conditional<CH == 1, int16_t, int>::type;  // one sample, or one packed L|R pair
   const int t = threadIdx.x;
-  const uint32_t first = blockIdx.x * kPairsPerBlock;
-  const uint32_t last = min(total_pairs, first + kPairsPerBlock);
+  const uint32_t first = blockIdx.x * pairs_per_block;
+  const uint32_t last = min(total_pairs, first + pairs_per_block);
   if (first >= last) return;
   const cd base0 = tw[t], base1 = tw[16 * (t >> 4)];  // W_4096^t, W_4096^{16 p}: loop-invariant twiddle bases
 
@@ -396,11 +397,13 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       }
       {
         KernelTimer timer("stft_chroma");
-        const uint32_t grid = (uint32_t)((pairs + kPairsPerBlock - 1) / kPairsPerBlock);
+        uint32_t ppb = kPairsPerBlock;
+        if (const char *e = getenv("NEEDLE_STFT_PAIRS")) ppb = (uint32_t)std::max(1, atoi(e));
+        const uint32_t grid = (uint32_t)((pairs + ppb - 1) / ppb);
         auto launch = [&](auto kernel) {
           hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm,
                              ws->streams.ptr, n, tab.tw, tab.window, tab.bin_slot, tab.class_start, ws->chroma.ptr,
-                             (uint32_t)pairs);
+                             (uint32_t)pairs, ppb);
         };
         if (channels == 1) launch(stft_chroma_kernel<1>); else launch(stft_chroma_kernel<2>);
       }

@@ -10,9 +10,10 @@ thread_local std::string g_last_error;
 std::mutex g_mu;
 std::map<int, hipStream_t> g_streams;
 
-struct TimerEvents {
-  hipEvent_t start = nullptr, stop = nullptr;
-  bool recorded = false;
+struct TimerEvents {  // two alternating event pairs, so the newest COMPLETED launch can be read without blocking
+  hipEvent_t start[2] = {nullptr, nullptr}, stop[2] = {nullptr, nullptr};
+  bool recorded[2] = {false, false};
+  int cur = 1;
 };
 std::map<std::string, TimerEvents> g_timers;  // keyed by "<device>:<kernel>"
 
@@ -66,28 +67,39 @@ KernelTimer::KernelTimer(const char *n) : name(n) {
   hipStream_t s = library_stream();
   std::lock_guard<std::mutex> lock(g_mu);
   TimerEvents &t = g_timers[timer_key(name)];
-  if (!t.start) {
-    (void)hipEventCreate(&t.start);
-    (void)hipEventCreate(&t.stop);
+  t.cur ^= 1;
+  if (!t.start[t.cur]) {
+    (void)hipEventCreate(&t.start[t.cur]);
+    (void)hipEventCreate(&t.stop[t.cur]);
   }
-  (void)hipEventRecord(t.start, s);
+  t.recorded[t.cur] = false;
+  (void)hipEventRecord(t.start[t.cur], s);
 }
 
 KernelTimer::~KernelTimer() {
   hipStream_t s = library_stream();
   std::lock_guard<std::mutex> lock(g_mu);
   TimerEvents &t = g_timers[timer_key(name)];
-  (void)hipEventRecord(t.stop, s);
-  t.recorded = true;
+  (void)hipEventRecord(t.stop[t.cur], s);
+  t.recorded[t.cur] = true;
 }
 
 double kernel_ms(const std::string &name) {
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_timers.find(timer_key(name.c_str()));
-  if (it == g_timers.end() || !it->second.recorded) return -1.0;
-  if (hipEventSynchronize(it->second.stop) != hipSuccess) return -1.0;
+  if (it == g_timers.end()) return -1.0;
+  TimerEvents &t = it->second;
+  // newest launch if it has finished, otherwise the one before it (never blocks behind queued work unless
+  // nothing has completed yet)
+  int idx = t.cur;
+  if (!t.recorded[idx] || hipEventQuery(t.stop[idx]) != hipSuccess) {
+    (void)hipGetLastError();
+    if (t.recorded[idx ^ 1]) idx ^= 1;
+  }
+  if (!t.recorded[idx]) return -1.0;
+  if (hipEventSynchronize(t.stop[idx]) != hipSuccess) return -1.0;
   float ms = 0.f;
-  if (hipEventElapsedTime(&ms, it->second.start, it->second.stop) != hipSuccess) return -1.0;
+  if (hipEventElapsedTime(&ms, t.start[idx], t.stop[idx]) != hipSuccess) return -1.0;
   return (double)ms;
 }
 

@@ -58,6 +58,19 @@ struct NeedleHipLibrary {
   std::vector<uint32_t> min_len;              // per row, for the durations below
   ns_t min_len_for[2] = {~0ull, ~0ull};
   std::vector<FrameHashesData> shells;        // per-video timestamps for the epilogue (hashes stay in HBM)
+  // double-buffered asynchronous run-list download (needle_hip_library_fetch_runs_begin / _end)
+  struct Fetch {
+    void *host = nullptr;  // pinned: u32 count, then max_runs NeedleHipRun
+    uint32_t max_runs = 0;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+  } fetch[2];
+  ~NeedleHipLibrary() {
+    for (Fetch &f : fetch) {
+      if (f.host) (void)hipHostFree(f.host);
+      if (f.done) (void)hipEventDestroy(f.done);
+    }
+  }
 
   size_t regions() const { return endings ? 2 : 1; }
   size_t rows() const { return n * regions(); }
@@ -264,6 +277,48 @@ enum NeedleError needle_hip_library_search(NeedleHipLibrary *lib, const struct N
     Status s = gpu_hamming_runs_device(lib->arena, seqs.data(), seqs.size(), problems.data(), problems.size(),
                                        cmp.hash_match_threshold(), d_runs, capacity, d_count, sync);
     return s.ok() ? NeedleError_Ok : report(s);
+  });
+}
+
+enum NeedleError needle_hip_library_fetch_runs_begin(NeedleHipLibrary *lib, int slot, const NeedleHipRun *d_runs,
+                                                     const uint32_t *d_count, uint32_t max_runs) {
+  if (!lib || !d_runs || !d_count) return NeedleError_NullArgument;
+  if (slot < 0 || slot > 1 || max_runs == 0) return NeedleError_InvalidArgument;
+  return guarded([&]() -> NeedleError {
+    NeedleHipLibrary::Fetch &f = lib->fetch[slot];
+    if (f.pending) return report(Status::Make(NeedleError_InvalidArgument, "fetch slot still pending"));
+    const size_t bytes = 16 + (size_t)max_runs * sizeof(NeedleHipRun);
+    if (f.max_runs < max_runs) {
+      if (f.host) (void)hipHostFree(f.host);
+      f.host = nullptr;
+      if (hipHostMalloc(&f.host, bytes, hipHostMallocDefault) != hipSuccess)
+        return report(Status::Make(NeedleError_Unknown, "pinned allocation failed"));
+      f.max_runs = max_runs;
+    }
+    if (!f.done && hipEventCreateWithFlags(&f.done, hipEventDisableTiming) != hipSuccess)
+      return report(Status::Make(NeedleError_Unknown, "event creation failed"));
+    hipStream_t stream = library_stream();
+    if (hipMemcpyAsync(f.host, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipMemcpyAsync(static_cast<char *>(f.host) + 16, d_runs, (size_t)max_runs * sizeof(NeedleHipRun),
+                       hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipEventRecord(f.done, stream) != hipSuccess)
+      return report(Status::Make(NeedleError_Unknown, "asynchronous run download failed"));
+    f.pending = true;
+    return NeedleError_Ok;
+  });
+}
+
+enum NeedleError needle_hip_library_fetch_runs_end(NeedleHipLibrary *lib, int slot, const NeedleHipRun **runs,
+                                                   uint32_t *num_runs) {
+  if (!lib || !runs || !num_runs) return NeedleError_NullArgument;
+  if (slot < 0 || slot > 1 || !lib->fetch[slot].pending) return NeedleError_InvalidArgument;
+  return guarded([&]() -> NeedleError {
+    NeedleHipLibrary::Fetch &f = lib->fetch[slot];
+    if (hipEventSynchronize(f.done) != hipSuccess) return report(Status::Make(NeedleError_Unknown, "run download failed"));
+    f.pending = false;
+    *num_runs = *static_cast<const uint32_t *>(f.host);  // total found; > max_runs means the list was truncated
+    *runs = reinterpret_cast<const NeedleHipRun *>(static_cast<const char *>(f.host) + 16);
+    return NeedleError_Ok;
   });
 }
 
