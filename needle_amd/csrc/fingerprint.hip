@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   const uint32_t first = blockIdx.x * pairs_per_block;
   const uint32_t last = min(total_pairs, first + pairs_per_block);
   if (first >= last) return;
-  const cd base0 = tw[t], base1 = tw[16 * (t >> 4)];  // W_4096^t, W_4096^{16 p}: loop-invariant twiddle bases
+  const cd base0 = tw[t], base1 = tw[16 * (t & 15)];  // W_4096^t, W_4096^{16 n0}: loop-invariant twiddle bases
 
   auto locate = [&](uint32_t g) {
     const int si = find_stream<&FpStream::pair_base>(streams, num_streams, g);
@@ -188,6 +188,10 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   issue_loads(cur);
 
   for (uint32_t g = first; g < last; g++) {
+    // all per-thread address arithmetic is redone per pair from this opaque copy of the thread index: kept
+    // loop-invariant by the compiler it costs more registers than the kernel has (spills to scratch)
+    int tt = t;
+    asm volatile("" : "+v"(tt));
     // window: loaded here every pair (hoisted out of the loop the 16 values would be spilled to scratch)
     const double *wptr = window;
     asm volatile("" : "+s"(wptr));
@@ -202,49 +206,45 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
         sa = ((int)(int16_t)ra[k] + (ra[k] >> 16)) / 2;
         sb = ((int)(int16_t)rb[k] + (rb[k] >> 16)) / 2;
       }
-      const double w = wptr[t + 256 * k];
+      const double w = wptr[tt + 256 * k];
       r[k] = cd{(double)sa * w, (double)sb * (w * cur.keep_b)};
     }
-    core::pass16_compute_write<0>(t, base0, lds, r);
+    // in-place decimation-in-frequency stages (fp_core.h): one barrier per exchange
+    core::dif0(tt, base0, lds, r);
     lds_barrier();
-    core::pass16_read(t, lds, r);
+    core::dif1(tt, base1, lds, r);
     lds_barrier();
-    core::pass16_compute_write<1>(t, base1, lds, r);
+    core::dif2(tt, lds, r);       // r[out16(j)] = Z[bin (t>>4) + 16 (t&15) + 256 j]
+    lds_barrier();                // every thread has read its 16 slots: they may be overwritten
+    core::dif2_publish(tt, lds, r);  // only the partner values Z[N - k] other threads need
     lds_barrier();
-    core::pass16_read(t, lds, r);
-    lds_barrier();
-    core::pass16_compute_write<2>(t, base1, lds, r);
-    lds_barrier();
-
-    // the next pair's PCM is fetched while this pair's spectrum is folded (last pair: harmless re-read)
-    const PairSrc nxt = locate(min(g + 1, last - 1));
-    issue_loads(nxt);
 
     double pa[core::kBinsPerThread], pb[core::kBinsPerThread];
+    int kf[core::kBinsPerThread];
+    bool own[core::kBinsPerThread];
 #pragma unroll
-    for (int i = 0; i < core::kBinsPerThread; i++) {
-      const int k = core::kMinBin + t + 256 * i;
-      pa[i] = pb[i] = 0.0;
-      if (k < core::kMaxBin) core::bin_power2(k, lds, &pa[i], &pb[i]);
-    }
+    for (int j = 0; j < core::kBinsPerThread; j++) own[j] = core::dif_bin_power(tt, j, lds, r, &kf[j], &pa[j], &pb[j]);
     lds_barrier();
+    // the next pair's PCM is fetched while this pair's powers are folded into pitch classes (the spectrum
+    // registers are dead by now; last pair: harmless re-read)
+    const PairSrc nxt = locate(min(g + 1, last - 1));
+    issue_loads(nxt);
     double *plds = reinterpret_cast<double *>(lds);  // class-sorted powers: frame A at [slot], frame B at [2048 + slot]
     const uint16_t *slot_tab = bin_slot;
     asm volatile("" : "+s"(slot_tab));  // keep these small table loads here rather than hoisted + spilled
 #pragma unroll
-    for (int i = 0; i < core::kBinsPerThread; i++) {
-      const int k = t + 256 * i;
-      if (k < core::kNumBins) {
-        const int slot = slot_tab[k];
-        plds[slot] = pa[i];
-        plds[2048 + slot] = pb[i];
+    for (int j = 0; j < core::kBinsPerThread; j++) {
+      if (own[j]) {
+        const int slot = slot_tab[kf[j] - core::kMinBin];
+        plds[slot] = pa[j];
+        plds[2048 + slot] = pb[j];
       }
     }
     lds_barrier();
     // 2 frames x 12 pitch classes x 8 lanes: each class is a contiguous slice; strided partial sums, then a
     // fixed-order 8-lane tree
-    if (t < 2 * kBands * 8) {
-      const int grp = t >> 3, l = t & 7;
+    if (tt < 2 * kBands * 8) {
+      const int grp = tt >> 3, l = tt & 7;
       const int which = grp >= kBands ? 1 : 0, c = grp - which * kBands;
       const uint32_t b0 = class_start[c], b1 = class_start[c + 1];
       const double *pw = plds + which * 2048;

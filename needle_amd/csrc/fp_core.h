@@ -242,6 +242,72 @@ NEEDLE_HD void bin_power2(int k, const cd *lds, double *pa, double *pb) {
   *pb = 0.25 * (br * br + bi * bi);
 }
 
+// ================================================================================================
+// v3 schedule of the same 4096-point transform: decimation in frequency IN PLACE.  With n = 256 n2 + 16 n1 + n0,
+//   stage 0 (thread t = 16 n1 + n0) transforms digit n2:  slots t + 256 k      -> same slots, * W_4096^{t j}
+//   stage 1 (thread t = 16 b  + n0) transforms digit n1:  slots 256 b + n0 + 16 k -> same slots, * W_4096^{16 n0 j}
+//   stage 2 (thread t = 16 b  + c ) transforms digit n0:  slots 16 t + k
+// so X[k0 + 16 k1 + 256 k2] ends in slot 256 k0 + 16 k1 + k2, i.e. in register j = k2 of thread t = 16 k0 + k1.
+// Every thread reads and writes the SAME slots within a stage: one barrier per exchange instead of two, and the
+// last stage only publishes the six registers (j = 10..15) that other threads need as partners Z[N - k] of the
+// bins 10..1307; the bins themselves (j = 0..5) never leave the registers.
+// ================================================================================================
+NEEDLE_HD int dif_slot_of_bin(int kf) { return 256 * (kf & 15) + 16 * ((kf >> 4) & 15) + (kf >> 8); }
+NEEDLE_HD int dif_bin_of(int t, int j) { return (t >> 4) + 16 * (t & 15) + 256 * j; }
+
+// stage 0: r holds the inputs x[t + 256 k]; leaves the stage's outputs in the same slots
+NEEDLE_HD void dif0(int t, cd base0, cd *lds, cd *r) {
+  fft16(r);
+  lds[pidx(t)] = r[out16(0)];
+  cd w = base0;
+#pragma unroll
+  for (int j = 1; j < 16; j++) {
+    lds[pidx(t + 256 * j)] = cmulf(r[out16(j)], w);
+    if (j < 15) w = cmulf(w, base0);
+  }
+}
+
+// stage 1, in place; base1 = W_4096^{16 (t & 15)}
+NEEDLE_HD void dif1(int t, cd base1, cd *lds, cd *r) {
+  const int o = 256 * (t >> 4) + (t & 15);
+#pragma unroll
+  for (int k = 0; k < 16; k++) r[k] = lds_get(lds, pidx(o + 16 * k));
+  fft16(r);
+  lds[pidx(o)] = r[out16(0)];
+  cd w = base1;
+#pragma unroll
+  for (int j = 1; j < 16; j++) {
+    lds[pidx(o + 16 * j)] = cmulf(r[out16(j)], w);
+    if (j < 15) w = cmulf(w, base1);
+  }
+}
+
+// stage 2: afterwards r[out16(j)] = Z[dif_bin_of(t, j)]
+NEEDLE_HD void dif2(int t, const cd *lds, cd *r) {
+#pragma unroll
+  for (int k = 0; k < 16; k++) r[k] = lds_get(lds, pidx(16 * t + k));
+  fft16(r);
+}
+
+// publish the registers other threads read as partners (bins >= 2789 live in j = 10..15), in place
+NEEDLE_HD void dif2_publish(int t, cd *lds, const cd *r) {
+#pragma unroll
+  for (int j = 10; j < 16; j++) lds[pidx(16 * t + j)] = r[out16(j)];
+}
+
+// powers of this thread's bin in register j (0..5) for the two frames; false if the bin is outside 10..1307
+NEEDLE_HD bool dif_bin_power(int t, int j, const cd *lds, const cd *r, int *kf_out, double *pa, double *pb) {
+  const int kf = dif_bin_of(t, j);
+  *kf_out = kf;
+  if (kf < kMinBin || kf >= kMaxBin) return false;
+  const cd z = r[out16(j)], y = lds_get(lds, pidx(dif_slot_of_bin(kFft2N - kf)));
+  const double ar = z.x + y.x, ai = z.y - y.y;  // 2 X_A
+  const double br = z.y + y.y, bi = y.x - z.x;  // 2 X_B
+  *pa = 0.25 * (ar * ar + ai * ai);
+  *pb = 0.25 * (br * br + bi * bi);
+  return true;
+}
+
 // ---- classifiers (chromaprint kClassifiersTest2) ---------------------------------
 struct ClassifierDef {
   int type, y, h, w;  // Filter(type, y, height, width)

@@ -168,6 +168,59 @@ void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, do
   }
 }
 
+// stft_chroma_kernel v3 (in-place DIF), one frame pair
+void emu_stft_chroma_pair_dif(const int16_t *fa, const int16_t *fb, int channels, double *chroma_a, double *chroma_b) {
+  const Tables &T = tables();
+  std::vector<cd> lds(kLds2Slots);
+  std::vector<cd> regs(256 * 16);
+  auto sample = [&](const int16_t *src, int n) -> int {
+    if (!src) return 0;
+    if (channels == 1) return src[n];
+    return ((int)src[2 * n] + (int)src[2 * n + 1]) / 2;
+  };
+  for (int t = 0; t < 256; t++)
+    for (int k = 0; k < 16; k++) {
+      const int n = t + 256 * k;
+      regs[t * 16 + k] = cd{(double)sample(fa, n) * T.window[n], (double)sample(fb, n) * T.window[n]};
+    }
+  for (int t = 0; t < 256; t++) dif0(t, T.tw[t], lds.data(), &regs[t * 16]);
+  for (int t = 0; t < 256; t++) dif1(t, T.tw[16 * (t & 15)], lds.data(), &regs[t * 16]);
+  for (int t = 0; t < 256; t++) dif2(t, lds.data(), &regs[t * 16]);
+  for (int t = 0; t < 256; t++) dif2_publish(t, lds.data(), &regs[t * 16]);
+  std::vector<double> pa(2048, 0.0), pb(2048, 0.0);
+  int seen = 0;
+  for (int t = 0; t < 256; t++)
+    for (int j = 0; j < 6; j++) {
+      int kf;
+      double a, b;
+      if (dif_bin_power(t, j, lds.data(), &regs[t * 16], &kf, &a, &b)) {
+        pa[kf] = a;
+        pb[kf] = b;
+        seen++;
+      }
+    }
+  if (seen != kNumBins) { chroma_a[0] = -1.0; return; }  // every bin must be owned by exactly one (t, j)
+  for (int which = 0; which < 2; which++) {
+    const std::vector<double> &pw = which ? pb : pa;
+    double *out = which ? chroma_b : chroma_a;
+    if (!out) continue;
+    for (int c = 0; c < 12; c++) {
+      double lane[8];
+      for (int l = 0; l < 8; l++) {
+        double acc = 0.0;
+        for (uint32_t b = T.class_start[c] + l; b < T.class_start[c + 1]; b += 8) acc += pw[T.class_bins[b]];
+        lane[l] = acc;
+      }
+      for (int off = 4; off >= 1; off >>= 1) {
+        double nxt[8];
+        for (int l = 0; l < 8; l++) nxt[l] = lane[l] + lane[l ^ off];
+        std::memcpy(lane, nxt, sizeof(lane));
+      }
+      out[c] = lane[0];
+    }
+  }
+}
+
 // classify_kernel, one item: 16 feature rows in, raw u32 out
 uint32_t emu_classify(const double *window16x12) { return classify_window(window16x12, &tables().thr); }
 
