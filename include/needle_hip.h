@@ -74,6 +74,17 @@ enum NeedleError needle_hip_fingerprint_device(const int16_t *d_pcm, const uint6
 enum NeedleError needle_hip_fingerprint_debug(const int16_t *pcm, size_t num_values, int channels,
                                               double *chroma, double *features);
 
+/* ---- resampler + down-mix: the step in FRONT of the path ---------------------------------------------
+ * The reference converts decoded audio to s16 @ 11025 Hz with FFmpeg's swresample before feeding chromaprint
+ * (analyzer.rs:180-187,231-282).  That library is out of scope and not bit-reproducible; this front-end is this
+ * project's own specification (integer down-mix, rational polyphase Kaiser-sinc FIR, f32 fused multiply-adds
+ * in tap order, round to nearest even; oracle/ora_resample.h) so that PCM at the usual decode rates can be
+ * analysed on the device.  Output: mono s16 at 11025 Hz, ceil(n * 11025 / rate) samples per stream.
+ * needle_audio_analyzer_run and needle_hip_analyzer_run_pcm apply it automatically when the rate differs. */
+size_t needle_hip_resample_out_len(size_t samples_per_channel, int sample_rate);
+enum NeedleError needle_hip_resample_host(const int16_t *const *pcm, const size_t *num_values, size_t num_streams,
+                                          int channels, int sample_rate, int16_t *const *out);
+
 /* ---- search: the LCS-Hamming DP replacement -------------------------------------------------------
  * Replaces Comparator::longest_common_hash_match's two table sweeps (comparator.rs:175-247).  For a
  * problem (src, dst, min_len) it reports every maximal diagonal run of cells (i >= 1, j >= 1) with
@@ -133,8 +144,8 @@ enum NeedleError needle_hip_header_md5(const char *path, char out[33]);         
 
 /* ---- Analyzer at the PCM boundary -----------------------------------------------------------------
  * Analyzer::run (analyzer.rs:425) with FFmpeg's half of process_frames already done by the caller:
- * pcm[i] is the whole decoded stream of video i, interleaved s16 at `sample_rate` (must be 11025;
- * resampling is the step before this path).  Applies the opening / ending search windows
+ * pcm[i] is the whole decoded stream of video i, interleaved s16 at `sample_rate` (anything but 11025 Hz is
+ * resampled on the device first, see above).  Applies the opening / ending search windows
  * (analyzer.rs:378,390), fingerprints on the GPU, attaches timestamps (:293-318), stores the
  * FrameHashes in the handle (retrieve with needle_audio_analyzer_get_frame_hashes) and persists
  * <video>.needle.dat when `persist`. */

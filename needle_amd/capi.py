@@ -73,7 +73,8 @@ NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_host_free", "needle_hip_last_kernel_ms", "needle_hip_fingerprint_sample_rate",
     "needle_hip_fingerprint_delay_ms", "needle_hip_fingerprint_item_duration_ms", "needle_hip_fingerprint_num_items",
     "needle_hip_fingerprint_num_kept", "needle_hip_fingerprint_host", "needle_hip_fingerprint_device",
-    "needle_hip_fingerprint_debug", "needle_hip_hamming_runs_device", "needle_hip_hamming_runs_host",
+    "needle_hip_fingerprint_debug", "needle_hip_resample_out_len", "needle_hip_resample_host",
+    "needle_hip_hamming_runs_device", "needle_hip_hamming_runs_host",
     "needle_hip_frame_hashes_new", "needle_hip_frame_hashes_free", "needle_hip_frame_hashes_len",
     "needle_hip_frame_hashes_copy", "needle_hip_frame_hashes_hash_duration_ns", "needle_hip_frame_hashes_md5",
     "needle_hip_frame_hashes_read", "needle_hip_frame_hashes_write", "needle_hip_header_md5",
@@ -139,6 +140,9 @@ def lib():
     L.needle_hip_fingerprint_device.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), sz, C.c_int, u32, vp,
                                                 C.POINTER(u64), b]
     L.needle_hip_fingerprint_debug.argtypes = [vp, sz, C.c_int, vp, vp]
+    L.needle_hip_resample_out_len.argtypes = [sz, C.c_int]
+    L.needle_hip_resample_out_len.restype = sz
+    L.needle_hip_resample_host.argtypes = [C.POINTER(vp), C.POINTER(sz), sz, C.c_int, C.c_int, C.POINTER(vp)]
     L.needle_hip_hamming_runs_device.argtypes = [vp, C.POINTER(Seq), sz, C.POINTER(Problem), sz, u32, vp, u32, vp, b]
     L.needle_hip_hamming_runs_host.argtypes = [vp, sz, C.POINTER(Seq), sz, C.POINTER(Problem), sz, u32,
                                                C.POINTER(C.POINTER(Run)), C.POINTER(sz)]
@@ -462,6 +466,19 @@ def fingerprint_debug(pcm: np.ndarray, channels: int = 1):
     feats = np.zeros((max(frames - 4, 1), 12))
     check(lib().needle_hip_fingerprint_debug(a.ctypes.data, a.size, channels, chroma.ctypes.data, feats.ctypes.data))
     return chroma[:frames], feats[:max(frames - 4, 0)]
+
+
+def resample(pcms: Sequence[np.ndarray], channels: int, sample_rate: int) -> List[np.ndarray]:
+    """needle_hip_resample_host: interleaved s16 at `sample_rate` -> mono s16 at 11025 Hz."""
+    arrs = [np.ascontiguousarray(p, dtype=np.int16) for p in pcms]
+    n = len(arrs)
+    lens_out = [lib().needle_hip_resample_out_len(a.size // channels, sample_rate) for a in arrs]
+    outs = [np.zeros(max(k, 1), dtype=np.int16) for k in lens_out]
+    ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+    lens = (C.c_size_t * max(n, 1))(*[a.size for a in arrs])
+    optrs = (C.c_void_p * max(n, 1))(*[o.ctypes.data for o in outs])
+    check(lib().needle_hip_resample_host(ptrs, lens, n, channels, sample_rate, optrs))
+    return [o[:k] for o, k in zip(outs, lens_out)]
 
 
 def hamming_runs(seqs: Sequence[np.ndarray], problems: Sequence[Tuple[int, int, int]], threshold: int) -> np.ndarray:

@@ -43,9 +43,8 @@ Status Analyzer::run_pcm(const std::vector<PcmView> &pcm, int channels, int samp
     return Status::Make(NeedleError_Unknown, "no paths provided to analyzer");
   if (pcm.size() != videos_.size())
     return Status::Make(NeedleError_InvalidArgument, "one PCM stream per video is required");
-  if (sample_rate != kSampleRate)
-    return Status::Make(NeedleError_Unknown,
-                        "PCM must already be at chromaprint's 11025 Hz (the resampler is the step before this path)");
+  if (sample_rate < 2000 || sample_rate > 768000)
+    return Status::Make(NeedleError_InvalidArgument, "unsupported sample rate");
   if (channels != 1 && channels != 2) return Status::Make(NeedleError_InvalidArgument, "channels must be 1 or 2");
   uint32_t step = 0;
   if (!step_for_hash_duration(hash_duration, &step))  // the reference panics in step_by(0), :293-304
@@ -70,7 +69,9 @@ Status Analyzer::run_pcm(const std::vector<PcmView> &pcm, int channels, int samp
     }
   }
   std::vector<std::vector<uint32_t>> kept;
-  Status s = gpu_fingerprint_host(ptrs, lens, channels, step, &kept);
+  // PCM at another rate than chromaprint's 11025 Hz goes through the device resampler (the reference
+  // resamples with swresample first, :180-187); the windows above are cut at the stream's own rate
+  Status s = gpu_fingerprint_host(ptrs, lens, channels, step, &kept, sample_rate);
   if (!s.ok()) return s;
 
   out->assign(n, {});
@@ -105,7 +106,7 @@ Status Analyzer::run(ns_t hash_duration, bool persist, bool /*threading*/, std::
   std::vector<char> cached(n, 0);
   std::vector<std::string> md5s(n);
   std::vector<WavData> wavs(n);
-  int channels = 0;
+  int channels = 0, rate = kSampleRate;
   for (size_t i = 0; i < n; i++) {
     // run_single :339-348
     Status s = header_md5(videos_[i], &md5s[i]);
@@ -129,11 +130,12 @@ Status Analyzer::run(ns_t hash_duration, bool persist, bool /*threading*/, std::
     }
     s = wav_read(videos_[i], &wavs[i]);
     if (!s.ok()) return s;
-    if (wavs[i].sample_rate != kSampleRate)
-      return Status::Make(NeedleError_Unknown, "audio must be 11025 Hz (resampling is outside this build): " + videos_[i]);
-    if (channels == 0) channels = wavs[i].channels;
-    if (wavs[i].channels != channels)
-      return Status::Make(NeedleError_Unknown, "all files of one run must share a channel count: " + videos_[i]);
+    if (channels == 0) {
+      channels = wavs[i].channels;
+      rate = wavs[i].sample_rate;
+    }
+    if (wavs[i].channels != channels || wavs[i].sample_rate != rate)
+      return Status::Make(NeedleError_Unknown, "all files of one run must share channel count and sample rate: " + videos_[i]);
   }
   // analyse everything that was not cached, as one GPU batch
   Analyzer sub = *this;
@@ -148,7 +150,7 @@ Status Analyzer::run(ns_t hash_duration, bool persist, bool /*threading*/, std::
   }
   if (!views.empty()) {
     std::vector<FrameHashesData> fresh;
-    Status s = sub.run_pcm(views, channels, kSampleRate, hash_duration, false, &fresh);
+    Status s = sub.run_pcm(views, channels, rate, hash_duration, false, &fresh);
     if (!s.ok()) return s;
     for (size_t k = 0; k < index.size(); k++) {
       fresh[k].md5 = md5s[index[k]];

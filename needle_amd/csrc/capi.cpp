@@ -447,6 +447,30 @@ enum NeedleError needle_hip_fingerprint_debug(const int16_t *pcm, size_t num_val
 }
 
 // ============================================================================================================
+// resampler front-end
+// ============================================================================================================
+size_t needle_hip_resample_out_len(size_t samples_per_channel, int sample_rate) {
+  return sample_rate > 0 ? resample_out_len(samples_per_channel, sample_rate) : 0;
+}
+
+enum NeedleError needle_hip_resample_host(const int16_t *const *pcm, const size_t *num_values, size_t num_streams,
+                                          int channels, int sample_rate, int16_t *const *out) {
+  if (!pcm || !num_values || !out) return NeedleError_NullArgument;
+  return guarded([&]() -> NeedleError {
+    std::vector<const int16_t *> p(pcm, pcm + num_streams);
+    std::vector<size_t> n(num_values, num_values + num_streams);
+    for (size_t i = 0; i < num_streams; i++)
+      if ((!p[i] && n[i]) || !out[i]) return NeedleError_NullArgument;
+    std::vector<std::vector<int16_t>> res;
+    Status s = gpu_resample_host(p, n, channels, sample_rate, &res);
+    if (!s.ok()) return report(s);
+    for (size_t i = 0; i < num_streams; i++)
+      if (!res[i].empty()) std::memcpy(out[i], res[i].data(), res[i].size() * sizeof(int16_t));
+    return NeedleError_Ok;
+  });
+}
+
+// ============================================================================================================
 // search
 // ============================================================================================================
 enum NeedleError needle_hip_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seqs, size_t num_seqs,

@@ -102,13 +102,27 @@ struct StreamSpan {
 Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan> &streams, int channels,
                               uint32_t step, uint32_t *d_items, bool sync, double *d_chroma_dbg = nullptr,
                               double *d_feat_dbg = nullptr);
+// `rate` != 11025 routes the streams through the device resampler first (resample.hip).
 Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
-                            int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items);
+                            int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items,
+                            int rate = kSampleRate);
 Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
                                const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
                                NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync);
 Status gpu_hamming_runs_host(const uint32_t *hashes, size_t num_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
                              const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
                              std::vector<NeedleHipRun> *runs);
+
+// ---- resampler front-end (resample.hip) -------------------------------------------------------------------
+struct ResampleSpan {
+  uint64_t in_off;   // offset into the input arena, in s16 values
+  uint64_t n_in;     // samples per channel
+  uint64_t out_off;  // offset into the output arena, in samples
+};
+size_t resample_out_len(size_t n_in, int rate);
+Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> &spans, int channels, int rate,
+                           int16_t *d_out, bool sync);
+Status gpu_resample_host(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values, int channels,
+                         int rate, std::vector<std::vector<int16_t>> *out);
 
 }  // namespace needle

@@ -434,13 +434,14 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
 }
 
 Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
-                            int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items) {
+                            int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items, int rate) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   Status s = ensure_device();
   if (!s.ok()) return s;
   if (channels != 1 && channels != 2)
     return Status::Make(NeedleError_InvalidArgument, "fingerprint: channels must be 1 or 2");
   if (step == 0) return Status::Make(NeedleError_InvalidArgument, "fingerprint: step must be >= 1");
+  const bool resample = rate != kSampleRate;
   const size_t n = pcm.size();
   items->assign(n, {});
   // Batches bounded by bytes so the device arena stays modest for huge libraries.
@@ -448,35 +449,50 @@ Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::
   hipStream_t stream = library_stream();
   size_t begin = 0;
   while (begin < n) {
-    std::vector<StreamSpan> spans;
-    uint64_t values = 0, kept = 0;
+    std::vector<StreamSpan> spans;        // what the fingerprinter reads (11025 Hz; mono if resampled)
+    std::vector<ResampleSpan> rspans;     // what the resampler reads, when the input rate differs
+    std::vector<uint64_t> in_off;
+    uint64_t values = 0, mono = 0, kept = 0;
     size_t end = begin;
     while (end < n) {
       if (!spans.empty() && values + num_values[end] > kMaxBatchValues) break;
-      StreamSpan sp;
-      sp.pcm_off = values;
-      sp.num_values = num_values[end];
-      sp.item_off = kept;
+      const size_t in_samples = num_values[end] / (size_t)channels;
+      const size_t out_samples = resample ? resample_out_len(in_samples, rate) : in_samples;
+      in_off.push_back(values);
+      if (resample) {
+        rspans.push_back(ResampleSpan{values, in_samples, mono});
+        spans.push_back(StreamSpan{mono, out_samples, kept});
+        mono += (out_samples + 1) & ~(uint64_t)1;
+      } else {
+        spans.push_back(StreamSpan{values, num_values[end], kept});
+      }
       values += (num_values[end] + 1) & ~(uint64_t)1;  // keep every stream 4-byte aligned in the arena
-      kept += num_kept(num_values[end] / (size_t)channels, step);
-      spans.push_back(sp);
+      kept += num_kept(out_samples, step);
       end++;
     }
-    DeviceBuffer<int16_t> d_pcm;
+    DeviceBuffer<int16_t> d_pcm, d_mono;
     DeviceBuffer<uint32_t> d_items;
     if (!(s = d_pcm.reserve(std::max<uint64_t>(values, 1))).ok()) return s;
     if (!(s = d_items.reserve(std::max<uint64_t>(kept, 1))).ok()) return s;
     for (size_t i = begin; i < end; i++)
       if (num_values[i])
-        NEEDLE_HIP_TRY(hipMemcpyAsync(d_pcm.ptr + spans[i - begin].pcm_off, pcm[i], num_values[i] * sizeof(int16_t),
+        NEEDLE_HIP_TRY(hipMemcpyAsync(d_pcm.ptr + in_off[i - begin], pcm[i], num_values[i] * sizeof(int16_t),
                                       hipMemcpyHostToDevice, stream));
-    s = gpu_fingerprint_device(d_pcm.ptr, spans, channels, step, d_items.ptr, false);
+    if (resample) {  // decode-rate PCM -> mono 11025 Hz, on the device, then straight into the fingerprinter
+      if (!(s = d_mono.reserve(std::max<uint64_t>(mono, 1))).ok()) return s;
+      s = gpu_resample_device(d_pcm.ptr, rspans, channels, rate, d_mono.ptr, false);
+      if (!s.ok()) return s;
+      s = gpu_fingerprint_device(d_mono.ptr, spans, 1, step, d_items.ptr, false);
+    } else {
+      s = gpu_fingerprint_device(d_pcm.ptr, spans, channels, step, d_items.ptr, false);
+    }
     if (!s.ok()) return s;
     std::vector<uint32_t> host(std::max<uint64_t>(kept, 1));
     NEEDLE_HIP_TRY(hipMemcpyAsync(host.data(), d_items.ptr, kept * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
     for (size_t i = begin; i < end; i++) {
-      const size_t k = num_kept(num_values[i] / (size_t)channels, step);
+      const size_t in_samples = num_values[i] / (size_t)channels;
+      const size_t k = num_kept(resample ? resample_out_len(in_samples, rate) : in_samples, step);
       (*items)[i].assign(host.begin() + spans[i - begin].item_off, host.begin() + spans[i - begin].item_off + k);
     }
     begin = end;

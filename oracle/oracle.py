@@ -111,6 +111,10 @@ def lib():
     L.ora_skip_file_json.argtypes = [C.POINTER(CSearchResult), C.c_char_p, C.c_char_p, C.c_size_t]
     L.ora_skip_file_json.restype = C.c_size_t
     L.ora_format_time.argtypes = [C.c_uint64, C.c_char_p]
+    L.ora_resample_out_len.argtypes = [C.c_size_t, C.c_int]
+    L.ora_resample_out_len.restype = C.c_size_t
+    L.ora_resample.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    L.ora_resample.restype = C.c_size_t
     L.free = C.CDLL(None).free
     L.free.argtypes = [C.c_void_p]
     _LIB = L
@@ -315,6 +319,16 @@ def analyze_batch(pcms: Sequence[np.ndarray], channels: int, hash_duration_ns: i
         res.append(FrameHashes.from_c(out[i]))
         lib().ora_frame_hashes_free(C.byref(out[i]))
     return res
+
+
+def resample(pcm: np.ndarray, channels: int, rate: int) -> np.ndarray:
+    """ora_resample: interleaved s16 at `rate` -> mono s16 at 11025 Hz (this project's own front-end spec)."""
+    a = np.ascontiguousarray(pcm, dtype=np.int16)
+    n = lib().ora_resample_out_len(a.size // channels, rate)
+    out = np.zeros(max(n, 1), dtype=np.int16)
+    got = lib().ora_resample(a.ctypes.data, a.size, channels, rate, out.ctypes.data, n)
+    assert got == n
+    return out[:n]
 
 
 def skip_file_json(r: SearchResult, md5: str) -> str:

@@ -520,3 +520,43 @@ def test_library_with_endings_matches_oracle():
     c2.handle()
     with pytest.raises(capi.NeedleError):
         plain.search(c2, 0, 1, d_runs.ptr, cap, d_count.ptr)
+
+
+def test_resampler_bit_exact_and_analyzer_accepts_decode_rates(tmp_path):
+    """The device resampler equals its oracle bit for bit (integer / f32 arithmetic in a fixed order), for the
+    usual decode rates, mono and stereo, ragged batches; and a 44.1 kHz stereo WAV analysed through the unchanged
+    needle-capi call gives the hashes of the oracle chain resample -> fingerprint."""
+    rng = np.random.default_rng(99)
+    for rate, ch in [(44100, 2), (48000, 2), (48000, 1), (22050, 1), (32000, 2), (8000, 1), (11025, 2)]:
+        pcms = []
+        for n in (0, 1, 777, rate * 3 + 17):
+            t = np.arange(n) / rate
+            x = 6000 * np.sin(2 * np.pi * (300 + 40 * len(pcms)) * t) + 2000 * rng.standard_normal(n)
+            x = np.clip(x, -32768, 32767).astype(np.int16)
+            if ch == 2:
+                x = np.stack([x, np.roll(x, 5)], axis=1).reshape(-1)
+            pcms.append(x)
+        got = capi.resample(pcms, ch, rate)
+        for g, p in zip(got, pcms):
+            assert g.tolist() == O.resample(p, ch, rate).tolist(), (rate, ch, len(p))
+    # full-scale square wave: clamping and rounding agree
+    sq = np.where((np.arange(48000) // 13) % 2 == 0, 32767, -32768).astype(np.int16)
+    assert capi.resample([sq], 1, 48000)[0].tolist() == O.resample(sq, 1, 48000).tolist()
+
+    # analyzer on a 44.1 kHz stereo WAV (what a decoder typically hands over)
+    e = synth.make_episode(3, 40.0, 15.0)
+    up = np.repeat(e.pcm, 4)                                    # crude 4x zero-order hold: any 44.1 kHz content will do
+    up = (up.astype(np.int32) + np.roll(up, 1)) // 2
+    stereo = np.stack([up, up], axis=1).reshape(-1).astype(np.int16)
+    p = str(tmp_path / "ep-44k.wav")
+    synth.write_wav(p, up.astype(np.int16), channels=2, rate=44100)
+    fh = capi.Analyzer.from_files([p]).run(0.3)[0]
+    total = len(up)
+    dur = O.duration_from_secs_f64(total * (1.0 / 44100.0))
+    n_open = O.duration_mul_f32(dur, 0.5) * 44100 // NS
+    mono = O.resample(stereo[: 2 * n_open], 2, 44100)
+    want = O.step_and_timestamp(O.fingerprint(mono), O.duration_from_secs_f32(0.3))
+    h, ts = fh.opening_data()
+    assert h.tolist() == [x for x, _ in want] and ts.tolist() == [t for _, t in want]
+    fh2 = capi.Analyzer.from_files([p]).run_pcm([stereo], channels=2, sample_rate=44100)[0]
+    assert fh2.opening_data()[0].tolist() == h.tolist()

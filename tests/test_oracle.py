@@ -315,3 +315,22 @@ def test_oracle_reproduces_committed_golden_vectors():
     for min_s, want in g["results"].items():
         res = O.run_with_frame_hashes(O.Comparator(min_opening_duration=int(min_s) * NS), fhs)
         assert [None if r is None else list(r.opening) if r.opening else [] for r in res] == want
+
+
+# ---- resampler front-end (own specification, oracle/ora_resample.h) -----------------------------------------------
+def test_resampler_oracle_is_a_sane_low_pass_to_11025():
+    for rate in (44100, 48000, 22050, 32000, 8000):
+        n = rate * 2
+        t = np.arange(n) / rate
+        hi = 9000.0 if rate > 20000 else 0.0                 # above the new Nyquist: must vanish
+        x = (8000 * np.sin(2 * np.pi * 440 * t) + 3000 * np.sin(2 * np.pi * hi * t)).astype(np.int16)
+        y = O.resample(x, 1, rate)
+        assert len(y) == -(-n * 11025 // rate)
+        ref = 8000 * np.sin(2 * np.pi * 440 * np.arange(len(y)) / 11025)
+        assert np.abs(y[300:-300] - ref[300:-300]).max() <= 3
+        stereo = np.repeat(x, 2)
+        assert O.resample(stereo, 2, rate).tolist() == y.tolist()
+    x = (np.arange(5000) % 700 - 350).astype(np.int16)
+    assert O.resample(x, 1, 11025).tolist() == x.tolist()     # same rate: identity
+    lr = np.stack([x, -x // 2], axis=1).reshape(-1)
+    assert O.resample(lr, 2, 11025).tolist() == ((x.astype(np.int32) + (-x // 2).astype(np.int32)) / 2).astype(np.int32).tolist()
