@@ -2,10 +2,9 @@
 // and tests/cpu_emu (a g++ build that steps the same per-thread code serially, phase by phase, to
 // validate indexing without a GPU; it is a test fixture, never a product path).
 //
-// STFT of one 4096-sample frame = 2048-point complex FFT of z[m] = x[2m] + i x[2m+1] (x = windowed
-// samples) followed by the real-input split.  The 2048-point transform is a Stockham autosort DIF in
-// four passes, radix 8,8,8,4, executed by 256 threads that each own one radix-8 butterfly per pass
-// (two radix-4 butterflies in the last), exchanging through one 32 KiB LDS buffer between passes.
+// STFT: TWO real frames per 4096-point complex FFT (z = frameA + i*frameB), radix 16,16,16, decimation in
+// frequency in place, executed by 256 threads that each own one 16-point butterfly per stage and exchange
+// through one padded LDS buffer; then the real-input split, |X|^2 and the 12-class chroma fold.
 #pragma once
 
 #include <stdint.h>
@@ -32,128 +31,14 @@ NEEDLE_HD cd cmulf(cd a, cd b) {
 }
 NEEDLE_HD cd mul_neg_i(cd a) { return cd{a.y, -a.x}; }
 
-constexpr int kFftN = 2048;      // complex points per frame
-constexpr int kThreads = 256;    // threads per frame
+constexpr int kThreads = 256;    // threads per frame pair
 constexpr int kMinBin = 10;      // max(1, round(4096*28/11025))
 constexpr int kMaxBin = 1308;    // min(2048, round(4096*3520/11025)), exclusive
 constexpr int kNumBins = kMaxBin - kMinBin;
-constexpr int kBinsPerThread = (kNumBins + kThreads - 1) / kThreads;  // 6
+constexpr int kBinsPerThread = 6;  // registers j = 0..5 of a thread hold every bin below 1536
 
-// 8-point DFT, forward (e^{-2 pi i jk/8}), natural-order output, in place.
-NEEDLE_HD void fft8(cd *a) {
-  const double h = 0.70710678118654752440;
-  cd s0 = cadd(a[0], a[4]), d0 = csub(a[0], a[4]);
-  cd s1 = cadd(a[1], a[5]), t1 = csub(a[1], a[5]);
-  cd s2 = cadd(a[2], a[6]), t2 = csub(a[2], a[6]);
-  cd s3 = cadd(a[3], a[7]), t3 = csub(a[3], a[7]);
-  cd d1 = cd{(t1.x + t1.y) * h, (t1.y - t1.x) * h};
-  cd d2 = mul_neg_i(t2);
-  cd d3 = cd{(t3.y - t3.x) * h, -(t3.x + t3.y) * h};
-  {
-    cd e0 = cadd(s0, s2), e1 = csub(s0, s2), e2 = cadd(s1, s3), e3 = mul_neg_i(csub(s1, s3));
-    a[0] = cadd(e0, e2);
-    a[4] = csub(e0, e2);
-    a[2] = cadd(e1, e3);
-    a[6] = csub(e1, e3);
-  }
-  {
-    cd e0 = cadd(d0, d2), e1 = csub(d0, d2), e2 = cadd(d1, d3), e3 = mul_neg_i(csub(d1, d3));
-    a[1] = cadd(e0, e2);
-    a[5] = csub(e0, e2);
-    a[3] = cadd(e1, e3);
-    a[7] = csub(e1, e3);
-  }
-}
-
-NEEDLE_HD void fft4(cd *a) {
-  cd e0 = cadd(a[0], a[2]), e1 = csub(a[0], a[2]), e2 = cadd(a[1], a[3]), e3 = mul_neg_i(csub(a[1], a[3]));
-  a[0] = cadd(e0, e2);
-  a[2] = csub(e0, e2);
-  a[1] = cadd(e1, e3);
-  a[3] = csub(e1, e3);
-}
-
-// LDS index map (identity for now; the hook for a conflict-avoiding swizzle).
-NEEDLE_HD int lidx(int i) { return i; }
-
-// Stockham DIF pass geometry for N = 2048: pass P has sub-length n, stride s, radix R;
-// thread t owns (p, q) = (t / s, t % s); inputs x[q + s*(p + (n/R)*k)], outputs y[q + s*(R*p + j)]
-// multiplied by W_n^{p*j} = tw4096[p*j*(4096/n)].
-//   pass 0: n=2048 s=1   R=8      pass 1: n=256 s=8  R=8
-//   pass 2: n=32   s=64  R=8      pass 3: n=4   s=512 R=4 (two butterflies per thread, no twiddle)
-template <int PASS>
-struct PassGeom;
-template <>
-struct PassGeom<0> {
-  static constexpr int n = 2048, s = 1, R = 8;
-};
-template <>
-struct PassGeom<1> {
-  static constexpr int n = 256, s = 8, R = 8;
-};
-template <>
-struct PassGeom<2> {
-  static constexpr int n = 32, s = 64, R = 8;
-};
-
-template <int PASS>
-NEEDLE_HD void pass_read(int t, const cd *lds, cd *r) {
-  using G = PassGeom<PASS>;
-  const int p = t / G::s, q = t % G::s;
-#pragma unroll
-  for (int k = 0; k < 8; k++) r[k] = lds[lidx(q + G::s * (p + (G::n / 8) * k))];
-}
-
-// butterfly + twiddle + scatter to LDS
-template <int PASS>
-NEEDLE_HD void pass_compute_write(int t, const cd *tw4096, cd *lds, cd *r) {
-  using G = PassGeom<PASS>;
-  const int p = t / G::s, q = t % G::s;
-  fft8(r);
-  lds[lidx(q + G::s * (8 * p))] = r[0];
-#pragma unroll
-  for (int j = 1; j < 8; j++) {
-    cd w = tw4096[p * j * (4096 / G::n)];
-    lds[lidx(q + G::s * (8 * p + j))] = cmul(r[j], w);
-  }
-}
-
-// last pass: n = 4, s = 512: butterflies q = t and q = t + 256, in place in LDS (each thread touches
-// only its own eight slots, so no barrier is needed between its read and write).
-NEEDLE_HD void pass3_inplace(int t, cd *lds) {
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    const int q = t + 256 * h;
-    cd a[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) a[k] = lds[lidx(q + 512 * k)];
-    fft4(a);
-#pragma unroll
-    for (int j = 0; j < 4; j++) lds[lidx(q + 512 * j)] = a[j];
-  }
-}
-
-// Real-input split + power for bin k (kMinBin <= k < kMaxBin):
-//   E = (Z[k] + conj Z[N-k])/2, O = (Z[k] - conj Z[N-k])/(2i), X[k] = E + W_4096^k O, P = |X[k]|^2
-NEEDLE_HD double bin_power(int k, const cd *lds, const cd *tw4096) {
-  cd z = lds[lidx(k)], y = lds[lidx(kFftN - k)], w = tw4096[k];
-  double er = 0.5 * (z.x + y.x), ei = 0.5 * (z.y - y.y);
-  double orr = 0.5 * (z.y + y.y), oi = 0.5 * (y.x - z.x);
-  double xr = er + (w.x * orr - w.y * oi);
-  double xi = ei + (w.x * oi + w.y * orr);
-  return xr * xr + xi * xi;
-}
-
-// ================================================================================================
-// v2 transform: TWO real frames per 4096-point complex FFT (z = frameA + i*frameB), radix 16,16,16.
-// 256 threads own one radix-16 butterfly per pass; every pass reads x[t + 256 k] (k = 0..15) and writes
-//   pass 0: y[16 t + j]            * W_4096^{t j}
-//   pass 1: y[q + 256 p + 16 j]    * W_4096^{16 p j}      (p = t / 16, q = t % 16)
-//   pass 2: y[t + 256 j]
-// through one LDS buffer whose index is padded by one slot per 16 (pidx) so that the stride-16 scatter of
-// pass 0 and every 16-lane group of the other accesses are bank-conflict free for 16-byte elements.
-// The split X_A = (Z[k] + conj Z[N-k])/2, X_B = (Z[k] - conj Z[N-k])/(2i) needs no twiddles.
-// ================================================================================================
+// One LDS buffer of 4096 complex slots whose index is padded by one slot per 16 (pidx): the stride-16 and
+// stride-17 access patterns of the stages are then bank-conflict free for 16-byte elements.
 constexpr int kFft2N = 4096;
 constexpr int kLds2Slots = kFft2N + kFft2N / 16;  // padded complex slots
 
@@ -205,45 +90,8 @@ NEEDLE_HD cd lds_get(const cd *lds, int slot) {
 #endif
 }
 
-NEEDLE_HD void pass16_read(int t, const cd *lds, cd *r) {
-#pragma unroll
-  for (int k = 0; k < 16; k++) r[k] = lds_get(lds, pidx(t + 256 * k));
-}
-
-// Twiddles W^j (j = 1..15) of one butterfly come from its base W = W_4096^{t} (pass 0) or W_4096^{16 p}
-// (pass 1) by the running product w_j = w_{j-1} * W: the base is a loop-invariant register pair, so there is
-// no per-pair table traffic and only one extra complex value is live at a time.
-template <int PASS>
-NEEDLE_HD void pass16_compute_write(int t, cd base, cd *lds, cd *r) {
-  fft16(r);
-  if (PASS == 2) {
-#pragma unroll
-    for (int j = 0; j < 16; j++) lds[pidx(t + 256 * j)] = r[out16(j)];
-    return;
-  }
-  // output j goes to slot o0 + j * stride (before padding)
-  const int o0 = PASS == 0 ? 16 * t : (t & 15) + 256 * (t >> 4);
-  constexpr int stride = PASS == 0 ? 1 : 16;
-  lds[pidx(o0)] = r[out16(0)];
-  cd w = base;
-#pragma unroll
-  for (int j = 1; j < 16; j++) {
-    lds[pidx(o0 + j * stride)] = cmulf(r[out16(j)], w);
-    if (j < 15) w = cmulf(w, base);
-  }
-}
-
-// powers of bin k for the two frames packed in Z (kMinBin <= k < kMaxBin)
-NEEDLE_HD void bin_power2(int k, const cd *lds, double *pa, double *pb) {
-  const cd z = lds_get(lds, pidx(k)), y = lds_get(lds, pidx(kFft2N - k));
-  const double ar = z.x + y.x, ai = z.y - y.y;  // 2 X_A
-  const double br = z.y + y.y, bi = y.x - z.x;  // 2 X_B
-  *pa = 0.25 * (ar * ar + ai * ai);
-  *pb = 0.25 * (br * br + bi * bi);
-}
-
 // ================================================================================================
-// v3 schedule of the same 4096-point transform: decimation in frequency IN PLACE.  With n = 256 n2 + 16 n1 + n0,
+// Schedule of the 4096-point transform: decimation in frequency IN PLACE.  With n = 256 n2 + 16 n1 + n0,
 //   stage 0 (thread t = 16 n1 + n0) transforms digit n2:  slots t + 256 k      -> same slots, * W_4096^{t j}
 //   stage 1 (thread t = 16 b  + n0) transforms digit n1:  slots 256 b + n0 + 16 k -> same slots, * W_4096^{16 n0 j}
 //   stage 2 (thread t = 16 b  + c ) transforms digit n0:  slots 16 t + k

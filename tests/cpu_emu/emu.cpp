@@ -19,7 +19,6 @@ struct Tables {
   std::vector<uint16_t> class_bins;
   uint32_t class_start[13];
   ClassifierThresholds thr;
-  std::vector<cd> tw0, tw1;  // v2: [15][256] W_4096^{t j}, [15][16] W_4096^{16 p j}
 };
 
 const double kThr[16][3] = {
@@ -55,121 +54,15 @@ const Tables &tables() {
   t.class_start[12] = (uint32_t)t.class_bins.size();
   for (int i = 0; i < 16; i++)
     for (int j = 0; j < 3; j++) t.thr.e[i][j] = std::exp(kThr[i][j]);
-  t.tw0.resize(15 * 256);
-  t.tw1.resize(15 * 16);
-  for (int j = 1; j < 16; j++) {
-    for (int q = 0; q < 256; q++) t.tw0[(j - 1) * 256 + q] = t.tw[(q * j) & 4095];
-    for (int q = 0; q < 16; q++) t.tw1[(j - 1) * 16 + q] = t.tw[(16 * q * j) & 4095];
-  }
   return t;
 }
 }  // namespace
 
 extern "C" {
 
-// stft_chroma_kernel, one frame: 256 emulated threads, phases separated exactly where the kernel syncs.
-void emu_stft_chroma(const int16_t *src, int channels, double *chroma12) {
-  const Tables &T = tables();
-  std::vector<cd> lds(kFftN);
-  std::vector<cd> regs(256 * 8);
-  for (int t = 0; t < 256; t++) {
-    cd *r = &regs[t * 8];
-    for (int k = 0; k < 8; k++) {
-      const int m = t + 256 * k;
-      int s0, s1;
-      if (channels == 1) {
-        s0 = src[2 * m];
-        s1 = src[2 * m + 1];
-      } else {
-        s0 = ((int)src[4 * m] + (int)src[4 * m + 1]) / 2;
-        s1 = ((int)src[4 * m + 2] + (int)src[4 * m + 3]) / 2;
-      }
-      r[k] = cd{(double)s0 * T.window[2 * m], (double)s1 * T.window[2 * m + 1]};
-    }
-  }
-  for (int t = 0; t < 256; t++) pass_compute_write<0>(t, T.tw.data(), lds.data(), &regs[t * 8]);
-  for (int t = 0; t < 256; t++) pass_read<1>(t, lds.data(), &regs[t * 8]);
-  for (int t = 0; t < 256; t++) pass_compute_write<1>(t, T.tw.data(), lds.data(), &regs[t * 8]);
-  for (int t = 0; t < 256; t++) pass_read<2>(t, lds.data(), &regs[t * 8]);
-  for (int t = 0; t < 256; t++) pass_compute_write<2>(t, T.tw.data(), lds.data(), &regs[t * 8]);
-  for (int t = 0; t < 256; t++) pass3_inplace(t, lds.data());
-  std::vector<double> pw(256 * kBinsPerThread, 0.0);
-  for (int t = 0; t < 256; t++)
-    for (int i = 0; i < kBinsPerThread; i++) {
-      const int k = kMinBin + t + 256 * i;
-      pw[t * kBinsPerThread + i] = k < kMaxBin ? bin_power(k, lds.data(), T.tw.data()) : 0.0;
-    }
-  double *plds = reinterpret_cast<double *>(lds.data());
-  for (int t = 0; t < 256; t++)
-    for (int i = 0; i < kBinsPerThread; i++) {
-      const int k = kMinBin + t + 256 * i;
-      if (k < kMaxBin) plds[k] = pw[t * kBinsPerThread + i];
-    }
-  for (int c = 0; c < 12; c++) {
-    double lane[16];
-    for (int l = 0; l < 16; l++) {
-      double acc = 0.0;
-      for (uint32_t b = T.class_start[c] + l; b < T.class_start[c + 1]; b += 16) acc += plds[T.class_bins[b]];
-      lane[l] = acc;
-    }
-    for (int off = 8; off >= 1; off >>= 1) {  // __shfl_xor tree: every lane adds its partner
-      double nxt[16];
-      for (int l = 0; l < 16; l++) nxt[l] = lane[l] + lane[l ^ off];
-      std::memcpy(lane, nxt, sizeof(lane));
-    }
-    chroma12[c] = lane[0];
-  }
-}
-
-// stft_chroma2_kernel, one frame pair (frame B may be NULL): radix-16 x3 on z = A + iB, padded LDS slots
+// stft_chroma_kernel, one frame pair (frame B may be NULL): 256 emulated threads, phases separated exactly
+// where the kernel has its barriers
 void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, double *chroma_a, double *chroma_b) {
-  const Tables &T = tables();
-  std::vector<cd> lds(kLds2Slots);
-  std::vector<cd> regs(256 * 16);
-  auto sample = [&](const int16_t *src, int n) -> int {
-    if (!src) return 0;
-    if (channels == 1) return src[n];
-    return ((int)src[2 * n] + (int)src[2 * n + 1]) / 2;
-  };
-  for (int t = 0; t < 256; t++)
-    for (int k = 0; k < 16; k++) {
-      const int n = t + 256 * k;
-      regs[t * 16 + k] = cd{(double)sample(fa, n) * T.window[n], (double)sample(fb, n) * T.window[n]};
-    }
-  for (int t = 0; t < 256; t++) pass16_compute_write<0>(t, T.tw[t], lds.data(), &regs[t * 16]);
-  for (int t = 0; t < 256; t++) pass16_read(t, lds.data(), &regs[t * 16]);
-  for (int t = 0; t < 256; t++) pass16_compute_write<1>(t, T.tw[16 * (t >> 4)], lds.data(), &regs[t * 16]);
-  for (int t = 0; t < 256; t++) pass16_read(t, lds.data(), &regs[t * 16]);
-  for (int t = 0; t < 256; t++) pass16_compute_write<2>(t, T.tw[0], lds.data(), &regs[t * 16]);
-  std::vector<double> pa(2048, 0.0), pb(2048, 0.0);
-  for (int t = 0; t < 256; t++)
-    for (int i = 0; i < kBinsPerThread; i++) {
-      const int k = kMinBin + t + 256 * i;
-      if (k < kMaxBin) bin_power2(k, lds.data(), &pa[k], &pb[k]);
-    }
-  for (int which = 0; which < 2; which++) {
-    const std::vector<double> &pw = which ? pb : pa;
-    double *out = which ? chroma_b : chroma_a;
-    if (!out) continue;
-    for (int c = 0; c < 12; c++) {
-      double lane[8];
-      for (int l = 0; l < 8; l++) {
-        double acc = 0.0;
-        for (uint32_t b = T.class_start[c] + l; b < T.class_start[c + 1]; b += 8) acc += pw[T.class_bins[b]];
-        lane[l] = acc;
-      }
-      for (int off = 4; off >= 1; off >>= 1) {
-        double nxt[8];
-        for (int l = 0; l < 8; l++) nxt[l] = lane[l] + lane[l ^ off];
-        std::memcpy(lane, nxt, sizeof(lane));
-      }
-      out[c] = lane[0];
-    }
-  }
-}
-
-// stft_chroma_kernel v3 (in-place DIF), one frame pair
-void emu_stft_chroma_pair_dif(const int16_t *fa, const int16_t *fb, int channels, double *chroma_a, double *chroma_b) {
   const Tables &T = tables();
   std::vector<cd> lds(kLds2Slots);
   std::vector<cd> regs(256 * 16);

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256, 2) void phases_kernel(const int16_t *__restric
                                                         unsigned long long *out, double *sink) {
   extern __shared__ cd lds[];
   const int t = threadIdx.x;
-  const cd base0 = tw[t], base1 = tw[16 * (t >> 4)];
+  const cd base0 = tw[t], base1 = tw[16 * (t & 15)];
   unsigned long long acc[kPhases] = {0};
   double keep = 0.0;
   for (int g = 0; g < pairs; g++) {
@@ -44,41 +44,39 @@ __global__ __launch_bounds__(256, 2) void phases_kernel(const int16_t *__restric
     }
     __builtin_amdgcn_s_waitcnt(0);
     unsigned long long t1 = stamp();
-    core::pass16_compute_write<0>(t, base0, lds, r);
+    core::dif0(t, base0, lds, r);
     unsigned long long t2 = stamp();
     __syncthreads();
     unsigned long long t3 = stamp();
-    core::pass16_read(t, lds, r);
+    core::dif1(t, base1, lds, r);
     __syncthreads();
     unsigned long long t4 = stamp();
-    core::pass16_compute_write<1>(t, base1, lds, r);
+    core::dif2(t, lds, r);
     __syncthreads();
     unsigned long long t5 = stamp();
-    core::pass16_read(t, lds, r);
+    core::dif2_publish(t, lds, r);
     __syncthreads();
     unsigned long long t6 = stamp();
-    core::pass16_compute_write<2>(t, base1, lds, r);
-    __syncthreads();
-    unsigned long long t7 = stamp();
     double pa[6], pb[6];
+    int kf[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-      const int k = core::kMinBin + t + 256 * i;
-      pa[i] = pb[i] = 0.0;
-      if (k < core::kMaxBin) core::bin_power2(k, lds, &pa[i], &pb[i]);
+    for (int j = 0; j < 6; j++) {
+      pa[j] = pb[j] = 0.0;
+      core::dif_bin_power(t, j, lds, r, &kf[j], &pa[j], &pb[j]);
     }
     __syncthreads();
-    unsigned long long t8 = stamp();
+    unsigned long long t7 = stamp();
+    unsigned long long t8 = t7;
 #pragma unroll
-    for (int i = 0; i < 6; i++) keep += pa[i] + pb[i];
+    for (int i = 0; i < 6; i++) keep += pa[i] + pb[i] + kf[i];
     acc[0] += t1 - t0;  // input loads + window
-    acc[1] += t2 - t1;  // pass 0 butterfly + twiddle + LDS write
+    acc[1] += t2 - t1;  // stage 0 butterfly + twiddle + LDS write
     acc[2] += t3 - t2;  // barrier
-    acc[3] += t4 - t3;  // read + barrier
-    acc[4] += t5 - t4;  // pass 1 + barrier
-    acc[5] += t6 - t5;  // read + barrier
-    acc[6] += t7 - t6;  // pass 2 + barrier
-    acc[7] += t8 - t7;  // split + power + barrier
+    acc[3] += t4 - t3;  // stage 1 in place + barrier
+    acc[4] += t5 - t4;  // stage 2 read + fft16 + barrier
+    acc[5] += t6 - t5;  // publish + barrier
+    acc[6] += t7 - t6;  // split + power + barrier
+    acc[7] += t8 - t7;  // (unused)
   }
   if ((t & 63) == 0)
     for (int p = 0; p < kPhases; p++) out[(blockIdx.x * 4 + (t >> 6)) * kPhases + p] = acc[p];
@@ -112,8 +110,8 @@ int main() {
   float ms; hipEventElapsedTime(&ms, a, b);
   std::vector<unsigned long long> out(blocks * 4 * kPhases);
   hipMemcpy(out.data(), d_out, out.size() * 8, hipMemcpyDeviceToHost);
-  const char *names[8] = {"input", "pass0+write", "barrier", "read+barrier", "pass1+write+barrier", "read+barrier",
-                          "pass2+write+barrier", "split+power+barrier"};
+  const char *names[8] = {"input", "stage0+write", "barrier", "stage1 (in place)+barrier", "stage2 read+fft+barrier",
+                          "publish+barrier", "split+power+barrier", "-"};
   double tot = 0, sums[8] = {0};
   for (int w = 0; w < blocks * 4; w++)
     for (int p = 0; p < 8; p++) sums[p] += (double)out[w * kPhases + p] / pairs;
