@@ -98,7 +98,11 @@ Status get_tables(FpTables *out) {
     for (int j = 0; j < 3; j++) thr.e[i][j] = std::exp(kThresholds[i][j]);
 
   std::vector<uint16_t> bin_slot(core::kNumBins);
-  for (size_t pos = 0; pos < bins.size(); pos++) bin_slot[bins[pos] - core::kMinBin] = (uint16_t)pos;
+  for (size_t pos = 0; pos < bins.size(); pos++)  // where the bin's power goes in the LDS image (frame A)
+    bin_slot[bins[pos] - core::kMinBin] = (uint16_t)core::dif_power_index((int)pos);
+  for (int c = 0; c < kBands; c++)
+    if (start[c + 1] - start[c] > (uint32_t)(core::kClassLanes * core::kClassLaneMax))
+      return Status::Make(NeedleError_Unknown, "pitch class larger than the fold's lane budget");
   FpTables t;
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.bin_slot, bin_slot.size() * sizeof(uint16_t)));
   NEEDLE_HIP_TRY(hipMemcpy(t.bin_slot, bin_slot.data(), bin_slot.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -139,6 +143,14 @@ constexpr int kPairsPerBlock = 16;  // default; NEEDLE_STFT_PAIRS overrides for 
 // (__syncthreads() would also drain vmcnt and with it the prefetch of the next pair's PCM).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Orders this wave's LDS writes before its later LDS reads for the compiler; the hardware executes one wave's LDS
+// operations in order, so lanes of the same wave see each other's data without a workgroup barrier.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct PairSrc {
   const int16_t *a, *b;  // first value of frame A / frame B (B = A when the stream has an odd frame count)
   double keep_b;         // 1.0, or 0.0 when there is no frame B
@@ -163,9 +175,29 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   if (first >= last) return;
   const cd base0 = tw[t], base1 = tw[16 * (t & 15)];  // W_4096^t, W_4096^{16 n0}: loop-invariant twiddle bases
 
-  auto locate = [&](uint32_t g) {
-    const int si = find_stream<&FpStream::pair_base>(streams, num_streams, g);
-    const FpStream st = streams[si];
+  // ---- loop invariants of this thread, packed so they cost few registers --------------------------------------
+  // where the powers of its six bins (register j of stage 2) go in the class-sorted LDS image; 0xffff = bin unused
+  uint32_t slot_pk[core::kBinsPerThread / 2];
+#pragma unroll
+  for (int j = 0; j < core::kBinsPerThread; j++) {
+    const int kf = core::dif_bin_of(t, j);
+    const uint32_t idx = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : 0xffffu;
+    slot_pk[j >> 1] = (j & 1) ? (slot_pk[j >> 1] | (idx << 16)) : idx;
+  }
+  // its share of the pitch-class fold: 2 frames x 12 classes x 8 lanes
+  const bool folds = t < 2 * kBands * core::kClassLanes;
+  const int fold_which = (t >> 3) >= kBands ? 1 : 0, fold_c = (t >> 3) - fold_which * kBands, fold_l = t & 7;
+  const uint32_t fold_bounds = folds ? (class_start[fold_c] | (class_start[fold_c + 1] << 16)) : 0;
+
+  // ---- the stream (region of the batch) the current pair belongs to; consecutive pairs rarely change it ------
+  int si = find_stream<&FpStream::pair_base>(streams, num_streams, first);
+  FpStream st = streams[si];
+  uint32_t st_end = st.pair_base + (st.frames + 1) / 2;
+  auto locate = [&](uint32_t g) {  // g must not decrease between calls
+    while (g >= st_end) {
+      st = streams[++si];
+      st_end = st.pair_base + (st.frames + 1) / 2;
+    }
     const uint32_t fa = 2 * (g - st.pair_base);
     PairSrc p;
     p.has_b = fa + 1 < st.frames;
@@ -176,13 +208,23 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     return p;
   };
   raw_t ra[16], rb[16];
+  double wv[16];
+  // PCM of both frames and the window row of this thread: issued one pair ahead, while the previous pair's powers
+  // are folded (the spectrum registers are dead then).  The window is re-read per pair on purpose: kept in
+  // registers across the transform it would not fit (spills to scratch).
   auto issue_loads = [&](const PairSrc &p) {
     const raw_t *qa = reinterpret_cast<const raw_t *>(p.a), *qb = reinterpret_cast<const raw_t *>(p.b);
+    const double *wptr = window;
+    asm volatile("" : "+s"(wptr));
+    int tt = t;
+    asm volatile("" : "+v"(tt));
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      ra[k] = qa[t + 256 * k];
-      rb[k] = qb[t + 256 * k];
+      ra[k] = qa[tt + 256 * k];
+      rb[k] = qb[tt + 256 * k];
     }
+#pragma unroll
+    for (int k = 0; k < 16; k++) wv[k] = wptr[tt + 256 * k];
   };
   PairSrc cur = locate(first);
   issue_loads(cur);
@@ -192,9 +234,6 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     // loop-invariant by the compiler it costs more registers than the kernel has (spills to scratch)
     int tt = t;
     asm volatile("" : "+v"(tt));
-    // window: loaded here every pair (hoisted out of the loop the 16 values would be spilled to scratch)
-    const double *wptr = window;
-    asm volatile("" : "+s"(wptr));
     cd r[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -206,53 +245,40 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
         sa = ((int)(int16_t)ra[k] + (ra[k] >> 16)) / 2;
         sb = ((int)(int16_t)rb[k] + (rb[k] >> 16)) / 2;
       }
-      const double w = wptr[tt + 256 * k];
-      r[k] = cd{(double)sa * w, (double)sb * (w * cur.keep_b)};
+      r[k] = cd{(double)sa * wv[k], (double)sb * (wv[k] * cur.keep_b)};
     }
-    // in-place decimation-in-frequency stages (fp_core.h): one barrier per exchange
+    // in-place decimation-in-frequency stages; which exchanges need a workgroup barrier: fp_core.h
     core::dif0(tt, base0, lds, r);
     lds_barrier();
     core::dif1(tt, base1, lds, r);
-    lds_barrier();
+    wave_lds_fence();             // stage 1 -> 2 stays inside 16 consecutive lanes
     core::dif2(tt, lds, r);       // r[out16(j)] = Z[bin (t>>4) + 16 (t&15) + 256 j]
-    lds_barrier();                // every thread has read its 16 slots: they may be overwritten
-    core::dif2_publish(tt, lds, r);  // only the partner values Z[N - k] other threads need
+    core::dif2_publish(tt, lds, r);  // own slots; only the partner values Z[N - k] other threads need
     lds_barrier();
 
-    double pa[core::kBinsPerThread], pb[core::kBinsPerThread];
-    int kf[core::kBinsPerThread];
-    bool own[core::kBinsPerThread];
-#pragma unroll
-    for (int j = 0; j < core::kBinsPerThread; j++) own[j] = core::dif_bin_power(tt, j, lds, r, &kf[j], &pa[j], &pb[j]);
-    lds_barrier();
-    // the next pair's PCM is fetched while this pair's powers are folded into pitch classes (the spectrum
-    // registers are dead by now; last pair: harmless re-read)
-    const PairSrc nxt = locate(min(g + 1, last - 1));
-    issue_loads(nxt);
-    double *plds = reinterpret_cast<double *>(lds);  // class-sorted powers: frame A at [slot], frame B at [2048 + slot]
-    const uint16_t *slot_tab = bin_slot;
-    asm volatile("" : "+s"(slot_tab));  // keep these small table loads here rather than hoisted + spilled
+    double *plds = reinterpret_cast<double *>(lds);
 #pragma unroll
     for (int j = 0; j < core::kBinsPerThread; j++) {
-      if (own[j]) {
-        const int slot = slot_tab[kf[j] - core::kMinBin];
-        plds[slot] = pa[j];
-        plds[2048 + slot] = pb[j];
+      const uint32_t idx = (slot_pk[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+      if (idx != 0xffffu) {
+        double pa, pb;
+        int kf;
+        core::dif_bin_power(tt, j, lds, r, &kf, &pa, &pb);
+        // class-sorted powers into dead slots (fp_core.h dif_power_index): no barrier after the partner reads
+        plds[idx] = pa;
+        plds[idx + core::dif_power_index(core::kPowerFrameB)] = pb;
       }
     }
+    const PairSrc nxt = locate(min(g + 1, last - 1));  // last pair: harmless re-read
+    issue_loads(nxt);
     lds_barrier();
-    // 2 frames x 12 pitch classes x 8 lanes: each class is a contiguous slice; strided partial sums, then a
-    // fixed-order 8-lane tree
-    if (tt < 2 * kBands * 8) {
-      const int grp = tt >> 3, l = tt & 7;
-      const int which = grp >= kBands ? 1 : 0, c = grp - which * kBands;
-      const uint32_t b0 = class_start[c], b1 = class_start[c + 1];
-      const double *pw = plds + which * 2048;
-      double acc = 0.0;
-      for (uint32_t b = b0 + l; b < b1; b += 8) acc += pw[b];
+    // each class is a contiguous slice of positions: strided partial sums, then a fixed-order 8-lane tree
+    if (folds) {
+      double acc = core::class_lane_sum(plds, fold_which * core::kPowerFrameB, (int)(fold_bounds & 0xffffu),
+                                        (int)(fold_bounds >> 16), fold_l);
 #pragma unroll
       for (int off = 4; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 8);
-      if (l == 0 && (which == 0 || cur.has_b)) chroma[(cur.row + which) * kBands + c] = acc;
+      if (fold_l == 0 && (fold_which == 0 || cur.has_b)) chroma[(cur.row + fold_which) * kBands + fold_c] = acc;
     }
     lds_barrier();
     cur = nxt;

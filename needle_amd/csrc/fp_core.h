@@ -96,9 +96,16 @@ NEEDLE_HD cd lds_get(const cd *lds, int slot) {
 //   stage 1 (thread t = 16 b  + n0) transforms digit n1:  slots 256 b + n0 + 16 k -> same slots, * W_4096^{16 n0 j}
 //   stage 2 (thread t = 16 b  + c ) transforms digit n0:  slots 16 t + k
 // so X[k0 + 16 k1 + 256 k2] ends in slot 256 k0 + 16 k1 + k2, i.e. in register j = k2 of thread t = 16 k0 + k1.
-// Every thread reads and writes the SAME slots within a stage: one barrier per exchange instead of two, and the
-// last stage only publishes the six registers (j = 10..15) that other threads need as partners Z[N - k] of the
-// bins 10..1307; the bins themselves (j = 0..5) never leave the registers.
+// Every thread reads and writes the SAME slots within a stage, so only two exchanges need a workgroup barrier:
+//   stage 0 -> 1  crosses waves (barrier);
+//   stage 1 -> 2  stays inside the 16 consecutive lanes b = t >> 4 (slots [256 b, 256 b + 256)): LDS operations of
+//                 one wave execute in order, no barrier;
+//   stage 2 -> publish: a thread overwrites only slots it alone has read, no barrier;
+//   publish -> partner reads crosses waves (barrier).
+// The last stage only publishes the six registers (j = 10..15) that other threads need as partners Z[N - k] of the
+// bins 10..1307; the bins themselves (j = 0..5) never leave the registers.  The class-sorted powers then go to the
+// slots of registers j = 0..7 (dif_power_index), which are dead by then and disjoint from the partner slots, so the
+// partner reads and the power stores need no barrier between them either.
 // ================================================================================================
 NEEDLE_HD int dif_slot_of_bin(int kf) { return 256 * (kf & 15) + 16 * ((kf >> 4) & 15) + (kf >> 8); }
 NEEDLE_HD int dif_bin_of(int t, int j) { return (t >> 4) + 16 * (t & 15) + 256 * j; }
@@ -154,6 +161,29 @@ NEEDLE_HD bool dif_bin_power(int t, int j, const cd *lds, const cd *r, int *kf_o
   *pa = 0.25 * (ar * ar + ai * ai);
   *pb = 0.25 * (br * br + bi * bi);
   return true;
+}
+
+// Class-sorted power position p (frame A: position in the class-sorted bin list; frame B: 2048 + that) -> index, in
+// doubles, into the LDS image: positions 16 q .. 16 q + 15 fill the slots of registers j = 0..7 of thread q's
+// stage-2 row (pidx(16 q + j) = 17 q + j).
+constexpr int kPowerFrameB = 2048;
+constexpr int kClassLanes = 8;       // lanes that share one pitch class in the fold
+constexpr int kClassLaneMax = 18;    // >= ceil(largest class / kClassLanes); checked where the tables are built
+NEEDLE_HD int dif_power_index(int p) { return 34 * (p >> 4) + (p & 15); }
+
+// One lane's share of a pitch class: positions b0 + l, b0 + l + 8, ... < b1 summed in that order (loads first, so
+// their latencies overlap; the trailing zeros do not change the sum).
+NEEDLE_HD double class_lane_sum(const double *plds, int frame_off, int b0, int b1, int l) {
+  double v[kClassLaneMax];
+#pragma unroll
+  for (int i = 0; i < kClassLaneMax; i++) {
+    const int b = b0 + l + kClassLanes * i;
+    v[i] = b < b1 ? plds[dif_power_index(frame_off + b)] : 0.0;
+  }
+  double acc = v[0];
+#pragma unroll
+  for (int i = 1; i < kClassLaneMax; i++) acc += v[i];
+  return acc;
 }
 
 // ---- classifiers (chromaprint kClassifiersTest2) ---------------------------------

@@ -18,6 +18,7 @@ struct Tables {
   std::vector<double> window;
   std::vector<uint16_t> class_bins;
   uint32_t class_start[13];
+  std::vector<uint16_t> bin_pos;  // bin - kMinBin -> position in the class-sorted list
   ClassifierThresholds thr;
 };
 
@@ -52,6 +53,8 @@ const Tables &tables() {
     t.class_bins.insert(t.class_bins.end(), by[c].begin(), by[c].end());
   }
   t.class_start[12] = (uint32_t)t.class_bins.size();
+  t.bin_pos.resize(kNumBins);
+  for (size_t pos = 0; pos < t.class_bins.size(); pos++) t.bin_pos[t.class_bins[pos] - kMinBin] = (uint16_t)pos;
   for (int i = 0; i < 16; i++)
     for (int j = 0; j < 3; j++) t.thr.e[i][j] = std::exp(kThr[i][j]);
   return t;
@@ -77,33 +80,49 @@ void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, do
       regs[t * 16 + k] = cd{(double)sample(fa, n) * T.window[n], (double)sample(fb, n) * T.window[n]};
     }
   for (int t = 0; t < 256; t++) dif0(t, T.tw[t], lds.data(), &regs[t * 16]);
-  for (int t = 0; t < 256; t++) dif1(t, T.tw[16 * (t & 15)], lds.data(), &regs[t * 16]);
-  for (int t = 0; t < 256; t++) dif2(t, lds.data(), &regs[t * 16]);
-  for (int t = 0; t < 256; t++) dif2_publish(t, lds.data(), &regs[t * 16]);
-  std::vector<double> pa(2048, 0.0), pb(2048, 0.0);
-  int seen = 0;
-  for (int t = 0; t < 256; t++)
-    for (int j = 0; j < 6; j++) {
-      int kf;
-      double a, b;
-      if (dif_bin_power(t, j, lds.data(), &regs[t * 16], &kf, &a, &b)) {
-        pa[kf] = a;
-        pb[kf] = b;
-        seen++;
+  // stage 1 -> stage 2 -> publish run group by group (16 consecutive lanes), the other groups still untouched:
+  // this is the order the kernel is allowed to take without a workgroup barrier between these phases
+  for (int grp = 15; grp >= 0; grp--) {
+    for (int t = 16 * grp; t < 16 * grp + 16; t++) dif1(t, T.tw[16 * (t & 15)], lds.data(), &regs[t * 16]);
+    for (int t = 16 * grp; t < 16 * grp + 16; t++) {
+      dif2(t, lds.data(), &regs[t * 16]);
+      dif2_publish(t, lds.data(), &regs[t * 16]);
+    }
+  }
+  // partner reads and power stores interleaved thread by thread (no barrier between them in the kernel); walking
+  // the threads in both directions must give the same image if the stores never touch a live partner slot
+  double *plds = reinterpret_cast<double *>(lds.data());
+  std::vector<cd> snapshot = lds;
+  std::vector<double> image[2];
+  for (int dir = 0; dir < 2; dir++) {
+    lds = snapshot;
+    plds = reinterpret_cast<double *>(lds.data());
+    int seen = 0;
+    for (int i = 0; i < 256; i++) {
+      const int t = dir ? 255 - i : i;
+      for (int j = 0; j < 6; j++) {
+        int kf;
+        double a, b;
+        if (dif_bin_power(t, j, lds.data(), &regs[t * 16], &kf, &a, &b)) {
+          const int idx = dif_power_index(T.bin_pos[kf - kMinBin]);
+          plds[idx] = a;
+          plds[idx + dif_power_index(kPowerFrameB)] = b;
+          seen++;
+        }
       }
     }
-  if (seen != kNumBins) { chroma_a[0] = -1.0; return; }  // every bin must be owned by exactly one (t, j)
+    if (seen != kNumBins) { chroma_a[0] = -1.0; return; }  // every bin must be owned by exactly one (t, j)
+    image[dir].assign(plds, plds + 2 * kLds2Slots);
+  }
+  for (int p = 0; p < 2 * kPowerFrameB; p++)
+    if (image[0][dif_power_index(p)] != image[1][dif_power_index(p)]) { chroma_a[0] = -2.0; return; }
   for (int which = 0; which < 2; which++) {
-    const std::vector<double> &pw = which ? pb : pa;
     double *out = which ? chroma_b : chroma_a;
     if (!out) continue;
     for (int c = 0; c < 12; c++) {
       double lane[8];
-      for (int l = 0; l < 8; l++) {
-        double acc = 0.0;
-        for (uint32_t b = T.class_start[c] + l; b < T.class_start[c + 1]; b += 8) acc += pw[T.class_bins[b]];
-        lane[l] = acc;
-      }
+      for (int l = 0; l < 8; l++)
+        lane[l] = class_lane_sum(plds, which * kPowerFrameB, (int)T.class_start[c], (int)T.class_start[c + 1], l);
       for (int off = 4; off >= 1; off >>= 1) {
         double nxt[8];
         for (int l = 0; l < 8; l++) nxt[l] = lane[l] + lane[l ^ off];

@@ -1,0 +1,174 @@
+// Diagnostic (not part of the product): the loop of stft_chroma_kernel (fingerprint.hip) with pieces switched off,
+// to see what each piece costs at the product's launch shape.  Outputs are wrong by construction; only times count.
+//   bit 0: window from a constant instead of the table      bit 1: no PCM loads
+//   bit 2: no pitch-class fold (power store, fold, 2 barriers)  bit 3: no stream lookup (pointer arithmetic only)
+//   bit 4: every second workgroup (by arrival parity on its CU, approximated by blockIdx) starts late
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../needle_amd/csrc/fp_core.h"
+
+using needle::core::cd;
+namespace core = needle::core;
+constexpr int kHop = 1365, kBands = 12;
+
+struct Stream { uint64_t pcm_off; uint32_t frames, frame_base, pair_base, pad; };
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int find_stream(const Stream *s, int n, uint32_t g) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (s[mid].pair_base <= g) lo = mid; else hi = mid - 1; }
+  return lo;
+}
+struct PairSrc { const int16_t *a, *b; double keep_b; uint64_t row; bool has_b; };
+
+template <int F>
+__global__ __launch_bounds__(256, 2) void kernel(const int16_t *__restrict__ pcm, const Stream *__restrict__ streams,
+                                                 int num_streams, const cd *__restrict__ tw,
+                                                 const double *__restrict__ window,
+                                                 const uint16_t *__restrict__ bin_slot,
+                                                 const uint32_t *__restrict__ class_start, double *__restrict__ chroma,
+                                                 uint32_t total_pairs, uint32_t pairs_per_block, int skew) {
+  extern __shared__ cd lds[];
+  const int t = threadIdx.x;
+  const uint32_t first = blockIdx.x * pairs_per_block;
+  const uint32_t last = min(total_pairs, first + pairs_per_block);
+  if (first >= last) return;
+  const cd base0 = tw[t], base1 = tw[16 * (t & 15)];
+  if (F & 16) {  // skew by the wave slot this workgroup's waves were given on their SIMD (HW_ID[3:0])
+    const int slot = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));
+    if (slot & 1) for (int i = 0; i < skew; i++) __builtin_amdgcn_s_sleep(16);
+  }
+  auto locate = [&](uint32_t g) {
+    PairSrc p;
+    if (F & 8) {
+      p.has_b = true; p.a = pcm + (uint64_t)g * 2 * kHop; p.b = p.a + kHop; p.keep_b = 1.0; p.row = 2 * (uint64_t)g;
+      return p;
+    }
+    const int si = find_stream(streams, num_streams, g);
+    const Stream st = streams[si];
+    const uint32_t fa = 2 * (g - st.pair_base);
+    p.has_b = fa + 1 < st.frames;
+    p.a = pcm + st.pcm_off + (uint64_t)fa * kHop;
+    p.b = p.has_b ? p.a + kHop : p.a;
+    p.keep_b = p.has_b ? 1.0 : 0.0;
+    p.row = (uint64_t)st.frame_base + fa;
+    return p;
+  };
+  int16_t ra[16], rb[16];
+  auto issue_loads = [&](const PairSrc &p) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (F & 2) { ra[k] = (int16_t)(t + k); rb[k] = (int16_t)(t - k); }
+      else { ra[k] = p.a[t + 256 * k]; rb[k] = p.b[t + 256 * k]; }
+    }
+  };
+  PairSrc cur = locate(first);
+  issue_loads(cur);
+  for (uint32_t g = first; g < last; g++) {
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    const double *wptr = window;
+    asm volatile("" : "+s"(wptr));
+    cd r[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      double w;
+      if (F & 1) { w = 3.0e-5; asm volatile("" : "+v"(w)); } else w = wptr[tt + 256 * k];
+      r[k] = cd{(double)ra[k] * w, (double)rb[k] * (w * cur.keep_b)};
+    }
+    core::dif0(tt, base0, lds, r);
+    lds_barrier();
+    core::dif1(tt, base1, lds, r);
+    wave_lds_fence();
+    core::dif2(tt, lds, r);
+    core::dif2_publish(tt, lds, r);
+    lds_barrier();
+    double *plds = reinterpret_cast<double *>(lds);
+    const uint16_t *slot_tab = bin_slot;
+    asm volatile("" : "+s"(slot_tab));
+    double keep = 0;
+#pragma unroll
+    for (int j = 0; j < core::kBinsPerThread; j++) {
+      double pa, pb; int kf;
+      if (core::dif_bin_power(tt, j, lds, r, &kf, &pa, &pb)) {
+        if (F & 4) keep += pa + pb;
+        else { const int idx = slot_tab[kf - core::kMinBin]; plds[idx] = pa; plds[idx + core::dif_power_index(core::kPowerFrameB)] = pb; }
+      }
+    }
+    const PairSrc nxt = locate(min(g + 1, last - 1));
+    issue_loads(nxt);
+    if (F & 4) {
+      if (keep == 1.2345) chroma[cur.row] = keep;
+      lds_barrier();
+    } else {
+      lds_barrier();
+      if (tt < 2 * kBands * core::kClassLanes) {
+        const int grp = tt >> 3, l = tt & 7;
+        const int which = grp >= kBands ? 1 : 0, c = grp - which * kBands;
+        double acc = core::class_lane_sum(plds, which * core::kPowerFrameB, (int)class_start[c], (int)class_start[c + 1], l);
+#pragma unroll
+        for (int off = 4; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 8);
+        if (l == 0 && (which == 0 || cur.has_b)) chroma[(cur.row + which) * kBands + c] = acc;
+      }
+      lds_barrier();
+    }
+    cur = nxt;
+  }
+}
+
+int main(int argc, char **argv) {
+  const int eps = 28, frames = 5813, pairs_per_ep = (frames + 1) / 2;
+  const size_t samples_per_ep = 7938000;
+  const uint32_t total_pairs = eps * pairs_per_ep;
+  std::vector<int16_t> pcm(samples_per_ep * eps + 8192);
+  for (size_t i = 0; i < pcm.size(); i++) pcm[i] = (int16_t)((i * 2654435761u) >> 17);
+  std::vector<Stream> st(eps);
+  for (int e = 0; e < eps; e++) st[e] = Stream{samples_per_ep * e, (uint32_t)frames, (uint32_t)(frames * e), (uint32_t)(pairs_per_ep * e), 0};
+  std::vector<cd> tw(4096); std::vector<double> win(4096);
+  for (int k = 0; k < 4096; k++) { tw[k] = cd{std::cos(-2 * M_PI * k / 4096), std::sin(-2 * M_PI * k / 4096)}; win[k] = (0.54 - 0.46 * std::cos(2 * M_PI * k / 4095)) / 32767; }
+  std::vector<uint16_t> slot(core::kNumBins); std::vector<uint32_t> cs(13);
+  for (int i = 0; i < core::kNumBins; i++) slot[i] = (uint16_t)core::dif_power_index(i);
+  for (int c = 0; c <= 12; c++) cs[c] = c * 108;
+  cs[12] = core::kNumBins;
+  int16_t *d_pcm; Stream *d_st; cd *d_tw; double *d_win, *d_chroma; uint16_t *d_slot; uint32_t *d_cs;
+  (void)hipMalloc(&d_pcm, pcm.size() * 2); (void)hipMalloc(&d_st, st.size() * sizeof(Stream)); (void)hipMalloc(&d_tw, 4096 * sizeof(cd));
+  (void)hipMalloc(&d_win, 4096 * 8); (void)hipMalloc(&d_chroma, (size_t)eps * (frames + 1) * 12 * 8); (void)hipMalloc(&d_slot, slot.size() * 2); (void)hipMalloc(&d_cs, 13 * 4);
+  (void)hipMemcpy(d_pcm, pcm.data(), pcm.size() * 2, hipMemcpyHostToDevice); (void)hipMemcpy(d_st, st.data(), st.size() * sizeof(Stream), hipMemcpyHostToDevice);
+  (void)hipMemcpy(d_tw, tw.data(), 4096 * sizeof(cd), hipMemcpyHostToDevice); (void)hipMemcpy(d_win, win.data(), 4096 * 8, hipMemcpyHostToDevice);
+  (void)hipMemcpy(d_slot, slot.data(), slot.size() * 2, hipMemcpyHostToDevice); (void)hipMemcpy(d_cs, cs.data(), 13 * 4, hipMemcpyHostToDevice);
+  const size_t lds = core::kLds2Slots * sizeof(cd);
+  hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  size_t lds_req = lds;
+  auto run = [&](auto kern, const char *name, uint32_t ppb, int skew) {
+    const size_t lds = lds_req;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const uint32_t grid = (total_pairs + ppb - 1) / ppb;
+    float best = 1e9;
+    for (int rep = 0; rep < 6; rep++) {
+      (void)hipEventRecord(a);
+      kern<<<grid, 256, lds>>>(d_pcm, d_st, eps, d_tw, d_win, d_slot, d_cs, d_chroma, total_pairs, ppb, skew);
+      (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+      float ms; (void)hipEventElapsedTime(&ms, a, b);
+      if (rep && ms < best) best = ms;
+    }
+    printf("%-44s ppb=%3u skew=%3d  %.3f ms\n", name, ppb, skew, best);
+  };
+  run(kernel<0>, "full", 16, 0);
+  run(kernel<15>, "FFT core only", 16, 0);
+  for (int skew : {2, 4, 8, 12}) run(kernel<31>, "FFT core only, persistent, slot-skewed", (total_pairs + 511) / 512, skew);
+  for (int skew : {2, 4, 8, 12}) run(kernel<31>, "FFT core only, slot-skewed", 16, skew);
+  lds_req = 100 * 1024;  // forces one workgroup per CU
+  run(kernel<0>, "full, 1 workgroup/CU", 16, 0);
+  run(kernel<15>, "FFT core only, 1 workgroup/CU", 16, 0);
+  return 0;
+}
