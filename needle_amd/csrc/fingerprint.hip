@@ -43,7 +43,7 @@ struct FpStream {
 struct FpTables {
   cd *tw = nullptr;                 // [4096] e^{-2 pi i k/4096}
   uint16_t *bin_slot = nullptr;     // [kNumBins] position of bin (kMinBin + i) in the class-sorted order
-  double *window = nullptr;         // [4096] Hamming / 32767
+  double *window = nullptr;         // [4096] Hamming / 32767 / 2 (fp_core.h kPairInputScale)
   uint16_t *class_bins = nullptr;   // [kNumBins] spectrum bins grouped by pitch class
   uint32_t *class_start = nullptr;  // [13]
   core::ClassifierThresholds *thr = nullptr;
@@ -76,8 +76,8 @@ Status get_tables(FpTables *out) {
     tw[k] = cd{(double)cosl(a), (double)sinl(a)};
   }
   std::vector<double> window(4096);
-  for (int i = 0; i < 4096; i++)  // chromaprint PrepareHammingWindow(scale = 1/INT16_MAX)
-    window[i] = (1.0 / 32767.0) * (0.54 - 0.46 * std::cos(i * 2.0 * M_PI / (4096 - 1)));
+  for (int i = 0; i < 4096; i++)  // chromaprint PrepareHammingWindow(scale = 1/INT16_MAX), times fp_core.h's 2^-1
+    window[i] = core::kPairInputScale * ((1.0 / 32767.0) * (0.54 - 0.46 * std::cos(i * 2.0 * M_PI / (4096 - 1))));
   // chromaprint Chroma::PrepareNotes: bin -> pitch class
   std::vector<std::vector<uint16_t>> by_class(kBands);
   for (int i = core::kMinBin; i < core::kMaxBin; i++) {
@@ -151,9 +151,16 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// x from another lane of the row, by a DPP control word (no LDS round trip, unlike __shfl_xor)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 struct PairSrc {
   const int16_t *a, *b;  // first value of frame A / frame B (B = A when the stream has an odd frame count)
-  double keep_b;         // 1.0, or 0.0 when there is no frame B
   uint64_t row;          // chroma row of frame A
   bool has_b;
 };
@@ -176,14 +183,15 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   const cd base0 = tw[t], base1 = tw[16 * (t & 15)];  // W_4096^t, W_4096^{16 n0}: loop-invariant twiddle bases
 
   // ---- loop invariants of this thread, packed so they cost few registers --------------------------------------
-  // where the powers of its six bins (register j of stage 2) go in the class-sorted LDS image; 0xffff = bin unused
+  // where the powers of its six bins (register j of stage 2) go in the class-sorted LDS image
   uint32_t slot_pk[core::kBinsPerThread / 2];
 #pragma unroll
   for (int j = 0; j < core::kBinsPerThread; j++) {
     const int kf = core::dif_bin_of(t, j);
-    const uint32_t idx = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : 0xffffu;
+    const uint32_t idx = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : core::kPowerTrash;
     slot_pk[j >> 1] = (j & 1) ? (slot_pk[j >> 1] | (idx << 16)) : idx;
   }
+  if (t == 0) reinterpret_cast<double *>(lds)[core::kPowerZero] = 0.0;  // first read after the loop's barriers
   // its share of the pitch-class fold: 2 frames x 12 classes x 8 lanes
   const bool folds = t < 2 * kBands * core::kClassLanes;
   const int fold_which = (t >> 3) >= kBands ? 1 : 0, fold_c = (t >> 3) - fold_which * kBands, fold_l = t & 7;
@@ -202,31 +210,52 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     PairSrc p;
     p.has_b = fa + 1 < st.frames;
     p.a = pcm + st.pcm_off + (uint64_t)fa * kHop * CH;
-    p.b = p.has_b ? p.a + kHop * CH : p.a;  // no frame B: read A again, weight 0 (branch-free)
-    p.keep_b = p.has_b ? 1.0 : 0.0;
+    p.b = p.has_b ? p.a + kHop * CH : p.a;  // no frame B: read A again, zeroed after conversion
     p.row = (uint64_t)st.frame_base + fa;
     return p;
   };
-  raw_t ra[16], rb[16];
+  using reg_t = int;  // one 16-bit sample sign-extended by the load, or one packed L|R pair
+  reg_t ra[16], rb[16];
   double wv[16];
   // PCM of both frames and the window row of this thread: issued one pair ahead, while the previous pair's powers
-  // are folded (the spectrum registers are dead then).  The window is re-read per pair on purpose: kept in
-  // registers across the transform it would not fit (spills to scratch).
+  // are still being produced (the spectrum registers are dead by then).  The window is re-read per pair on
+  // purpose: kept in registers across the transform it would not fit (spills to scratch).
   auto issue_loads = [&](const PairSrc &p) {
     const raw_t *qa = reinterpret_cast<const raw_t *>(p.a), *qb = reinterpret_cast<const raw_t *>(p.b);
-    const double *wptr = window;
-    asm volatile("" : "+s"(wptr));
+    // an opaque copy of the thread index keeps these loads (and their addresses) in the loop; laundering the
+    // POINTER would do that too but loses its address space: flat loads, which count in lgkmcnt and so stall
+    // every LDS-only barrier
     int tt = t;
     asm volatile("" : "+v"(tt));
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      ra[k] = qa[tt + 256 * k];
-      rb[k] = qb[tt + 256 * k];
+      ra[k] = (reg_t)qa[tt + 256 * k];
+      rb[k] = (reg_t)qb[tt + 256 * k];
     }
 #pragma unroll
-    for (int k = 0; k < 16; k++) wv[k] = wptr[tt + 256 * k];
+    for (int k = 0; k < 16; k++) wv[k] = window[tt + 256 * k];
   };
-  PairSrc cur = locate(first);
+  // The pitch-class fold of a pair runs one pair late, between the next pair's sample conversion and its first
+  // butterflies: the LDS reads are issued, the conversion hides their latency, then 8 lanes per class add up.
+  double *plds = reinterpret_cast<double *>(lds);
+  double fv[core::kClassLaneMax];
+  auto fold_issue = [&]() {
+    if (folds) {
+      uint32_t fb = fold_bounds;
+      asm volatile("" : "+v"(fb));  // recompute the 18 addresses per pair rather than keep them in registers
+      core::class_lane_load(plds, fold_which * core::kPowerFrameB, (int)(fb & 0xffffu), (int)(fb >> 16), fold_l, fv);
+    }
+  };
+  auto fold_finish = [&](const PairSrc &p) {
+    if (folds) {
+      double acc = core::class_lane_add(fv);
+      acc += dpp_f64<0xB1>(acc);   // quad_perm [1,0,3,2]: lane ^ 1
+      acc += dpp_f64<0x4E>(acc);   // quad_perm [2,3,0,1]: lane ^ 2
+      acc += dpp_f64<0x141>(acc);  // row_half_mirror: lane -> 7 - lane within 8 (fp_core.h class_tree_partner)
+      if (fold_l == 0 && (fold_which == 0 || p.has_b)) chroma[(p.row + fold_which) * kBands + fold_c] = acc;
+    }
+  };
+  PairSrc cur = locate(first), prev = cur;
   issue_loads(cur);
 
   for (uint32_t g = first; g < last; g++) {
@@ -234,6 +263,7 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     // loop-invariant by the compiler it costs more registers than the kernel has (spills to scratch)
     int tt = t;
     asm volatile("" : "+v"(tt));
+    if (g != first) fold_issue();
     cd r[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -245,10 +275,17 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
         sa = ((int)(int16_t)ra[k] + (ra[k] >> 16)) / 2;
         sb = ((int)(int16_t)rb[k] + (rb[k] >> 16)) / 2;
       }
-      r[k] = cd{(double)sa * wv[k], (double)sb * (wv[k] * cur.keep_b)};
+      r[k] = cd{(double)sa * wv[k], (double)sb * wv[k]};
     }
+    if (!cur.has_b) {  // odd frame count: the stream's last pair has no frame B (uniform branch)
+#pragma unroll
+      for (int k = 0; k < 16; k++) r[k].y = 0.0;
+    }
+    if (g != first) fold_finish(prev);
     // in-place decimation-in-frequency stages; which exchanges need a workgroup barrier: fp_core.h
-    core::dif0(tt, base0, lds, r);
+    core::fft16(r);
+    lds_barrier();                // every thread has read its share of the previous pair's powers
+    core::dif0_store(tt, base0, lds, r);
     lds_barrier();
     core::dif1(tt, base1, lds, r);
     wave_lds_fence();             // stage 1 -> 2 stays inside 16 consecutive lanes
@@ -256,33 +293,30 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     core::dif2_publish(tt, lds, r);  // own slots; only the partner values Z[N - k] other threads need
     lds_barrier();
 
-    double *plds = reinterpret_cast<double *>(lds);
+    uint32_t spk[core::kBinsPerThread / 2];
+#pragma unroll
+    for (int j = 0; j < core::kBinsPerThread / 2; j++) {
+      spk[j] = slot_pk[j];
+      asm volatile("" : "+v"(spk[j]));  // unpack per pair: unpacked copies kept across the loop would spill
+    }
 #pragma unroll
     for (int j = 0; j < core::kBinsPerThread; j++) {
-      const uint32_t idx = (slot_pk[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-      if (idx != 0xffffu) {
-        double pa, pb;
-        int kf;
-        core::dif_bin_power(tt, j, lds, r, &kf, &pa, &pb);
-        // class-sorted powers into dead slots (fp_core.h dif_power_index): no barrier after the partner reads
-        plds[idx] = pa;
-        plds[idx + core::dif_power_index(core::kPowerFrameB)] = pb;
-      }
+      const uint32_t idx = (spk[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+      double pa, pb;
+      core::dif_bin_power_any(tt, j, lds, r, &pa, &pb);
+      // class-sorted powers into dead slots (fp_core.h dif_power_index): no barrier after the partner reads;
+      // bins outside 10..1307 land in a pad slot nobody reads
+      plds[idx] = pa;
+      plds[idx + core::dif_power_index(core::kPowerFrameB)] = pb;
     }
     const PairSrc nxt = locate(min(g + 1, last - 1));  // last pair: harmless re-read
     issue_loads(nxt);
-    lds_barrier();
-    // each class is a contiguous slice of positions: strided partial sums, then a fixed-order 8-lane tree
-    if (folds) {
-      double acc = core::class_lane_sum(plds, fold_which * core::kPowerFrameB, (int)(fold_bounds & 0xffffu),
-                                        (int)(fold_bounds >> 16), fold_l);
-#pragma unroll
-      for (int off = 4; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 8);
-      if (fold_l == 0 && (fold_which == 0 || cur.has_b)) chroma[(cur.row + fold_which) * kBands + fold_c] = acc;
-    }
-    lds_barrier();
+    lds_barrier();                // the power image is complete
+    prev = cur;
     cur = nxt;
   }
+  fold_issue();
+  fold_finish(prev);
 }
 
 // ---- kernel 2: temporal FIR + L2 normalise, one thread per output row -------------------------------------

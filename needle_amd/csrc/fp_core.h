@@ -110,9 +110,9 @@ NEEDLE_HD cd lds_get(const cd *lds, int slot) {
 NEEDLE_HD int dif_slot_of_bin(int kf) { return 256 * (kf & 15) + 16 * ((kf >> 4) & 15) + (kf >> 8); }
 NEEDLE_HD int dif_bin_of(int t, int j) { return (t >> 4) + 16 * (t & 15) + 256 * j; }
 
-// stage 0: r holds the inputs x[t + 256 k]; leaves the stage's outputs in the same slots
-NEEDLE_HD void dif0(int t, cd base0, cd *lds, cd *r) {
-  fft16(r);
+// stage 0: r holds the inputs x[t + 256 k]; leaves the stage's outputs in the same slots.  Split in two so the
+// kernel can keep the register-only half ahead of the barrier that frees the LDS image of the previous pair.
+NEEDLE_HD void dif0_store(int t, cd base0, cd *lds, const cd *r) {
   lds[pidx(t)] = r[out16(0)];
   cd w = base0;
 #pragma unroll
@@ -120,6 +120,10 @@ NEEDLE_HD void dif0(int t, cd base0, cd *lds, cd *r) {
     lds[pidx(t + 256 * j)] = cmulf(r[out16(j)], w);
     if (j < 15) w = cmulf(w, base0);
   }
+}
+NEEDLE_HD void dif0(int t, cd base0, cd *lds, cd *r) {
+  fft16(r);
+  dif0_store(t, base0, lds, r);
 }
 
 // stage 1, in place; base1 = W_4096^{16 (t & 15)}
@@ -150,16 +154,27 @@ NEEDLE_HD void dif2_publish(int t, cd *lds, const cd *r) {
   for (int j = 10; j < 16; j++) lds[pidx(16 * t + j)] = r[out16(j)];
 }
 
-// powers of this thread's bin in register j (0..5) for the two frames; false if the bin is outside 10..1307
+// The transform's inputs carry this factor (it is folded into the window table), so that the split of Z into the
+// two real spectra needs no halving: X_A = (Z[k] + conj Z[N-k]) / 2, X_B = (Z[k] - conj Z[N-k]) / 2i.  A power of
+// two, so every intermediate is the unscaled one times 2^-1 exactly and the powers are bit-identical.
+constexpr double kPairInputScale = 0.5;
+
+// powers of this thread's bin in register j for the two frames (any bin 0 < k < 4096; bin 0 reads a slot that
+// holds something else, for callers that discard it)
+NEEDLE_HD void dif_bin_power_any(int t, int j, const cd *lds, const cd *r, double *pa, double *pb) {
+  const int kf = dif_bin_of(t, j);
+  const cd z = r[out16(j)], y = lds_get(lds, pidx(dif_slot_of_bin(kFft2N - kf)));
+  const double ar = z.x + y.x, ai = z.y - y.y;  // X_A
+  const double br = z.y + y.y, bi = y.x - z.x;  // X_B
+  *pa = ar * ar + ai * ai;
+  *pb = br * br + bi * bi;
+}
+// the same, j = 0..5; false if the bin is outside 10..1307
 NEEDLE_HD bool dif_bin_power(int t, int j, const cd *lds, const cd *r, int *kf_out, double *pa, double *pb) {
   const int kf = dif_bin_of(t, j);
   *kf_out = kf;
   if (kf < kMinBin || kf >= kMaxBin) return false;
-  const cd z = r[out16(j)], y = lds_get(lds, pidx(dif_slot_of_bin(kFft2N - kf)));
-  const double ar = z.x + y.x, ai = z.y - y.y;  // 2 X_A
-  const double br = z.y + y.y, bi = y.x - z.x;  // 2 X_B
-  *pa = 0.25 * (ar * ar + ai * ai);
-  *pb = 0.25 * (br * br + bi * bi);
+  dif_bin_power_any(t, j, lds, r, pa, pb);
   return true;
 }
 
@@ -170,21 +185,29 @@ constexpr int kPowerFrameB = 2048;
 constexpr int kClassLanes = 8;       // lanes that share one pitch class in the fold
 constexpr int kClassLaneMax = 18;    // >= ceil(largest class / kClassLanes); checked where the tables are built
 NEEDLE_HD int dif_power_index(int p) { return 34 * (p >> 4) + (p & 15); }
+// The pad slots 17 q + 16 of the image are touched by no stage and no power.  Two of them serve as constants, so
+// that neither the power stores nor the fold's loads need a branch: kPowerZero (doubles of pad slot 0) holds 0.0
+// for the fold's out-of-range loads; kPowerTrash (pad slot 1; + dif_power_index(kPowerFrameB) is pad slot 129)
+// takes the powers of the bins outside 10..1307.
+constexpr int kPowerZero = 32, kPowerTrash = 66;
 
-// One lane's share of a pitch class: positions b0 + l, b0 + l + 8, ... < b1 summed in that order (loads first, so
-// their latencies overlap; the trailing zeros do not change the sum).
-NEEDLE_HD double class_lane_sum(const double *plds, int frame_off, int b0, int b1, int l) {
-  double v[kClassLaneMax];
+// One lane's share of a pitch class: positions b0 + l, b0 + l + 8, ... < b1, summed in that order.  Split into
+// the loads and the sum so the kernel can put other work between them (the trailing zeros do not change the sum).
+NEEDLE_HD void class_lane_load(const double *plds, int frame_off, int b0, int b1, int l, double *v) {
 #pragma unroll
   for (int i = 0; i < kClassLaneMax; i++) {
     const int b = b0 + l + kClassLanes * i;
-    v[i] = b < b1 ? plds[dif_power_index(frame_off + b)] : 0.0;
+    v[i] = plds[b < b1 ? dif_power_index(frame_off + b) : kPowerZero];
   }
+}
+NEEDLE_HD double class_lane_add(const double *v) {
   double acc = v[0];
 #pragma unroll
   for (int i = 1; i < kClassLaneMax; i++) acc += v[i];
   return acc;
 }
+// The 8 lane sums of a class are then combined in three exchange steps; partner of lane l in step s:
+NEEDLE_HD int class_tree_partner(int l, int s) { return s == 0 ? (l ^ 1) : s == 1 ? (l ^ 2) : (7 - l); }
 
 // ---- classifiers (chromaprint kClassifiersTest2) ---------------------------------
 struct ClassifierDef {

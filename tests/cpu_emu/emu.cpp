@@ -40,7 +40,7 @@ const Tables &tables() {
     t.tw[k] = cd{(double)cosl(a), (double)sinl(a)};
   }
   t.window.resize(4096);
-  for (int i = 0; i < 4096; i++) t.window[i] = (1.0 / 32767.0) * (0.54 - 0.46 * std::cos(i * 2.0 * M_PI / 4095));
+  for (int i = 0; i < 4096; i++) t.window[i] = kPairInputScale * ((1.0 / 32767.0) * (0.54 - 0.46 * std::cos(i * 2.0 * M_PI / 4095)));
   std::vector<std::vector<uint16_t>> by(12);
   for (int i = kMinBin; i < kMaxBin; i++) {
     double freq = (double)i * 11025 / 4096;
@@ -68,6 +68,7 @@ extern "C" {
 void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, double *chroma_a, double *chroma_b) {
   const Tables &T = tables();
   std::vector<cd> lds(kLds2Slots);
+  reinterpret_cast<double *>(lds.data())[kPowerZero] = 0.0;  // the kernel's constant zero (a pad slot)
   std::vector<cd> regs(256 * 16);
   auto sample = [&](const int16_t *src, int n) -> int {
     if (!src) return 0;
@@ -121,11 +122,14 @@ void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, do
     if (!out) continue;
     for (int c = 0; c < 12; c++) {
       double lane[8];
-      for (int l = 0; l < 8; l++)
-        lane[l] = class_lane_sum(plds, which * kPowerFrameB, (int)T.class_start[c], (int)T.class_start[c + 1], l);
-      for (int off = 4; off >= 1; off >>= 1) {
+      for (int l = 0; l < 8; l++) {
+        double v[kClassLaneMax];
+        class_lane_load(plds, which * kPowerFrameB, (int)T.class_start[c], (int)T.class_start[c + 1], l, v);
+        lane[l] = class_lane_add(v);
+      }
+      for (int step = 0; step < 3; step++) {
         double nxt[8];
-        for (int l = 0; l < 8; l++) nxt[l] = lane[l] + lane[l ^ off];
+        for (int l = 0; l < 8; l++) nxt[l] = lane[l] + lane[class_tree_partner(l, step)];
         std::memcpy(lane, nxt, sizeof(lane));
       }
       out[c] = lane[0];

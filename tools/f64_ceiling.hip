@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256, 2) void pair_kernel(const cd *__restrict__ tw,
   for (int g = 0; g < pairs; g++) {
     int tt = t;
     asm volatile("" : "+v"(tt));
-    if (MODE == 0) {
+    const int mode = MODE == 3 ? (blockIdx.x < gridDim.x / 2 ? 0 : 1) : MODE;
+    if (mode == 0) {
       for (int st = 0; st < 3; st++) {
         core::fft16(r);
         if (st < 2) {
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void pair_kernel(const cd *__restrict__ tw,
       }
 #pragma unroll
       for (int k = 0; k < 16; k++) { r[k].x *= 1e-3; r[k].y *= 1e-3; }
-    } else if (MODE == 1) {
+    } else if (mode == 1) {
 #pragma unroll
       for (int j = 0; j < 16; j++) lds[core::pidx(tt + 256 * j)] = r[j];
       lds_barrier();
@@ -138,7 +139,7 @@ int main() {
     printf("%-14s %s %.3f ms  %.2f cycles/wave-instr/SIMD at 2.4 GHz (2 waves/SIMD)\n", ops[OP], V ? "vgpr operand" : "sgpr operand", ms,            \
            ms * 1e-3 * 2.4e9 / (instr / (256 * 4)));                                                          \
   }
-  RATE(0, 0) RATE(0, 1) RATE(1, 0) RATE(1, 1) RATE(2, 0) RATE(2, 1) RATE(3, 0)
+  RATE(0, 0) RATE(0, 1) RATE(0, 1) RATE(2, 1)
   const int pairs = 160;  // per block; the product's 28 x 24 min batch is 81 382 pairs = 159 per block at 512 blocks
   const char *modes[3] = {"arithmetic only (3 fft16 + 2 twiddle passes)", "LDS traffic only", "arithmetic + LDS (no global loads, no fold)"};
 #define PAIR(M)                                                                                               \
@@ -149,5 +150,13 @@ int main() {
            ms * 1e-3 * 2.4e9 / (blocks * pairs / 256.0));                                                     \
   }
   PAIR(0) PAIR(1) PAIR(2)
+  {
+    const char *names[3] = {"256 workgroups arithmetic only (1/CU)", "256 workgroups LDS only (1/CU)", "256 arithmetic + 256 LDS workgroups together"};
+    hipFuncSetAttribute(reinterpret_cast<const void *>(pair_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    float m0 = time([&](int small) { pair_kernel<0><<<256, 256, lds>>>(d_tw, d_out, small ? 2 : pairs); });
+    float m1 = time([&](int small) { pair_kernel<1><<<256, 256, lds>>>(d_tw, d_out, small ? 2 : pairs); });
+    float m3 = time([&](int small) { pair_kernel<3><<<512, 256, lds>>>(d_tw, d_out, small ? 2 : pairs); });
+    printf("%s: %.3f ms\n%s: %.3f ms\n%s: %.3f ms\n", names[0], m0, names[1], m1, names[2], m3);
+  }
   return 0;
 }

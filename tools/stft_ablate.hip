@@ -48,14 +48,26 @@ __global__ __launch_bounds__(256, 2) void kernel(const int16_t *__restrict__ pcm
     const int slot = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));
     if (slot & 1) for (int i = 0; i < skew; i++) __builtin_amdgcn_s_sleep(16);
   }
+  int si = find_stream(streams, num_streams, first);
+  Stream st = streams[si];
+  uint32_t st_end = st.pair_base + (st.frames + 1) / 2;
+  uint32_t slot_pk[3];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    const int kf = core::dif_bin_of(t, j);
+    const uint32_t idx = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : 0xffffu;
+    slot_pk[j >> 1] = (j & 1) ? (slot_pk[j >> 1] | (idx << 16)) : idx;
+  }
+  const bool folds = t < 192;
+  const int fold_which = (t >> 3) >= kBands ? 1 : 0, fold_c = (t >> 3) - fold_which * kBands, fold_l = t & 7;
+  const uint32_t fold_bounds = folds ? (class_start[fold_c] | (class_start[fold_c + 1] << 16)) : 0;
   auto locate = [&](uint32_t g) {
     PairSrc p;
     if (F & 8) {
       p.has_b = true; p.a = pcm + (uint64_t)g * 2 * kHop; p.b = p.a + kHop; p.keep_b = 1.0; p.row = 2 * (uint64_t)g;
       return p;
     }
-    const int si = find_stream(streams, num_streams, g);
-    const Stream st = streams[si];
+    while (g >= st_end) { st = streams[++si]; st_end = st.pair_base + (st.frames + 1) / 2; }
     const uint32_t fa = 2 * (g - st.pair_base);
     p.has_b = fa + 1 < st.frames;
     p.a = pcm + st.pcm_off + (uint64_t)fa * kHop;
@@ -65,25 +77,28 @@ __global__ __launch_bounds__(256, 2) void kernel(const int16_t *__restrict__ pcm
     return p;
   };
   int16_t ra[16], rb[16];
+  double wv[16];
   auto issue_loads = [&](const PairSrc &p) {
+    int tt = t;
+    asm volatile("" : "+v"(tt));
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      if (F & 2) { ra[k] = (int16_t)(t + k); rb[k] = (int16_t)(t - k); }
-      else { ra[k] = p.a[t + 256 * k]; rb[k] = p.b[t + 256 * k]; }
+      if (F & 2) { ra[k] = (int16_t)(tt + k); rb[k] = (int16_t)(tt - k); }
+      else { ra[k] = p.a[tt + 256 * k]; rb[k] = p.b[tt + 256 * k]; }
     }
+#pragma unroll
+    for (int k = 0; k < 16; k++) wv[k] = window[tt + 256 * k];
   };
   PairSrc cur = locate(first);
   issue_loads(cur);
   for (uint32_t g = first; g < last; g++) {
     int tt = t;
     asm volatile("" : "+v"(tt));
-    const double *wptr = window;
-    asm volatile("" : "+s"(wptr));
     cd r[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       double w;
-      if (F & 1) { w = 3.0e-5; asm volatile("" : "+v"(w)); } else w = wptr[tt + 256 * k];
+      if (F & 1) { w = 3.0e-5; asm volatile("" : "+v"(w)); } else w = wv[k];
       r[k] = cd{(double)ra[k] * w, (double)rb[k] * (w * cur.keep_b)};
     }
     core::dif0(tt, base0, lds, r);
@@ -94,15 +109,15 @@ __global__ __launch_bounds__(256, 2) void kernel(const int16_t *__restrict__ pcm
     core::dif2_publish(tt, lds, r);
     lds_barrier();
     double *plds = reinterpret_cast<double *>(lds);
-    const uint16_t *slot_tab = bin_slot;
-    asm volatile("" : "+s"(slot_tab));
     double keep = 0;
 #pragma unroll
     for (int j = 0; j < core::kBinsPerThread; j++) {
-      double pa, pb; int kf;
-      if (core::dif_bin_power(tt, j, lds, r, &kf, &pa, &pb)) {
+      const uint32_t idx = (slot_pk[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+      if (idx != 0xffffu) {
+        double pa, pb; int kf;
+        core::dif_bin_power(tt, j, lds, r, &kf, &pa, &pb);
         if (F & 4) keep += pa + pb;
-        else { const int idx = slot_tab[kf - core::kMinBin]; plds[idx] = pa; plds[idx + core::dif_power_index(core::kPowerFrameB)] = pb; }
+        else { plds[idx] = pa; plds[idx + core::dif_power_index(core::kPowerFrameB)] = pb; }
       }
     }
     const PairSrc nxt = locate(min(g + 1, last - 1));
@@ -112,13 +127,11 @@ __global__ __launch_bounds__(256, 2) void kernel(const int16_t *__restrict__ pcm
       lds_barrier();
     } else {
       lds_barrier();
-      if (tt < 2 * kBands * core::kClassLanes) {
-        const int grp = tt >> 3, l = tt & 7;
-        const int which = grp >= kBands ? 1 : 0, c = grp - which * kBands;
-        double acc = core::class_lane_sum(plds, which * core::kPowerFrameB, (int)class_start[c], (int)class_start[c + 1], l);
+      if (folds) {
+        double acc = core::class_lane_sum(plds, fold_which * core::kPowerFrameB, (int)(fold_bounds & 0xffffu), (int)(fold_bounds >> 16), fold_l);
 #pragma unroll
         for (int off = 4; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 8);
-        if (l == 0 && (which == 0 || cur.has_b)) chroma[(cur.row + which) * kBands + c] = acc;
+        if (fold_l == 0 && (fold_which == 0 || cur.has_b)) chroma[(cur.row + fold_which) * kBands + fold_c] = acc;
       }
       lds_barrier();
     }
@@ -164,11 +177,8 @@ int main(int argc, char **argv) {
     printf("%-44s ppb=%3u skew=%3d  %.3f ms\n", name, ppb, skew, best);
   };
   run(kernel<0>, "full", 16, 0);
+  run(kernel<1>, "no window loads", 16, 0);
+  run(kernel<4>, "no fold", 16, 0);
   run(kernel<15>, "FFT core only", 16, 0);
-  for (int skew : {2, 4, 8, 12}) run(kernel<31>, "FFT core only, persistent, slot-skewed", (total_pairs + 511) / 512, skew);
-  for (int skew : {2, 4, 8, 12}) run(kernel<31>, "FFT core only, slot-skewed", 16, skew);
-  lds_req = 100 * 1024;  // forces one workgroup per CU
-  run(kernel<0>, "full, 1 workgroup/CU", 16, 0);
-  run(kernel<15>, "FFT core only, 1 workgroup/CU", 16, 0);
   return 0;
 }
