@@ -15,7 +15,8 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 NS = 1_000_000_000
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libneedle_capi.so")
+# NEEDLE_CAPI_LIB: another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("NEEDLE_CAPI_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libneedle_capi.so")
 
 ERROR_NAMES = ["Ok", "InvalidUtf8String", "NullArgument", "InvalidArgument", "FrameHashDataNotFound",
                "FrameHashDataInvalidVersion", "InvalidFrameHashData", "ComparatorMinimumPaths",

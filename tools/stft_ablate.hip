@@ -1,4 +1,5 @@
-// Diagnostic (not part of the product): the loop of stft_chroma_kernel (fingerprint.hip) with pieces switched off,
+// Diagnostic (not part of the product): the loop of stft_chroma_kernel (fingerprint.hip, as of the 4-barrier
+// version with the fold at the end of the pair) with pieces switched off,
 // to see what each piece costs at the product's launch shape.  Outputs are wrong by construction; only times count.
 //   bit 0: window from a constant instead of the table      bit 1: no PCM loads
 //   bit 2: no pitch-class fold (power store, fold, 2 barriers)  bit 3: no stream lookup (pointer arithmetic only)
@@ -128,7 +129,9 @@ __global__ __launch_bounds__(256, 2) void kernel(const int16_t *__restrict__ pcm
     } else {
       lds_barrier();
       if (folds) {
-        double acc = core::class_lane_sum(plds, fold_which * core::kPowerFrameB, (int)(fold_bounds & 0xffffu), (int)(fold_bounds >> 16), fold_l);
+        double fv[core::kClassLaneMax];
+        core::class_lane_load(plds, fold_which * core::kPowerFrameB, (int)(fold_bounds & 0xffffu), (int)(fold_bounds >> 16), fold_l, fv);
+        double acc = core::class_lane_add(fv);
 #pragma unroll
         for (int off = 4; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 8);
         if (fold_l == 0 && (fold_which == 0 || cur.has_b)) chroma[(cur.row + fold_which) * kBands + fold_c] = acc;
