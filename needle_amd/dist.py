@@ -39,15 +39,19 @@ def pair_count(n: int) -> int:
     return n * (n - 1) // 2 if n >= 2 else 0
 
 
-def gather_rows(arena, world: int, rank: int):
+def gather_rows(arena, world: int, rank: int, row_block=None):
     """In-place all-gather of the row blocks of `arena` (torch tensor [world*block, stride]); rank r's block
-    must already hold its rows."""
+    must already hold its rows.  `row_block`: optional preallocated [block, stride] staging tensor."""
     import torch.distributed as dist
     if world == 1:
         return arena
     b = arena.shape[0] // world
     mine = arena[rank * b:(rank + 1) * b]
-    dist.all_gather_into_tensor(arena, mine.clone())
+    if row_block is None:
+        row_block = mine.clone()
+    else:
+        row_block.copy_(mine)
+    dist.all_gather_into_tensor(arena, row_block)
     return arena
 
 
@@ -71,53 +75,78 @@ def gather_runs(local_runs, world: int):
     return torch.cat([out[r * width: r * width + counts[r]] for r in range(world)], dim=0)
 
 
+class SlabGather:
+    """Latency-lean gather for short run lists: ONE fixed-size all-gather and no host round trip before it.
+    Each rank contributes a slab of 1 + `slab` rows whose row 0 carries its run count (which may exceed the slab);
+    buffers are allocated once and reused by every job."""
+
+    def __init__(self, run_buffer, world: int, slab: int = 512):
+        import torch
+        self.world, self.slab, self.cols = world, slab, run_buffer.shape[1]
+        self.mine = torch.zeros((1 + slab, self.cols), dtype=run_buffer.dtype, device=run_buffer.device)
+        self.out = torch.zeros((world, 1 + slab, self.cols), dtype=run_buffer.dtype, device=run_buffer.device)
+        self.host = torch.zeros((world, 1 + slab, self.cols), dtype=run_buffer.dtype)
+        if run_buffer.device.type == "cuda":
+            self.host = self.host.pin_memory()
+
+    def __call__(self, run_buffer, count_tensor):
+        """`run_buffer` [capacity, words] and `count_tensor` [1] (int32, total runs found) live on the collective's
+        device.  Returns (runs ndarray [total, words], complete): `complete` is False when some rank found more than
+        `slab` runs, in which case the caller falls back to gather_runs."""
+        import torch.distributed as dist
+        self.mine[0, 0:1] = count_tensor
+        self.mine[1:] = run_buffer[: self.slab]
+        if self.world == 1:
+            self.out[0] = self.mine
+        else:
+            dist.all_gather_into_tensor(self.out.view(self.world * (1 + self.slab), self.cols), self.mine)
+        self.host.copy_(self.out)          # device -> (pinned) host, synchronous for the host
+        host = self.host.numpy()
+        counts = [int(host[r, 0, 0]) for r in range(self.world)]
+        complete = all(c <= self.slab for c in counts)
+        runs = np.concatenate([host[r, 1:1 + min(counts[r], self.slab)] for r in range(self.world)], axis=0)
+        return runs, complete
+
+
 def gather_runs_slab(run_buffer, count_tensor, world: int, slab: int = 512):
-    """Latency-lean variant for short run lists: ONE fixed-size all-gather and no host round trip before it.
-    `run_buffer` [capacity, words] and `count_tensor` [1] (int32, total runs found, may exceed the slab) live on
-    the collective's device.  Each rank contributes a slab of 1 + `slab` rows whose row 0 carries its count.
-    Returns (runs ndarray [total, words], complete): `complete` is False when some rank found more than `slab`
-    runs, in which case the caller falls back to gather_runs."""
-    import torch
-    import torch.distributed as dist
-    cols = run_buffer.shape[1]
-    mine = torch.zeros((1 + slab, cols), dtype=run_buffer.dtype, device=run_buffer.device)
-    mine[0, 0] = count_tensor[0]
-    mine[1:] = run_buffer[:slab]
-    if world == 1:
-        out = mine.unsqueeze(0)
-    else:
-        out = torch.empty((world, 1 + slab, cols), dtype=run_buffer.dtype, device=run_buffer.device)
-        dist.all_gather_into_tensor(out.view(world * (1 + slab), cols), mine)
-    host = out.cpu().numpy()
-    counts = [int(host[r, 0, 0]) for r in range(world)]
-    complete = all(c <= slab for c in counts)
-    runs = np.concatenate([host[r, 1:1 + min(counts[r], slab)] for r in range(world)], axis=0)
-    return runs, complete
+    """One-shot form of SlabGather."""
+    return SlabGather(run_buffer, world, slab)(run_buffer, count_tensor)
 
 
 def run_job(n_videos: int, world: int, rank: int, arena, analyze_rows: Callable[[int, int], None],
             search_pairs: Callable[[int, int], "object"], finalize: Callable[[np.ndarray], "object"],
-            sync: Callable[[], None], slab: int = 512):
+            sync: Callable[[], None], slab: int = 512, gather=None, defer_finalize: bool = False,
+            while_analyzing: Callable[[], None] = None, row_block=None):
     """One analyze+search pass.  analyze_rows(first, count) fills this rank's arena rows; search_pairs(first,
     count) returns this rank's runs, either as a torch tensor [k, words] or as a (run_buffer, count_tensor) pair
-    of device tensors for the single-collective slab gather; finalize(runs ndarray) builds the per-video results
-    (rank 0 only; other ranks get None).  sync() orders the compute stream against the collective."""
+    of device tensors for the single-collective slab gather (`gather`: a reusable SlabGather); finalize(runs
+    ndarray) builds the per-video results (rank 0 only; other ranks get None).  sync() orders the compute stream
+    against the collective.  while_analyzing() runs on the host right after this rank's analyze work has been
+    enqueued (the caller's place for the previous job's epilogue); with defer_finalize the gathered runs are
+    returned instead of the results, for the caller to finalize later.  row_block: a reusable staging tensor for
+    this rank's row block (the all-gather's input must not alias its output)."""
     first, count = shard(n_videos, world, rank)
     if count:
         analyze_rows(first, count)
+    if while_analyzing is not None:
+        while_analyzing()
     sync()
-    gather_rows(arena, world, rank)
+    gather_rows(arena, world, rank, row_block)
     sync()
     pfirst, pcount = shard(pair_count(n_videos), world, rank)
     local = search_pairs(pfirst, pcount)
     sync()
     if isinstance(local, tuple):
         run_buffer, count_tensor = local
-        runs, complete = gather_runs_slab(run_buffer, count_tensor, world, slab)
+        if gather is None:
+            gather = SlabGather(run_buffer, world, slab)
+        runs, complete = gather(run_buffer, count_tensor)
         if not complete:  # a rank overflowed its slab: exact two-step gather
             runs = gather_runs(run_buffer[: int(count_tensor.item())], world).cpu().numpy()
     else:
         runs = gather_runs(local, world).cpu().numpy()
+    if defer_finalize:
+        return runs
     if rank != 0:
         return None
     return finalize(runs)

@@ -73,8 +73,27 @@ def main():
     res = ndist.run_job(n, world, rank, arena, analyze_rows, search_pairs, lambda runs: runs.tolist(), lambda: None,
                         slab=int(os.environ.get("NEEDLE_TEST_SLAB", "512")))
     ok_arena = bool(np.array_equal(arena.numpy().view(np.uint32)[:n], truth))
+    pipelined = None
+    if os.environ.get("NEEDLE_TEST_SLAB"):
+        # bench.py's form: reusable gather and row-block buffers, the epilogue deferred to the next job's analyze
+        slab = int(os.environ["NEEDLE_TEST_SLAB"])
+        gather = ndist.SlabGather(torch.zeros((4096, 4), dtype=torch.int32), world, slab)
+        row_block = torch.zeros((b, stride), dtype=torch.int32)
+        done, pending = [], []
+
+        def finish_previous():
+            if pending:
+                done.append(pending.pop().tolist())
+
+        for _ in range(3):
+            arena.zero_()
+            pending.append(ndist.run_job(n, world, rank, arena, analyze_rows, search_pairs, None, lambda: None,
+                                         slab=slab, gather=gather, defer_finalize=True,
+                                         while_analyzing=finish_previous, row_block=row_block))
+        finish_previous()
+        pipelined = done
     with open(f"{out_path}.{rank}", "w") as f:
-        json.dump({"rank": rank, "arena_complete": ok_arena, "runs": res}, f)
+        json.dump({"rank": rank, "arena_complete": ok_arena, "runs": res, "pipelined": pipelined}, f)
     dist.barrier()
     dist.destroy_process_group()
 

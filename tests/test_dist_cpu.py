@@ -58,3 +58,8 @@ def test_gloo_job_equals_single_process(tmp_path, world, n):
     for slab in (512, 4):
         got = _launch(world, n, str(tmp_path / f"s{world}_{slab}"), slab=slab)
         assert sorted(map(tuple, got[0]["runs"])) == sorted(map(tuple, single["runs"]))
+        # bench.py's pipelined form (reused buffers, epilogue deferred into the next job): every job, every rank
+        for m in got:
+            assert len(m["pipelined"]) == 3
+            for job in m["pipelined"]:
+                assert sorted(map(tuple, job)) == sorted(map(tuple, single["runs"]))
