@@ -275,3 +275,39 @@ def test_chromaprint_compat_exports_and_constants(has_gpu):
     L.chromaprint_free(ctx)
     L.chromaprint_free(None)
     L.chromaprint_dealloc(None)
+
+
+# ---- the command-line front-end (needle/src/main.rs) --------------------------------------------------------------
+NEEDLE_BIN = os.path.join(os.path.dirname(capi.LIB_PATH), "..", "bin", "needle")
+
+
+def _cli(*args):
+    import subprocess
+    return subprocess.run([NEEDLE_BIN, *args], capture_output=True, text=True, timeout=60)
+
+
+def test_cli_validation_matches_reference_messages(tmp_path):
+    """Cli::validate and the search arm's minimum-paths check (main.rs:196-241,306-317): same messages, exit 2."""
+    r = _cli("info")
+    assert r.returncode == 0 and "needle version:" in r.stdout and "HIP devices:" in r.stdout
+    for args, msg in [
+        (["analyze", str(tmp_path), "--opening-search-percentage", "1.0"], "opening_search_percentage must be less than 1.0"),
+        (["analyze", str(tmp_path), "--ending-search-percentage=1.5"], "ending_search_percentage must be less than 1.0"),
+        (["analyze", str(tmp_path), "--hash-duration", "0"], "hash_duration must be greater than 0"),
+        (["search", str(tmp_path), "--hash-match-threshold", "33"], "hash_match_threshold cannot be larger than 32"),
+        (["search", str(tmp_path)], "need at least 2 valid video files, but only found 1 in provided video paths"),
+        (["search", str(tmp_path / "missing")], "path does not exist"),
+        (["analyze"], "required arguments were not provided"),
+        (["frobnicate"], "wasn't expected"),
+        ([], "requires a subcommand"),
+        (["search", str(tmp_path), "--min-opening-duration", "70000"], "Invalid value"),
+        (["analyze", str(tmp_path), "--mode", "video"], "isn't a valid value"),
+    ]:
+        r = _cli(*args)
+        assert r.returncode == 2, (args, r.stderr)
+        # (the C ABI itself logs "needle error: ..." first where the failure comes from the library, lib.rs:124)
+        assert "\nerror: " in "\n" + r.stderr and msg in r.stderr, (args, r.stderr)
+    # global flags are accepted on either side of the subcommand; discovery ignores non-media files
+    (tmp_path / "notes.txt").write_text("x")
+    r = _cli("--no-threading", "search", str(tmp_path), "--file-headers-only", "--no-display")
+    assert r.returncode == 2 and "need at least 2 valid video files" in r.stderr

@@ -560,3 +560,38 @@ def test_resampler_bit_exact_and_analyzer_accepts_decode_rates(tmp_path):
     assert h.tolist() == [x for x, _ in want] and ts.tolist() == [t for _, t in want]
     fh2 = capi.Analyzer.from_files([p]).run_pcm([stereo], channels=2, sample_rate=44100)[0]
     assert fh2.opening_data()[0].tolist() == h.tolist()
+
+
+def test_cli_analyze_then_search_matches_oracle(lib3, tmp_path):
+    """The reference's command lines (README: `needle analyze <dir>`, `needle search <dir>`) through the needle
+    binary: .needle.dat files, the displayed results and the skip files all equal the oracle's."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(capi.LIB_PATH), "..", "bin", "needle")
+    paths = []
+    for k, e in enumerate(lib3):
+        p = str(tmp_path / f"s01e0{k}.wav")
+        synth.write_wav(p, e.pcm, channels=2)
+        paths.append(p)
+    (tmp_path / "readme.txt").write_text("not media")
+    r = subprocess.run([exe, "analyze", str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    hd = O.duration_from_secs_f32(0.3)
+    ref = O.analyze_batch([e.pcm[: len(e.pcm) // 2] for e in lib3], 1, hd)
+    for p, want in zip(paths, ref):
+        rc, disk = O.frame_hashes_read(p[:-4] + ".needle.dat")
+        assert rc == 0 and disk.opening == want.opening and disk.md5 == O.header_md5(p)
+    r = subprocess.run([exe, "search", str(tmp_path), "--min-opening-duration", "10", "--write-skip-files"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    want = O.run_with_frame_hashes(O.Comparator(min_opening_duration=10 * NS), ref)
+    for p, w in zip(paths, want):
+        assert f'{p}\n\n* Opening - "{O.format_time(w.opening[0])}"-"{O.format_time(w.opening[1])}"' in r.stdout
+        assert open(p[:-4] + ".needle.skip.json").read() == O.skip_file_json(w, O.header_md5(p))
+    # default minimum (20 s) on a 20 s intro: nothing found, by both (SURVEY.md §7.6); --no-display prints nothing
+    r = subprocess.run([exe, "search", str(tmp_path), "--no-display"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Opening" not in r.stdout
+    # a second analyze finds the cached data (analyzer.rs:338-348); --force recomputes
+    r = subprocess.run([exe, "analyze", *paths], capture_output=True, text=True, timeout=300)
+    assert r.stdout.count("Skipping analysis for") == 3
+    r = subprocess.run([exe, "analyze", "--force", *paths], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Skipping analysis" not in r.stdout
