@@ -1,0 +1,141 @@
+//! Raw declarations of include/needle.h and the part of include/needle_hip.h this crate uses.
+//! Keep in step with those headers; tests/test_capi_cpu.py checks that the library exports every symbol.
+#![allow(non_camel_case_types, dead_code)]
+
+use std::os::raw::{c_char, c_int};
+
+/// `enum NeedleError` (needle-capi/src/lib.rs:58-85): repr(C), values 0..=11.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum NeedleError {
+    Ok = 0,
+    InvalidUtf8String,
+    NullArgument,
+    InvalidArgument,
+    FrameHashDataNotFound,
+    FrameHashDataInvalidVersion,
+    InvalidFrameHashData,
+    ComparatorMinimumPaths,
+    AnalyzerInvalidHashPeriod,
+    AnalyzerInvalidHashDuration,
+    IOError,
+    Unknown,
+}
+
+#[repr(C)]
+pub struct NeedleAudioAnalyzer {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct NeedleAudioComparator {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct FrameHashes {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct NeedleHipSearchResult {
+    pub has_result: bool,
+    pub has_opening: bool,
+    pub has_ending: bool,
+    pub opening_start_ns: u64,
+    pub opening_end_ns: u64,
+    pub ending_start_ns: u64,
+    pub ending_end_ns: u64,
+}
+
+extern "C" {
+    // ---- needle.h ------------------------------------------------------------------------------------
+    pub fn needle_error_to_str(error: NeedleError) -> *const c_char;
+    pub fn needle_audio_analyzer_new(
+        paths: *const *const c_char,
+        num_paths: usize,
+        opening_search_percentage: f32,
+        ending_search_percentage: f32,
+        include_endings: bool,
+        threaded_decoding: bool,
+        force: bool,
+        output: *mut *mut NeedleAudioAnalyzer,
+    ) -> NeedleError;
+    pub fn needle_audio_analyzer_free(analyzer: *const NeedleAudioAnalyzer);
+    pub fn needle_audio_analyzer_get_frame_hashes(
+        analyzer: *const NeedleAudioAnalyzer,
+        index: usize,
+        output: *mut *const FrameHashes,
+    ) -> NeedleError;
+    pub fn needle_audio_analyzer_run(
+        analyzer: *mut NeedleAudioAnalyzer,
+        hash_duration: f32,
+        persist: bool,
+        threading: bool,
+    ) -> NeedleError;
+    pub fn needle_audio_comparator_new(
+        paths: *const *const c_char,
+        num_paths: usize,
+        include_endings: bool,
+        hash_match_threshold: u16,
+        min_opening_duration: u16,
+        min_ending_duration: u16,
+        time_padding: f32,
+        output: *mut *const NeedleAudioComparator,
+    ) -> NeedleError;
+    pub fn needle_audio_comparator_free(comparator: *const NeedleAudioComparator);
+    pub fn needle_audio_comparator_run(
+        comparator: *const NeedleAudioComparator,
+        analyze: bool,
+        display: bool,
+        use_skip_files: bool,
+        write_skip_files: bool,
+        threading: bool,
+    ) -> NeedleError;
+
+    // ---- needle_hip.h --------------------------------------------------------------------------------
+    pub fn needle_hip_last_error_message() -> *const c_char;
+    pub fn needle_hip_device_count(count: *mut c_int) -> NeedleError;
+    pub fn needle_hip_set_device(ordinal: c_int) -> NeedleError;
+    pub fn needle_hip_analyzer_run_pcm(
+        analyzer: *mut NeedleAudioAnalyzer,
+        pcm: *const *const i16,
+        num_values: *const usize,
+        channels: c_int,
+        sample_rate: c_int,
+        hash_duration: f32,
+        persist: bool,
+    ) -> NeedleError;
+    pub fn needle_hip_comparator_run_with_frame_hashes(
+        comparator: *const NeedleAudioComparator,
+        frame_hashes: *const *const FrameHashes,
+        num_videos: usize,
+        display: bool,
+        use_skip_files: bool,
+        write_skip_files: bool,
+        results: *mut NeedleHipSearchResult,
+    ) -> NeedleError;
+    pub fn needle_hip_frame_hashes_new(
+        opening_hashes: *const u32,
+        opening_ts_ns: *const u64,
+        num_opening: usize,
+        ending_hashes: *const u32,
+        ending_ts_ns: *const u64,
+        num_ending: usize,
+        hash_duration_ns: u64,
+        md5: *const c_char,
+        output: *mut *mut FrameHashes,
+    ) -> NeedleError;
+    pub fn needle_hip_frame_hashes_free(frame_hashes: *mut FrameHashes);
+    pub fn needle_hip_frame_hashes_len(frame_hashes: *const FrameHashes, ending: bool) -> usize;
+    pub fn needle_hip_frame_hashes_copy(
+        frame_hashes: *const FrameHashes,
+        ending: bool,
+        hashes: *mut u32,
+        ts_ns: *mut u64,
+        capacity: usize,
+    ) -> NeedleError;
+    pub fn needle_hip_frame_hashes_hash_duration_ns(frame_hashes: *const FrameHashes) -> u64;
+    pub fn needle_hip_frame_hashes_md5(frame_hashes: *const FrameHashes) -> *const c_char;
+    pub fn needle_hip_frame_hashes_read(path: *const c_char, output: *mut *mut FrameHashes) -> NeedleError;
+    pub fn needle_hip_frame_hashes_write(frame_hashes: *const FrameHashes, path: *const c_char) -> NeedleError;
+}
