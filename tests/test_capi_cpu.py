@@ -311,3 +311,18 @@ def test_cli_validation_matches_reference_messages(tmp_path):
     (tmp_path / "notes.txt").write_text("x")
     r = _cli("--no-threading", "search", str(tmp_path), "--file-headers-only", "--no-display")
     assert r.returncode == 2 and "need at least 2 valid video files" in r.stderr
+
+
+def test_rust_ffi_declarations_name_exported_symbols():
+    """rust/needle-hip cannot be compiled here (no toolchain); at least every function its ffi.rs declares must
+    be a symbol libneedle_capi.so exports and one of the headers declares."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    src = open(os.path.join(root, "rust", "needle-hip", "src", "ffi.rs")).read()
+    names = re.findall(r"pub fn (needle_\w+)\(", src)
+    assert len(names) > 20
+    headers = open(os.path.join(root, "include", "needle.h")).read() + open(os.path.join(root, "include", "needle_hip.h")).read()
+    L = capi.lib()
+    for n in names:
+        assert hasattr(L, n), n
+        assert re.search(r"\b%s\(" % n, headers), n
