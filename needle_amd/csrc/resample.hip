@@ -5,8 +5,22 @@
 // multiply-adds in tap order, round-to-nearest-even, clamp.  Integer/f32 work with a fixed operation order, so
 // the GPU output equals the oracle's bit for bit.
 //
-// HBM-stream-bound: each input sample is read once from HBM (a workgroup stages the span of input its 256
-// outputs need in LDS, neighbouring workgroups overlap by the filter length only) and each output written once.
+// Each output is a serial chain of T (100-300) FMAs, so the kernel's job is to feed two operands per FMA
+// cheaply (measured: the first version, one LDS read and one scattered coefficient load per tap, ran at 4-8 % of
+// the HBM rate; the integer VALU work of addressing alone was the next limit).  A workgroup owns a tile of n*L
+// consecutive outputs and stages the n*M + T input samples they read in LDS once, as f32.  Lanes are grouped by
+// filter PHASE: the n lanes of a group compute the outputs p, p + L, p + 2L, ... of the tile, which share one
+// coefficient row and read inputs exactly M samples apart.
+//  * samples: four at a time from 16-byte aligned LDS reads at compile-time offsets from one address per lane.
+//    The misalignment of a lane's first tap is absorbed by using the coefficient row pre-shifted by 0..3 taps
+//    (rows are stored four times, zero-padded: a zero coefficient leaves the accumulator unchanged).  When M is
+//    large the region is stored as n rows of M + T samples (the T samples after a row repeat the start of the
+//    next row), row pitch odd in 16-byte slots: a lane's window never leaves its row, and the 16 lanes of an LDS
+//    lane group, one row apart, hit 16 different banks.
+//  * coefficients: each wave copies the rows of its (at most four) phases into a private LDS scratch with one
+//    coalesced load per row and reads them back as broadcast LDS reads: a broadcast vector-memory load returns
+//    16 bytes to every lane whatever the addresses (16 cycles of the CU's L1 path per 4 taps), a broadcast LDS
+//    read costs 4.
 #include "hipctx.h"
 
 #include <algorithm>
@@ -22,12 +36,13 @@ constexpr int kTarget = 11025;
 constexpr int kZeroCrossings = 16;
 constexpr double kRolloff = 0.94;
 constexpr double kKaiserBeta = 9.0;
-constexpr int kOutPerBlock = 256;
 
 struct Design {
   int L = 1, M = 1, T = 0;
+  int G = 0;                // 16-byte groups per shifted row
+  int n = 0;                // lanes (outputs L apart) that share a phase within a tile
   std::vector<float> coef;  // [L][T]
-  float *d_coef = nullptr;
+  float *d_coef = nullptr;  // [4 shifts][L][4 G]: row a holds coef[phase][k - a] at k, zero elsewhere
 };
 
 double bessel_i0(double x) {
@@ -93,43 +108,149 @@ struct RsStream {
   uint32_t pad;
 };
 
-template <int CH>
-__global__ __launch_bounds__(256) void resample_kernel(const int16_t *__restrict__ in, const RsStream *__restrict__ streams,
-                                                       int num_streams, const float *__restrict__ coef, int L, int M,
-                                                       int T, int span, int16_t *__restrict__ out) {
-  extern __shared__ float stage[];  // `span` mono samples this workgroup's outputs read
+constexpr int kMaxRegionSamples = 30000;  // f32 region of a tile in LDS (120 KB) at most
+constexpr int kThreads = 512;
+constexpr int kRowModeMinM = 64;   // row layout from this decimation step on (below it lanes are few slots apart)
+constexpr int kRowModeMaxN = 32;
+
+// Orders this wave's LDS writes before its later LDS reads for the compiler; the hardware executes one wave's LDS
+// operations in order.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct RsGeom {
+  int L, M, T, G;   // L/M = 11025/rate in lowest terms, T taps, G 16-byte groups per shifted coefficient row
+  int n_log2;       // lanes per phase
+  int pitch;        // row layout: 16-byte slots per row (odd); 0 = the region is stored contiguously
+  int region_slots; // 16-byte slots of samples
+};
+
+// ROWS_IN_LDS needs the shift of a row to be the same for all lanes of its phase: always so in the row layout,
+// and in the contiguous layout when M % 4 == 0.
+template <int CH, bool ROWS_IN_LDS>
+__global__ __launch_bounds__(kThreads) void resample_kernel(const int16_t *__restrict__ in,
+                                                            const RsStream *__restrict__ streams, int num_streams,
+                                                            const float4 *__restrict__ coef, RsGeom geo,
+                                                            int16_t *__restrict__ out) {
+  extern __shared__ float4 lds4[];  // samples | the tile's outputs (s16) | per-wave coefficient rows
+  float *stage = reinterpret_cast<float *>(lds4);
+  const int L = geo.L, M = geo.M, G = geo.G, n_log2 = geo.n_log2;
   int lo = 0, hi = num_streams - 1;
   while (lo < hi) {
     int mid = (lo + hi + 1) >> 1;
     if (streams[mid].block_base <= blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const RsStream st = streams[lo];
-  const uint64_t m0 = (uint64_t)(blockIdx.x - st.block_base) * kOutPerBlock;
-  const int half = T / 2;
-  const long long first0 = (long long)((m0 * (uint64_t)M) / (uint64_t)L) - half + 1;
+  const int n = 1 << n_log2;
+  const int tile_outputs = n * L;
+  const uint64_t tile = blockIdx.x - st.block_base;
+  const uint64_t tile_base = tile * (uint64_t)tile_outputs;          // first output of the tile
+  const int half = geo.T / 2;
+  const long long first0 = (long long)(tile * (uint64_t)n * (uint64_t)M) - half + 1;  // input index of region[0]
   const int16_t *src = in + st.in_off;
-  for (int i = threadIdx.x; i < span; i += blockDim.x) {
-    const long long idx = first0 + i;
-    int s = 0;
-    if (idx >= 0 && (uint64_t)idx < st.n_in) {
-      if (CH == 1) s = src[idx];
-      else s = ((int)src[2 * idx] + (int)src[2 * idx + 1]) / 2;  // integer down-mix, C truncation
+  // one down-mixed input sample, 0 outside the stream.  Branch-free (the load is always issued, at an index
+  // clamped into the stream) so that the unrolled staging loops keep their loads in flight; a stereo sample is
+  // one aligned 32-bit load.
+  auto sample = [&](long long idx) -> int {
+    const bool ok = idx >= 0 && (uint64_t)idx < st.n_in;
+    const long long at = idx < 0 ? 0 : ((uint64_t)idx < st.n_in ? idx : (long long)st.n_in - 1);
+    int sv;
+    if (CH == 1) {
+      sv = src[at];
+    } else {
+      const int v = reinterpret_cast<const int *>(src)[at];
+      sv = ((int)(int16_t)v + (v >> 16)) / 2;  // integer down-mix, C truncation
     }
-    stage[i] = (float)s;
+    return ok ? sv : 0;
+  };
+  // staging: `count` samples from input index `from`, by `nt` cooperating threads of which this is number `me`;
+  // whole passes keep eight loads in flight per thread (one at a time would pay a memory latency per pass), the
+  // ragged tail is a plain loop (no dummy loads: thousands of workgroups reading one dummy address made that
+  // cache line the bottleneck)
+  auto stage_run = [&](float *dst, long long from, int count, int me, int nt) {
+    constexpr int kStageUnroll = 8;
+    int o = me;
+    for (; o + (kStageUnroll - 1) * nt < count; o += nt * kStageUnroll) {
+      int v[kStageUnroll];
+#pragma unroll
+      for (int u = 0; u < kStageUnroll; u++) v[u] = sample(from + o + u * nt);
+#pragma unroll
+      for (int u = 0; u < kStageUnroll; u++) dst[o + u * nt] = (float)v[u];
+    }
+    for (; o < count; o += nt) dst[o] = (float)sample(from + o);
+  };
+  if (geo.pitch) {  // row r: its own M samples and the overlap into the next row
+    const int tpr = kThreads >> n_log2;  // threads per row
+    const int r = threadIdx.x / tpr;
+    stage_run(stage + 4 * geo.pitch * r, first0 + (long long)r * M, M + 4 * G + 4, threadIdx.x % tpr, tpr);
+  } else {
+    stage_run(stage, first0, 4 * geo.region_slots, threadIdx.x, kThreads);
+  }
+  int16_t *out_tile = reinterpret_cast<int16_t *>(lds4 + geo.region_slots);
+  const int rows_per_wave = n >= 64 ? 1 : (64 >> n_log2);
+  float4 *scratch = lds4 + geo.region_slots + ((tile_outputs * 2 + 15) >> 4) + (threadIdx.x >> 6) * rows_per_wave * G;
+  const int lane = threadIdx.x & 63;
+  // Work index of a lane within its wave: a 128-bit LDS read is served in four groups of 16 lanes that are NOT
+  // consecutive ({0-3,12-15,20-27}, {4-11,16-19,28-31}, and the same + 32); numbering the lanes group by group
+  // gives each hardware group one phase (one coefficient row, 16 sample windows one row pitch apart: 16 banks).
+  const int quad = (lane & 31) >> 2;
+  const int vlane = (lane & 32) | (((0x96 >> quad) & 1) << 4) | ((quad >> 1) << 2) | (lane & 3);
+  __syncthreads();
+  const size_t shift_stride = (size_t)L * G;  // float4 per shifted copy of the table
+  const int rounds = (tile_outputs + kThreads - 1) / kThreads;
+  for (int it = 0; it < rounds; it++) {
+    const int idx = it * kThreads + (threadIdx.x - lane) + vlane;
+    const int p_first = (idx - vlane) >> n_log2;  // phase class of the wave's first work item
+    if (ROWS_IN_LDS) {  // (fetching the rows a round ahead into registers was measured: slower)
+      wave_lds_fence();  // the previous round's reads of the scratch are done
+      for (int r = 0; r < rows_per_wave; r++) {
+        const int pr = p_first + r;
+        if (pr < L) {
+          const int pm = pr * M, cp = pm / L, phase = pm - cp * L;
+          const float4 *row = coef + (size_t)(cp & 3) * shift_stride + (size_t)phase * G;
+          for (int g = lane; g < G; g += 64) scratch[r * G + g] = row[g];
+        }
+      }
+      wave_lds_fence();
+    }
+    if (idx < tile_outputs) {
+      const int p = idx >> n_log2, j = idx & (n - 1);
+      const uint64_t m = tile_base + (uint64_t)p + (uint64_t)L * j;
+      // pos = m * M = (tile * n * M + j * M) * L + p * M: centre and phase follow from p alone
+      const int pm = p * M;
+      const int cp = pm / L, phase = pm - cp * L;
+      // first tap of this output: sample cp of row j, or sample cp + j M of the contiguous region
+      const int rel = geo.pitch ? cp : cp + j * M;
+      const float4 *xs = lds4 + (geo.pitch ? j * geo.pitch : 0) + (rel >> 2);
+      const float4 *row = ROWS_IN_LDS ? scratch + (p - p_first) * G
+                                      : coef + (size_t)(rel & 3) * shift_stride + (size_t)phase * G;
+      float acc = 0.0f;
+      for (int g = 0; g < G; g += 4) {  // G is a multiple of 4: eight loads in flight, then sixteen FMAs in tap order
+        float4 x[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          x[u] = xs[g + u];
+          c[u] = row[g + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          acc = fmaf(c[u].x, x[u].x, acc);
+          acc = fmaf(c[u].y, x[u].y, acc);
+          acc = fmaf(c[u].z, x[u].z, acc);
+          acc = fmaf(c[u].w, x[u].w, acc);
+        }
+      }
+      float r = rintf(acc);
+      r = fminf(fmaxf(r, -32768.0f), 32767.0f);
+      if (m < st.n_out) out_tile[p + L * j] = (int16_t)r;
+    }
   }
   __syncthreads();
-  const uint64_t m = m0 + threadIdx.x;
-  if (m >= st.n_out) return;
-  const uint64_t pos = m * (uint64_t)M;
-  const long long center = (long long)(pos / (uint64_t)L);
-  const int phase = (int)(pos % (uint64_t)L);
-  const int rel = (int)(center - half + 1 - first0);
-  const float *c = coef + (size_t)phase * T;
-  float acc = 0.0f;
-  for (int k = 0; k < T; k++) acc = fmaf(c[k], stage[rel + k], acc);
-  float r = rintf(acc);
-  r = fminf(fmaxf(r, -32768.0f), 32767.0f);
-  out[st.out_off + m] = (int16_t)r;
+  for (int i = threadIdx.x; i < tile_outputs; i += kThreads)
+    if (tile_base + i < st.n_out) out[st.out_off + tile_base + i] = out_tile[i];
 }
 
 }  // namespace
@@ -147,6 +268,11 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   if (channels != 1 && channels != 2) return Status::Make(NeedleError_InvalidArgument, "resample: channels must be 1 or 2");
   if (rate < 2000 || rate > 768000) return Status::Make(NeedleError_InvalidArgument, "resample: unsupported sample rate");
+  if (channels == 2) {  // the kernel reads a stereo sample as one aligned 32-bit word
+    if (reinterpret_cast<uintptr_t>(d_in) & 3) return Status::Make(NeedleError_InvalidArgument, "resample: stereo PCM must be 4-byte aligned");
+    for (const ResampleSpan &sp : spans)
+      if (sp.in_off & 1) return Status::Make(NeedleError_InvalidArgument, "resample: stereo streams must start on an even value offset");
+  }
   Status s = ensure_device();
   if (!s.ok()) return s;
   int dev = 0;
@@ -157,10 +283,29 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
     d = &g_designs[{dev, rate}];
     if (d->T == 0) {
       design_filter(rate, d);
-      NEEDLE_HIP_TRY(hipMalloc((void **)&d->d_coef, d->coef.size() * sizeof(float)));
-      NEEDLE_HIP_TRY(hipMemcpy(d->d_coef, d->coef.data(), d->coef.size() * sizeof(float), hipMemcpyHostToDevice));
+      d->G = (((d->T + 3) / 4 + 1) + 3) & ~3;  // 16-byte groups per shifted row, a multiple of 4 for the kernel's unroll
+      // lanes per phase: 16 (one LDS lane group) when a tile then has plenty of outputs (L >= 256), more for small L;
+      // fewer when M is so large that 16 inputs M apart do not fit the LDS region
+      int n = 16;
+      while (n * d->L < 4096) n *= 2;  // small L: tiles of >= 4096 outputs amortise the per-tile latencies
+      auto footprint = [&](int lanes) {  // samples of LDS the tile's inputs take (row layout repeats the overlaps)
+        const bool rows = d->M >= kRowModeMinM && lanes <= kRowModeMaxN;
+        return rows ? (long long)lanes * (d->M + 4 * d->G + 8) : (long long)lanes * d->M + 4 * d->G + 8;
+      };
+      while (n > 1 && footprint(n) > kMaxRegionSamples) n /= 2;
+      if (footprint(n) > kMaxRegionSamples)
+        return Status::Make(NeedleError_InvalidArgument, "resample: rate ratio too large for this kernel");
+      d->n = n;
+      std::vector<float> shifted((size_t)4 * d->L * 4 * d->G, 0.f);
+      for (int a = 0; a < 4; a++)
+        for (int p = 0; p < d->L; p++)
+          for (int k = 0; k < d->T; k++)
+            shifted[((size_t)a * d->L + p) * 4 * d->G + k + a] = d->coef[(size_t)p * d->T + k];
+      NEEDLE_HIP_TRY(hipMalloc((void **)&d->d_coef, shifted.size() * sizeof(float)));
+      NEEDLE_HIP_TRY(hipMemcpy(d->d_coef, shifted.data(), shifted.size() * sizeof(float), hipMemcpyHostToDevice));
     }
   }
+  const uint64_t tile_outputs = (uint64_t)d->n * d->L;
   std::vector<RsStream> meta;
   uint64_t blocks = 0;
   for (const ResampleSpan &sp : spans) {
@@ -171,7 +316,7 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
     m.n_out = resample_out_len(sp.n_in, rate);
     m.block_base = (uint32_t)blocks;
     m.pad = 0;
-    blocks += (m.n_out + kOutPerBlock - 1) / kOutPerBlock;
+    blocks += (m.n_out + tile_outputs - 1) / tile_outputs;
     if (m.n_out) meta.push_back(m);
   }
   if (blocks > 0x7FFFFFFFull) return Status::Make(NeedleError_InvalidArgument, "resample: batch too large for one launch");
@@ -188,14 +333,44 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
     std::memcpy(w.second->ptr, meta.data(), meta.size() * sizeof(RsStream));
     NEEDLE_HIP_TRY(hipMemcpyAsync(w.first->ptr, w.second->ptr, meta.size() * sizeof(RsStream), hipMemcpyHostToDevice, stream));
     w.second->mark(stream);
-    const int span = (int)(((uint64_t)(kOutPerBlock - 1) * d->M) / d->L) + d->T + 2;
+    RsGeom geo;
+    geo.L = d->L; geo.M = d->M; geo.T = d->T; geo.G = d->G;
+    geo.n_log2 = 0;
+    while ((1 << geo.n_log2) < d->n) geo.n_log2++;
+    const bool row_mode = d->M >= kRowModeMinM && d->n <= kRowModeMaxN;
+    if (row_mode) {  // n rows of M + 4G + 4 samples, pitch odd in slots
+      geo.pitch = ((d->M + 4 * d->G + 4 + 3) / 4) | 1;
+      geo.region_slots = d->n * geo.pitch;
+    } else {         // the n M + T - 1 inputs a tile reads, plus the taps the shifted rows add at either end
+      geo.pitch = 0;
+      geo.region_slots = (d->n * d->M + 4 * d->G + 4 + 3) / 4;
+    }
+    const int rows_per_wave = d->n >= 64 ? 1 : 64 / d->n;
+    const bool rows_in_lds = row_mode || d->M % 4 == 0;
+    const size_t lds_bytes = (size_t)geo.region_slots * 16 + ((tile_outputs * 2 + 15) & ~(size_t)15) +
+                             (rows_in_lds ? (size_t)(kThreads / 64) * rows_per_wave * d->G * 16 : 0);
+    if (lds_bytes > 160 * 1024) return Status::Make(NeedleError_InvalidArgument, "resample: rate ratio too large for this kernel");
+    const void *variants[4] = {reinterpret_cast<const void *>(resample_kernel<1, false>),
+                               reinterpret_cast<const void *>(resample_kernel<1, true>),
+                               reinterpret_cast<const void *>(resample_kernel<2, false>),
+                               reinterpret_cast<const void *>(resample_kernel<2, true>)};
+    static std::map<int, size_t> lds_attr;  // largest dynamic LDS size announced per device
+    if (lds_attr[dev] < lds_bytes) {
+      for (const void *fn : variants)
+        NEEDLE_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      lds_attr[dev] = lds_bytes;
+    }
     KernelTimer timer("resample");
-    if (channels == 1)
-      hipLaunchKernelGGL(resample_kernel<1>, dim3((uint32_t)blocks), dim3(256), span * sizeof(float), stream, d_in,
-                         w.first->ptr, (int)meta.size(), d->d_coef, d->L, d->M, d->T, span, d_out);
-    else
-      hipLaunchKernelGGL(resample_kernel<2>, dim3((uint32_t)blocks), dim3(256), span * sizeof(float), stream, d_in,
-                         w.first->ptr, (int)meta.size(), d->d_coef, d->L, d->M, d->T, span, d_out);
+    const float4 *coef4 = reinterpret_cast<const float4 *>(d->d_coef);
+    auto launch = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(kThreads), lds_bytes, stream, d_in, w.first->ptr,
+                         (int)meta.size(), coef4, geo, d_out);
+    };
+    if (channels == 1) {
+      if (rows_in_lds) launch(resample_kernel<1, true>); else launch(resample_kernel<1, false>);
+    } else {
+      if (rows_in_lds) launch(resample_kernel<2, true>); else launch(resample_kernel<2, false>);
+    }
     NEEDLE_HIP_TRY(hipGetLastError());
   }
   if (sync) NEEDLE_HIP_TRY(hipStreamSynchronize(library_stream()));
