@@ -189,7 +189,15 @@ def main() -> None:
         t_runs = torch.zeros((cap, capi.RUN_WORDS), dtype=torch.int32, device="cuda")
         t_count = torch.zeros(1, dtype=torch.int32, device="cuda")
 
+        # torch's "current stream" becomes the library's own stream: the staging copies and the collectives'
+        # stream dependencies are then ordered against the library's kernels by the stream itself, and the only
+        # host wait of a job is the download of the gathered run list
+        torch.cuda.set_stream(torch.cuda.ExternalStream(capi.stream_ptr(), device=torch.device("cuda", local_rank)))
+
         def sync():
+            pass
+
+        def full_sync():
             capi.synchronize()
             torch.cuda.synchronize()
 
@@ -224,7 +232,7 @@ def main() -> None:
 
         def barrier():
             finish_previous()               # every job's epilogue completes inside the timed region
-            sync()
+            full_sync()
             dist.barrier()
             torch.cuda.synchronize()
 

@@ -27,6 +27,10 @@ extern "C" {
 enum NeedleError needle_hip_device_count(int *count);
 enum NeedleError needle_hip_set_device(int ordinal);
 enum NeedleError needle_hip_synchronize(void);
+/* The HIP stream (a hipStream_t) every kernel and copy of this library is enqueued on, for the current device:
+ * lets a caller order its own device work (collectives, framework kernels) against the library's by stream
+ * order or events instead of host synchronisation.  NULL without a device. */
+void *needle_hip_stream(void);
 const char *needle_hip_last_error_message(void);
 const char *needle_hip_version(void);
 

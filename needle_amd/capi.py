@@ -69,7 +69,8 @@ NEEDLE_H_SYMBOLS = [
     "needle_audio_comparator_new_default", "needle_audio_comparator_new", "needle_audio_comparator_free",
     "needle_audio_comparator_run"]
 NEEDLE_HIP_H_SYMBOLS = [
-    "needle_hip_device_count", "needle_hip_set_device", "needle_hip_synchronize", "needle_hip_last_error_message",
+    "needle_hip_device_count", "needle_hip_set_device", "needle_hip_synchronize", "needle_hip_stream",
+    "needle_hip_last_error_message",
     "needle_hip_version", "needle_hip_malloc", "needle_hip_free", "needle_hip_memcpy_h2d", "needle_hip_memcpy_d2h",
     "needle_hip_host_free", "needle_hip_last_kernel_ms", "needle_hip_fingerprint_sample_rate",
     "needle_hip_fingerprint_delay_ms", "needle_hip_fingerprint_item_duration_ms", "needle_hip_fingerprint_num_items",
@@ -205,6 +206,16 @@ def set_device(ordinal: int) -> None:
 
 def synchronize() -> None:
     check(lib().needle_hip_synchronize())
+
+
+def stream_ptr() -> int:
+    """The library's hipStream_t as an integer (e.g. for torch.cuda.ExternalStream)."""
+    L = lib()
+    L.needle_hip_stream.restype = C.c_void_p
+    p = L.needle_hip_stream()
+    if not p:
+        raise RuntimeError("no HIP device: the library has no stream")
+    return int(p)
 
 
 def last_kernel_ms(name: str) -> float:

@@ -335,6 +335,17 @@ enum NeedleError needle_hip_synchronize(void) {
   });
 }
 
+void *needle_hip_stream(void) {
+  void *out = nullptr;
+  guarded([&]() -> NeedleError {
+    Status s = ensure_device();
+    if (!s.ok()) return report(s);
+    out = reinterpret_cast<void *>(library_stream());
+    return NeedleError_Ok;
+  });
+  return out;
+}
+
 const char *needle_hip_last_error_message(void) { return last_error(); }
 const char *needle_hip_version(void) { return "needle-mi355x 0.1.0 (gfx950, f64 fingerprint, exact integer search)"; }
 
