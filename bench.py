@@ -83,8 +83,8 @@ def cpu_baseline(eps, results_gpu, hashes_gpu):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--episodes", type=int, default=28)
     ap.add_argument("--minutes", type=float, default=24.0)
     ap.add_argument("--intro-seconds", type=float, default=90.0)
@@ -210,6 +210,14 @@ def main() -> None:
             state["runs"] = len(runs)
             return lib.finalize(cmp, runs)
 
+        # communicator set-up (RCCL creates its channels lazily on first use): two throw-away collectives of the
+        # job's own shapes, so that it never lands in a timed step however short the warm-up is
+        warm = torch.zeros((b * world, stride), dtype=torch.int32, device="cuda")
+        for _ in range(2):
+            ndist.gather_rows(warm, world, rank)
+        dist.barrier()
+        torch.cuda.synchronize()
+        del warm
         gather = ndist.SlabGather(t_runs, world)
         row_block = torch.zeros((b, stride), dtype=torch.int32, device="cuda")
         pending = []

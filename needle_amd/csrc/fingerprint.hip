@@ -373,6 +373,7 @@ struct FpWorkspace {
   DeviceBuffer<double> chroma, feat;
   DeviceBuffer<FpStream> streams;
   PinnedStage stage;
+  DescriptorUpload<FpStream> upload;
   bool lds_attr_set = false;  // the STFT kernel's 68 KiB of dynamic LDS needs an explicit opt-in
 };
 std::mutex g_ws_mu;
@@ -437,15 +438,9 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       end++;
     }
     if (frames > 0) {
-      if (!(s = ws->streams.reserve(meta.size())).ok()) return s;
       if (!(s = ws->chroma.reserve(frames * kBands)).ok()) return s;
       if (!(s = ws->feat.reserve(std::max<uint64_t>(rows, 1) * kBands)).ok()) return s;
-      // descriptors go through a pinned staging buffer so the async copy never reads freed host memory
-      if (!(s = ws->stage.acquire(meta.size() * sizeof(FpStream))).ok()) return s;
-      std::memcpy(ws->stage.ptr, meta.data(), meta.size() * sizeof(FpStream));
-      NEEDLE_HIP_TRY(hipMemcpyAsync(ws->streams.ptr, ws->stage.ptr, meta.size() * sizeof(FpStream),
-                                    hipMemcpyHostToDevice, stream));
-      ws->stage.mark(stream);
+      if (!(s = ws->upload.put(&ws->streams, &ws->stage, meta, stream)).ok()) return s;
       const int n = (int)meta.size();
       if (!ws->lds_attr_set) {
         const void *variants[2] = {reinterpret_cast<const void *>(stft_chroma_kernel<1>),

@@ -4,6 +4,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+#include <vector>
+
 #include <map>
 #include <mutex>
 #include <string>
@@ -77,6 +80,30 @@ struct PinnedStage {
   }
   void mark(hipStream_t stream) {
     if (hipEventRecord(done, stream) == hipSuccess) pending = true;
+  }
+};
+
+
+// Descriptor arrays (a few KB of offsets and lengths per launch) rarely change between launches of a job that
+// is run again and again: the upload through pinned staging -- one more dispatch on the stream and a host wait
+// for the staging buffer -- is skipped when the device copy already holds exactly these bytes.
+template <class T>
+struct DescriptorUpload {
+  std::vector<T> resident;     // what dst holds (or will hold, by stream order)
+  const T *resident_at = nullptr;
+  Status put(DeviceBuffer<T> *dst, PinnedStage *stage, const std::vector<T> &items, hipStream_t stream) {
+    Status s = dst->reserve(items.size());
+    if (!s.ok()) return s;
+    if (dst->ptr == resident_at && resident.size() == items.size() &&
+        std::memcmp(resident.data(), items.data(), items.size() * sizeof(T)) == 0)
+      return Status::Ok();
+    if (!(s = stage->acquire(items.size() * sizeof(T))).ok()) return s;
+    std::memcpy(stage->ptr, items.data(), items.size() * sizeof(T));
+    NEEDLE_HIP_TRY(hipMemcpyAsync(dst->ptr, stage->ptr, items.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+    stage->mark(stream);
+    resident = items;
+    resident_at = dst->ptr;
+    return Status::Ok();
   }
 };
 

@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256) void simhash_runs_kernel(const uint32_t *__res
 struct SearchWorkspace {
   DeviceBuffer<SearchProblem> problems;
   PinnedStage stage;
+  DescriptorUpload<SearchProblem> upload;
 };
 std::mutex g_ws_mu;
 std::map<int, SearchWorkspace *> g_ws;
@@ -437,12 +438,7 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
       return Status::Make(NeedleError_InvalidArgument,
                           "hamming_runs: a sequence pair exceeds the 160 KiB LDS staging limit (~40000 hashes)");
     SearchWorkspace *ws = workspace();
-    if (!(s = ws->problems.reserve(meta.size())).ok()) return s;
-    if (!(s = ws->stage.acquire(meta.size() * sizeof(SearchProblem))).ok()) return s;
-    std::memcpy(ws->stage.ptr, meta.data(), meta.size() * sizeof(SearchProblem));
-    NEEDLE_HIP_TRY(hipMemcpyAsync(ws->problems.ptr, ws->stage.ptr, meta.size() * sizeof(SearchProblem),
-                                  hipMemcpyHostToDevice, stream));
-    ws->stage.mark(stream);
+    if (!(s = ws->upload.put(&ws->problems, &ws->stage, meta, stream)).ok()) return s;
     if (lds_bytes > 64 * 1024 && !g_lds_attr_set) {
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
