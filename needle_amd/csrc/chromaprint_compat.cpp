@@ -12,6 +12,7 @@
 struct ChromaprintContextPrivate {
   int algorithm = CHROMAPRINT_ALGORITHM_DEFAULT;
   int channels = 1;
+  int rate = 11025;
   bool started = false, finished = false;
   std::vector<int16_t> pcm;        // everything fed since start()
   std::vector<uint32_t> raw;       // raw fingerprint after finish()
@@ -39,9 +40,12 @@ int chromaprint_get_delay_ms(ChromaprintContext *) { return needle_hip_fingerpri
 
 int chromaprint_start(ChromaprintContext *ctx, int sample_rate, int num_channels) {
   if (!ctx) return 0;
-  if (sample_rate != needle_hip_fingerprint_sample_rate()) return 0;  // no resampler here: needle feeds 11025 Hz
+  // needle feeds chromaprint's own 11025 Hz (analyzer.rs:179-187); any other rate goes through the device
+  // resampler first, as libchromaprint's internal resampler would
+  if (sample_rate < 2000 || sample_rate > 768000) return 0;
   if (num_channels != 1 && num_channels != 2) return 0;
   ctx->channels = num_channels;
+  ctx->rate = sample_rate;
   ctx->pcm.clear();
   ctx->raw.clear();
   ctx->started = true;
@@ -64,12 +68,24 @@ int chromaprint_finish(ChromaprintContext *ctx) {
   if (!ctx || !ctx->started) return 0;
   if (ctx->finished) return 1;
   try {
-    const size_t n = needle_hip_fingerprint_num_items(ctx->pcm.size() / (size_t)ctx->channels);
+    std::vector<int16_t> mono;
+    int channels = ctx->channels;
+    if (ctx->rate != needle_hip_fingerprint_sample_rate()) {  // down-mix + resample to mono 11025 Hz on the device
+      mono.assign(needle_hip_resample_out_len(ctx->pcm.size() / (size_t)ctx->channels, ctx->rate) + 1, 0);
+      const int16_t *in[1] = {ctx->pcm.data()};
+      const size_t in_len[1] = {ctx->pcm.size()};
+      int16_t *out[1] = {mono.data()};
+      if (needle_hip_resample_host(in, in_len, 1, ctx->channels, ctx->rate, out) != NeedleError_Ok) return 0;
+      mono.pop_back();
+      channels = 1;
+    }
+    const std::vector<int16_t> &pcm = ctx->rate == needle_hip_fingerprint_sample_rate() ? ctx->pcm : mono;
+    const size_t n = needle_hip_fingerprint_num_items(pcm.size() / (size_t)channels);
     ctx->raw.assign(n ? n : 1, 0);
-    const int16_t *ptrs[1] = {ctx->pcm.data()};
-    const size_t lens[1] = {ctx->pcm.size()};
+    const int16_t *ptrs[1] = {pcm.data()};
+    const size_t lens[1] = {pcm.size()};
     uint32_t *outs[1] = {ctx->raw.data()};
-    if (needle_hip_fingerprint_host(ptrs, lens, 1, ctx->channels, 1, outs) != NeedleError_Ok) return 0;
+    if (needle_hip_fingerprint_host(ptrs, lens, 1, channels, 1, outs) != NeedleError_Ok) return 0;
     ctx->raw.resize(n);
     ctx->pcm.clear();
     ctx->pcm.shrink_to_fit();

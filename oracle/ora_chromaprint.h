@@ -17,7 +17,9 @@
  * (its only analyzer test is #[ignore]d with a stale snapshot of AAC media nothing here can decode,
  * analyzer.rs:472-480) and neither the Rust crate nor libchromaprint can be built in this image.
  * This file therefore DEFINES the expected hashes; agreement with a real libchromaprint build is
- * untested. FFT arithmetic is double (= chromaprint built against FFTW3, the README-recommended
+ * untested, except at one point: libchromaprint's own API test on silence (tests/test_api.cpp
+ * Test2SilenceFp / Test2SilenceRawFp: three items 627964279) is reproduced
+ * (tests/golden/chromaprint_silence.json, tests/test_oracle.py). FFT arithmetic is double (= chromaprint built against FFTW3, the README-recommended
  * backend, README.md:168); other chromaprint FFT backends are single precision and may differ in
  * low-order hash bits among themselves already.
  */

@@ -263,7 +263,8 @@ def test_chromaprint_compat_exports_and_constants(has_gpu):
     assert L.chromaprint_get_delay_ms(ctx) == O.delay_ms() and L.chromaprint_get_item_duration_ms(ctx) == O.item_duration_ms()
     pcm = np.zeros(30000, np.int16)
     assert L.chromaprint_feed(ctx, pcm.ctypes.data, 100) == 0                   # not started
-    assert L.chromaprint_start(ctx, 44100, 2) == 0                              # no resampler: needle feeds 11025 Hz
+    assert L.chromaprint_start(ctx, 44100, 2) == 1                              # other rates: device resampler first
+    assert L.chromaprint_start(ctx, 100, 2) == 0
     assert L.chromaprint_start(ctx, 11025, 6) == 0
     assert L.chromaprint_start(ctx, 11025, 2) == 1
     assert L.chromaprint_feed(ctx, pcm.ctypes.data, 101) == 0                   # not a multiple of the channel count

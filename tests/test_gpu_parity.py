@@ -598,3 +598,28 @@ def test_cli_analyze_then_search_matches_oracle(lib3, tmp_path):
     assert r.stdout.count("Skipping analysis for") == 3
     r = subprocess.run([exe, "analyze", "--force", *paths], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "Skipping analysis" not in r.stdout
+
+
+def test_gpu_reproduces_chromaprints_own_silence_vector():
+    """libchromaprint's API test Test2SilenceRawFp replayed call for call against libneedle_chromaprint.so
+    (tests/golden/chromaprint_silence.json): start(44100, 1), 130 feeds of 1024 zeros, finish, raw fingerprint =
+    three items 627964279 -- through the device resampler and the three fingerprint kernels."""
+    import ctypes as C
+    import json
+    from .test_capi_cpu import _chromaprint_lib
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "chromaprint_silence.json")))
+    L = _chromaprint_lib()
+    ctx = L.chromaprint_new(1)                                    # CHROMAPRINT_ALGORITHM_TEST2
+    assert L.chromaprint_start(ctx, g["sample_rate"], g["channels"]) == 1
+    zeroes = np.zeros(g["samples_per_feed"], dtype=np.int16)
+    for _ in range(g["feeds"]):
+        assert L.chromaprint_feed(ctx, zeroes.ctypes.data, len(zeroes)) == 1
+    assert L.chromaprint_finish(ctx) == 1
+    fp = C.POINTER(C.c_uint32)()
+    n = C.c_int(0)
+    assert L.chromaprint_get_raw_fingerprint(ctx, C.byref(fp), C.byref(n)) == 1
+    assert [fp[i] for i in range(n.value)] == g["raw_fingerprint"]
+    L.chromaprint_dealloc(fp)
+    L.chromaprint_free(ctx)
+    # and straight through the fingerprint entry point at 11025 Hz
+    assert capi.fingerprint([np.zeros(33280, dtype=np.int16)], 1)[0].tolist() == g["raw_fingerprint"]

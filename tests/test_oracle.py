@@ -334,3 +334,39 @@ def test_resampler_oracle_is_a_sane_low_pass_to_11025():
     assert O.resample(x, 1, 11025).tolist() == x.tolist()     # same rate: identity
     lr = np.stack([x, -x // 2], axis=1).reshape(-1)
     assert O.resample(lr, 2, 11025).tolist() == ((x.astype(np.int32) + (-x // 2).astype(np.int32)) / 2).astype(np.int32).tolist()
+
+
+def test_oracle_reproduces_chromaprints_own_silence_vector():
+    """The one known answer of libchromaprint's own test-suite that needs no audio file (tests/test_api.cpp,
+    Test2SilenceFp / Test2SilenceRawFp): 130 x 1024 zero samples at 44100 Hz -> three items 627964279.  It pins,
+    for the all-zero feature vector, every classifier's quantiser (which side of its thresholds 0 falls), the
+    Gray code and the bit packing order, and through the item count the frame / latency arithmetic (4096-sample
+    frames, hop 1365, 19 frames of latency).  The compressed form upstream prints decodes to the same items."""
+    import base64
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "chromaprint_silence.json")))
+    n_in = g["feeds"] * g["samples_per_feed"]
+    mono = O.resample(np.zeros(n_in, dtype=np.int16), g["channels"], g["sample_rate"])
+    assert len(mono) == n_in // 4 and not mono.any()
+    items = O.fingerprint(mono)
+    assert items.tolist() == g["raw_fingerprint"]
+    assert O.simhash32(items) == g["fingerprint_hash"]
+    # chromaprint's FingerprintCompressor: header (algorithm, 24-bit length), then 3-bit gaps between set bits of
+    # each XOR-delta, 0 = end of item (no gap >= 7 occurs here)
+    s = g["compressed_base64"]
+    raw = base64.urlsafe_b64decode(s + "=" * (-len(s) % 4))
+    assert raw[0] == 1 and int.from_bytes(raw[1:4], "big") == len(items)
+    bits = int.from_bytes(raw[4:], "little")
+    decoded, value, last = [], 0, 0
+    while len(decoded) < len(items):
+        gap, bits = bits & 7, bits >> 3
+        assert gap != 7
+        if gap == 0:
+            decoded.append(value)
+            value, last = 0, 0
+        else:
+            last += gap
+            value |= 1 << (last - 1)
+    for i in range(1, len(decoded)):
+        decoded[i] ^= decoded[i - 1]
+    assert decoded == g["raw_fingerprint"]
