@@ -25,6 +25,7 @@ constexpr int kDiagsPerBlock = 256;
 constexpr int kBandR = 7, kBandU = 3;          // band kernel: 7 diagonals per lane, checkpoint every 21 rows
 constexpr int kBandB = 64 * kBandR;
 constexpr int kSampleW = 8;                     // sampled kernel: rows per aligned window
+constexpr int kSampleHead = 3;                  // rows of a window evaluated before the first early-out
 
 struct SearchProblem {
   uint32_t src_off, n;  // hash arena offset + length of the source sequence
@@ -211,7 +212,8 @@ __global__ __launch_bounds__(256) void hamming_runs_band_kernel(const uint32_t *
 // the reference's table walk (comparator.rs:191-247) for every run long enough to matter.
 //
 // Per evaluated cell: v_xor, v_bcnt, v_cmp (+ one scalar AND of lane masks); at the default 20 s minimum
-// (min_len 82, W 8, P 75) that is 3 VALU on 10.7 % of the cells instead of 4 VALU on all of them.
+// (min_len 82, W 8, P 75) that is 3 VALU on at most 10.7 % of the cells -- typically 4 % (the first three rows of
+// each window) -- instead of 4 VALU on all of them.
 template <int R, int W>
 __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_t *__restrict__ hashes,
                                                                    const SearchProblem *__restrict__ problems,
@@ -229,13 +231,27 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
   const int n = (int)pr.n, m = (int)pr.m;
   const uint32_t *__restrict__ src = hashes + pr.src_off;
   const uint32_t *__restrict__ dst = hashes + pr.dst_off;
-  // LDS: dst with B zero slots on both sides (ldst[B + j] = dst[j]), then src (lsrc[i] = src[i])
-  uint32_t *ldst = lds, *lsrc = lds + (m + 2 * B);
-  for (int k = threadIdx.x; k < m + 2 * B; k += blockDim.x) {
-    const int j = k - B;
-    ldst[k] = (j >= 0 && j < m) ? dst[j] : 0u;
+  // LDS: dst with B zero slots on both sides (ldst[B + j] = dst[j]).  src is read through the scalar cache in the
+  // window loop and from global memory in the (rare) exact resolution of a candidate, so it is not staged.
+  uint32_t *ldst = lds;
+  for (int k = threadIdx.x; k < B; k += blockDim.x) {
+    ldst[k] = 0u;
+    ldst[B + m + k] = 0u;
   }
-  for (int k = threadIdx.x; k < n; k += blockDim.x) lsrc[k] = src[k];
+  {  // body: eight loads in flight per thread, then a plain tail
+    constexpr int kU = 8;
+    const int nt = (int)blockDim.x;
+    int k = threadIdx.x;
+    for (; k + (kU - 1) * nt < m; k += kU * nt) {
+      uint32_t v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; u++) v[u] = dst[k + u * nt];
+#pragma unroll
+      for (int u = 0; u < kU; u++) ldst[B + k + u * nt] = v[u];
+    }
+    for (; k < m; k += nt) ldst[B + k] = dst[k];
+  }
+  const uint32_t *__restrict__ lsrc = src;
   __syncthreads();
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -252,20 +268,35 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
   // first aligned window (rows 1 + kP ...) that starts at or after i_start
   int k0 = (i_start - 1 + P - 1) / P;
   for (int w0 = 1 + k0 * P; w0 + W - 1 <= i_end; w0 += P) {
-    // the W + R - 1 destination hashes this lane's R diagonals meet in rows w0 .. w0+W-1
+    // the W + R - 1 destination hashes this lane's R diagonals meet in rows w0 .. w0+W-1; the rows are taken in
+    // two parts: after the first kSampleHead rows hardly any of the wave's 64 R diagonals still matches on
+    // unrelated audio (a random cell matches with probability 2.5 % at threshold 10), and then the rest of the
+    // window is skipped -- nothing can pass that has already failed
     uint32_t E[W + R - 1];
 #pragma unroll
-    for (int q = 0; q < W + R - 1; q++) E[q] = ldst[B + w0 + d_l + q];
+    for (int q = 0; q < kSampleHead + R - 1; q++) E[q] = ldst[B + w0 + d_l + q];
     bool ok[R];
 #pragma unroll
     for (int r = 0; r < R; r++) ok[r] = true;
 #pragma unroll
-    for (int s = 0; s < W; s++) {
+    for (int s = 0; s < kSampleHead; s++) {
       const uint32_t sv = src[w0 + s];
 #pragma unroll
       for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv ^ E[s + r]) <= threshold);
     }
     bool any = false;
+#pragma unroll
+    for (int r = 0; r < R; r++) any |= ok[r];
+    if (!__any(any)) continue;
+#pragma unroll
+    for (int q = kSampleHead + R - 1; q < W + R - 1; q++) E[q] = ldst[B + w0 + d_l + q];
+#pragma unroll
+    for (int s = kSampleHead; s < W; s++) {
+      const uint32_t sv = src[w0 + s];
+#pragma unroll
+      for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv ^ E[s + r]) <= threshold);
+    }
+    any = false;
 #pragma unroll
     for (int r = 0; r < R; r++) any |= ok[r];
     if (!__any(any)) continue;
@@ -429,7 +460,7 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
         const uint64_t diags = (uint64_t)m.n + m.m - 3;
         const uint64_t bands = (diags + kBandB - 1) / kBandB;
         fb += (bands + 3) / 4;
-        need = std::max<size_t>(need, (size_t)m.m + 2 * kBandB + (sampled ? m.n : 0));
+        need = std::max<size_t>(need, (size_t)m.m + 2 * kBandB);
       }
       blocks = fb;
       lds_bytes = need * sizeof(uint32_t);
