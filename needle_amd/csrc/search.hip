@@ -386,6 +386,7 @@ struct SearchWorkspace {
   DeviceBuffer<SearchProblem> problems;
   PinnedStage stage;
   DescriptorUpload<SearchProblem> upload;
+  bool lds_attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in, per device
 };
 std::mutex g_ws_mu;
 std::map<int, SearchWorkspace *> g_ws;
@@ -401,7 +402,6 @@ SearchWorkspace *workspace() {
   return w;
 }
 
-bool g_lds_attr_set = false;
 
 }  // namespace
 
@@ -470,14 +470,14 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
                           "hamming_runs: a sequence pair exceeds the 160 KiB LDS staging limit (~40000 hashes)");
     SearchWorkspace *ws = workspace();
     if (!(s = ws->upload.put(&ws->problems, &ws->stage, meta, stream)).ok()) return s;
-    if (lds_bytes > 64 * 1024 && !g_lds_attr_set) {
+    if (lds_bytes > 64 * 1024 && !ws->lds_attr_set) {
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_band_kernel<kBandR, kBandU>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_sampled_kernel<kBandR, kSampleW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      g_lds_attr_set = true;
+      ws->lds_attr_set = true;
     }
     {
       KernelTimer timer("hamming_runs");
