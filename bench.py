@@ -220,36 +220,31 @@ def main() -> None:
         del warm
         gather = ndist.SlabGather(t_runs, world)
         row_block = torch.zeros((b, stride), dtype=torch.int32, device="cuda")
-        pending = []
+        pipe = ndist.JobPipeline(n, world, rank, arena, lambda f, c: lib.analyze(f, c, sync=False), search_pairs,
+                                 finalize, gather, row_block, side_stream=torch.cuda.Stream(priority=-1))
 
-        def finish_previous():
-            # the previous job's order-sensitive epilogue (rank 0), while this job's fingerprint kernels run
-            if pending:
-                runs_np = pending.pop()
-                if rank == 0:
-                    state["results"] = finalize(runs_np)
-
-        def step(collect):
-            runs_np = ndist.run_job(n, world, rank, arena, lambda f, c: lib.analyze(f, c, sync=False),
-                                    search_pairs, finalize, sync, gather=gather, defer_finalize=True,
-                                    while_analyzing=finish_previous, row_block=row_block)
-            pending.append(runs_np)
+        def step(collect, prefetch=True):
+            res = pipe.step(prefetch)
+            if rank == 0:
+                state["results"] = res
             if collect:
                 for k in kernel_names:
                     kernel_ms[k] += max(capi.last_kernel_ms(k), 0.0)
 
         def barrier():
-            finish_previous()               # every job's epilogue completes inside the timed region
             full_sync()
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    # N > 1: a step enqueues the NEXT job's fingerprinting before it waits for its own run list, except on the
+    # last step of a phase, so the timed region holds exactly `steps` analyses and `steps` searches
+    ahead = (lambda i, total: {"prefetch": i + 1 < total}) if distributed else (lambda i, total: {})
+    for i in range(args.warmup):
+        step(False, **ahead(i, args.warmup))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for i in range(args.steps):
+        step(True, **ahead(i, args.steps))
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:

@@ -150,3 +150,65 @@ def run_job(n_videos: int, world: int, rank: int, arena, analyze_rows: Callable[
     if rank != 0:
         return None
     return finalize(runs)
+
+
+class JobPipeline:
+    """Repeated analyze+search jobs over the same sharding plan, with job k+1's fingerprinting enqueued before
+    the host blocks on job k's gathered run list: the device then works on the next job's fingerprints while the
+    run-list collective, its download and rank 0's epilogue of job k proceed.  All device work is issued in ONE
+    stream order (analyze_k, rows gather_k, search_k, analyze_k+1, ...), so a single hash arena and a single run
+    buffer suffice: analyze_k+1 runs after search_k on the device, and search_k+1 is enqueued only after job k's
+    runs have reached the host.
+
+    step(prefetch) completes one job -- its analyze was enqueued by the previous step's prefetch, or is enqueued
+    now -- and returns its results (rank 0; None elsewhere).  A caller that times K steps passes prefetch=False
+    on the last of them, so exactly K analyses and K searches are issued inside the timed steps."""
+
+    def __init__(self, n_videos: int, world: int, rank: int, arena, analyze_rows, search_pairs, finalize,
+                 gather: "SlabGather", row_block=None, side_stream=None):
+        """side_stream (GPU only): a second stream for the run-list staging copies, collective and download.  In
+        the main stream they would queue behind the prefetched fingerprint kernels and the host would wait for
+        those too; on the side stream they wait only for an event recorded after the search."""
+        self.n, self.world, self.rank, self.arena = n_videos, world, rank, arena
+        self.analyze_rows, self.search_pairs, self.finalize = analyze_rows, search_pairs, finalize
+        self.gather, self.row_block, self.side = gather, row_block, side_stream
+        self.analyzed = False
+        self.results = None
+
+    def _analyze(self):
+        first, count = shard(self.n, self.world, self.rank)
+        if count:
+            self.analyze_rows(first, count)
+        self.analyzed = True
+
+    def _gather_runs(self, run_buffer, count_tensor):
+        runs, complete = self.gather(run_buffer, count_tensor)   # blocks the host until this job's runs are here
+        if not complete:
+            # a rank overflowed its slab: exact two-step gather.  The run buffer is intact (the prefetched analyze
+            # does not touch it).
+            runs = gather_runs(run_buffer[: int(count_tensor.item())], self.world).cpu().numpy()
+        return runs
+
+    def step(self, prefetch: bool = True):
+        if not self.analyzed:
+            self._analyze()
+        gather_rows(self.arena, self.world, self.rank, self.row_block)
+        pfirst, pcount = shard(pair_count(self.n), self.world, self.rank)
+        run_buffer, count_tensor = self.search_pairs(pfirst, pcount)
+        self.analyzed = False
+        if self.side is None:
+            if prefetch:
+                self._analyze()
+            runs = self._gather_runs(run_buffer, count_tensor)
+        else:
+            import torch
+            searched = torch.cuda.Event()
+            searched.record()                    # main stream: after this job's search (and simhash) kernels
+            if prefetch:
+                self._analyze()                  # next job's fingerprints run under the gather below
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(searched)
+                runs = self._gather_runs(run_buffer, count_tensor)
+        if self.rank == 0:
+            self.results = self.finalize(runs)
+        return self.results

@@ -92,6 +92,10 @@ def main():
                                          while_analyzing=finish_previous, row_block=row_block))
         finish_previous()
         pipelined = done
+        # and the prefetching pipeline (next job's analyze issued before this job's run list is awaited)
+        pipe = ndist.JobPipeline(n, world, rank, arena, analyze_rows, search_pairs, lambda runs: runs.tolist(), gather,
+                                 row_block)
+        pipelined = pipelined + [pipe.step(prefetch=(k < 2)) or pipelined[0] for k in range(3)]
     with open(f"{out_path}.{rank}", "w") as f:
         json.dump({"rank": rank, "arena_complete": ok_arena, "runs": res, "pipelined": pipelined}, f)
     dist.barrier()

@@ -60,6 +60,6 @@ def test_gloo_job_equals_single_process(tmp_path, world, n):
         assert sorted(map(tuple, got[0]["runs"])) == sorted(map(tuple, single["runs"]))
         # bench.py's pipelined form (reused buffers, epilogue deferred into the next job): every job, every rank
         for m in got:
-            assert len(m["pipelined"]) == 3
+            assert len(m["pipelined"]) == 6           # 3 deferred-epilogue jobs + 3 JobPipeline steps
             for job in m["pipelined"]:
                 assert sorted(map(tuple, job)) == sorted(map(tuple, single["runs"]))
