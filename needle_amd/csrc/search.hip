@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
                                                                    const SearchProblem *__restrict__ problems,
                                                                    int num_problems, uint32_t threshold,
                                                                    NeedleHipRun *__restrict__ runs,
-                                                                   uint32_t capacity, uint32_t *__restrict__ count) {
+                                                                   uint32_t capacity, uint32_t *__restrict__ count,
+                                                                   int bands_per_wave) {
   constexpr int B = 64 * R;
   extern __shared__ uint32_t lds[];
   int lo = 0, hi = num_problems - 1;
@@ -256,13 +257,16 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
-  const int band = (int)(blockIdx.x - pr.block_base) * 4 + wave;
-  const int D0 = band * B - (n - 2);
-  if (D0 > m - 2) return;
-  const int i_start = max(1, 2 - D0 - B);
-  const int i_end = min(n - 1, m - 1 - D0);
   const int min_len = (int)pr.min_len;
   const int P = min_len - W + 1;  // >= W: the host selects this kernel only when min_len >= 2W - 1
+  // a workgroup stages the destination once and its four waves walk bands_per_wave bands each (large launches:
+  // one workgroup per pair instead of one per four bands, so the staging is not repeated)
+  for (int round = 0; round < bands_per_wave; round++) {
+  const int band = ((int)(blockIdx.x - pr.block_base) * bands_per_wave + round) * 4 + wave;
+  const int D0 = band * B - (n - 2);
+  if (D0 > m - 2) break;
+  const int i_start = max(1, 2 - D0 - B);
+  const int i_end = min(n - 1, m - 1 - D0);
   const int d_l = D0 + lane * R;
 
   // first aligned window (rows 1 + kP ...) that starts at or after i_start
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
       }
     }
   }
+  }  // bands of this wave
 }
 
 // ---- simhash of every emitted run (comparator.rs:149-153,226-229) -----------------------------------------------
@@ -452,14 +457,22 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
     const bool sampled = !generic_only && smallest >= (uint32_t)(2 * kSampleW - 1 + 8) && !getenv("NEEDLE_HIP_BAND_SEARCH");
     const bool fast = !generic_only && !sampled && smallest >= (uint32_t)(kBandR * kBandU);
     size_t lds_bytes = max_lds;
+    int bands_per_wave = 1;
     if (fast || sampled) {
-      uint64_t fb = 0;
+      uint64_t fb = 0, total_bands = 0;
       size_t need = 0;
+      for (const SearchProblem &m : meta) total_bands += ((uint64_t)m.n + m.m - 3 + kBandB - 1) / kBandB;
+      // enough workgroups to fill the chip several times over with one band per wave; beyond that, more bands
+      // per wave so that each workgroup's staging of the destination sequence serves more of its pair
+      bands_per_wave = 1;
+      if (sampled)
+        while (bands_per_wave < 8 && total_bands / (4 * (uint64_t)bands_per_wave * 2) >= 16384) bands_per_wave *= 2;
       for (SearchProblem &m : meta) {
         m.block_base = (uint32_t)fb;
         const uint64_t diags = (uint64_t)m.n + m.m - 3;
         const uint64_t bands = (diags + kBandB - 1) / kBandB;
-        fb += (bands + 3) / 4;
+        const uint64_t per_block = 4 * (uint64_t)(sampled ? bands_per_wave : 1);
+        fb += (bands + per_block - 1) / per_block;
         need = std::max<size_t>(need, (size_t)m.m + 2 * kBandB);
       }
       blocks = fb;
@@ -484,7 +497,7 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
       if (sampled)
         hipLaunchKernelGGL((hamming_runs_sampled_kernel<kBandR, kSampleW>), dim3((uint32_t)blocks), dim3(256),
                            lds_bytes, stream, d_hashes, ws->problems.ptr, (int)meta.size(), threshold, d_runs,
-                           capacity, d_count);
+                           capacity, d_count, bands_per_wave);
       else if (fast)
         hipLaunchKernelGGL((hamming_runs_band_kernel<kBandR, kBandU>), dim3((uint32_t)blocks), dim3(256), lds_bytes,
                            stream, d_hashes, ws->problems.ptr, (int)meta.size(), threshold, d_runs, capacity, d_count);
