@@ -363,26 +363,41 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
 // ---- simhash of every emitted run (comparator.rs:149-153,226-229) -----------------------------------------------
 // The scan kernels leave NeedleHipRun.problem = index of the problem descriptor; this pass computes
 // chromaprint's simhash32 over the L+1 hashes [end-len ..= end] of both sequences and replaces the index by
-// the caller's tag.  One wave per run: lanes 0-31 count bit `lane` over the source slice, lanes 32-63 over
-// the destination slice; bit set iff ones > zeros (a tie leaves it clear), collected with one ballot.
+// the caller's tag.  One wave per run.  The slice is read 64 hashes at a time (one coalesced load); bit b of the
+// 64 hashes is counted with one ballot + scalar popcount, so the 32 counters are wave-uniform (scalar registers)
+// and a hash costs about two instructions instead of a dependent load per hash and bit-plane lane.
+__device__ __forceinline__ uint32_t wave_simhash32(const uint32_t *__restrict__ slice, uint32_t count, uint32_t lane) {
+  uint32_t ones[32];
+#pragma unroll
+  for (int b = 0; b < 32; b++) ones[b] = 0;
+  for (uint32_t q0 = 0; q0 < count; q0 += 64) {
+    const uint32_t q = q0 + lane;
+    const uint32_t h = q < count ? slice[q] : 0u;  // beyond the slice: no ones
+#pragma unroll
+    for (int b = 0; b < 32; b++) ones[b] += (uint32_t)__popcll(__ballot((h >> b) & 1u));
+  }
+  uint32_t out = 0;
+#pragma unroll
+  for (int b = 0; b < 32; b++) out |= (2u * ones[b] > count ? 1u : 0u) << b;  // set iff ones > zeros; a tie leaves it clear
+  return out;
+}
+
 __global__ __launch_bounds__(256) void simhash_runs_kernel(const uint32_t *__restrict__ hashes,
                                                            const SearchProblem *__restrict__ problems,
                                                            NeedleHipRun *__restrict__ runs, uint32_t capacity,
                                                            const uint32_t *__restrict__ count) {
   const uint32_t total = min(*count, capacity);
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t lane = threadIdx.x & 63, bit = lane & 31;
+  const uint32_t lane = threadIdx.x & 63;
   for (uint32_t k = wave; k < total; k += waves) {
     const NeedleHipRun r = runs[k];
     const SearchProblem pr = problems[r.problem];
-    const uint32_t *base = lane < 32 ? hashes + pr.src_off + (r.src_end - r.len) : hashes + pr.dst_off + (r.dst_end - r.len);
-    uint32_t ones = 0;
-    for (uint32_t q = 0; q <= r.len; q++) ones += (base[q] >> bit) & 1u;
-    const unsigned long long mask = __ballot(2u * ones > r.len + 1u);
+    const uint32_t src_hash = wave_simhash32(hashes + pr.src_off + (r.src_end - r.len), r.len + 1u, lane);
+    const uint32_t dst_hash = wave_simhash32(hashes + pr.dst_off + (r.dst_end - r.len), r.len + 1u, lane);
     if (lane == 0) {
       runs[k].problem = pr.tag;
-      runs[k].src_match_hash = (uint32_t)mask;
-      runs[k].dst_match_hash = (uint32_t)(mask >> 32);
+      runs[k].src_match_hash = src_hash;
+      runs[k].dst_match_hash = dst_hash;
     }
   }
 }
