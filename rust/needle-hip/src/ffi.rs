@@ -2,7 +2,7 @@
 //! Keep in step with those headers; tests/test_capi_cpu.py checks that the library exports every symbol.
 #![allow(non_camel_case_types, dead_code)]
 
-use std::os::raw::{c_char, c_int};
+use std::os::raw::{c_char, c_int, c_void};
 
 /// `enum NeedleError` (needle-capi/src/lib.rs:58-85): repr(C), values 0..=11.
 #[repr(C)]
@@ -96,6 +96,9 @@ extern "C" {
     pub fn needle_hip_last_error_message() -> *const c_char;
     pub fn needle_hip_device_count(count: *mut c_int) -> NeedleError;
     pub fn needle_hip_set_device(ordinal: c_int) -> NeedleError;
+    pub fn needle_hip_synchronize() -> NeedleError;
+    /// The library's `hipStream_t` on the current device (NULL without one).
+    pub fn needle_hip_stream() -> *mut c_void;
     pub fn needle_hip_analyzer_run_pcm(
         analyzer: *mut NeedleAudioAnalyzer,
         pcm: *const *const i16,
