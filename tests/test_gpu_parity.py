@@ -623,3 +623,40 @@ def test_gpu_reproduces_chromaprints_own_silence_vector():
     L.chromaprint_free(ctx)
     # and straight through the fingerprint entry point at 11025 Hz
     assert capi.fingerprint([np.zeros(33280, dtype=np.int16)], 1)[0].tolist() == g["raw_fingerprint"]
+
+
+def test_cli_endings_padding_and_threshold_flags(tmp_path):
+    """`needle analyze --include-endings --opening-search-percentage ... --ending-search-percentage ...` then
+    `needle search --include-endings --min-*-duration --time-padding --hash-match-threshold`: the flags reach the
+    library (same skip files as the in-process Comparator with the same settings, which is checked against the
+    oracle in test_endings_and_parameters_match_oracle)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(capi.LIB_PATH), "..", "bin", "needle")
+    eps = synth.make_library(4, 120.0, 25.0, 22.0)
+    paths = []
+    for k, e in enumerate(eps):
+        p = str(tmp_path / f"e{k}.wav")
+        synth.write_wav(p, e.pcm, channels=1)
+        paths.append(p)
+    r = subprocess.run([exe, "analyze", *paths, "--include-endings", "--opening-search-percentage", "0.4",
+                        "--ending-search-percentage=0.35"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    fhs = capi.Analyzer.from_files(paths).with_include_endings(True).with_opening_search_percentage(0.4) \
+        .with_ending_search_percentage(0.35).run_pcm([e.pcm for e in eps])
+    for p, f in zip(paths, fhs):
+        rc, disk = O.frame_hashes_read(p[:-4] + ".needle.dat")
+        assert rc == 0
+        assert [h for h, _ in disk.opening] == f.opening_data()[0].tolist()
+        assert [h for h, _ in disk.ending] == f.ending_data()[0].tolist() and len(disk.ending) > 0
+    r = subprocess.run([exe, "search", *paths, "--include-endings", "--min-opening-duration", "12",
+                        "--min-ending-duration", "12", "--time-padding", "1.5", "--hash-match-threshold", "9",
+                        "--write-skip-files", "--no-display"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "", r.stderr
+    cli_skip = [open(p[:-4] + ".needle.skip.json").read() for p in paths]
+    for p in paths:
+        os.remove(p[:-4] + ".needle.skip.json")
+    c = capi.Comparator(paths, include_endings=True, min_opening_duration=12, min_ending_duration=12, time_padding=1.5,
+                        hash_match_threshold=9)
+    c.run(analyze=False, display=False, write_skip_files=True)
+    assert cli_skip == [open(p[:-4] + ".needle.skip.json").read() for p in paths]
+    assert all('"ending":[' in s for s in cli_skip)
