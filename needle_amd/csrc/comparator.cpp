@@ -2,8 +2,11 @@
 // the GPU diagonal scan (search.hip).  Everything that depends on order — the reverse table walk,
 // BinaryHeap pushes, candidate numbering, tie-breaks — is reproduced on the host from the run list.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
+#include <thread>
 #include <tuple>
 
 #include "needle_core.h"
@@ -156,29 +159,29 @@ Status Comparator::best_matches(size_t num_videos, const std::vector<std::vector
     info_map[j].push_back({p, false});
   }
   const uint32_t bound = hash_match_threshold_ + hash_match_threshold_ / 2;  // :441
-  for (size_t v = 0; v < num_videos; v++) {
-    const std::string &path = v < videos_.size() ? videos_[v] : std::string();
-    if (display) std::printf("\n%s\n\n", path.c_str());  // :595-597
-    if (use_skip_files) {                                 // :600-605, check_skip_file :310-327
+  // The reference walks the videos in order: skip-file check, find_best_match, display, skip-file write
+  // (:593-626).  Here the three kinds of work are separated so that find_best_match -- quadratic in a video's
+  // candidate count, i.e. the dominant host cost at library scale -- runs for all videos on host threads, while
+  // everything with side effects stays sequential and in the reference's order.
+  std::vector<char> skipped(num_videos, 0);
+  if (use_skip_files) {  // :600-605, check_skip_file :310-327
+    for (size_t v = 0; v < num_videos; v++) {
+      const std::string &path = v < videos_.size() ? videos_[v] : std::string();
       const std::string skip = with_extension(path, SKIP_FILE_NAME);
       std::ifstream probe(skip);
-      if (probe) {
-        std::string md5, stored;
-        Status s = header_md5(path, &md5);
-        if (!s.ok()) return s;
-        s = read_skip_file_md5(skip, &stored);
-        if (!s.ok()) return s;
-        if (stored == md5) {
-          if (display) std::printf("Skipping due to existing skip file...\n");
-          continue;
-        }
-      }
+      if (!probe) continue;
+      std::string md5, stored;
+      Status s = header_md5(path, &md5);
+      if (!s.ok()) return s;
+      s = read_skip_file_md5(skip, &stored);
+      if (!s.ok()) return s;
+      skipped[v] = stored == md5;
     }
-    // find_best_match (:405-515)
-    if (info_map[v].empty()) {
-      if (display) std::printf(include_endings_ ? "No opening or ending found.\n" : "No opening found.\n");
-      continue;
-    }
+  }
+
+  // find_best_match (:405-515) of one video
+  std::vector<Status> status(num_videos);
+  auto find_best = [&](size_t v) {
     std::vector<Candidate> cand;
     for (const auto &[p, is_source] : info_map[v]) {
       for (int pass = 0; pass < 2; pass++) {  // openings first, then endings (:414-431)
@@ -225,8 +228,10 @@ Status Comparator::best_matches(size_t num_videos, const std::vector<std::vector
       }
       if (!have) continue;
       const Candidate &w = cand[best_idx];
-      if (w.end < time_padding_ || w.end - time_padding_ < w.hash_duration)  // Duration underflow panics upstream
-        return Status::Make(NeedleError_Unknown, "overflow when subtracting durations (time_padding / hash_duration exceed the match end)");
+      if (w.end < time_padding_ || w.end - time_padding_ < w.hash_duration) {  // Duration underflow panics upstream
+        status[v] = Status::Make(NeedleError_Unknown, "overflow when subtracting durations (time_padding / hash_duration exceed the match end)");
+        return;
+      }
       const ns_t start = w.start + time_padding_;                   // :479
       const ns_t end = w.end - time_padding_ - w.hash_duration;     // :481
       if (want_opening) {
@@ -239,6 +244,44 @@ Status Comparator::best_matches(size_t num_videos, const std::vector<std::vector
         vr.result.ending_end = end;
       }
     }
+  };
+  std::vector<size_t> todo;
+  uint64_t work = 0;  // candidate pairs to compare
+  for (size_t v = 0; v < num_videos; v++) {
+    if (skipped[v] || info_map[v].empty()) continue;
+    todo.push_back(v);
+    uint64_t c = 0;
+    for (const auto &pi : info_map[v]) c += pair_entries[pi.first].size();
+    work += c * c / 2;
+  }
+  unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  if (const char *e = std::getenv("NEEDLE_HOST_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));  // 1 = sequential
+  const unsigned workers = (work < (1u << 22) || hw == 1) ? 1u : (unsigned)std::min<uint64_t>({hw, 64, todo.size()});
+  if (workers <= 1) {
+    for (size_t v : todo) find_best(v);
+  } else {
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < workers; w++)
+      pool.emplace_back([&]() {
+        for (size_t k = next.fetch_add(1); k < todo.size(); k = next.fetch_add(1)) find_best(todo[k]);
+      });
+    for (std::thread &t : pool) t.join();
+  }
+
+  for (size_t v = 0; v < num_videos; v++) {
+    const std::string &path = v < videos_.size() ? videos_[v] : std::string();
+    if (display) std::printf("\n%s\n\n", path.c_str());  // :595-597
+    if (skipped[v]) {
+      if (display) std::printf("Skipping due to existing skip file...\n");
+      continue;
+    }
+    if (info_map[v].empty()) {
+      if (display) std::printf(include_endings_ ? "No opening or ending found.\n" : "No opening found.\n");
+      continue;
+    }
+    if (!status[v].ok()) return status[v];
+    const VideoResult &vr = (*per_video)[v];
     if (display) {  // display_opening_ending_info (:356-381)
       if (vr.result.has_opening)
         std::printf("* Opening - \"%s\"-\"%s\"\n", format_time(vr.result.opening_start).c_str(),

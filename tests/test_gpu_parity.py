@@ -660,3 +660,28 @@ def test_cli_endings_padding_and_threshold_flags(tmp_path):
     c.run(analyze=False, display=False, write_skip_files=True)
     assert cli_skip == [open(p[:-4] + ".needle.skip.json").read() for p in paths]
     assert all('"ending":[' in s for s in cli_skip)
+
+
+def test_best_match_on_host_threads_equals_sequential(monkeypatch):
+    """At library scale find_best_match (quadratic in a video's candidates) runs for all videos on host threads;
+    the results must be those of the sequential walk.  160 videos sharing one planted run: every pair matches, so
+    each video has 2 x 159 candidates and the threaded path is taken."""
+    rng = np.random.default_rng(5)
+    n, length, intro = 160, 400, 120
+    hd = O.duration_from_secs_f32(0.3)
+    ts = [t for _, t in O.step_and_timestamp(np.zeros(2 * length, dtype=np.uint32), hd)][:length]
+    shared = rng.integers(0, 2 ** 32, intro, dtype=np.uint64).astype(np.uint32)
+    fhs = []
+    for v in range(n):
+        h = rng.integers(0, 2 ** 32, length, dtype=np.uint64).astype(np.uint32)
+        a = 10 + (13 * v) % 200
+        flips = (np.uint32(1) << rng.integers(0, 32, intro).astype(np.uint32)) * (rng.random(intro) < 0.5)
+        h[a:a + intro] = shared ^ flips
+        fhs.append(capi.FrameHashes.new(list(zip(h.tolist(), ts)), (), hd, ""))
+    cmp = capi.Comparator([f"v{v}.wav" for v in range(n)], min_opening_duration=20)
+    monkeypatch.setenv("NEEDLE_HOST_THREADS", "1")
+    seq = cmp.run_with_frame_hashes(fhs)
+    monkeypatch.delenv("NEEDLE_HOST_THREADS")
+    par = cmp.run_with_frame_hashes(fhs)
+    assert all(r is not None and r.opening is not None for r in seq)
+    assert [(r.opening, r.ending) for r in seq] == [(r.opening, r.ending) for r in par]
