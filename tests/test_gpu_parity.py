@@ -685,3 +685,26 @@ def test_best_match_on_host_threads_equals_sequential(monkeypatch):
     par = cmp.run_with_frame_hashes(fhs)
     assert all(r is not None and r.opening is not None for r in seq)
     assert [(r.opening, r.ending) for r in seq] == [(r.opening, r.ending) for r in par]
+
+
+def test_fingerprint_signal_zoo_bit_exact():
+    """Hashes equal the oracle's on signal kinds the synthetic episodes do not contain: noise from +-1 LSB (where the
+    feature norm sits around chromaprint's 0.01 cut-off and rows flip between zeroed and normalised) to clipping,
+    DC, chirps, impulse trains, a signal that fades in from digital silence."""
+    rng = np.random.default_rng(11)
+    n = 14 * 11025
+    t = np.arange(n) / 11025.0
+    zoo = {}
+    for amp in (0.6, 1, 2, 5, 20, 100, 1000, 12000, 60000):
+        zoo[f"noise{amp}"] = np.clip(np.rint(rng.standard_normal(n) * amp), -32768, 32767)
+    zoo["dc"] = np.full(n, 1234.0)
+    zoo["dc+lsb"] = 20000 + (rng.random(n) < 0.5)
+    zoo["chirp"] = 9000 * np.sin(2 * np.pi * (40 * t + 0.5 * 380 * t * t))
+    zoo["impulses"] = np.where(np.arange(n) % 997 == 0, 30000.0, 0.0)
+    zoo["nyquist"] = np.where(np.arange(n) % 2 == 0, 32767.0, -32768.0)
+    zoo["fade-in"] = 8000 * np.sin(2 * np.pi * 440 * t) * np.clip((t - 5.0) / 6.0, 0, 1) ** 4
+    zoo["two-tones"] = 3000 * np.sin(2 * np.pi * 261.63 * t) + 3000 * np.sin(2 * np.pi * 2093.0 * t)
+    pcms = [np.asarray(v).astype(np.int16) for v in zoo.values()]
+    got = capi.fingerprint(pcms, step=1)
+    for name, g, p in zip(zoo, got, pcms):
+        assert g.tolist() == O.fingerprint(p).tolist(), name
