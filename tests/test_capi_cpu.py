@@ -327,3 +327,28 @@ def test_rust_ffi_declarations_name_exported_symbols():
     for n in names:
         assert hasattr(L, n), n
         assert re.search(r"\b%s\(" % n, headers), n
+
+
+def test_every_function_the_headers_declare_is_exported():
+    """include/needle.h and include/needle_hip.h against libneedle_capi.so, include/needle_chromaprint.h against
+    libneedle_chromaprint.so: parsed from the headers, so a declaration added without a definition fails here."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+    def declared(header, prefix):
+        text = open(os.path.join(root, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        return sorted(set(re.findall(r"\b(%s\w+)\s*\(" % prefix, text)))
+
+    L = capi.lib()
+    names = declared("needle.h", "needle_") + declared("needle_hip.h", "needle_hip_")
+    assert len(names) >= 13 + 40
+    for n in names:
+        assert hasattr(L, n), n
+    assert set(capi.NEEDLE_H_SYMBOLS) == set(declared("needle.h", "needle_"))
+    assert set(capi.NEEDLE_HIP_H_SYMBOLS) == set(declared("needle_hip.h", "needle_hip_"))
+    CL = _chromaprint_lib()
+    cnames = declared("needle_chromaprint.h", "chromaprint_")
+    assert len(cnames) >= 10
+    for n in cnames:
+        assert hasattr(CL, n), n
