@@ -708,3 +708,65 @@ def test_fingerprint_signal_zoo_bit_exact():
     got = capi.fingerprint(pcms, step=1)
     for name, g, p in zip(zoo, got, pcms):
         assert g.tolist() == O.fingerprint(p).tolist(), name
+
+
+def test_two_simulated_ranks_on_one_device_equal_single_library():
+    """The multi-GPU plan of needle_amd/dist.py with two Library objects standing in for two ranks on one device:
+    each holds the PCM of its own episode block only, fingerprints it into a caller-owned arena, the arenas exchange
+    row blocks (what the all-gather does), each scans its own range of the pair list, the run lists are
+    concatenated and rank 0 finalises.  Result = the single-library result = the oracle's."""
+    from needle_amd import dist as ndist
+    n, world = 7, 2
+    eps = synth.make_library(n, 90.0, 20.0)
+    lens = [len(e.pcm) for e in eps]
+    cmp = capi.Comparator([f"ep{k}.wav" for k in range(n)], min_opening_duration=10)
+    L = capi.lib()
+    b = ndist.block(n, world)
+    libs, arenas, stride = [], [], None
+    for rank in range(world):
+        first, count = ndist.shard(n, world, rank)
+        lib = capi.Library(n)
+        lib.set_pcm([e.pcm if first <= k < first + count else None for k, e in enumerate(eps)], lens)
+        _, stride = lib.hash_arena()
+        buf = capi.DeviceBuffer(b * world * stride * 4)
+        zeros = np.zeros(b * world * stride, dtype=np.uint32)
+        capi.check(L.needle_hip_memcpy_h2d(buf.ptr, zeros.ctypes.data, zeros.nbytes))
+        lib.use_hash_arena(buf.ptr, b * world, stride)
+        lib.analyze(first, count)
+        libs.append(lib)
+        arenas.append(buf)
+    # the all-gather of row blocks, by hand
+    host = [a.to_host(np.uint32, b * world * stride).reshape(b * world, stride) for a in arenas]
+    full = np.zeros_like(host[0])
+    for rank in range(world):
+        full[rank * b:(rank + 1) * b] = host[rank][rank * b:(rank + 1) * b]
+    assert not full[n:].any()
+    for a in arenas:
+        capi.check(L.needle_hip_memcpy_h2d(a.ptr, full.ctypes.data, full.nbytes))
+    # pair ranges
+    cap = 4096
+    runs = []
+    for rank in range(world):
+        pfirst, pcount = ndist.shard(ndist.pair_count(n), world, rank)
+        d_runs, d_count = capi.DeviceBuffer(cap * capi.RUN_DTYPE.itemsize), capi.DeviceBuffer(4)
+        libs[rank].search(cmp, pfirst, pcount, d_runs.ptr, cap, d_count.ptr, sync=True)
+        found = int(d_count.to_host(np.uint32, 1)[0])
+        part = d_runs.to_host(capi.RUN_DTYPE, found)
+        assert all(pfirst <= int(p) < pfirst + pcount for p in part["problem"])
+        runs.append(part)
+    got = libs[0].finalize(cmp, np.concatenate(runs))
+    # single library
+    one = capi.Library(n)
+    one.set_pcm([e.pcm for e in eps], lens)
+    one.analyze(0, n)
+    d_runs, d_count = capi.DeviceBuffer(cap * capi.RUN_DTYPE.itemsize), capi.DeviceBuffer(4)
+    one.search(cmp, 0, one.num_pairs(), d_runs.ptr, cap, d_count.ptr, sync=True)
+    want = one.finalize(cmp, d_runs.to_host(capi.RUN_DTYPE, int(d_count.to_host(np.uint32, 1)[0])))
+    assert [(r.opening, r.ending) for r in got] == [(r.opening, r.ending) for r in want]
+    hd = O.duration_from_secs_f32(0.3)
+    ref = O.run_with_frame_hashes(O.Comparator(min_opening_duration=10 * NS),
+                                  O.analyze_batch([e.pcm[: len(e.pcm) // 2] for e in eps], 1, hd))
+    _same_results(got, ref)
+    # a rank can also hand out the FrameHashes of a video another rank fingerprinted (rows arrived by the gather)
+    assert libs[0].frame_hashes(n - 1).opening_data()[0].tolist() == [h for h, _ in O.analyze_batch(
+        [eps[n - 1].pcm[: lens[n - 1] // 2]], 1, hd)[0].opening]
