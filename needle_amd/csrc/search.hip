@@ -522,7 +522,7 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
     }
     {
       KernelTimer timer("simhash_runs");
-      hipLaunchKernelGGL(simhash_runs_kernel, dim3(256), dim3(256), 0, stream, d_hashes, ws->problems.ptr, d_runs,
+      hipLaunchKernelGGL(simhash_runs_kernel, dim3(2048), dim3(256), 0, stream, d_hashes, ws->problems.ptr, d_runs,
                          capacity, d_count);
     }
     NEEDLE_HIP_TRY(hipGetLastError());
