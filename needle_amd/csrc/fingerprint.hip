@@ -521,7 +521,7 @@ Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::
       } else {
         spans.push_back(StreamSpan{values, num_values[end], kept});
       }
-      values += (num_values[end] + 1) & ~(uint64_t)1;  // keep every stream 4-byte aligned in the arena
+      values += (num_values[end] + 7) & ~(uint64_t)7;  // keep every stream 16-byte aligned in the arena
       kept += num_kept(out_samples, step);
       end++;
     }

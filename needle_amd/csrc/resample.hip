@@ -126,11 +126,14 @@ struct RsGeom {
   int n_log2;       // lanes per phase
   int pitch;        // row layout: 16-byte slots per row (odd); 0 = the region is stored contiguously
   int region_slots; // 16-byte slots of samples
+  int delta;        // region[0] is input sample first-tap-of-the-tile minus delta, so that it is a multiple of 4
 };
 
 // ROWS_IN_LDS needs the shift of a row to be the same for all lanes of its phase: always so in the row layout,
 // and in the contiguous layout when M % 4 == 0.
-template <int CH, bool ROWS_IN_LDS>
+// VEC4: M % 4 == 0, so every row (and the region) starts a multiple of 4 samples after the stream's first sample
+// and may be staged by aligned groups of four.
+template <int CH, bool ROWS_IN_LDS, bool VEC4>
 __global__ __launch_bounds__(kThreads) void resample_kernel(const int16_t *__restrict__ in,
                                                             const RsStream *__restrict__ streams, int num_streams,
                                                             const float4 *__restrict__ coef, RsGeom geo,
@@ -149,7 +152,8 @@ __global__ __launch_bounds__(kThreads) void resample_kernel(const int16_t *__res
   const uint64_t tile = blockIdx.x - st.block_base;
   const uint64_t tile_base = tile * (uint64_t)tile_outputs;          // first output of the tile
   const int half = geo.T / 2;
-  const long long first0 = (long long)(tile * (uint64_t)n * (uint64_t)M) - half + 1;  // input index of region[0]
+  // input index of region[0]: the first tap of the tile's first output, moved down by delta to a multiple of 4
+  const long long first0 = (long long)(tile * (uint64_t)n * (uint64_t)M) - half + 1 - geo.delta;
   const int16_t *src = in + st.in_off;
   // one down-mixed input sample, 0 outside the stream.  Branch-free (the load is always issued, at an index
   // clamped into the stream) so that the unrolled staging loops keep their loads in flight; a stereo sample is
@@ -182,12 +186,52 @@ __global__ __launch_bounds__(kThreads) void resample_kernel(const int16_t *__res
     }
     for (; o < count; o += nt) dst[o] = (float)sample(from + o);
   };
+  // the same by groups of four samples: one 16-byte (stereo) or 8-byte (mono) load and one 128-bit LDS store per
+  // group.  `from` and the stream's first sample are multiples of 4 samples from a 16-byte boundary; groups that
+  // stick out of the stream take the scalar path.
+  auto stage_run4 = [&](float4 *dst, long long from, int groups, int me, int nt) {
+    constexpr int kStageUnroll = 4;
+    const long long last_group = ((long long)st.n_in - 4) & ~3ll;  // last aligned group wholly inside the stream
+    auto group = [&](long long idx) -> float4 {  // branch-free: out-of-range groups load a clamped one (fixed below)
+      const long long at = idx < 0 ? 0 : (idx > last_group ? last_group : idx);
+      int s0, s1, s2, s3;
+      if (CH == 1) {
+        const int2 v = *reinterpret_cast<const int2 *>(src + at);
+        s0 = (int16_t)v.x; s1 = v.x >> 16; s2 = (int16_t)v.y; s3 = v.y >> 16;
+      } else {
+        const int4 v = *reinterpret_cast<const int4 *>(src + 2 * at);
+        s0 = ((int)(int16_t)v.x + (v.x >> 16)) / 2; s1 = ((int)(int16_t)v.y + (v.y >> 16)) / 2;
+        s2 = ((int)(int16_t)v.z + (v.z >> 16)) / 2; s3 = ((int)(int16_t)v.w + (v.w >> 16)) / 2;
+      }
+      return float4{(float)s0, (float)s1, (float)s2, (float)s3};
+    };
+    int o = me;
+    for (; o + (kStageUnroll - 1) * nt < groups; o += nt * kStageUnroll) {
+      float4 v[kStageUnroll];
+#pragma unroll
+      for (int u = 0; u < kStageUnroll; u++) v[u] = group(from + 4 * (o + u * nt));
+#pragma unroll
+      for (int u = 0; u < kStageUnroll; u++) dst[o + u * nt] = v[u];
+    }
+    for (; o < groups; o += nt) dst[o] = group(from + 4 * o);
+    // groups that stick out of the stream (only in its first and last tiles): sample by sample, zeros outside
+    for (o = me; o < groups; o += nt) {
+      const long long idx = from + 4 * o;
+      if (idx < 0 || idx > last_group)
+        dst[o] = float4{(float)sample(idx), (float)sample(idx + 1), (float)sample(idx + 2), (float)sample(idx + 3)};
+    }
+  };
+  const bool by_groups = VEC4 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && st.n_in >= 4;
   if (geo.pitch) {  // row r: its own M samples and the overlap into the next row
     const int tpr = kThreads >> n_log2;  // threads per row
     const int r = threadIdx.x / tpr;
-    stage_run(stage + 4 * geo.pitch * r, first0 + (long long)r * M, M + 4 * G + 4, threadIdx.x % tpr, tpr);
+    if (by_groups)
+      stage_run4(lds4 + geo.pitch * r, first0 + (long long)r * M, (M + 4 * G + 4 + 3) >> 2, threadIdx.x % tpr, tpr);
+    else
+      stage_run(stage + 4 * geo.pitch * r, first0 + (long long)r * M, M + 4 * G + 4, threadIdx.x % tpr, tpr);
   } else {
-    stage_run(stage, first0, 4 * geo.region_slots, threadIdx.x, kThreads);
+    if (by_groups) stage_run4(lds4, first0, geo.region_slots, threadIdx.x, kThreads);
+    else stage_run(stage, first0, 4 * geo.region_slots, threadIdx.x, kThreads);
   }
   int16_t *out_tile = reinterpret_cast<int16_t *>(lds4 + geo.region_slots);
   const int rows_per_wave = n >= 64 ? 1 : (64 >> n_log2);
@@ -210,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void resample_kernel(const int16_t *__res
         const int pr = p_first + r;
         if (pr < L) {
           const int pm = pr * M, cp = pm / L, phase = pm - cp * L;
-          const float4 *row = coef + (size_t)(cp & 3) * shift_stride + (size_t)phase * G;
+          const float4 *row = coef + (size_t)((cp + geo.delta) & 3) * shift_stride + (size_t)phase * G;
           for (int g = lane; g < G; g += 64) scratch[r * G + g] = row[g];
         }
       }
@@ -223,7 +267,7 @@ __global__ __launch_bounds__(kThreads) void resample_kernel(const int16_t *__res
       const int pm = p * M;
       const int cp = pm / L, phase = pm - cp * L;
       // first tap of this output: sample cp of row j, or sample cp + j M of the contiguous region
-      const int rel = geo.pitch ? cp : cp + j * M;
+      const int rel = (geo.pitch ? cp : cp + j * M) + geo.delta;
       const float4 *xs = lds4 + (geo.pitch ? j * geo.pitch : 0) + (rel >> 2);
       const float4 *row = ROWS_IN_LDS ? scratch + (p - p_first) * G
                                       : coef + (size_t)(rel & 3) * shift_stride + (size_t)phase * G;
@@ -347,13 +391,19 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
     }
     const int rows_per_wave = d->n >= 64 ? 1 : 64 / d->n;
     const bool rows_in_lds = row_mode || d->M % 4 == 0;
+    // M % 4 == 0: a tile's first tap is a fixed number of samples past a multiple of 4; the region starts at that
+    // multiple, so rows can be staged by aligned groups of four samples
+    const bool vec4 = d->M % 4 == 0;
+    geo.delta = vec4 ? ((1 - d->T / 2) % 4 + 4) % 4 : 0;
     const size_t lds_bytes = (size_t)geo.region_slots * 16 + ((tile_outputs * 2 + 15) & ~(size_t)15) +
                              (rows_in_lds ? (size_t)(kThreads / 64) * rows_per_wave * d->G * 16 : 0);
     if (lds_bytes > 160 * 1024) return Status::Make(NeedleError_InvalidArgument, "resample: rate ratio too large for this kernel");
-    const void *variants[4] = {reinterpret_cast<const void *>(resample_kernel<1, false>),
-                               reinterpret_cast<const void *>(resample_kernel<1, true>),
-                               reinterpret_cast<const void *>(resample_kernel<2, false>),
-                               reinterpret_cast<const void *>(resample_kernel<2, true>)};
+    const void *variants[6] = {reinterpret_cast<const void *>(resample_kernel<1, false, false>),
+                               reinterpret_cast<const void *>(resample_kernel<1, true, false>),
+                               reinterpret_cast<const void *>(resample_kernel<1, true, true>),
+                               reinterpret_cast<const void *>(resample_kernel<2, false, false>),
+                               reinterpret_cast<const void *>(resample_kernel<2, true, false>),
+                               reinterpret_cast<const void *>(resample_kernel<2, true, true>)};
     static std::map<int, size_t> lds_attr;  // largest dynamic LDS size announced per device
     if (lds_attr[dev] < lds_bytes) {
       for (const void *fn : variants)
@@ -367,9 +417,13 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
                          (int)meta.size(), coef4, geo, d_out);
     };
     if (channels == 1) {
-      if (rows_in_lds) launch(resample_kernel<1, true>); else launch(resample_kernel<1, false>);
+      if (vec4) launch(resample_kernel<1, true, true>);
+      else if (rows_in_lds) launch(resample_kernel<1, true, false>);
+      else launch(resample_kernel<1, false, false>);
     } else {
-      if (rows_in_lds) launch(resample_kernel<2, true>); else launch(resample_kernel<2, false>);
+      if (vec4) launch(resample_kernel<2, true, true>);
+      else if (rows_in_lds) launch(resample_kernel<2, true, false>);
+      else launch(resample_kernel<2, false, false>);
     }
     NEEDLE_HIP_TRY(hipGetLastError());
   }
@@ -391,7 +445,7 @@ Status gpu_resample_host(const std::vector<const int16_t *> &pcm, const std::vec
     spans[i].in_off = in_total;
     spans[i].n_in = num_values[i] / (size_t)channels;
     spans[i].out_off = out_total;
-    in_total += (num_values[i] + 1) & ~(uint64_t)1;
+    in_total += (num_values[i] + 7) & ~(uint64_t)7;  // 16-byte aligned stream starts: staging by aligned groups
     out_total += (resample_out_len(spans[i].n_in, rate) + 1) & ~(uint64_t)1;
   }
   DeviceBuffer<int16_t> d_in, d_out;
