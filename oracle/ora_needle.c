@@ -810,3 +810,50 @@ void ora_format_time(ora_ns t, char out[32]) {
   uint64_t secs = t / 1000000000ull;
   snprintf(out, 32, "%02llu:%02llus", (unsigned long long)(secs / 60), (unsigned long long)(secs % 60));
 }
+
+/* ---- optimised CPU variant of the scan (NOT the reference's cost structure; see ora_needle.h) ------------------ */
+size_t ora_diagonal_runs_all_pairs(const uint32_t *const *hashes, const size_t *lens, size_t n_videos,
+                                   uint32_t threshold, uint32_t min_len, uint32_t *runs, size_t cap) {
+  const long np = n_videos < 2 ? 0 : (long)(n_videos * (n_videos - 1) / 2);
+  size_t total = 0;
+  if (min_len < 1) min_len = 1;
+  enum { kChunks = 8 }; /* tasks = pairs x slices of the diagonals: enough of them for hundreds of threads */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+  for (long task = 0; task < np * kChunks; task++) {
+    const long p = task / kChunks, chunk = task % kChunks;
+    size_t i = 0, rest = (size_t)p; /* lexicographic pair index -> (i, j), comparator.rs:534-545 */
+    while (rest >= n_videos - 1 - i) {
+      rest -= n_videos - 1 - i;
+      i++;
+    }
+    const size_t j = i + 1 + rest;
+    const uint32_t *s = hashes[i], *t = hashes[j];
+    const long n = (long)lens[i], m = (long)lens[j];
+    if (n < 2 || m < 2) continue;
+    const long d_first = -(n - 2), d_count = (m - 2) - d_first + 1;
+    const long d_lo = d_first + d_count * chunk / kChunks, d_hi = d_first + d_count * (chunk + 1) / kChunks;
+    for (long d = d_lo; d < d_hi; d++) { /* diagonal dst - src = d; cells with both indices >= 1 */
+      const long lo = d < 0 ? 1 - d : 1, hi = (n - 1) < (m - 1 - d) ? (n - 1) : (m - 1 - d);
+      uint32_t run = 0;
+      for (long a = lo; a <= hi + 1; a++) {
+        if (a <= hi && (uint32_t)__builtin_popcount(s[a] ^ t[a + d]) <= threshold) {
+          run++;
+          continue;
+        }
+        if (run >= min_len) { /* the run ended on row a - 1 */
+          size_t slot;
+#pragma omp atomic capture
+          slot = total++;
+          if (runs && slot < cap) {
+            runs[4 * slot + 0] = (uint32_t)p;
+            runs[4 * slot + 1] = (uint32_t)(a - 1);
+            runs[4 * slot + 2] = (uint32_t)(a - 1 + d);
+            runs[4 * slot + 3] = run;
+          }
+        }
+        run = 0;
+      }
+    }
+  }
+  return total;
+}

@@ -96,6 +96,14 @@ int ora_run_with_frame_hashes(const ora_comparator *c, const ora_frame_hashes *f
                               ora_search_result *out);
 
 /* thread count used by ora_run_with_frame_hashes / ora_analyze_batch (the rayon pool stand-in) */
+/* An OPTIMISED CPU variant of the pair scan, for an honest second CPU baseline: no table, every
+ * diagonal walked once with a running match length, runs shorter than min_len dropped on the spot.  Returns the
+ * number of runs with L >= min_len over all pairs of `n_videos` hash sequences (parallel over pairs with the
+ * threads of ora_set_threads); if `runs` is not NULL the first `cap` runs are stored as (pair, src_end, dst_end,
+ * len) quadruples, in no particular order.  The same runs as the table walk of comparator.rs:175-247 reports. */
+size_t ora_diagonal_runs_all_pairs(const uint32_t *const *hashes, const size_t *lens, size_t n_videos,
+                                   uint32_t threshold, uint32_t min_len, uint32_t *runs, size_t cap);
+
 void ora_set_threads(int n);
 int ora_get_threads(void);
 

@@ -303,6 +303,25 @@ def run_with_frame_hashes(cmp: Comparator, fhs: Sequence[FrameHashes], threads: 
     return out
 
 
+def diagonal_runs_all_pairs(seqs: Sequence[np.ndarray], threshold: int, min_len: int, threads: int = 1,
+                            capacity: int = 0):
+    """The optimised CPU variant of the pair scan (no table; ora_needle.h).  Returns (total, runs ndarray [k, 4] of
+    (pair, src_end, dst_end, len))."""
+    seqs = [np.ascontiguousarray(q, dtype=np.uint32) for q in seqs]
+    ptrs = (C.c_void_p * len(seqs))(*[q.ctypes.data for q in seqs])
+    lens = (C.c_size_t * len(seqs))(*[q.size for q in seqs])
+    out = np.zeros((max(capacity, 1), 4), dtype=np.uint32)
+    L = lib()
+    L.ora_diagonal_runs_all_pairs.restype = C.c_size_t
+    L.ora_diagonal_runs_all_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p,
+                                              C.c_size_t]
+    L.ora_set_threads(threads)
+    total = L.ora_diagonal_runs_all_pairs(ptrs, lens, len(seqs), threshold, min_len,
+                                          out.ctypes.data if capacity else None, capacity)
+    L.ora_set_threads(1)
+    return int(total), out[: min(total, capacity)]
+
+
 def analyze_batch(pcms: Sequence[np.ndarray], channels: int, hash_duration_ns: int, threads: int = 1):
     """Opening-window analyze of already-cropped PCM streams -> list[FrameHashes] (md5 empty)."""
     pcms = [np.ascontiguousarray(p, dtype=np.int16) for p in pcms]

@@ -370,3 +370,26 @@ def test_oracle_reproduces_chromaprints_own_silence_vector():
     for i in range(1, len(decoded)):
         decoded[i] ^= decoded[i - 1]
     assert decoded == g["raw_fingerprint"]
+
+
+def test_optimised_cpu_scan_reports_the_table_walks_runs():
+    """The second CPU baseline (diagonal scan, no table) finds exactly the runs the literal table walk reports."""
+    rng = np.random.default_rng(21)
+    seqs = [rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32) for n in (90, 140, 61, 2, 1)]
+    seqs[1][20:75] = seqs[0][30:85]
+    seqs[2][5:40] = seqs[0][50:85] ^ np.uint32(1 << 7)
+    seqs[2][41:60] = seqs[1][100:119]
+    for thr, min_len in [(10, 1), (10, 12), (0, 5), (32, 3)]:
+        total, runs = O.diagonal_runs_all_pairs(seqs, thr, min_len, threads=3, capacity=100000)
+        assert total == len(runs)
+        got = sorted(map(tuple, runs.tolist()))
+        want = []
+        pair = 0
+        for i in range(len(seqs)):
+            for j in range(i + 1, len(seqs)):
+                ents = O.longest_common_hash_match(
+                    O.Comparator(hash_match_threshold=thr, min_opening_duration=0),
+                    [(int(h), k) for k, h in enumerate(seqs[i])], [(int(h), k) for k, h in enumerate(seqs[j])], 0, 0)
+                want += [(pair, e["src_end_idx"], e["dst_end_idx"], e["score"]) for e in ents if e["score"] >= min_len]
+                pair += 1
+        assert got == sorted(want)
