@@ -58,6 +58,10 @@ std::string with_extension(const std::string &path, const std::string &ext);    
 std::string format_time(ns_t t);                                                  // util.rs:8-12
 std::string format_f32_json(float v);                                             // serde_json/ryu f32
 
+// Host CPUs this process may use: hardware threads capped by its affinity mask and by the cgroup CPU quota (a
+// container can see every core of the machine and be granted a few CPUs of time).
+unsigned usable_cpus();
+
 // ---- chromaprint-facing constants -------------------------------------------------
 constexpr int kSampleRate = 11025;
 constexpr int kFrameSize = 4096;

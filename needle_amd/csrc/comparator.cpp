@@ -254,7 +254,7 @@ Status Comparator::best_matches(size_t num_videos, const std::vector<std::vector
     for (const auto &pi : info_map[v]) c += pair_entries[pi.first].size();
     work += c * c / 2;
   }
-  unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  unsigned hw = usable_cpus();
   if (const char *e = std::getenv("NEEDLE_HOST_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));  // 1 = sequential
   const unsigned workers = (work < (1u << 22) || hw == 1) ? 1u : (unsigned)std::min<uint64_t>({hw, 64, todo.size()});
   if (workers <= 1) {

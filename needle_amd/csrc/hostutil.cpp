@@ -9,6 +9,14 @@
 
 #include "common.h"
 
+#include <sched.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
 namespace needle {
 
 // ---- Duration ------------------------------------------------------------------------------------------
@@ -363,6 +371,29 @@ Status wav_read(const std::string &path, WavData *out) {
     off = body + len + (len & 1);
   }
   return Status::Make(NeedleError_Unknown, "malformed WAV (no fmt/data chunk): " + path);
+}
+
+unsigned usable_cpus() {
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+  if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+    char quota[32] = {0};
+    long period = 0;
+    if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0)
+      n = std::min(n, (unsigned)std::max(1L, std::atol(quota) / period));
+    std::fclose(f);
+  } else if (FILE *q = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+    long quota = -1, period = 0;
+    if (std::fscanf(q, "%ld", &quota) != 1) quota = -1;
+    std::fclose(q);
+    if (FILE *p = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (std::fscanf(p, "%ld", &period) != 1) period = 0;
+      std::fclose(p);
+    }
+    if (quota > 0 && period > 0) n = std::min(n, (unsigned)std::max(1L, quota / period));
+  }
+  return n;
 }
 
 }  // namespace needle
