@@ -99,7 +99,7 @@ Status get_tables(FpTables *out) {
 
   std::vector<uint16_t> bin_slot(core::kNumBins);
   for (size_t pos = 0; pos < bins.size(); pos++)  // where the bin's power goes in the LDS image (frame A)
-    bin_slot[bins[pos] - core::kMinBin] = (uint16_t)core::dif_power_index((int)pos);
+    bin_slot[bins[pos] - core::kMinBin] = (uint16_t)core::dif_power_slot((int)pos);
   for (int c = 0; c < kBands; c++)
     if (start[c + 1] - start[c] > (uint32_t)(core::kClassLanes * core::kClassLaneMax))
       return Status::Make(NeedleError_Unknown, "pitch class larger than the fold's lane budget");
@@ -188,13 +188,13 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
 #pragma unroll
   for (int j = 0; j < core::kBinsPerThread; j++) {
     const int kf = core::dif_bin_of(t, j);
-    const uint32_t idx = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : core::kPowerTrash;
+    const uint32_t idx = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : core::kPowerTrashSlot;
     slot_pk[j >> 1] = (j & 1) ? (slot_pk[j >> 1] | (idx << 16)) : idx;
   }
-  if (t == 0) reinterpret_cast<double *>(lds)[core::kPowerZero] = 0.0;  // first read after the loop's barriers
-  // its share of the pitch-class fold: 2 frames x 12 classes x 8 lanes
-  const bool folds = t < 2 * kBands * core::kClassLanes;
-  const int fold_which = (t >> 3) >= kBands ? 1 : 0, fold_c = (t >> 3) - fold_which * kBands, fold_l = t & 7;
+  if (t == 0) lds[core::kPowerZeroSlot] = cd{0.0, 0.0};  // first read after the loop's barriers
+  // its share of the pitch-class fold: 12 classes x 16 lanes (one DPP row per class), each lane both frames
+  const bool folds = t < kBands * core::kClassLanes;
+  const int fold_c = t >> 4, fold_l = t & 15;
   const uint32_t fold_bounds = folds ? (class_start[fold_c] | (class_start[fold_c + 1] << 16)) : 0;
 
   // ---- the stream (region of the batch) the current pair belongs to; consecutive pairs rarely change it ------
@@ -237,22 +237,26 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   };
   // The pitch-class fold of a pair runs one pair late, between the next pair's sample conversion and its first
   // butterflies: the LDS reads are issued, the conversion hides their latency, then 8 lanes per class add up.
-  double *plds = reinterpret_cast<double *>(lds);
-  double fv[core::kClassLaneMax];
+  cd fv[core::kClassLaneMax];
   auto fold_issue = [&]() {
     if (folds) {
       uint32_t fb = fold_bounds;
-      asm volatile("" : "+v"(fb));  // recompute the 18 addresses per pair rather than keep them in registers
-      core::class_lane_load(plds, fold_which * core::kPowerFrameB, (int)(fb & 0xffffu), (int)(fb >> 16), fold_l, fv);
+      asm volatile("" : "+v"(fb));  // recompute the addresses per pair rather than keep them in registers
+      core::class_lane_load(lds, (int)(fb & 0xffffu), (int)(fb >> 16), fold_l, fv);
     }
   };
   auto fold_finish = [&](const PairSrc &p) {
     if (folds) {
-      double acc = core::class_lane_add(fv);
-      acc += dpp_f64<0xB1>(acc);   // quad_perm [1,0,3,2]: lane ^ 1
-      acc += dpp_f64<0x4E>(acc);   // quad_perm [2,3,0,1]: lane ^ 2
-      acc += dpp_f64<0x141>(acc);  // row_half_mirror: lane -> 7 - lane within 8 (fp_core.h class_tree_partner)
-      if (fold_l == 0 && (fold_which == 0 || p.has_b)) chroma[(p.row + fold_which) * kBands + fold_c] = acc;
+      cd acc = core::class_lane_add(fv);
+      // fixed-order tree over the class's 16 lanes (fp_core.h class_tree_partner)
+      acc = cd{acc.x + dpp_f64<0xB1>(acc.x), acc.y + dpp_f64<0xB1>(acc.y)};    // quad_perm [1,0,3,2]
+      acc = cd{acc.x + dpp_f64<0x4E>(acc.x), acc.y + dpp_f64<0x4E>(acc.y)};    // quad_perm [2,3,0,1]
+      acc = cd{acc.x + dpp_f64<0x141>(acc.x), acc.y + dpp_f64<0x141>(acc.y)};  // row_half_mirror
+      acc = cd{acc.x + dpp_f64<0x140>(acc.x), acc.y + dpp_f64<0x140>(acc.y)};  // row_mirror
+      if (fold_l == 0) {
+        chroma[p.row * kBands + fold_c] = acc.x;
+        if (p.has_b) chroma[(p.row + 1) * kBands + fold_c] = acc.y;
+      }
     }
   };
   PairSrc cur = locate(first), prev = cur;
@@ -304,10 +308,9 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
       const uint32_t idx = (spk[j >> 1] >> (16 * (j & 1))) & 0xffffu;
       double pa, pb;
       core::dif_bin_power_any(tt, j, lds, r, &pa, &pb);
-      // class-sorted powers into dead slots (fp_core.h dif_power_index): no barrier after the partner reads;
-      // bins outside 10..1307 land in a pad slot nobody reads
-      plds[idx] = pa;
-      plds[idx + core::dif_power_index(core::kPowerFrameB)] = pb;
+      // class-sorted power pairs into dead slots (fp_core.h dif_power_slot): no barrier after the partner reads;
+      // bins outside 10..1307 land in a slot nobody reads
+      lds[idx] = cd{pa, pb};
     }
     const PairSrc nxt = locate(min(g + 1, last - 1));  // last pair: harmless re-read
     issue_loads(nxt);

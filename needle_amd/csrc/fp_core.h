@@ -178,36 +178,37 @@ NEEDLE_HD bool dif_bin_power(int t, int j, const cd *lds, const cd *r, int *kf_o
   return true;
 }
 
-// Class-sorted power position p (frame A: position in the class-sorted bin list; frame B: 2048 + that) -> index, in
-// doubles, into the LDS image: positions 16 q .. 16 q + 15 fill the slots of registers j = 0..7 of thread q's
-// stage-2 row (pidx(16 q + j) = 17 q + j).
-constexpr int kPowerFrameB = 2048;
-constexpr int kClassLanes = 8;       // lanes that share one pitch class in the fold
-constexpr int kClassLaneMax = 18;    // >= ceil(largest class / kClassLanes); checked where the tables are built
-NEEDLE_HD int dif_power_index(int p) { return 34 * (p >> 4) + (p & 15); }
-// The pad slots 17 q + 16 of the image are touched by no stage and no power.  Two of them serve as constants, so
-// that neither the power stores nor the fold's loads need a branch: kPowerZero (doubles of pad slot 0) holds 0.0
-// for the fold's out-of-range loads; kPowerTrash (pad slot 1; + dif_power_index(kPowerFrameB) is pad slot 129)
-// takes the powers of the bins outside 10..1307.
-constexpr int kPowerZero = 32, kPowerTrash = 66;
+// Class-sorted power image.  Position p (0..1297, the bins sorted by pitch class) holds the PAIR (power in frame
+// A, power in frame B) in one 16-byte slot: slot 17 (p >> 3) + (p & 7), i.e. registers j = 0..7 of thread
+// (p >> 3)'s stage-2 row (pidx(16 q + j) = 17 q + j), dead by then and disjoint from the partner slots.  One
+// 128-bit store per bin, and one 128-bit load gives a fold lane both frames' powers: LDS operations, not their
+// bytes, are what this kernel pays for.
+constexpr int kClassLanes = 16;      // lanes that share one pitch class in the fold (one DPP row)
+constexpr int kClassLaneMax = 9;     // >= ceil(largest class / kClassLanes); checked where the tables are built
+NEEDLE_HD int dif_power_slot(int p) { return 17 * (p >> 3) + (p & 7); }
+// Two constant slots make the stores and the fold's loads branch-free.  kPowerZeroSlot: a pad slot (17 q + 16:
+// touched by no stage and no power) that holds (0, 0), read in place of positions outside a class.
+// kPowerTrashSlot: a row beyond the last position, where the powers of the bins outside 10..1307 go.
+constexpr int kPowerZeroSlot = 16, kPowerTrashSlot = 17 * 200;
 
-// One lane's share of a pitch class: positions b0 + l, b0 + l + 8, ... < b1, summed in that order.  Split into
-// the loads and the sum so the kernel can put other work between them (the trailing zeros do not change the sum).
-NEEDLE_HD void class_lane_load(const double *plds, int frame_off, int b0, int b1, int l, double *v) {
+// One lane's share of a pitch class [b0, b1): positions b0 + l, b0 + l + 16, ... (every other row of the image:
+// slots 34 apart), both frames at once (x = frame A, y = frame B).  Split into the loads and the sums so the
+// kernel can put other work between them.
+NEEDLE_HD void class_lane_load(const cd *lds, int b0, int b1, int l, cd *v) {
 #pragma unroll
   for (int i = 0; i < kClassLaneMax; i++) {
     const int b = b0 + l + kClassLanes * i;
-    v[i] = plds[b < b1 ? dif_power_index(frame_off + b) : kPowerZero];
+    v[i] = lds_get(lds, b < b1 ? dif_power_slot(b) : kPowerZeroSlot);
   }
 }
-NEEDLE_HD double class_lane_add(const double *v) {
-  double acc = v[0];
+NEEDLE_HD cd class_lane_add(const cd *v) {
+  cd acc = v[0];
 #pragma unroll
-  for (int i = 1; i < kClassLaneMax; i++) acc += v[i];
+  for (int i = 1; i < kClassLaneMax; i++) acc = cadd(acc, v[i]);
   return acc;
 }
-// The 8 lane sums of a class are then combined in three exchange steps; partner of lane l in step s:
-NEEDLE_HD int class_tree_partner(int l, int s) { return s == 0 ? (l ^ 1) : s == 1 ? (l ^ 2) : (7 - l); }
+// The 16 lane sums of a class are then combined in four exchange steps; partner of lane l in step s:
+NEEDLE_HD int class_tree_partner(int l, int s) { return s == 0 ? (l ^ 1) : s == 1 ? (l ^ 2) : s == 2 ? ((l & 8) | (7 - (l & 7))) : (15 - l); }
 
 // ---- classifiers (chromaprint kClassifiersTest2) ---------------------------------
 struct ClassifierDef {

@@ -68,7 +68,7 @@ extern "C" {
 void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, double *chroma_a, double *chroma_b) {
   const Tables &T = tables();
   std::vector<cd> lds(kLds2Slots);
-  reinterpret_cast<double *>(lds.data())[kPowerZero] = 0.0;  // the kernel's constant zero (a pad slot)
+  lds[kPowerZeroSlot] = cd{0.0, 0.0};  // the kernel's constant zero (a pad slot)
   std::vector<cd> regs(256 * 16);
   auto sample = [&](const int16_t *src, int n) -> int {
     if (!src) return 0;
@@ -92,12 +92,10 @@ void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, do
   }
   // partner reads and power stores interleaved thread by thread (no barrier between them in the kernel); walking
   // the threads in both directions must give the same image if the stores never touch a live partner slot
-  double *plds = reinterpret_cast<double *>(lds.data());
   std::vector<cd> snapshot = lds;
-  std::vector<double> image[2];
+  std::vector<cd> image[2];
   for (int dir = 0; dir < 2; dir++) {
     lds = snapshot;
-    plds = reinterpret_cast<double *>(lds.data());
     int seen = 0;
     for (int i = 0; i < 256; i++) {
       const int t = dir ? 255 - i : i;
@@ -105,35 +103,32 @@ void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, do
         int kf;
         double a, b;
         if (dif_bin_power(t, j, lds.data(), &regs[t * 16], &kf, &a, &b)) {
-          const int idx = dif_power_index(T.bin_pos[kf - kMinBin]);
-          plds[idx] = a;
-          plds[idx + dif_power_index(kPowerFrameB)] = b;
+          lds[dif_power_slot(T.bin_pos[kf - kMinBin])] = cd{a, b};
           seen++;
         }
       }
     }
     if (seen != kNumBins) { chroma_a[0] = -1.0; return; }  // every bin must be owned by exactly one (t, j)
-    image[dir].assign(plds, plds + 2 * kLds2Slots);
+    image[dir] = lds;
   }
-  for (int p = 0; p < 2 * kPowerFrameB; p++)
-    if (image[0][dif_power_index(p)] != image[1][dif_power_index(p)]) { chroma_a[0] = -2.0; return; }
-  for (int which = 0; which < 2; which++) {
-    double *out = which ? chroma_b : chroma_a;
-    if (!out) continue;
-    for (int c = 0; c < 12; c++) {
-      double lane[8];
-      for (int l = 0; l < 8; l++) {
-        double v[kClassLaneMax];
-        class_lane_load(plds, which * kPowerFrameB, (int)T.class_start[c], (int)T.class_start[c + 1], l, v);
-        lane[l] = class_lane_add(v);
-      }
-      for (int step = 0; step < 3; step++) {
-        double nxt[8];
-        for (int l = 0; l < 8; l++) nxt[l] = lane[l] + lane[class_tree_partner(l, step)];
-        std::memcpy(lane, nxt, sizeof(lane));
-      }
-      out[c] = lane[0];
+  for (int p = 0; p < kNumBins; p++) {
+    const cd u = image[0][dif_power_slot(p)], v = image[1][dif_power_slot(p)];
+    if (u.x != v.x || u.y != v.y) { chroma_a[0] = -2.0; return; }
+  }
+  for (int c = 0; c < 12; c++) {
+    cd lane[kClassLanes];
+    for (int l = 0; l < kClassLanes; l++) {
+      cd v[kClassLaneMax];
+      class_lane_load(lds.data(), (int)T.class_start[c], (int)T.class_start[c + 1], l, v);
+      lane[l] = class_lane_add(v);
     }
+    for (int step = 0; step < 4; step++) {
+      cd nxt[kClassLanes];
+      for (int l = 0; l < kClassLanes; l++) nxt[l] = cadd(lane[l], lane[class_tree_partner(l, step)]);
+      std::memcpy(lane, nxt, sizeof(lane));
+    }
+    chroma_a[c] = lane[0].x;
+    if (chroma_b) chroma_b[c] = lane[0].y;
   }
 }
 
