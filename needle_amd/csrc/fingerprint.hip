@@ -43,7 +43,8 @@ struct FpStream {
 struct FpTables {
   cd *tw = nullptr;                 // [4096] e^{-2 pi i k/4096}
   uint16_t *bin_slot = nullptr;     // [kNumBins] position of bin (kMinBin + i) in the class-sorted order
-  double *window = nullptr;         // [4096] Hamming / 32767 / 2 (fp_core.h kPairInputScale)
+  double *wcos = nullptr;           // [512] cos(theta (i - 256)), theta = 2 pi / 4095: window recurrence seeds
+  core::WindowConst wconst;         // fp_core.h window_step
   uint16_t *class_bins = nullptr;   // [kNumBins] spectrum bins grouped by pitch class
   uint32_t *class_start = nullptr;  // [13]
   core::ClassifierThresholds *thr = nullptr;
@@ -75,9 +76,14 @@ Status get_tables(FpTables *out) {
     long double a = -2.0L * 3.14159265358979323846264338327950288L * k / 4096.0L;
     tw[k] = cd{(double)cosl(a), (double)sinl(a)};
   }
-  std::vector<double> window(4096);
-  for (int i = 0; i < 4096; i++)  // chromaprint PrepareHammingWindow(scale = 1/INT16_MAX), times fp_core.h's 2^-1
-    window[i] = core::kPairInputScale * ((1.0 / 32767.0) * (0.54 - 0.46 * std::cos(i * 2.0 * M_PI / (4096 - 1))));
+  // chromaprint PrepareHammingWindow(scale = 1/INT16_MAX), times fp_core.h's 2^-1, as recurrence seeds and constants
+  const long double theta = 2.0L * 3.14159265358979323846264338327950288L / 4095.0L;
+  std::vector<double> wcos(512);
+  for (int i = 0; i < 512; i++) wcos[i] = (double)cosl(theta * (long double)(i - 256));
+  core::WindowConst wconst;
+  wconst.k2 = (double)(2.0L * cosl(256.0L * theta));
+  wconst.a = core::kPairInputScale * (0.54 / 32767.0);
+  wconst.b = core::kPairInputScale * (0.46 / 32767.0);
   // chromaprint Chroma::PrepareNotes: bin -> pitch class
   std::vector<std::vector<uint16_t>> by_class(kBands);
   for (int i = core::kMinBin; i < core::kMaxBin; i++) {
@@ -107,12 +113,13 @@ Status get_tables(FpTables *out) {
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.bin_slot, bin_slot.size() * sizeof(uint16_t)));
   NEEDLE_HIP_TRY(hipMemcpy(t.bin_slot, bin_slot.data(), bin_slot.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.tw, tw.size() * sizeof(cd)));
-  NEEDLE_HIP_TRY(hipMalloc((void **)&t.window, window.size() * sizeof(double)));
+  NEEDLE_HIP_TRY(hipMalloc((void **)&t.wcos, wcos.size() * sizeof(double)));
+  t.wconst = wconst;
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.class_bins, bins.size() * sizeof(uint16_t)));
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.class_start, start.size() * sizeof(uint32_t)));
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.thr, sizeof(thr)));
   NEEDLE_HIP_TRY(hipMemcpy(t.tw, tw.data(), tw.size() * sizeof(cd), hipMemcpyHostToDevice));
-  NEEDLE_HIP_TRY(hipMemcpy(t.window, window.data(), window.size() * sizeof(double), hipMemcpyHostToDevice));
+  NEEDLE_HIP_TRY(hipMemcpy(t.wcos, wcos.data(), wcos.size() * sizeof(double), hipMemcpyHostToDevice));
   NEEDLE_HIP_TRY(hipMemcpy(t.class_bins, bins.data(), bins.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   NEEDLE_HIP_TRY(hipMemcpy(t.class_start, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   NEEDLE_HIP_TRY(hipMemcpy(t.thr, &thr, sizeof(thr), hipMemcpyHostToDevice));
@@ -169,7 +176,7 @@ template <int CH>
 __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__restrict__ pcm,
                                                              const FpStream *__restrict__ streams, int num_streams,
                                                              const cd *__restrict__ tw,
-                                                             const double *__restrict__ window,
+                                                             const double *__restrict__ wcos, core::WindowConst wconst,
                                                              const uint16_t *__restrict__ bin_slot,
                                                              const uint32_t *__restrict__ class_start,
                                                              double *__restrict__ chroma, uint32_t total_pairs,
@@ -216,10 +223,10 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   };
   using reg_t = int;  // one 16-bit sample sign-extended by the load, or one packed L|R pair
   reg_t ra[16], rb[16];
-  double wv[16];
-  // PCM of both frames and the window row of this thread: issued one pair ahead, while the previous pair's powers
-  // are still being produced (the spectrum registers are dead by then).  The window is re-read per pair on
-  // purpose: kept in registers across the transform it would not fit (spills to scratch).
+  // PCM of both frames: issued one pair ahead, while the previous pair's powers are still being produced (the
+  // spectrum registers are dead by then).  The window comes from a recurrence (fp_core.h window_step), seeded per
+  // thread with cos(theta (t - 256)) and cos(theta t).
+  const double wseed_prev = wcos[t], wseed = wcos[t + 256];
   auto issue_loads = [&](const PairSrc &p) {
     const raw_t *qa = reinterpret_cast<const raw_t *>(p.a), *qb = reinterpret_cast<const raw_t *>(p.b);
     // an opaque copy of the thread index keeps these loads (and their addresses) in the loop; laundering the
@@ -232,8 +239,6 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
       ra[k] = (reg_t)qa[tt + 256 * k];
       rb[k] = (reg_t)qb[tt + 256 * k];
     }
-#pragma unroll
-    for (int k = 0; k < 16; k++) wv[k] = window[tt + 256 * k];
   };
   // The pitch-class fold of a pair runs one pair late, between the next pair's sample conversion and its first
   // butterflies: the LDS reads are issued, the conversion hides their latency, then 8 lanes per class add up.
@@ -269,6 +274,8 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     asm volatile("" : "+v"(tt));
     if (g != first) fold_issue();
     cd r[16];
+    double wc = wseed, wc_prev = wseed_prev;
+    asm volatile("" : "+v"(wc), "+v"(wc_prev));  // per pair: the 16 window values are not kept across the loop
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       int sa, sb;
@@ -279,7 +286,8 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
         sa = ((int)(int16_t)ra[k] + (ra[k] >> 16)) / 2;
         sb = ((int)(int16_t)rb[k] + (rb[k] >> 16)) / 2;
       }
-      r[k] = cd{(double)sa * wv[k], (double)sb * wv[k]};
+      const double w = core::window_step(wconst, &wc, &wc_prev);
+      r[k] = cd{(double)sa * w, (double)sb * w};
     }
     if (!cur.has_b) {  // odd frame count: the stream's last pair has no frame B (uniform branch)
 #pragma unroll
@@ -460,7 +468,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
         const uint32_t grid = (uint32_t)((pairs + ppb - 1) / ppb);
         auto launch = [&](auto kernel) {
           hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm,
-                             ws->streams.ptr, n, tab.tw, tab.window, tab.bin_slot, tab.class_start, ws->chroma.ptr,
+                             ws->streams.ptr, n, tab.tw, tab.wcos, tab.wconst, tab.bin_slot, tab.class_start, ws->chroma.ptr,
                              (uint32_t)pairs, ppb);
         };
         if (channels == 1) launch(stft_chroma_kernel<1>); else launch(stft_chroma_kernel<2>);

@@ -154,6 +154,25 @@ NEEDLE_HD void dif2_publish(int t, cd *lds, const cd *r) {
   for (int j = 10; j < 16; j++) lds[pidx(16 * t + j)] = r[out16(j)];
 }
 
+// ---- Hamming window by recurrence -------------------------------------------------------------------------------
+// chromaprint's window is w[n] = (0.54 - 0.46 cos(theta n)) / 32767, theta = 2 pi / 4095.  A thread needs it at
+// n = t + 256 k, k = 0..15: cos(theta (t + 256 (k + 1))) = 2 cos(256 theta) cos(theta (t + 256 k)) -
+// cos(theta (t + 256 (k - 1))), one fused multiply-add per step from two per-thread starting values, and one more
+// for A - B cos: two instructions per sample instead of an 8-byte load per sample from a 32 KB table that every
+// workgroup re-read for every frame pair (measured: 6 % of the kernel).  Over 16 steps the recurrence stays
+// within 8e-15 (relative) of the table values.
+struct WindowConst {
+  double k2;    // 2 cos(256 theta)
+  double a, b;  // w = a - b cos(theta n); both carry kPairInputScale / 32767
+};
+NEEDLE_HD double window_step(const WindowConst &wc, double *c, double *c_prev) {
+  const double w = __builtin_fma(-wc.b, *c, wc.a);
+  const double next = __builtin_fma(wc.k2, *c, -*c_prev);
+  *c_prev = *c;
+  *c = next;
+  return w;
+}
+
 // The transform's inputs carry this factor (it is folded into the window table), so that the split of Z into the
 // two real spectra needs no halving: X_A = (Z[k] + conj Z[N-k]) / 2, X_B = (Z[k] - conj Z[N-k]) / 2i.  A power of
 // two, so every intermediate is the unscaled one times 2^-1 exactly and the powers are bit-identical.

@@ -15,7 +15,8 @@ using namespace needle::core;
 namespace {
 struct Tables {
   std::vector<cd> tw;
-  std::vector<double> window;
+  std::vector<double> wcos;  // recurrence seeds, as the kernel's table
+  WindowConst wconst;
   std::vector<uint16_t> class_bins;
   uint32_t class_start[13];
   std::vector<uint16_t> bin_pos;  // bin - kMinBin -> position in the class-sorted list
@@ -39,8 +40,12 @@ const Tables &tables() {
     long double a = -2.0L * 3.14159265358979323846264338327950288L * k / 4096.0L;
     t.tw[k] = cd{(double)cosl(a), (double)sinl(a)};
   }
-  t.window.resize(4096);
-  for (int i = 0; i < 4096; i++) t.window[i] = kPairInputScale * ((1.0 / 32767.0) * (0.54 - 0.46 * std::cos(i * 2.0 * M_PI / 4095)));
+  const long double theta = 2.0L * 3.14159265358979323846264338327950288L / 4095.0L;
+  t.wcos.resize(512);
+  for (int i = 0; i < 512; i++) t.wcos[i] = (double)cosl(theta * (long double)(i - 256));
+  t.wconst.k2 = (double)(2.0L * cosl(256.0L * theta));
+  t.wconst.a = kPairInputScale * (0.54 / 32767.0);
+  t.wconst.b = kPairInputScale * (0.46 / 32767.0);
   std::vector<std::vector<uint16_t>> by(12);
   for (int i = kMinBin; i < kMaxBin; i++) {
     double freq = (double)i * 11025 / 4096;
@@ -75,11 +80,14 @@ void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, do
     if (channels == 1) return src[n];
     return ((int)src[2 * n] + (int)src[2 * n + 1]) / 2;
   };
-  for (int t = 0; t < 256; t++)
+  for (int t = 0; t < 256; t++) {
+    double c = T.wcos[t + 256], c_prev = T.wcos[t];
     for (int k = 0; k < 16; k++) {
       const int n = t + 256 * k;
-      regs[t * 16 + k] = cd{(double)sample(fa, n) * T.window[n], (double)sample(fb, n) * T.window[n]};
+      const double w = window_step(T.wconst, &c, &c_prev);
+      regs[t * 16 + k] = cd{(double)sample(fa, n) * w, (double)sample(fb, n) * w};
     }
+  }
   for (int t = 0; t < 256; t++) dif0(t, T.tw[t], lds.data(), &regs[t * 16]);
   // stage 1 -> stage 2 -> publish run group by group (16 consecutive lanes), the other groups still untouched:
   // this is the order the kernel is allowed to take without a workgroup barrier between these phases

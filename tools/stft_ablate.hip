@@ -1,5 +1,4 @@
-// Diagnostic (not part of the product): the loop of stft_chroma_kernel (fingerprint.hip, as of the 4-barrier
-// version with the fold at the end of the pair) with pieces switched off,
+// Diagnostic (not part of the product): the loop of stft_chroma_kernel (fingerprint.hip) with pieces switched off,
 // to see what each piece costs at the product's launch shape.  Outputs are wrong by construction; only times count.
 //   bit 0: window from a constant instead of the table      bit 1: no PCM loads
 //   bit 2: no pitch-class fold (power store, fold, 2 barriers)  bit 3: no stream lookup (pointer arithmetic only)
@@ -56,11 +55,12 @@ __global__ __launch_bounds__(256, 2) void kernel(const int16_t *__restrict__ pcm
 #pragma unroll
   for (int j = 0; j < 6; j++) {
     const int kf = core::dif_bin_of(t, j);
-    const uint32_t idx = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : 0xffffu;
+    const uint32_t idx = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : core::kPowerTrashSlot;
     slot_pk[j >> 1] = (j & 1) ? (slot_pk[j >> 1] | (idx << 16)) : idx;
   }
-  const bool folds = t < 192;
-  const int fold_which = (t >> 3) >= kBands ? 1 : 0, fold_c = (t >> 3) - fold_which * kBands, fold_l = t & 7;
+  if (t == 0) lds[core::kPowerZeroSlot] = cd{0.0, 0.0};
+  const bool folds = t < kBands * core::kClassLanes;
+  const int fold_c = t >> 4, fold_l = t & 15;
   const uint32_t fold_bounds = folds ? (class_start[fold_c] | (class_start[fold_c + 1] << 16)) : 0;
   auto locate = [&](uint32_t g) {
     PairSrc p;
@@ -88,57 +88,67 @@ __global__ __launch_bounds__(256, 2) void kernel(const int16_t *__restrict__ pcm
       else { ra[k] = p.a[tt + 256 * k]; rb[k] = p.b[tt + 256 * k]; }
     }
 #pragma unroll
-    for (int k = 0; k < 16; k++) wv[k] = window[tt + 256 * k];
+    for (int k = 0; k < 16; k++) {
+      if (F & 1) { wv[k] = 3.0e-5; asm volatile("" : "+v"(wv[k])); } else wv[k] = window[tt + 256 * k];
+    }
   };
-  PairSrc cur = locate(first);
+  cd fv[core::kClassLaneMax];
+  auto fold_issue = [&]() {
+    if (folds) {
+      uint32_t fb = fold_bounds;
+      asm volatile("" : "+v"(fb));
+      core::class_lane_load(lds, (int)(fb & 0xffffu), (int)(fb >> 16), fold_l, fv);
+    }
+  };
+  auto fold_finish = [&](const PairSrc &p) {
+    if (folds) {
+      cd acc = core::class_lane_add(fv);
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) acc = cd{acc.x + __shfl_xor(acc.x, off, 16), acc.y + __shfl_xor(acc.y, off, 16)};
+      if (fold_l == 0) {
+        chroma[p.row * kBands + fold_c] = acc.x;
+        if (p.has_b) chroma[(p.row + 1) * kBands + fold_c] = acc.y;
+      }
+    }
+  };
+  PairSrc cur = locate(first), prev = cur;
   issue_loads(cur);
   for (uint32_t g = first; g < last; g++) {
     int tt = t;
     asm volatile("" : "+v"(tt));
+    if (!(F & 4) && g != first) fold_issue();
     cd r[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      double w;
-      if (F & 1) { w = 3.0e-5; asm volatile("" : "+v"(w)); } else w = wv[k];
-      r[k] = cd{(double)ra[k] * w, (double)rb[k] * (w * cur.keep_b)};
-    }
-    core::dif0(tt, base0, lds, r);
+    for (int k = 0; k < 16; k++) r[k] = cd{(double)ra[k] * wv[k], (double)rb[k] * wv[k]};
+    if (!(F & 4) && g != first) fold_finish(prev);
+    core::fft16(r);
+    lds_barrier();
+    core::dif0_store(tt, base0, lds, r);
     lds_barrier();
     core::dif1(tt, base1, lds, r);
     wave_lds_fence();
     core::dif2(tt, lds, r);
     core::dif2_publish(tt, lds, r);
     lds_barrier();
-    double *plds = reinterpret_cast<double *>(lds);
     double keep = 0;
 #pragma unroll
     for (int j = 0; j < core::kBinsPerThread; j++) {
       const uint32_t idx = (slot_pk[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-      if (idx != 0xffffu) {
-        double pa, pb; int kf;
-        core::dif_bin_power(tt, j, lds, r, &kf, &pa, &pb);
-        if (F & 4) keep += pa + pb;
-        else { plds[idx] = pa; plds[idx + core::dif_power_index(core::kPowerFrameB)] = pb; }
-      }
+      double pa, pb;
+      core::dif_bin_power_any(tt, j, lds, r, &pa, &pb);
+      if (F & 4) keep += pa + pb;
+      else lds[idx] = cd{pa, pb};
     }
     const PairSrc nxt = locate(min(g + 1, last - 1));
     issue_loads(nxt);
-    if (F & 4) {
-      if (keep == 1.2345) chroma[cur.row] = keep;
-      lds_barrier();
-    } else {
-      lds_barrier();
-      if (folds) {
-        double fv[core::kClassLaneMax];
-        core::class_lane_load(plds, fold_which * core::kPowerFrameB, (int)(fold_bounds & 0xffffu), (int)(fold_bounds >> 16), fold_l, fv);
-        double acc = core::class_lane_add(fv);
-#pragma unroll
-        for (int off = 4; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 8);
-        if (fold_l == 0 && (fold_which == 0 || cur.has_b)) chroma[(cur.row + fold_which) * kBands + fold_c] = acc;
-      }
-      lds_barrier();
-    }
+    if ((F & 4) && keep == 1.2345) chroma[cur.row] = keep;
+    lds_barrier();
+    prev = cur;
     cur = nxt;
+  }
+  if (!(F & 4)) {
+    fold_issue();
+    fold_finish(prev);
   }
 }
 
@@ -153,7 +163,7 @@ int main(int argc, char **argv) {
   std::vector<cd> tw(4096); std::vector<double> win(4096);
   for (int k = 0; k < 4096; k++) { tw[k] = cd{std::cos(-2 * M_PI * k / 4096), std::sin(-2 * M_PI * k / 4096)}; win[k] = (0.54 - 0.46 * std::cos(2 * M_PI * k / 4095)) / 32767; }
   std::vector<uint16_t> slot(core::kNumBins); std::vector<uint32_t> cs(13);
-  for (int i = 0; i < core::kNumBins; i++) slot[i] = (uint16_t)core::dif_power_index(i);
+  for (int i = 0; i < core::kNumBins; i++) slot[i] = (uint16_t)core::dif_power_slot(i);
   for (int c = 0; c <= 12; c++) cs[c] = c * 108;
   cs[12] = core::kNumBins;
   int16_t *d_pcm; Stream *d_st; cd *d_tw; double *d_win, *d_chroma; uint16_t *d_slot; uint32_t *d_cs;
