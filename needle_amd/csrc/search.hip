@@ -482,6 +482,7 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
       bands_per_wave = 1;
       if (sampled)
         while (bands_per_wave < 8 && total_bands / (4 * (uint64_t)bands_per_wave * 2) >= 16384) bands_per_wave *= 2;
+      if (const char *e = getenv("NEEDLE_HIP_BANDS_PER_WAVE")) bands_per_wave = std::max(1, atoi(e));  // tests, tuning
       for (SearchProblem &m : meta) {
         m.block_base = (uint32_t)fb;
         const uint64_t diags = (uint64_t)m.n + m.m - 3;

@@ -771,3 +771,34 @@ def test_two_simulated_ranks_on_one_device_equal_single_library(n, world):
     # a rank can also hand out the FrameHashes of a video another rank fingerprinted (rows arrived by the gather)
     assert libs[0].frame_hashes(n - 1).opening_data()[0].tolist() == [h for h, _ in O.analyze_batch(
         [eps[n - 1].pcm[: lens[n - 1] // 2]], 1, hd)[0].opening]
+
+
+@pytest.mark.parametrize("bands_per_wave", [1, 2, 3, 8])
+def test_sampled_kernel_on_sustained_hashes_and_multi_band_workgroups(bands_per_wave, monkeypatch):
+    """Hashes that repeat for a few frames, as sustained notes produce, give short chance runs on many diagonals:
+    windows survive the early-out far more often than on random hashes and candidates that fail the length test
+    get resolved.  Checked against the oracle's table-free scan for every pair of 14 sequences, with one band
+    per wave (small launches) and several (large launches: one workgroup walks many bands of its pair)."""
+    monkeypatch.setenv("NEEDLE_HIP_BANDS_PER_WAVE", str(bands_per_wave))
+    rng = np.random.default_rng(100 + bands_per_wave)
+    palette = rng.integers(0, 2 ** 32, 40, dtype=np.uint64).astype(np.uint32)     # few distinct "notes"
+    seqs = []
+    for v in range(14):
+        n = int(rng.integers(900, 2400))
+        notes = rng.integers(0, len(palette), n // 3 + 2)
+        h = np.repeat(palette[notes], rng.integers(1, 7, len(notes)))[:n].copy()
+        h ^= (np.uint32(1) << rng.integers(0, 32, n).astype(np.uint32)) * (rng.random(n) < 0.8)   # a flipped bit or none
+        seqs.append(h)
+    shared = seqs[0][100:400].copy()
+    for v in range(1, 14, 2):
+        a = 50 + 37 * v
+        seqs[v][a:a + 300] = shared
+    min_len = 30
+    problems = [(i, j, min_len) for i in range(14) for j in range(i + 1, 14)]
+    got = _gpu_runs(seqs, problems, 10)
+    total, runs = O.diagonal_runs_all_pairs(seqs, 10, min_len, threads=4, capacity=200000)
+    assert total == len(runs) and total > 20
+    want = {}
+    for p, a, b, L in runs.tolist():
+        want.setdefault(p, []).append((a, b, L))
+    assert {p: sorted((a, b, L) for a, b, L, _, _ in v) for p, v in got.items()} == {p: sorted(v) for p, v in want.items()}
