@@ -390,7 +390,9 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
       geo.region_slots = (d->n * d->M + 4 * d->G + 4 + 3) / 4;
     }
     const int rows_per_wave = d->n >= 64 ? 1 : 64 / d->n;
-    const bool rows_in_lds = row_mode || d->M % 4 == 0;
+    // (very long filters, from rates far above 100 kHz: the per-wave row scratch would not fit; coefficients then
+    // come straight from global memory)
+    const bool rows_in_lds = (row_mode || d->M % 4 == 0) && (size_t)(kThreads / 64) * (d->n >= 64 ? 1 : 64 / d->n) * d->G * 16 <= 48 * 1024;
     // M % 4 == 0: a tile's first tap is a fixed number of samples past a multiple of 4; the region starts at that
     // multiple, so rows can be staged by aligned groups of four samples
     const bool vec4 = d->M % 4 == 0;
@@ -417,11 +419,11 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
                          (int)meta.size(), coef4, geo, d_out);
     };
     if (channels == 1) {
-      if (vec4) launch(resample_kernel<1, true, true>);
+      if (vec4 && rows_in_lds) launch(resample_kernel<1, true, true>);
       else if (rows_in_lds) launch(resample_kernel<1, true, false>);
       else launch(resample_kernel<1, false, false>);
     } else {
-      if (vec4) launch(resample_kernel<2, true, true>);
+      if (vec4 && rows_in_lds) launch(resample_kernel<2, true, true>);
       else if (rows_in_lds) launch(resample_kernel<2, true, false>);
       else launch(resample_kernel<2, false, false>);
     }
