@@ -419,7 +419,8 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
   FpWorkspace *ws = workspace();
 
   // Streams are processed in chunks so the f64 chroma/feature workspaces stay bounded (96 B/frame each).
-  const uint64_t kMaxFramesPerChunk = 8u << 20;
+  uint64_t kMaxFramesPerChunk = 8u << 20;  // workspace bound: 8 M frames = 0.8 GB of chroma + as much of features
+  if (const char *e = getenv("NEEDLE_HIP_MAX_FRAMES_PER_CHUNK")) kMaxFramesPerChunk = (uint64_t)std::max(1, atoi(e));  // tests
   size_t begin = 0;
   while (begin < spans.size()) {
     std::vector<FpStream> meta;

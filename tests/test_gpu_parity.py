@@ -803,3 +803,17 @@ def test_sampled_kernel_on_sustained_hashes_and_multi_band_workgroups(bands_per_
     for p, a, b, L in runs.tolist():
         want.setdefault(p, []).append((a, b, L))
     assert {p: sorted((a, b, L) for a, b, L, _, _ in v) for p, v in got.items()} == {p: sorted(v) for p, v in want.items()}
+
+
+def test_fingerprint_batch_split_into_chunks_equals_one_launch(lib3, monkeypatch):
+    """Huge batches are fingerprinted in chunks that reuse the workspaces and the descriptor buffer; with the chunk
+    bound forced down to a few hundred frames the same ragged batch must give the same items."""
+    pcms = [lib3[0].pcm[: 20 * 11025], lib3[1].pcm[: 3 * 11025 + 1], np.zeros(10, np.int16), lib3[2].pcm[: 31 * 11025],
+            lib3[1].pcm[: 9 * 11025], lib3[0].pcm[: 4096 + 19 * 1365]]
+    whole = capi.fingerprint(pcms, step=2)
+    for bound in ("1", "100", "300"):                      # 1: every stream its own chunk
+        monkeypatch.setenv("NEEDLE_HIP_MAX_FRAMES_PER_CHUNK", bound)
+        split = capi.fingerprint(pcms, step=2)
+        assert [s.tolist() for s in split] == [w.tolist() for w in whole]
+    monkeypatch.delenv("NEEDLE_HIP_MAX_FRAMES_PER_CHUNK")
+    assert whole[0].tolist() == O.fingerprint(pcms[0])[::2].tolist()
