@@ -817,3 +817,15 @@ def test_fingerprint_batch_split_into_chunks_equals_one_launch(lib3, monkeypatch
         assert [s.tolist() for s in split] == [w.tolist() for w in whole]
     monkeypatch.delenv("NEEDLE_HIP_MAX_FRAMES_PER_CHUNK")
     assert whole[0].tolist() == O.fingerprint(pcms[0])[::2].tolist()
+
+
+def test_run_list_larger_than_the_first_buffer():
+    """More than 65 536 runs in one call: the host entry point sizes its buffer from the count and scans again.
+    Threshold 40 makes every cell match, so each diagonal of each of 140 problems is one run."""
+    rng = np.random.default_rng(12)
+    seqs = [_rand_hashes(rng, 300), _rand_hashes(rng, 260)]
+    problems = [(0, 1, 1)] * 140
+    got = _gpu_runs(seqs, problems, 40)
+    want = _oracle_runs(seqs[0], seqs[1], 40, 1)
+    assert len(want) == 300 + 260 - 3 and 140 * len(want) > 65536
+    assert len(got) == 140 and all(got[p] == want for p in range(140))
