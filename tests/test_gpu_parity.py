@@ -829,3 +829,35 @@ def test_run_list_larger_than_the_first_buffer():
     want = _oracle_runs(seqs[0], seqs[1], 40, 1)
     assert len(want) == 300 + 260 - 3 and 140 * len(want) > 65536
     assert len(got) == 140 and all(got[p] == want for p in range(140))
+
+
+def test_device_resident_fingerprint_entry_point(lib3):
+    """needle_hip_fingerprint_device: PCM already in HBM (offsets in s16 values), kept items written to a device
+    buffer at caller-chosen offsets -- the entry point a decoder that writes into device memory would use."""
+    import ctypes as C
+    L = capi.lib()
+    pcms = [np.ascontiguousarray(lib3[0].pcm[: 9 * 11025]), np.ascontiguousarray(lib3[2].pcm[: 6 * 11025 + 3])]
+    offs = [0, (len(pcms[0]) + 7) & ~7]
+    total = offs[1] + len(pcms[1])
+    d_pcm = capi.DeviceBuffer(total * 2)
+    for p, o in zip(pcms, offs):
+        capi.check(L.needle_hip_memcpy_h2d(d_pcm.ptr + 2 * o, p.ctypes.data, p.nbytes))
+    step = 2
+    kept = [L.needle_hip_fingerprint_num_kept(len(p), step) for p in pcms]
+    item_offs = [5, 5 + kept[0] + 11]                       # gaps on purpose
+    d_items = capi.DeviceBuffer(4 * (item_offs[1] + kept[1] + 3))
+    u64 = C.c_uint64 * 2
+    capi.check(L.needle_hip_fingerprint_device(d_pcm.ptr, u64(*offs), u64(*[len(p) for p in pcms]), 2, 1, step,
+                                               d_items.ptr, u64(*item_offs), True))
+    items = d_items.to_host(np.uint32, item_offs[1] + kept[1] + 3)
+    for p, o, k in zip(pcms, item_offs, kept):
+        assert items[o:o + k].tolist() == O.fingerprint(p)[::step].tolist()
+
+
+def test_pair_too_long_for_lds_is_an_error_not_a_crash():
+    rng = np.random.default_rng(3)
+    seqs = [_rand_hashes(rng, 50), _rand_hashes(rng, 45000)]
+    with pytest.raises(capi.NeedleError) as ei:
+        capi.hamming_runs(seqs, [(0, 1, 82)], 10)
+    assert ei.value.name == "InvalidArgument"
+    assert "LDS" in str(ei.value)
