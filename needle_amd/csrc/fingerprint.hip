@@ -512,7 +512,8 @@ Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::
   const size_t n = pcm.size();
   items->assign(n, {});
   // Batches bounded by bytes so the device arena stays modest for huge libraries.
-  const uint64_t kMaxBatchValues = 1ull << 30;  // 2 GiB of s16
+  uint64_t kMaxBatchValues = 1ull << 30;  // 2 GiB of s16
+  if (const char *e = getenv("NEEDLE_HIP_MAX_BATCH_VALUES")) kMaxBatchValues = (uint64_t)std::max(1ll, atoll(e));  // tests
   hipStream_t stream = library_stream();
   size_t begin = 0;
   while (begin < n) {

@@ -817,6 +817,11 @@ def test_fingerprint_batch_split_into_chunks_equals_one_launch(lib3, monkeypatch
         assert [s.tolist() for s in split] == [w.tolist() for w in whole]
     monkeypatch.delenv("NEEDLE_HIP_MAX_FRAMES_PER_CHUNK")
     assert whole[0].tolist() == O.fingerprint(pcms[0])[::2].tolist()
+    # and the host entry point's upload batches (2 GiB of PCM each by default), also through the resampler
+    for bound in ("1", "250000"):
+        monkeypatch.setenv("NEEDLE_HIP_MAX_BATCH_VALUES", bound)
+        assert [s.tolist() for s in capi.fingerprint(pcms, step=2)] == [w.tolist() for w in whole]
+    monkeypatch.delenv("NEEDLE_HIP_MAX_BATCH_VALUES")
 
 
 def test_run_list_larger_than_the_first_buffer():
