@@ -866,3 +866,30 @@ def test_pair_too_long_for_lds_is_an_error_not_a_crash():
         capi.hamming_runs(seqs, [(0, 1, 82)], 10)
     assert ei.value.name == "InvalidArgument"
     assert "LDS" in str(ei.value)
+
+
+def test_concurrent_callers_get_their_own_results(lib3):
+    """Several host threads inside the library at once (ctypes releases the GIL): the shared per-device workspaces
+    and staging buffers are serialised by the library, so every caller gets what it would get alone."""
+    import threading
+    rng = np.random.default_rng(4)
+    jobs = []
+    for k in range(6):
+        pcm = lib3[k % 3].pcm[k * 11025: (k + 9) * 11025]
+        src, dst = _rand_hashes(rng, 300 + 40 * k), _rand_hashes(rng, 500)
+        dst[30:130] = src[20:120]
+        jobs.append((pcm, src, dst))
+    want = [(capi.fingerprint([p])[0].tolist(), _gpu_runs([s, d], [(0, 1, 25)], 10)) for p, s, d in jobs]
+    got = [None] * len(jobs)
+
+    def work(i):
+        p, s, d = jobs[i]
+        for _ in range(5):
+            got[i] = (capi.fingerprint([p])[0].tolist(), _gpu_runs([s, d], [(0, 1, 25)], 10))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert got == want
