@@ -342,8 +342,8 @@ Status wav_read(const std::string &path, WavData *out) {
   auto u32 = [&](size_t o) { uint32_t v; std::memcpy(&v, buf.data() + o, 4); return v; };
   auto u16 = [&](size_t o) { uint16_t v; std::memcpy(&v, buf.data() + o, 2); return v; };
   if (buf.size() < 12 || buf.compare(0, 4, "RIFF") != 0 || buf.compare(8, 4, "WAVE") != 0)
-    return Status::Make(NeedleError_Unknown, "unsupported media (only RIFF/WAVE PCM s16 is decoded here; "
-                                             "FFmpeg decode is outside this build): " + path);
+    return Status::Make(NeedleError_Unknown, "unsupported media (only RIFF/WAVE PCM is read here; FFmpeg decode is "
+                                             "outside this build): " + path);
   size_t off = 12;
   bool have_fmt = false;
   int format = 0, bits = 0;
@@ -360,12 +360,44 @@ Status wav_read(const std::string &path, WavData *out) {
       have_fmt = true;
     } else if (id == "data") {
       if (!have_fmt) break;
-      if (format != 1 || bits != 16 || out->channels < 1 || out->channels > 2)
-        return Status::Make(NeedleError_Unknown, "unsupported WAV encoding (need PCM s16, 1-2 channels): " + path);
+      const bool integer = format == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32);
+      const bool floating = format == 3 && (bits == 32 || bits == 64);
+      if ((!integer && !floating) || out->channels < 1 || out->channels > 2)
+        return Status::Make(NeedleError_Unknown,
+                            "unsupported WAV encoding (need PCM 8/16/24/32-bit or IEEE float, 1-2 channels): " + path);
       const size_t avail = std::min(len, buf.size() - body);
-      const size_t values = avail / 2;
+      const size_t width = (size_t)bits / 8;
+      const size_t values = avail / width;
       out->pcm.resize(values - values % (size_t)out->channels);
-      std::memcpy(out->pcm.data(), buf.data() + body, out->pcm.size() * 2);
+      const unsigned char *p = reinterpret_cast<const unsigned char *>(buf.data()) + body;
+      // to s16 the way the reference's resampler does when it is asked for AV_SAMPLE_FMT_S16 (analyzer.rs:180-187;
+      // swresample's sample-format conversions): integers keep their top 16 bits, u8 is re-centred, floats are
+      // scaled by 2^15, rounded to nearest and clipped
+      for (size_t i = 0; i < out->pcm.size(); i++, p += width) {
+        int16_t v;
+        if (integer && bits == 16) {
+          std::memcpy(&v, p, 2);
+        } else if (integer && bits == 8) {
+          v = (int16_t)(((int)p[0] - 0x80) << 8);
+        } else if (integer && bits == 24) {
+          v = (int16_t)((uint16_t)p[1] | ((uint16_t)p[2] << 8));
+        } else if (integer) {
+          v = (int16_t)((uint16_t)p[2] | ((uint16_t)p[3] << 8));
+        } else {
+          double x;
+          if (bits == 32) {
+            float f32;
+            std::memcpy(&f32, p, 4);
+            x = (double)std::nearbyintf(f32 * 32768.0f);
+          } else {
+            double f64;
+            std::memcpy(&f64, p, 8);
+            x = std::nearbyint(f64 * 32768.0);
+          }
+          v = (int16_t)(x != x ? 0.0 : std::min(32767.0, std::max(-32768.0, x)));
+        }
+        out->pcm[i] = v;
+      }
       return Status::Ok();
     }
     off = body + len + (len & 1);

@@ -893,3 +893,42 @@ def test_concurrent_callers_get_their_own_results(lib3):
     for t in threads:
         t.join()
     assert got == want
+
+
+def test_wav_sample_formats_reach_the_same_hashes(tmp_path):
+    """The WAV reader converts 8/24/32-bit integer and float PCM to s16 the way the reference's resampler output
+    format does (top 16 bits; floats scaled by 2^15, rounded, clipped): analysing such a file equals analysing the
+    s16 stream that rule gives."""
+    e = synth.make_episode(5, 40.0, 12.0)
+    pcm = e.pcm[: 30 * 11025]
+
+    def write(path, fmt, bits, payload):
+        with open(path, "wb") as f:
+            n = len(payload)
+            f.write(b"RIFF" + (36 + n).to_bytes(4, "little") + b"WAVE")
+            f.write(b"fmt " + (16).to_bytes(4, "little") + fmt.to_bytes(2, "little") + (1).to_bytes(2, "little")
+                    + (11025).to_bytes(4, "little") + (11025 * bits // 8).to_bytes(4, "little")
+                    + (bits // 8).to_bytes(2, "little") + bits.to_bytes(2, "little"))
+            f.write(b"data" + n.to_bytes(4, "little") + payload)
+
+    rng = np.random.default_rng(8)
+    x = pcm.astype(np.int64)
+    s24 = (x << 8) + rng.integers(0, 256, len(x))                 # low byte is dropped by the reader
+    s32 = (x << 16) + rng.integers(0, 65536, len(x))
+    u8 = ((x >> 8) + 128).astype(np.uint8)
+    flt = (pcm.astype(np.float32) / np.float32(32768.0))
+    cases = {
+        "s24": (1, 24, b"".join(int(v).to_bytes(3, "little", signed=True) for v in s24[:40000]), pcm[:40000]),
+        "s32": (1, 32, s32.astype("<i4").tobytes(), pcm),
+        "u8": (1, 8, u8.tobytes(), (((u8.astype(np.int32) - 128) << 8)).astype(np.int16)),
+        "f32": (3, 32, flt.astype("<f4").tobytes(), pcm),
+        "f64": (3, 64, (pcm.astype(np.float64) * 1.7 / 32768.0).astype("<f8").tobytes(),
+                np.clip(np.rint(pcm.astype(np.float64) * 1.7), -32768, 32767).astype(np.int16)),
+    }
+    hd = O.duration_from_secs_f32(0.3)
+    for name, (fmt, bits, payload, expect) in cases.items():
+        p = str(tmp_path / f"{name}.wav")
+        write(p, fmt, bits, payload)
+        fh = capi.Analyzer.from_files([p]).run(0.3)[0]
+        want = O.analyze_batch([expect[: len(expect) // 2]], 1, hd)[0]
+        assert fh.opening_data()[0].tolist() == [h for h, _ in want.opening], name
