@@ -103,8 +103,8 @@ bool is_valid_media_file(const std::string &path, bool full) {
   f.read(head, 12);
   if (f.gcount() != 12 || std::memcmp(head, "RIFF", 4) != 0 || std::memcmp(head + 8, "WAVE", 4) != 0) return false;
   if (!full) return true;
-  WavData w;
-  return wav_read(path, &w).ok();
+  WavInfo w;  // `full`: the header has to describe an encoding this build decodes (util.rs:33-49 opens the demuxer)
+  return wav_probe(path, &w).ok();
 }
 
 void fill_result(const VideoResult &v, NeedleHipSearchResult *r) {

@@ -3,6 +3,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -94,7 +95,16 @@ struct WavData {
   int sample_rate = 0;
   std::vector<int16_t> pcm;  // interleaved
 };
-Status wav_read(const std::string &path, WavData *out);
+Status wav_read(const std::string &path, WavData *out);  // the whole data chunk
+struct WavInfo {
+  int channels = 0, sample_rate = 0;
+  int format = 0, bits = 0;  // 1 = integer PCM, 3 = IEEE float
+  uint64_t data_offset = 0;  // byte offset of the first sample in the file
+  uint64_t frames = 0;       // samples per channel in the data chunk
+};
+Status wav_probe(const std::string &path, WavInfo *out);  // reads chunk headers only
+// frames [first, first+count) as interleaved s16 (count * channels values)
+Status wav_read_frames(const std::string &path, const WavInfo &info, uint64_t first, uint64_t count, int16_t *dst);
 
 // ---- GPU entry points used by the host classes (fingerprint.hip / search.hip) ----------------------------
 struct StreamSpan {
@@ -110,6 +120,21 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
 Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
                             int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items,
                             int rate = kSampleRate);
+// Same with the PCM produced by `read` (stream index, first value, value count -> interleaved s16 at dst, which is
+// pinned host memory): up to `readers` threads call it concurrently for different segments while earlier segments
+// are on their way to the device.  Host memory stays a fixed ring of slabs whatever the streams' lengths.
+using PcmReader = std::function<Status(size_t stream, uint64_t first_value, uint64_t num_values, int16_t *dst)>;
+// The upload alone (hipctx.hip): stream i goes to d_pcm + dev_off[i] (offsets in values, multiples of 8).  On
+// return the copies have executed.
+Status gpu_upload_pcm_streamed(const std::vector<size_t> &num_values, const std::vector<uint64_t> &dev_off,
+                               const PcmReader &read, unsigned readers, int16_t *d_pcm);
+// Same from host pointers; enqueues plain asynchronous copies when the total is small (then nothing has executed
+// on return, as with hipMemcpyAsync).
+Status gpu_upload_pcm(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
+                      const std::vector<uint64_t> &dev_off, int16_t *d_pcm);
+Status gpu_fingerprint_streamed(const std::vector<size_t> &num_values, const PcmReader &read, unsigned readers,
+                                int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items,
+                                int rate = kSampleRate);
 Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
                                const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
                                NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync);

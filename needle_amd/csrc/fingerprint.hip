@@ -14,6 +14,10 @@
 #include "hipctx.h"
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -500,8 +504,33 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
   return Status::Ok();
 }
 
-Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
-                            int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items, int rate) {
+namespace {
+
+// Per device, kept for the life of the process like the other workspaces (never destroyed: HIP may already be
+// gone when static destructors run).  The arenas grow to the largest batch seen (at most 2 GiB of PCM).
+struct HostEntryWorkspace {
+  DeviceBuffer<int16_t> d_pcm, d_mono;
+  DeviceBuffer<uint32_t> d_items;
+};
+
+HostEntryWorkspace *host_entry_workspace() {
+  static std::mutex mu;
+  static std::map<int, HostEntryWorkspace *> all;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  HostEntryWorkspace *&w = all[dev];
+  if (!w) w = new HostEntryWorkspace();
+  return w;
+}
+
+// Plans device batches over the streams, has `upload` put each batch's PCM at in_off[] of the device arena, runs
+// (resampler +) fingerprinter and scatters the kept items.
+using BatchUpload = std::function<Status(size_t begin, size_t end, const std::vector<uint64_t> &in_off, int16_t *d_pcm,
+                                         hipStream_t stream)>;
+
+Status fingerprint_in_batches(const std::vector<size_t> &num_values, int channels, uint32_t step,
+                              std::vector<std::vector<uint32_t>> *items, int rate, const BatchUpload &upload) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   Status s = ensure_device();
   if (!s.ok()) return s;
@@ -509,12 +538,15 @@ Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::
     return Status::Make(NeedleError_InvalidArgument, "fingerprint: channels must be 1 or 2");
   if (step == 0) return Status::Make(NeedleError_InvalidArgument, "fingerprint: step must be >= 1");
   const bool resample = rate != kSampleRate;
-  const size_t n = pcm.size();
+  const size_t n = num_values.size();
   items->assign(n, {});
   // Batches bounded by bytes so the device arena stays modest for huge libraries.
   uint64_t kMaxBatchValues = 1ull << 30;  // 2 GiB of s16
   if (const char *e = getenv("NEEDLE_HIP_MAX_BATCH_VALUES")) kMaxBatchValues = (uint64_t)std::max(1ll, atoll(e));  // tests
   hipStream_t stream = library_stream();
+  HostEntryWorkspace *ws = host_entry_workspace();  // grow-only arenas, guarded by gpu_mutex()
+  DeviceBuffer<int16_t> &d_pcm = ws->d_pcm, &d_mono = ws->d_mono;
+  DeviceBuffer<uint32_t> &d_items = ws->d_items;
   size_t begin = 0;
   while (begin < n) {
     std::vector<StreamSpan> spans;        // what the fingerprinter reads (11025 Hz; mono if resampled)
@@ -538,14 +570,21 @@ Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::
       kept += num_kept(out_samples, step);
       end++;
     }
-    DeviceBuffer<int16_t> d_pcm, d_mono;
-    DeviceBuffer<uint32_t> d_items;
+    const bool trace = getenv("NEEDLE_HIP_TRACE") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+      if (!trace) return;
+      (void)hipStreamSynchronize(stream);
+      const auto now = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[needle_hip] fingerprint_host %s: %.2f ms\n", what,
+                   std::chrono::duration<double, std::milli>(now - t0).count());
+      t0 = now;
+    };
     if (!(s = d_pcm.reserve(std::max<uint64_t>(values, 1))).ok()) return s;
     if (!(s = d_items.reserve(std::max<uint64_t>(kept, 1))).ok()) return s;
-    for (size_t i = begin; i < end; i++)
-      if (num_values[i])
-        NEEDLE_HIP_TRY(hipMemcpyAsync(d_pcm.ptr + in_off[i - begin], pcm[i], num_values[i] * sizeof(int16_t),
-                                      hipMemcpyHostToDevice, stream));
+    lap("device allocations");
+    if (!(s = upload(begin, end, in_off, d_pcm.ptr, stream)).ok()) return s;
+    lap("upload");
     if (resample) {  // decode-rate PCM -> mono 11025 Hz, on the device, then straight into the fingerprinter
       if (!(s = d_mono.reserve(std::max<uint64_t>(mono, 1))).ok()) return s;
       s = gpu_resample_device(d_pcm.ptr, rspans, channels, rate, d_mono.ptr, false);
@@ -555,6 +594,7 @@ Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::
       s = gpu_fingerprint_device(d_pcm.ptr, spans, channels, step, d_items.ptr, false);
     }
     if (!s.ok()) return s;
+    lap("kernels");
     std::vector<uint32_t> host(std::max<uint64_t>(kept, 1));
     NEEDLE_HIP_TRY(hipMemcpyAsync(host.data(), d_items.ptr, kept * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
@@ -563,9 +603,37 @@ Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::
       const size_t k = num_kept(resample ? resample_out_len(in_samples, rate) : in_samples, step);
       (*items)[i].assign(host.begin() + spans[i - begin].item_off, host.begin() + spans[i - begin].item_off + k);
     }
+    lap("download + scatter");
     begin = end;
   }
   return Status::Ok();
+}
+
+}  // namespace
+
+Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
+                            int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items, int rate) {
+  if (pcm.size() != num_values.size())
+    return Status::Make(NeedleError_InvalidArgument, "fingerprint: one length per stream is required");
+  return fingerprint_in_batches(
+      num_values, channels, step, items, rate,
+      [&](size_t begin, size_t end, const std::vector<uint64_t> &in_off, int16_t *d_pcm, hipStream_t) -> Status {
+        return gpu_upload_pcm(std::vector<const int16_t *>(pcm.begin() + begin, pcm.begin() + end),
+                              std::vector<size_t>(num_values.begin() + begin, num_values.begin() + end), in_off, d_pcm);
+      });
+}
+
+Status gpu_fingerprint_streamed(const std::vector<size_t> &num_values, const PcmReader &read, unsigned readers,
+                                int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items, int rate) {
+  return fingerprint_in_batches(
+      num_values, channels, step, items, rate,
+      [&](size_t begin, size_t end, const std::vector<uint64_t> &in_off, int16_t *d_pcm, hipStream_t) -> Status {
+        const PcmReader shifted = [&](size_t stream, uint64_t first, uint64_t count, int16_t *dst) {
+          return read(begin + stream, first, count, dst);
+        };
+        return gpu_upload_pcm_streamed(std::vector<size_t>(num_values.begin() + begin, num_values.begin() + end), in_off,
+                                       shifted, readers, d_pcm);
+      });
 }
 
 }  // namespace needle

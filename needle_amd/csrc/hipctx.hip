@@ -1,7 +1,13 @@
 #include "hipctx.h"
 
+#include <algorithm>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
 #include <mutex>
+#include <thread>
 
 namespace needle {
 
@@ -101,6 +107,204 @@ double kernel_ms(const std::string &name) {
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, t.start[idx], t.stop[idx]) != hipSuccess) return -1.0;
   return (double)ms;
+}
+
+namespace {
+
+// ---- PCM upload from a reader through a ring of pinned slabs ------------------------------------------------------
+// What the file analyzer uses: reader threads fill slabs (pread straight into pinned memory), this thread issues
+// one H2D copy per slab in segment order and hands slabs back when their copy has executed.  Host memory is the ring
+// (kSlabs x slab bytes) whatever the size of the library, nothing is allocated or freed per run, and reading,
+// sample-format conversion and the PCIe copy overlap.
+struct Segment {
+  size_t stream;
+  uint64_t first, count;  // values of the stream
+  uint64_t dev_off;       // values into the device arena
+};
+
+struct SlabRing {
+  static constexpr size_t kSlabs = 16;
+  char *base = nullptr;
+  size_t slab_bytes = 0;
+  hipEvent_t done[kSlabs] = {};
+  Status ensure(size_t bytes) {
+    if (bytes > slab_bytes) {
+      if (base) (void)hipHostFree(base);
+      base = nullptr;
+      slab_bytes = 0;
+      NEEDLE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&base), bytes * kSlabs, hipHostMallocDefault));
+      slab_bytes = bytes;
+    }
+    for (hipEvent_t &e : done)
+      if (!e) NEEDLE_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return Status::Ok();
+  }
+  int16_t *slab(size_t seg) const { return reinterpret_cast<int16_t *>(base + (seg % kSlabs) * slab_bytes); }
+};
+
+SlabRing *slab_ring() {  // per device, never destroyed (HIP may be gone when static destructors run)
+  static std::mutex mu;
+  static std::map<int, SlabRing *> all;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  SlabRing *&r = all[dev];
+  if (!r) r = new SlabRing();
+  return r;
+}
+
+size_t upload_slab_bytes() {
+  size_t v = 8u << 20;
+  if (const char *e = getenv("NEEDLE_HIP_UPLOAD_SLAB_BYTES")) v = (size_t)std::max(16ll, atoll(e));  // tests: tiny slabs
+  return (v + 15) & ~(size_t)15;
+}
+
+Status upload_through_ring(const std::vector<Segment> &segs, const PcmReader &read, unsigned readers, int16_t *d_pcm,
+                           hipStream_t stream) {
+  SlabRing &ring = *slab_ring();  // guarded by gpu_mutex(), which the callers hold
+  constexpr size_t K = SlabRing::kSlabs;
+  const size_t N = segs.size();
+  if (N == 0) return Status::Ok();
+  Status s = ring.ensure(upload_slab_bytes());
+  if (!s.ok()) return s;
+
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<uint8_t> filled(N, 0);  // 1 = slab holds the segment, 2 = the reader failed
+  size_t released = K;                // segments below this index may write their slab
+  size_t next = 0;
+  bool abort = false;
+  Status failure;
+  auto reader = [&]() {
+    for (;;) {
+      size_t seg;
+      {
+        std::unique_lock<std::mutex> lock(mu);
+        seg = next++;
+        if (seg >= N) return;
+        cv.wait(lock, [&] { return abort || seg < released; });
+        if (abort) return;
+      }
+      Status rs = read(segs[seg].stream, segs[seg].first, segs[seg].count, ring.slab(seg));
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        filled[seg] = rs.ok() ? 1 : 2;
+        if (!rs.ok() && failure.ok()) failure = rs;
+      }
+      cv.notify_all();
+    }
+  };
+  readers = (unsigned)std::max<size_t>(1, std::min<size_t>({readers, N, K}));
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < readers; t++) pool.emplace_back(reader);
+
+  size_t completed = 0;  // copies known to have executed, in segment order
+  auto retire = [&](size_t upto, bool wait) {  // hands slabs of finished copies back to the readers
+    bool moved = false;
+    while (completed < upto) {
+      hipEvent_t e = ring.done[completed % K];
+      if (wait) {
+        if (hipEventSynchronize(e) != hipSuccess) break;
+      } else if (hipEventQuery(e) != hipSuccess) {
+        break;
+      }
+      completed++;
+      moved = true;
+    }
+    if (moved) {
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        released = completed + K;
+      }
+      cv.notify_all();
+    }
+  };
+  Status result;
+  size_t issued = 0;
+  for (; issued < N; issued++) {
+    retire(issued, false);
+    if (issued - completed >= K / 2) retire(issued - K / 2 + 1, true);  // keep half the ring for the readers
+    uint8_t state;
+    {
+      std::unique_lock<std::mutex> lock(mu);
+      cv.wait(lock, [&] { return filled[issued] != 0; });
+      state = filled[issued];
+    }
+    if (state != 1) {
+      result = failure;
+      break;
+    }
+    const Segment &g = segs[issued];
+    hipError_t e = hipMemcpyAsync(d_pcm + g.dev_off, ring.slab(issued), g.count * sizeof(int16_t),
+                                  hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipEventRecord(ring.done[issued % K], stream);
+    if (e != hipSuccess) {
+      result = Status::Make(NeedleError_Unknown, std::string("PCM upload failed: ") + hipGetErrorString(e));
+      break;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    abort = !result.ok();
+    if (abort) next = N;
+  }
+  cv.notify_all();
+  // the ring is reused by the next call: every copy out of it has to be over before this one returns
+  const hipError_t e = hipStreamSynchronize(stream);
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    released = N + K;
+  }
+  cv.notify_all();
+  for (std::thread &t : pool) t.join();
+  if (result.ok() && e != hipSuccess)
+    result = Status::Make(NeedleError_Unknown, std::string("PCM upload failed: ") + hipGetErrorString(e));
+  return result;
+}
+
+
+}  // namespace
+
+Status gpu_upload_pcm_streamed(const std::vector<size_t> &num_values, const std::vector<uint64_t> &dev_off,
+                               const PcmReader &read, unsigned readers, int16_t *d_pcm) {
+  std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
+  Status s = ensure_device();
+  if (!s.ok()) return s;
+  const uint64_t slab_values = upload_slab_bytes() / sizeof(int16_t);
+  std::vector<Segment> segs;
+  for (size_t i = 0; i < num_values.size(); i++)
+    for (uint64_t at = 0; at < num_values[i]; at += slab_values)
+      segs.push_back(Segment{i, at, std::min<uint64_t>(slab_values, num_values[i] - at), dev_off[i] + at});
+  return upload_through_ring(segs, read, readers, d_pcm, library_stream());
+}
+
+// PCM that already sits in (pageable) host memory: small uploads go as plain asynchronous copies, large ones
+// through the ring with a few threads doing the copy into pinned memory -- the runtime's own staging of a
+// pageable source reaches about half the PCIe rate.
+Status gpu_upload_pcm(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
+                      const std::vector<uint64_t> &dev_off, int16_t *d_pcm) {
+  std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
+  Status s = ensure_device();
+  if (!s.ok()) return s;
+  uint64_t total = 0;
+  for (size_t v : num_values) total += v;
+  size_t threshold = 16u << 20;
+  if (const char *e = getenv("NEEDLE_HIP_RING_UPLOAD_MIN_BYTES")) threshold = (size_t)std::max(0ll, atoll(e));
+  if (total * sizeof(int16_t) < threshold) {
+    hipStream_t stream = library_stream();
+    for (size_t i = 0; i < pcm.size(); i++)
+      if (num_values[i])
+        NEEDLE_HIP_TRY(hipMemcpyAsync(d_pcm + dev_off[i], pcm[i], num_values[i] * sizeof(int16_t),
+                                      hipMemcpyHostToDevice, stream));
+    return Status::Ok();
+  }
+  const PcmReader read = [&](size_t stream, uint64_t first, uint64_t count, int16_t *dst) {
+    std::memcpy(dst, pcm[stream] + first, count * sizeof(int16_t));
+    return Status::Ok();
+  };
+  unsigned threads = std::min(usable_cpus(), 16u);
+  if (const char *e = getenv("NEEDLE_HIP_UPLOAD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
+  return gpu_upload_pcm_streamed(num_values, dev_off, read, threads, d_pcm);
 }
 
 }  // namespace needle

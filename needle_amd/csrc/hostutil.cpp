@@ -1,6 +1,7 @@
 // Host-side helpers of the needle path: std::time::Duration semantics, the bincode image of
 // FrameHashes (needle/src/audio/data.rs), header MD5 (needle/src/util.rs:99-105), serde_json-style f32
 // text, the step/timestamp rule of analyzer.rs:288-323 and a minimal RIFF/WAVE reader.
+#include <cerrno>
 #include <charconv>
 #include <cmath>
 #include <cstdio>
@@ -9,7 +10,10 @@
 
 #include "common.h"
 
+#include <fcntl.h>
 #include <sched.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -334,75 +338,140 @@ Status frame_hashes_read(const std::string &path, FrameHashesData *out) {
   return Status::Ok();
 }
 
-// ---- RIFF/WAVE PCM s16 --------------------------------------------------------------------------------------------
-Status wav_read(const std::string &path, WavData *out) {
-  std::ifstream f(path, std::ios::binary);
-  if (!f) return Status::Make(NeedleError_IOError, "IO error: cannot open " + path);
-  std::string buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-  auto u32 = [&](size_t o) { uint32_t v; std::memcpy(&v, buf.data() + o, 4); return v; };
-  auto u16 = [&](size_t o) { uint16_t v; std::memcpy(&v, buf.data() + o, 2); return v; };
-  if (buf.size() < 12 || buf.compare(0, 4, "RIFF") != 0 || buf.compare(8, 4, "WAVE") != 0)
+// ---- RIFF/WAVE -----------------------------------------------------------------------------------------------------
+// The header walk reads chunk headers only, and samples are read by byte range, so a library of long files costs
+// the bytes of its search windows and nothing else (the reference likewise stops decoding at the end of the opening
+// window and seeks to the ending window, analyzer.rs:231-282,384-402).
+namespace {
+
+struct Fd {
+  int fd = -1;
+  explicit Fd(const std::string &path) : fd(::open(path.c_str(), O_RDONLY | O_CLOEXEC)) {}
+  ~Fd() { if (fd >= 0) ::close(fd); }
+  Fd(const Fd &) = delete;
+  Fd &operator=(const Fd &) = delete;
+  // all of [off, off+len) or as much as the file holds
+  size_t read_at(void *dst, size_t len, uint64_t off) const {
+    size_t done = 0;
+    while (done < len) {
+      const ssize_t r = ::pread(fd, (char *)dst + done, len - done, (off_t)(off + done));
+      if (r < 0 && errno == EINTR) continue;
+      if (r <= 0) break;
+      done += (size_t)r;
+    }
+    return done;
+  }
+};
+
+// to s16 the way the reference's resampler does when it is asked for AV_SAMPLE_FMT_S16 (analyzer.rs:180-187;
+// swresample's sample-format conversions): integers keep their top 16 bits, u8 is re-centred, floats are
+// scaled by 2^15, rounded to nearest and clipped
+void wav_convert(const unsigned char *p, int format, int bits, size_t values, int16_t *dst) {
+  const size_t width = (size_t)bits / 8;
+  if (format == 1 && bits == 16) {
+    std::memcpy(dst, p, values * 2);
+  } else if (format == 1 && bits == 8) {
+    for (size_t i = 0; i < values; i++) dst[i] = (int16_t)(((int)p[i] - 0x80) << 8);
+  } else if (format == 1) {  // 24 / 32 bit: the two most significant bytes
+    p += width - 2;
+    for (size_t i = 0; i < values; i++, p += width) dst[i] = (int16_t)((uint16_t)p[0] | ((uint16_t)p[1] << 8));
+  } else {
+    for (size_t i = 0; i < values; i++, p += width) {
+      double x;
+      if (bits == 32) {
+        float f32;
+        std::memcpy(&f32, p, 4);
+        x = (double)std::nearbyintf(f32 * 32768.0f);
+      } else {
+        double f64;
+        std::memcpy(&f64, p, 8);
+        x = std::nearbyint(f64 * 32768.0);
+      }
+      dst[i] = (int16_t)(x != x ? 0.0 : std::min(32767.0, std::max(-32768.0, x)));
+    }
+  }
+}
+
+}  // namespace
+
+Status wav_probe(const std::string &path, WavInfo *out) {
+  const Fd f(path);
+  if (f.fd < 0) return Status::Make(NeedleError_IOError, "IO error: cannot open " + path);
+  struct stat st;
+  if (::fstat(f.fd, &st) != 0) return Status::Make(NeedleError_IOError, "IO error: cannot stat " + path);
+  const uint64_t size = (uint64_t)st.st_size;
+  unsigned char head[12];
+  if (f.read_at(head, 12, 0) != 12 || std::memcmp(head, "RIFF", 4) != 0 || std::memcmp(head + 8, "WAVE", 4) != 0)
     return Status::Make(NeedleError_Unknown, "unsupported media (only RIFF/WAVE PCM is read here; FFmpeg decode is "
                                              "outside this build): " + path);
-  size_t off = 12;
+  auto u32 = [](const unsigned char *p) { uint32_t v; std::memcpy(&v, p, 4); return v; };
+  auto u16 = [](const unsigned char *p) { uint16_t v; std::memcpy(&v, p, 2); return v; };
+  uint64_t off = 12;
   bool have_fmt = false;
-  int format = 0, bits = 0;
-  while (off + 8 <= buf.size()) {
-    const std::string id = buf.substr(off, 4);
-    const size_t len = u32(off + 4);
-    const size_t body = off + 8;
-    if (id == "fmt " && body + 16 <= buf.size()) {
-      format = u16(body);
-      out->channels = u16(body + 2);
-      out->sample_rate = (int)u32(body + 4);
-      bits = u16(body + 14);
-      if (format == 0xFFFE && len >= 26) format = u16(body + 24);  // WAVE_FORMAT_EXTENSIBLE sub-format
+  *out = WavInfo{};
+  while (off + 8 <= size) {
+    unsigned char ch[8];
+    if (f.read_at(ch, 8, off) != 8) break;
+    const uint64_t len = u32(ch + 4), body = off + 8;
+    if (std::memcmp(ch, "fmt ", 4) == 0 && body + 16 <= size) {
+      unsigned char fmt[40] = {0};
+      f.read_at(fmt, (size_t)std::min<uint64_t>({len, sizeof(fmt), size - body}), body);
+      out->format = u16(fmt);
+      out->channels = u16(fmt + 2);
+      out->sample_rate = (int)u32(fmt + 4);
+      out->bits = u16(fmt + 14);
+      if (out->format == 0xFFFE && len >= 26) out->format = u16(fmt + 24);  // WAVE_FORMAT_EXTENSIBLE sub-format
       have_fmt = true;
-    } else if (id == "data") {
+    } else if (std::memcmp(ch, "data", 4) == 0) {
       if (!have_fmt) break;
-      const bool integer = format == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32);
-      const bool floating = format == 3 && (bits == 32 || bits == 64);
+      const bool integer = out->format == 1 && (out->bits == 8 || out->bits == 16 || out->bits == 24 || out->bits == 32);
+      const bool floating = out->format == 3 && (out->bits == 32 || out->bits == 64);
       if ((!integer && !floating) || out->channels < 1 || out->channels > 2)
         return Status::Make(NeedleError_Unknown,
                             "unsupported WAV encoding (need PCM 8/16/24/32-bit or IEEE float, 1-2 channels): " + path);
-      const size_t avail = std::min(len, buf.size() - body);
-      const size_t width = (size_t)bits / 8;
-      const size_t values = avail / width;
-      out->pcm.resize(values - values % (size_t)out->channels);
-      const unsigned char *p = reinterpret_cast<const unsigned char *>(buf.data()) + body;
-      // to s16 the way the reference's resampler does when it is asked for AV_SAMPLE_FMT_S16 (analyzer.rs:180-187;
-      // swresample's sample-format conversions): integers keep their top 16 bits, u8 is re-centred, floats are
-      // scaled by 2^15, rounded to nearest and clipped
-      for (size_t i = 0; i < out->pcm.size(); i++, p += width) {
-        int16_t v;
-        if (integer && bits == 16) {
-          std::memcpy(&v, p, 2);
-        } else if (integer && bits == 8) {
-          v = (int16_t)(((int)p[0] - 0x80) << 8);
-        } else if (integer && bits == 24) {
-          v = (int16_t)((uint16_t)p[1] | ((uint16_t)p[2] << 8));
-        } else if (integer) {
-          v = (int16_t)((uint16_t)p[2] | ((uint16_t)p[3] << 8));
-        } else {
-          double x;
-          if (bits == 32) {
-            float f32;
-            std::memcpy(&f32, p, 4);
-            x = (double)std::nearbyintf(f32 * 32768.0f);
-          } else {
-            double f64;
-            std::memcpy(&f64, p, 8);
-            x = std::nearbyint(f64 * 32768.0);
-          }
-          v = (int16_t)(x != x ? 0.0 : std::min(32767.0, std::max(-32768.0, x)));
-        }
-        out->pcm[i] = v;
-      }
+      const uint64_t avail = std::min(len, size - body);  // a truncated file ends the data chunk early
+      out->data_offset = body;
+      out->frames = avail / ((uint64_t)out->bits / 8) / (uint64_t)out->channels;
       return Status::Ok();
     }
     off = body + len + (len & 1);
   }
   return Status::Make(NeedleError_Unknown, "malformed WAV (no fmt/data chunk): " + path);
+}
+
+Status wav_read_frames(const std::string &path, const WavInfo &info, uint64_t first, uint64_t count, int16_t *dst) {
+  if (first > info.frames || count > info.frames - first)
+    return Status::Make(NeedleError_InvalidArgument, "WAV frame range outside the data chunk: " + path);
+  if (count == 0) return Status::Ok();
+  const Fd f(path);
+  if (f.fd < 0) return Status::Make(NeedleError_IOError, "IO error: cannot open " + path);
+  const size_t width = (size_t)info.bits / 8, frame_bytes = width * (size_t)info.channels;
+  const uint64_t at = info.data_offset + first * frame_bytes;
+  if (info.format == 1 && info.bits == 16) {  // already s16: straight into the destination
+    if (f.read_at(dst, count * frame_bytes, at) != count * frame_bytes)
+      return Status::Make(NeedleError_IOError, "IO error: short read from " + path);
+    return Status::Ok();
+  }
+  const uint64_t block = (1u << 20) / frame_bytes * frame_bytes;  // ~1 MiB of source per conversion pass
+  std::vector<unsigned char> buf((size_t)std::min<uint64_t>(block, count * frame_bytes));
+  for (uint64_t done = 0; done < count * frame_bytes;) {
+    const size_t n = (size_t)std::min<uint64_t>(block, count * frame_bytes - done);
+    if (f.read_at(buf.data(), n, at + done) != n)
+      return Status::Make(NeedleError_IOError, "IO error: short read from " + path);
+    wav_convert(buf.data(), info.format, info.bits, n / width, dst + done / width);
+    done += n;
+  }
+  return Status::Ok();
+}
+
+Status wav_read(const std::string &path, WavData *out) {
+  WavInfo info;
+  Status s = wav_probe(path, &info);
+  if (!s.ok()) return s;
+  out->channels = info.channels;
+  out->sample_rate = info.sample_rate;
+  out->pcm.resize((size_t)info.frames * (size_t)info.channels);
+  return wav_read_frames(path, info, 0, info.frames, out->pcm.data());
 }
 
 unsigned usable_cpus() {

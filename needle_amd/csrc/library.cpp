@@ -177,15 +177,19 @@ enum NeedleError needle_hip_library_set_pcm(NeedleHipLibrary *lib, const int16_t
     lib->arena = lib->d_arena.ptr;
     if (hipMemsetAsync(lib->arena, 0, lib->rows() * lib->stride * sizeof(uint32_t), stream) != hipSuccess)
       return report(Status::Make(NeedleError_Unknown, "hipMemset failed"));
+    std::vector<const int16_t *> src;
+    std::vector<size_t> len;
+    std::vector<uint64_t> dst;
     for (size_t v = 0; v < lib->n; v++) {
       for (size_t r = 0; r < R; r++) {
         const Window &w = lib->win[v * R + r];
         if (!pcm[v] || !w.values) continue;
-        if (hipMemcpyAsync(lib->d_pcm.ptr + w.pcm_off, pcm[v] + first_sample[v * R + r] * (size_t)channels,
-                           w.values * sizeof(int16_t), hipMemcpyHostToDevice, stream) != hipSuccess)
-          return report(Status::Make(NeedleError_Unknown, "PCM upload failed"));
+        src.push_back(pcm[v] + first_sample[v * R + r] * (size_t)channels);
+        len.push_back(w.values);
+        dst.push_back(w.pcm_off);
       }
     }
+    if (!(s = gpu_upload_pcm(src, len, dst, lib->d_pcm.ptr)).ok()) return report(s);
     if (hipStreamSynchronize(stream) != hipSuccess) return report(Status::Make(NeedleError_Unknown, "PCM upload failed"));
     lib->have_pcm = true;
     lib->min_len.clear();

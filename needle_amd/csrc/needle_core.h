@@ -41,9 +41,10 @@ class Analyzer {
   Analyzer &with_threaded_decoding(bool v) { threaded_decoding_ = v; return *this; }                   // :142
   Analyzer &with_force(bool v) { force_ = v; return *this; }                                           // :148
 
-  // Analyzer::run (:425): every video is a RIFF/WAVE file here (decode is out of scope); all videos
-  // that need analysis go to the GPU as one batch.  `threading` is accepted for API parity — the
-  // batch is already data-parallel on the device.
+  // Analyzer::run (:425): every video is a RIFF/WAVE file here (decode is out of scope).  Only the search
+  // windows are read from each file, streamed to the GPU through a fixed ring of pinned slabs, one device
+  // pass per distinct (channel count, sample rate).  `threading` threads the file reads (the fingerprint
+  // batch is data-parallel on the device either way).
   Status run(ns_t hash_duration, bool persist, bool threading, std::vector<FrameHashesData> *out) const;
 
   // Same, with FFmpeg's half of process_frames (:180-284) done by the caller.
@@ -57,6 +58,9 @@ class Analyzer {
 
  private:
   friend class Comparator;
+  struct WindowPcm;
+  Status fingerprint_windows(const std::vector<WindowPcm> &win, int channels, int sample_rate, uint32_t step,
+                             ns_t hash_duration, std::vector<FrameHashesData> *out) const;
   std::vector<std::string> videos_;
   float opening_search_percentage_ = DEFAULT_OPENING_SEARCH_PERCENTAGE;
   float ending_search_percentage_ = DEFAULT_ENDING_SEARCH_PERCENTAGE;

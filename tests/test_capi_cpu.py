@@ -127,6 +127,23 @@ def test_find_video_files(tmp_path):
         assert got == [str(d / "a.wav"), str(d / "b.wav"), str(single)]
         L.needle_util_video_files_free(videos, n)
     L.needle_util_video_files_free(None, 0)
+    # `full` looks at the WAV header only: an encoding this build cannot decode (A-law) is dropped, and a
+    # 3 GB (sparse) file costs a few header reads, not a pass over its samples
+    alaw = bytearray(open(str(single), "rb").read()[:4096])
+    alaw[20:22] = (6).to_bytes(2, "little")
+    (d / "c-alaw.wav").write_bytes(bytes(alaw))
+    big = d / "d-big.wav"
+    hdr = bytearray(open(str(single), "rb").read()[:44])
+    hdr[40:44] = (0xFFFFFFFF).to_bytes(4, "little")
+    big.write_bytes(bytes(hdr))
+    os.truncate(str(big), 3 << 30)
+    import time
+    for full, want in ((False, ["a.wav", "b.wav", "c-alaw.wav", "d-big.wav"]), (True, ["a.wav", "b.wav", "d-big.wav"])):
+        t0 = time.perf_counter()
+        assert L.needle_util_find_video_files(ptr, 1, full, True, C.byref(videos), C.byref(n)) == 0
+        assert time.perf_counter() - t0 < 1.0
+        assert [videos[i].decode() for i in range(n.value)] == [str(d / w) for w in want]
+        L.needle_util_video_files_free(videos, n)
     assert L.needle_util_find_video_files(ptr, 0, False, True, C.byref(videos), C.byref(n)) == 3
     assert L.needle_util_find_video_files(None, 1, False, True, C.byref(videos), C.byref(n)) == 2
     missing, k2 = _cpaths([str(tmp_path / "nope")])

@@ -932,3 +932,101 @@ def test_wav_sample_formats_reach_the_same_hashes(tmp_path):
         fh = capi.Analyzer.from_files([p]).run(0.3)[0]
         want = O.analyze_batch([expect[: len(expect) // 2]], 1, hd)[0]
         assert fh.opening_data()[0].tolist() == [h for h, _ in want.opening], name
+
+
+def test_file_analyzer_mixed_library_bounded_batches_and_threads(tmp_path, monkeypatch):
+    """Analyzer::run over files of different channel counts, sample rates and encodings in ONE call: only the
+    search windows are read from each file, by reader threads, into a ring of pinned slabs that feeds the device, one
+    pass per distinct (channels, rate).  Every video must come out as if analysed alone from its whole
+    PCM (run_pcm, itself pinned to the oracle above), whatever the batch size and reader count; one resampled
+    stereo file is also checked against the oracle chain directly, opening and ending."""
+    lib = synth.make_library(6, 50.0, 12.0)
+    spec = [(1, 11025), (2, 44100), (1, 11025), (1, 48000), (2, 11025), (2, 44100)]
+    paths, streams = [], []
+    for k, (ch, rate) in enumerate(spec):
+        x = lib[k].pcm
+        if rate != 11025:
+            m = {44100: 4, 48000: 5}[rate]                      # zero-order hold then a 2-tap smoother: any content will do
+            x = np.repeat(x, m)[: len(x) * m - 7 * k]
+            x = ((x.astype(np.int32) + np.roll(x, 1)) // 2).astype(np.int16)
+        inter = x if ch == 1 else np.stack([x, np.roll(x, 3)], axis=1).reshape(-1).astype(np.int16)
+        p = str(tmp_path / f"ep-{k}.wav")
+        with open(p, "wb") as f:                                  # junk chunk before fmt, odd-sized chunk before data
+            body = (b"LIST" + (5).to_bytes(4, "little") + b"hello\0"
+                    + b"fmt " + (16).to_bytes(4, "little") + (1).to_bytes(2, "little") + ch.to_bytes(2, "little")
+                    + rate.to_bytes(4, "little") + (rate * ch * 2).to_bytes(4, "little")
+                    + (ch * 2).to_bytes(2, "little") + (16).to_bytes(2, "little")
+                    + b"data" + (inter.nbytes).to_bytes(4, "little") + inter.astype("<i2").tobytes())
+            f.write(b"RIFF" + (4 + len(body)).to_bytes(4, "little") + b"WAVE" + body)
+        paths.append(p)
+        streams.append(inter)
+
+    def alone(k):
+        ch, rate = spec[k]
+        a = capi.Analyzer.from_files([paths[k]]).with_include_endings(True)
+        return a.run_pcm([streams[k]], channels=ch, sample_rate=rate)[0]
+
+    want = [alone(k) for k in range(len(spec))]
+
+    def same(got):
+        for k, (g, w) in enumerate(zip(got, want)):
+            for part in ("opening_data", "ending_data"):
+                gh, gt = getattr(g, part)()
+                wh, wt = getattr(w, part)()
+                assert gh.tolist() == wh.tolist() and gt.tolist() == wt.tolist(), (k, part)
+            assert g.md5() == O.header_md5(paths[k])
+
+    # slab size of the upload ring (default 8 MiB; 4 KiB = hundreds of segments per window, many trips round the
+    # ring; 48 bytes = stereo frames split across slabs as finely as alignment allows), device batch size, readers
+    for slab, batch, threading in [(None, None, True), ("4096", None, True), ("4096", "300000", False),
+                                   ("48", "1", True)]:
+        for name, v in (("NEEDLE_HIP_UPLOAD_SLAB_BYTES", slab), ("NEEDLE_HIP_MAX_BATCH_VALUES", batch)):
+            if v is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, v)
+        if slab == "48":   # keep the finest split affordable: three short files
+            sub = [0, 1, 4]
+            got = capi.Analyzer.from_files([paths[k] for k in sub]).with_include_endings(True).run(0.3, threading=threading)
+            for g, k in zip(got, sub):
+                assert g.opening_data()[0].tolist() == want[k].opening_data()[0].tolist()
+                assert g.ending_data()[1].tolist() == want[k].ending_data()[1].tolist()
+            continue
+        same(capi.Analyzer.from_files(paths).with_include_endings(True).run(0.3, threading=threading))
+    monkeypatch.delenv("NEEDLE_HIP_UPLOAD_SLAB_BYTES", raising=False)
+    monkeypatch.delenv("NEEDLE_HIP_MAX_BATCH_VALUES", raising=False)
+
+    # the oracle chain for video 1 (44.1 kHz stereo): windows at the stream's rate, resample, fingerprint, timestamps
+    k, ch, rate = 1, 2, 44100
+    total = len(streams[k]) // ch
+    dur = O.duration_from_secs_f64(total * (1.0 / rate))
+    n_open = O.duration_mul_f32(dur, 0.5) * rate // NS
+    seek = O.duration_mul_f32(dur, 1.0 - 0.25)
+    first = seek * rate // NS
+    hd = O.duration_from_secs_f32(0.3)
+    op = O.step_and_timestamp(O.fingerprint(O.resample(streams[k][: ch * n_open], ch, rate)), hd)
+    en = O.step_and_timestamp(O.fingerprint(O.resample(streams[k][ch * first:], ch, rate)), hd, seek)
+    h, ts = want[k].opening_data()
+    assert h.tolist() == [x for x, _ in op] and ts.tolist() == [t for _, t in op]
+    h, ts = want[k].ending_data()
+    assert h.tolist() == [x for x, _ in en] and ts.tolist() == [t for _, t in en]
+
+
+def test_file_analyzer_truncated_and_unreadable_files(tmp_path):
+    """A data chunk that claims more bytes than the file holds ends at the end of the file (the reader never reads
+    past it); a file that is not RIFF/WAVE is an error, not a crash."""
+    e = synth.make_episode(2, 40.0, 10.0)
+    p = str(tmp_path / "short.wav")
+    synth.write_wav(p, e.pcm)
+    raw = open(p, "rb").read()
+    cut = 44 + 2 * (len(e.pcm) * 3 // 4) + 1                     # ends in the middle of a sample
+    open(p, "wb").write(raw[:cut])
+    fh = capi.Analyzer.from_files([p]).run(0.3)[0]
+    kept = e.pcm[: len(e.pcm) * 3 // 4]
+    want = O.analyze_batch([kept[: O.duration_mul_f32(O.duration_from_secs_f64(len(kept) * (1.0 / 11025.0)), 0.5)
+                                  * 11025 // NS]], 1, O.duration_from_secs_f32(0.3))[0]
+    assert fh.opening_data()[0].tolist() == [h for h, _ in want.opening]
+    bad = str(tmp_path / "bad.wav")
+    open(bad, "wb").write(b"not a wave file at all" * 10)
+    with pytest.raises(capi.NeedleError):
+        capi.Analyzer.from_files([bad]).run(0.3)
