@@ -40,6 +40,17 @@ def algorithmic_bytes(kernel: str, windows, kept, n_pairs: int, n_runs: int) -> 
     return float(sum(2 * s + 4 * h for s, h in zip(windows, kept)))
 
 
+F64_VALU_PEAK_TFLOPS = 78.6    # vector f64 = half the 157.3 TFLOP/s f32 vector rate of MI355X_MICROARCH.md (no faster f64 MFMA)
+
+
+def stft_flops(windows) -> float:
+    """Floating-point work of stft_chroma_kernel that no implementation can skip much of: one 4096-point complex
+    FFT (5 N log2 N) per PAIR of frames (two real frames ride in one complex transform).  Window, un-mixing of the
+    two spectra and |X|^2 add about 15 % and are not counted."""
+    pairs = sum(((max(s - 4096, -1365) // 1365 + 1) + 1) // 2 for s in windows)
+    return pairs * 5.0 * 4096 * 12
+
+
 def usable_cpus() -> int:
     """Host CPUs this process may actually use: its affinity mask, capped by the cgroup CPU quota (a container can
     see every core of the machine and still be throttled to a few CPUs' worth of time; more threads than that
@@ -302,6 +313,12 @@ def main() -> None:
                 traffic = json.load(open(tpath)).get(dominant)
             except Exception:
                 traffic = None
+        compute = None
+        if dominant == "stft_chroma" and avg[dominant] > 0:   # what actually bounds it: f64 issue + LDS exchange latency
+            fl = stft_flops(windows[f0:f0 + c0])
+            tf = fl / (avg[dominant] * 1e-3) / 1e12
+            compute = {"bound": "f64 valu", "achieved": round(tf, 2), "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(tf / F64_VALU_PEAK_TFLOPS, 4), "flops_per_launch": int(fl)}
         out = {
             "metric": "episode-pairs/sec (analyze+search)", "value": round(value, 2), "unit": "episode-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -317,7 +334,7 @@ def main() -> None:
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(abytes),
-                         "avg_launch_ms": round(avg[dominant], 5)},
+                         "avg_launch_ms": round(avg[dominant], 5), "compute": compute},
             "kernel_ms_per_step": {k: round(v, 5) for k, v in avg.items()},
             "host_ms_per_step": ({k: round(v / args.steps, 4) for k, v in host_ms.items()} if not distributed else None),
             "runs_per_step": state["runs"],
