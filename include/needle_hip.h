@@ -44,8 +44,12 @@ void needle_hip_host_free(void *ptr); /* frees arrays this library malloc'd for 
 /* GPU timing of the most recent COMPLETED launch of a kernel (it never waits behind queued work unless no
  * launch has finished yet), measured with HIP events on the
  * library's own stream (rocprofv3 sees the same kernels).  Names: "stft_chroma", "fir_norm",
- * "classify", "hamming_runs".  Returns milliseconds, <0 if unknown. */
+ * "classify", "hamming_runs", "simhash_runs", "resample".  Returns milliseconds, <0 if unknown or not timed. */
 double needle_hip_last_kernel_ms(const char *kernel);
+/* Selects the kernels that get those events: "all", a comma-separated list of names, or NULL / "" / "none".
+ * Default: none (each event record is one more packet between dependent dispatches: timing all five kernels of
+ * a 28 x 24 min job costs 3 % of its time), unless the environment variable NEEDLE_HIP_KERNEL_TIMING is set. */
+void needle_hip_set_kernel_timing(const char *kernels);
 
 /* ---- fingerprint: the chromaprint Context replacement -------------------------------------------
  * Replaces chromaprint::Context::{start,feed,finish,get_fingerprint_raw,get_delay,get_item_duration,

@@ -72,7 +72,7 @@ NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_device_count", "needle_hip_set_device", "needle_hip_synchronize", "needle_hip_stream",
     "needle_hip_last_error_message",
     "needle_hip_version", "needle_hip_malloc", "needle_hip_free", "needle_hip_memcpy_h2d", "needle_hip_memcpy_d2h",
-    "needle_hip_host_free", "needle_hip_last_kernel_ms", "needle_hip_fingerprint_sample_rate",
+    "needle_hip_host_free", "needle_hip_last_kernel_ms", "needle_hip_set_kernel_timing", "needle_hip_fingerprint_sample_rate",
     "needle_hip_fingerprint_delay_ms", "needle_hip_fingerprint_item_duration_ms", "needle_hip_fingerprint_num_items",
     "needle_hip_fingerprint_num_kept", "needle_hip_fingerprint_host", "needle_hip_fingerprint_device",
     "needle_hip_fingerprint_debug", "needle_hip_resample_out_len", "needle_hip_resample_host",
@@ -131,6 +131,8 @@ def lib():
     L.needle_hip_host_free.restype = None
     L.needle_hip_last_kernel_ms.argtypes = [C.c_char_p]
     L.needle_hip_last_kernel_ms.restype = C.c_double
+    L.needle_hip_set_kernel_timing.argtypes = [C.c_char_p]
+    L.needle_hip_set_kernel_timing.restype = None
     L.needle_hip_fingerprint_sample_rate.restype = C.c_int
     L.needle_hip_fingerprint_delay_ms.restype = C.c_int
     L.needle_hip_fingerprint_item_duration_ms.restype = C.c_int
@@ -220,6 +222,11 @@ def stream_ptr() -> int:
 
 def last_kernel_ms(name: str) -> float:
     return lib().needle_hip_last_kernel_ms(name.encode())
+
+
+def set_kernel_timing(kernels: Optional[str]) -> None:
+    """"all", a comma-separated list of kernel names, or None: which launches get HIP timing events."""
+    lib().needle_hip_set_kernel_timing(kernels.encode() if kernels else None)
 
 
 def _paths(paths: Sequence[str]):

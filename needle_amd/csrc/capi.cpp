@@ -386,6 +386,7 @@ enum NeedleError needle_hip_memcpy_d2h(void *host_dst, const void *device_src, s
 void needle_hip_host_free(void *ptr) { std::free(ptr); }
 
 double needle_hip_last_kernel_ms(const char *kernel) { return kernel ? kernel_ms(kernel) : -1.0; }
+void needle_hip_set_kernel_timing(const char *kernels) { set_kernel_timing(kernels); }
 
 // ============================================================================================================
 // fingerprint

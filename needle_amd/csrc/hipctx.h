@@ -107,13 +107,18 @@ struct DescriptorUpload {
   }
 };
 
-// Records start/stop events around a kernel launch on the library stream; elapsed time is read
+// Records start/stop events around a kernel launch on the library stream, for the kernels selected with
+// set_kernel_timing; elapsed time is read
 // lazily (after a sync) by needle_hip_last_kernel_ms.
 struct KernelTimer {
   explicit KernelTimer(const char *name);
   ~KernelTimer();
   const char *name;
+  bool active = false;
 };
 double kernel_ms(const std::string &name);
+// "all", a comma-separated list of kernel names, or NULL / "" / "none" (the default, unless the environment
+// variable NEEDLE_HIP_KERNEL_TIMING says otherwise)
+void set_kernel_timing(const char *kernels);
 
 }  // namespace needle

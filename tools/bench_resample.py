@@ -8,6 +8,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from needle_amd import capi  # noqa: E402
 
+capi.set_kernel_timing("all")
+
 for rate, ch in ((48000, 2), (44100, 2), (48000, 1)):
     n = rate * 720                                   # one 12-minute opening window
     rng = np.random.default_rng(rate)

@@ -13,6 +13,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from needle_amd import capi  # noqa: E402
 
+capi.set_kernel_timing("all")
+
 
 def main():
     ap = argparse.ArgumentParser()
