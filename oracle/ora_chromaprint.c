@@ -80,10 +80,84 @@ typedef struct {
   cpx tw[FFT_N];
   double window[FFT_N];
   signed char notes[FFT_N / 2 + 1];
+  double notes_frac[FFT_N / 2 + 1];
   int min_index, max_index;
 } tables_t;
 
 static tables_t *g_tab;
+
+/* ---- stage functions: each is what the pipeline below runs AND what tests/test_oracle.py checks against
+ * libchromaprint's own unit-test vectors (tests/golden/chromaprint_unit_vectors.json) ------------------ */
+
+/* Chroma::PrepareNotes (chroma.cpp): bins [min_index, max_index) -> pitch class 0..11 counted from A
+ * (27.5 Hz * 2^k), and the position inside the class (used only by the interpolating variant). */
+void ora_chroma_prepare_notes(int min_freq, int max_freq, int frame_size, int sample_rate, signed char *notes,
+                              double *notes_frac, int *min_index, int *max_index) {
+  int lo = (int)round((double)frame_size * min_freq / sample_rate); /* FreqToIndex */
+  int hi = (int)round((double)frame_size * max_freq / sample_rate);
+  *min_index = lo > 1 ? lo : 1;
+  *max_index = hi < frame_size / 2 ? hi : frame_size / 2;
+  for (int i = *min_index; i < *max_index; i++) {
+    double freq = (double)i * sample_rate / frame_size; /* IndexToFreq */
+    double octave = log(freq / (440.0 / 16.0)) / log(2.0); /* FreqToOctave, base = A0 */
+    double note = ORA_NUM_BANDS * (octave - floor(octave));
+    notes[i] = (signed char)note;
+    if (notes_frac) notes_frac[i] = note - notes[i];
+  }
+}
+
+/* Chroma::Consume: energy of every bin added to its class; with `interpolate`, split between the class and
+ * its nearer neighbour (the default fingerprinter uses interpolate = false). */
+void ora_chroma_consume(const signed char *notes, const double *notes_frac, int min_index, int max_index,
+                        int interpolate, const double *frame, double *features) {
+  for (int c = 0; c < ORA_NUM_BANDS; c++) features[c] = 0.0;
+  for (int i = min_index; i < max_index; i++) {
+    int note = notes[i];
+    double energy = frame[i];
+    if (interpolate) {
+      int note2 = note;
+      double a = 1.0;
+      if (notes_frac[i] < 0.5) {
+        note2 = (note + ORA_NUM_BANDS - 1) % ORA_NUM_BANDS;
+        a = 0.5 + notes_frac[i];
+      }
+      if (notes_frac[i] > 0.5) {
+        note2 = (note + 1) % ORA_NUM_BANDS;
+        a = 1.5 - notes_frac[i];
+      }
+      features[note] += energy * a;
+      features[note2] += energy * (1.0 - a);
+    } else {
+      features[note] += energy;
+    }
+  }
+}
+
+/* ChromaFilter::Consume for one output row: rows[0] is the OLDEST of the `taps` buffered rows. */
+void ora_chroma_filter_row(const double *const *rows, const double *coefficients, int taps, int bands, double *out) {
+  for (int c = 0; c < bands; c++) {
+    out[c] = 0.0;
+    for (int j = 0; j < taps; j++) out[c] += rows[j][c] * coefficients[j];
+  }
+}
+
+/* NormalizeVector(begin, end, EuclideanNorm, threshold) of utils.h as ChromaNormalizer calls it. */
+void ora_normalize_vector(double *v, int n, double threshold) {
+  double squares = 0.0;
+  for (int c = 0; c < n; c++) squares += v[c] * v[c];
+  double norm = squares > 0.0 ? sqrt(squares) : 0.0;
+  if (norm < threshold) {
+    for (int c = 0; c < n; c++) v[c] = 0.0;
+  } else {
+    for (int c = 0; c < n; c++) v[c] /= norm;
+  }
+}
+
+/* Quantizer::Quantize */
+int ora_quantize(double value, double t0, double t1, double t2) {
+  if (value < t1) return value < t0 ? 0 : 1;
+  return value < t2 ? 2 : 3;
+}
 
 static const tables_t *tables(void) {
   if (g_tab) return g_tab;
@@ -96,17 +170,8 @@ static const tables_t *tables(void) {
   /* PrepareHammingWindow(first, last, scale = 1/INT16_MAX) */
   for (int i = 0; i < FFT_N; i++)
     t->window[i] = (1.0 / 32767.0) * (0.54 - 0.46 * cos(i * 2.0 * M_PI / (FFT_N - 1)));
-  /* Chroma::PrepareNotes */
-  int lo = (int)round((double)FFT_N * MIN_FREQ / ORA_SAMPLE_RATE);
-  int hi = (int)round((double)FFT_N * MAX_FREQ / ORA_SAMPLE_RATE);
-  t->min_index = lo > 1 ? lo : 1;
-  t->max_index = hi < FFT_N / 2 ? hi : FFT_N / 2;
-  for (int i = t->min_index; i < t->max_index; i++) {
-    double freq = (double)i * ORA_SAMPLE_RATE / FFT_N;
-    double octave = log(freq / (440.0 / 16.0)) / log(2.0);
-    double note = ORA_NUM_BANDS * (octave - floor(octave));
-    t->notes[i] = (signed char)note;
-  }
+  ora_chroma_prepare_notes(MIN_FREQ, MAX_FREQ, FFT_N, ORA_SAMPLE_RATE, t->notes, t->notes_frac, &t->min_index,
+                           &t->max_index);
   g_tab = t;
   return t;
 }
@@ -230,10 +295,7 @@ static double filter_apply(const classifier_t *c, const integral_t *im, size_t x
   return subtract_log(a, b);
 }
 
-static int quantize(const classifier_t *c, double v) {
-  if (v < c->t1) return v < c->t0 ? 0 : 1;
-  return v < c->t2 ? 2 : 3;
-}
+static int quantize(const classifier_t *c, double v) { return ora_quantize(v, c->t0, c->t1, c->t2); }
 
 size_t ora_chromaprint_fingerprint(const int16_t *pcm, size_t num_values, int channels,
                                    uint32_t *items, size_t cap, double *chroma_out,
@@ -287,8 +349,7 @@ size_t ora_chromaprint_fingerprint(const int16_t *pcm, size_t num_values, int ch
       size_t f = f0 + (size_t)which;
       /* Chroma::Consume (interpolate = false) */
       double feat[ORA_NUM_BANDS];
-      for (int c = 0; c < ORA_NUM_BANDS; c++) feat[c] = 0.0;
-      for (int i = t->min_index; i < t->max_index; i++) feat[t->notes[i]] += power[which][i];
+      ora_chroma_consume(t->notes, t->notes_frac, t->min_index, t->max_index, 0, power[which], feat);
       if (chroma_out) memcpy(chroma_out + f * ORA_NUM_BANDS, feat, sizeof(feat));
 
       /* ChromaFilter::Consume */
@@ -300,19 +361,11 @@ size_t ora_chromaprint_fingerprint(const int16_t *pcm, size_t num_values, int ch
       }
       int off = (ring_off + 8 - ORA_FIR_TAPS) % 8;
       double res[ORA_NUM_BANDS];
-      for (int c = 0; c < ORA_NUM_BANDS; c++) {
-        res[c] = 0.0;
-        for (int j = 0; j < ORA_FIR_TAPS; j++) res[c] += ring[(off + j) % 8][c] * kFir[j];
-      }
+      const double *rows[ORA_FIR_TAPS];
+      for (int j = 0; j < ORA_FIR_TAPS; j++) rows[j] = ring[(off + j) % 8];
+      ora_chroma_filter_row(rows, kFir, ORA_FIR_TAPS, ORA_NUM_BANDS, res);
       /* ChromaNormalizer: Euclidean norm, threshold 0.01 */
-      double squares = 0.0;
-      for (int c = 0; c < ORA_NUM_BANDS; c++) squares += res[c] * res[c];
-      double norm = squares > 0.0 ? sqrt(squares) : 0.0;
-      if (norm < 0.01) {
-        for (int c = 0; c < ORA_NUM_BANDS; c++) res[c] = 0.0;
-      } else {
-        for (int c = 0; c < ORA_NUM_BANDS; c++) res[c] /= norm;
-      }
+      ora_normalize_vector(res, ORA_NUM_BANDS, 0.01);
       if (feature_out) memcpy(feature_out + fir_rows * ORA_NUM_BANDS, res, sizeof(res));
       fir_rows++;
 

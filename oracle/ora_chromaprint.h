@@ -13,15 +13,21 @@
  *   hop 1365, power spectrum, 12-class chroma fold over 28..3520 Hz, 5-tap temporal FIR, L2 normalise,
  *   16 Haar-like classifiers on a rolling integral image, 2-bit Gray-coded quantisation -> u32/item.
  *
- * PARITY UNPINNED (analyze stage): the reference holds no usable golden vector for this stage
- * (its only analyzer test is #[ignore]d with a stale snapshot of AAC media nothing here can decode,
- * analyzer.rs:472-480) and neither the Rust crate nor libchromaprint can be built in this image.
- * This file therefore DEFINES the expected hashes; agreement with a real libchromaprint build is
- * untested, except at one point: libchromaprint's own API test on silence (tests/test_api.cpp
- * Test2SilenceFp / Test2SilenceRawFp: three items 627964279) is reproduced
- * (tests/golden/chromaprint_silence.json, tests/test_oracle.py). FFT arithmetic is double (= chromaprint built against FFTW3, the README-recommended
- * backend, README.md:168); other chromaprint FFT backends are single precision and may differ in
- * low-order hash bits among themselves already.
+ * PINNING (analyze stage).  The reference holds no usable golden vector for this stage (its only analyzer
+ * test is #[ignore]d with a stale snapshot of AAC media nothing here can decode, analyzer.rs:472-480) and neither
+ * the Rust crate nor libchromaprint can be built in this image.  What pins this file instead are libchromaprint's
+ * OWN known answers, written down from its published test-suite and replayed in tests/test_oracle.py:
+ *   - tests/test_api.cpp Test2SilenceFp / Test2SilenceRawFp: the whole pipeline on silence, three items
+ *     627964279 (tests/golden/chromaprint_silence.json): frame/latency arithmetic, every classifier's
+ *     thresholds around 0, Gray code, bit packing;
+ *   - tests/test_chroma.cpp (6 vectors incl. the six-digit interpolated ones), test_chroma_filter.cpp (3),
+ *     test_chroma_normalizer.cpp (3), test_quantizer.cpp (8) against the stage functions below, which are the
+ *     functions ora_chromaprint_fingerprint itself runs (tests/golden/chromaprint_unit_vectors.json).
+ * PARITY UNPINNED for what those cannot reach: hashes of non-silent audio end to end against a real
+ * libchromaprint build (window + FFT round-off feeding the quantisers) -- there this file DEFINES the expected
+ * hashes.  FFT arithmetic is double (= chromaprint built against FFTW3, the backend the reference's README,
+ * Dockerfile and release workflow install, README.md:168, Dockerfile:11, .github/workflows/release-needle.yml:58);
+ * chromaprint's other FFT backends are single precision and differ among themselves in low-order hash bits.
  */
 #ifndef ORA_CHROMAPRINT_H
 #define ORA_CHROMAPRINT_H
@@ -60,5 +66,17 @@ size_t ora_chromaprint_fingerprint(const int16_t *pcm, size_t num_values, int ch
 
 /* chromaprint simhash (chromaprint-rust simhash::simhash32, called from comparator.rs:152). */
 uint32_t ora_simhash32(const uint32_t *data, size_t n);
+
+/* The stages of the pipeline one by one, with libchromaprint's constructor parameters, so that its own unit-test
+ * vectors (tests/test_chroma.cpp, test_chroma_filter.cpp, test_chroma_normalizer.cpp, test_quantizer.cpp) can be
+ * replayed against exactly the code ora_chromaprint_fingerprint runs. */
+void ora_chroma_prepare_notes(int min_freq, int max_freq, int frame_size, int sample_rate, signed char *notes,
+                              double *notes_frac, int *min_index, int *max_index);
+void ora_chroma_consume(const signed char *notes, const double *notes_frac, int min_index, int max_index,
+                        int interpolate, const double *frame, double *features /* 12 */);
+void ora_chroma_filter_row(const double *const *rows /* oldest first */, const double *coefficients, int taps,
+                           int bands, double *out);
+void ora_normalize_vector(double *v, int n, double threshold);
+int ora_quantize(double value, double t0, double t1, double t2);
 
 #endif

@@ -74,6 +74,17 @@ def lib():
     L.ora_chromaprint_fingerprint.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
                                               C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     L.ora_chromaprint_fingerprint.restype = C.c_size_t
+    L.ora_chroma_prepare_notes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]
+    L.ora_chroma_prepare_notes.restype = None
+    L.ora_chroma_consume.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.ora_chroma_consume.restype = None
+    L.ora_chroma_filter_row.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.ora_chroma_filter_row.restype = None
+    L.ora_normalize_vector.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.ora_normalize_vector.restype = None
+    L.ora_quantize.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double]
+    L.ora_quantize.restype = C.c_int
     L.ora_simhash32.argtypes = [C.c_void_p, C.c_size_t]
     L.ora_simhash32.restype = C.c_uint32
     L.ora_duration_from_secs_f32.argtypes = [C.c_float]
@@ -202,6 +213,47 @@ def fingerprint(pcm: np.ndarray, channels: int = 1, debug: bool = False):
                                             chroma.ctypes.data, feats.ctypes.data, C.byref(margin))
     assert got == n
     return out[:n], chroma[:frames], feats[:max(frames - 4, 0)], margin.value
+
+
+# ---- the pipeline's stages one by one (what libchromaprint's unit tests exercise) --------------------------------
+def chroma_features(min_freq: int, max_freq: int, frame_size: int, sample_rate: int, frame: Sequence[float],
+                    interpolate: bool = False) -> List[float]:
+    """Chroma(min_freq, max_freq, frame_size, sample_rate).Consume(frame) -> 12 pitch-class energies."""
+    L = lib()
+    half = frame_size // 2
+    notes = (C.c_byte * (half + 1))()
+    frac = (C.c_double * (half + 1))()
+    lo, hi = C.c_int(0), C.c_int(0)
+    L.ora_chroma_prepare_notes(min_freq, max_freq, frame_size, sample_rate, notes, frac, C.byref(lo), C.byref(hi))
+    f = (C.c_double * max(len(frame), half + 1))(*frame)
+    out = (C.c_double * 12)()
+    L.ora_chroma_consume(notes, frac, lo.value, hi.value, int(interpolate), f, out)
+    return list(out)
+
+
+def chroma_filter(coefficients: Sequence[float], rows: Sequence[Sequence[float]]) -> List[List[float]]:
+    """ChromaFilter(coefficients): one output row per input row once len(coefficients) rows are buffered."""
+    L = lib()
+    taps, bands = len(coefficients), len(rows[0])
+    coef = (C.c_double * taps)(*coefficients)
+    bufs = [(C.c_double * bands)(*r) for r in rows]
+    outs = []
+    for i in range(len(rows) - taps + 1):
+        ptrs = (C.POINTER(C.c_double) * taps)(*[C.cast(bufs[i + j], C.POINTER(C.c_double)) for j in range(taps)])
+        out = (C.c_double * bands)()
+        L.ora_chroma_filter_row(ptrs, coef, taps, bands, out)
+        outs.append(list(out))
+    return outs
+
+
+def normalize_vector(v: Sequence[float], threshold: float = 0.01) -> List[float]:
+    a = (C.c_double * len(v))(*v)
+    lib().ora_normalize_vector(a, len(v), C.c_double(threshold))
+    return list(a)
+
+
+def quantize(value: float, t0: float, t1: float, t2: float) -> int:
+    return lib().ora_quantize(C.c_double(value), C.c_double(t0), C.c_double(t1), C.c_double(t2))
 
 
 def simhash32(data: Sequence[int]) -> int:

@@ -393,3 +393,43 @@ def test_optimised_cpu_scan_reports_the_table_walks_runs():
                 want += [(pair, e["src_end_idx"], e["dst_end_idx"], e["score"]) for e in ents if e["score"] >= min_len]
                 pair += 1
         assert got == sorted(want)
+
+
+def test_oracle_stages_reproduce_chromaprints_unit_test_vectors():
+    """libchromaprint's own unit tests hold known answers for the stages of the pipeline taken one at a time: the
+    bin -> pitch-class map (with and without interpolation: the six-digit expectations fix base frequency, rounding
+    and class origin of Chroma::PrepareNotes), the temporal FIR (which coefficient meets the oldest row), the
+    Euclidean normaliser with its 0.01 threshold, and the quantiser's `<` at the thresholds.  The oracle's stage
+    functions -- the same ones ora_chromaprint_fingerprint runs -- must reproduce every one of them."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "chromaprint_unit_vectors.json")))
+    c = g["chroma"]
+    k = c["constructor"]
+    for case in c["cases"]:
+        frame = [0.0] * c["frame_bins"]
+        frame[case["bin"]] = 1.0
+        got = O.chroma_features(k["min_freq"], k["max_freq"], k["frame_size"], k["sample_rate"], frame,
+                                case["interpolate"])
+        assert np.allclose(got, case["expected"], rtol=0, atol=c["tolerance"]), case["name"]
+    for case in g["chroma_filter"]["cases"]:
+        rows = [r + [0.0] * 10 for r in case["rows"]]
+        got = O.chroma_filter(case["coefficients"], rows)
+        assert len(got) == len(case["expected"]), case["name"]
+        for g_row, e_row in zip(got, case["expected"]):
+            assert np.allclose(g_row[:2], e_row, rtol=1e-6, atol=0) and not any(g_row[2:]), case["name"]
+    n = g["normalize_vector"]
+    for case in n["cases"]:
+        got = O.normalize_vector(case["input"], n["threshold"])
+        assert np.allclose(got, case["expected"], rtol=0, atol=n["tolerance"]), case["name"]
+    q = g["quantizer"]
+    for value, level in q["cases"]:
+        assert O.quantize(value, *q["thresholds"]) == level, value
+    # and the default fingerprinter's own constants go through the same map: 28..3520 Hz of a 4096-point frame at
+    # 11025 Hz = bins 10..1307, A4 = 440 Hz (bin 163.5) on the class-0 / class-11 border
+    frame = [0.0] * 2049
+    frame[164] = 1.0
+    assert O.chroma_features(28, 3520, 4096, 11025, frame)[0] == 1.0
+    frame = [0.0] * 2049
+    frame[163] = frame[9] = frame[1308] = 1.0
+    feats = O.chroma_features(28, 3520, 4096, 11025, frame)
+    assert feats[11] == 1.0 and sum(feats) == 1.0
