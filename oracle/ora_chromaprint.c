@@ -89,6 +89,11 @@ static tables_t *g_tab;
 /* ---- stage functions: each is what the pipeline below runs AND what tests/test_oracle.py checks against
  * libchromaprint's own unit-test vectors (tests/golden/chromaprint_unit_vectors.json) ------------------ */
 
+/* PrepareHammingWindow(first, last, scale) of utils.h: the denominator is size - 1. */
+void ora_prepare_hamming_window(double *w, int size, double scale) {
+  for (int i = 0; i < size; i++) w[i] = scale * (0.54 - 0.46 * cos(i * 2.0 * M_PI / (size - 1)));
+}
+
 /* Chroma::PrepareNotes (chroma.cpp): bins [min_index, max_index) -> pitch class 0..11 counted from A
  * (27.5 Hz * 2^k), and the position inside the class (used only by the interpolating variant). */
 void ora_chroma_prepare_notes(int min_freq, int max_freq, int frame_size, int sample_rate, signed char *notes,
@@ -167,9 +172,7 @@ static const tables_t *tables(void) {
     t->tw[k].re = (double)cosl(a);
     t->tw[k].im = (double)sinl(a);
   }
-  /* PrepareHammingWindow(first, last, scale = 1/INT16_MAX) */
-  for (int i = 0; i < FFT_N; i++)
-    t->window[i] = (1.0 / 32767.0) * (0.54 - 0.46 * cos(i * 2.0 * M_PI / (FFT_N - 1)));
+  ora_prepare_hamming_window(t->window, FFT_N, 1.0 / 32767.0); /* scale = 1 / INT16_MAX (fft.cpp) */
   ora_chroma_prepare_notes(MIN_FREQ, MAX_FREQ, FFT_N, ORA_SAMPLE_RATE, t->notes, t->notes_frac, &t->min_index,
                            &t->max_index);
   g_tab = t;

@@ -20,7 +20,8 @@
  *   - tests/test_api.cpp Test2SilenceFp / Test2SilenceRawFp: the whole pipeline on silence, three items
  *     627964279 (tests/golden/chromaprint_silence.json): frame/latency arithmetic, every classifier's
  *     thresholds around 0, Gray code, bit packing;
- *   - tests/test_chroma.cpp (6 vectors incl. the six-digit interpolated ones), test_chroma_filter.cpp (3),
+ *   - tests/test_utils.cpp PrepareHammingWindow (the 10-point window: denominator size - 1),
+ *     test_chroma.cpp (6 vectors incl. the six-digit interpolated ones), test_chroma_filter.cpp (3),
  *     test_chroma_normalizer.cpp (3), test_quantizer.cpp (8) against the stage functions below, which are the
  *     functions ora_chromaprint_fingerprint itself runs (tests/golden/chromaprint_unit_vectors.json).
  * PARITY UNPINNED for what those cannot reach: hashes of non-silent audio end to end against a real
@@ -68,8 +69,9 @@ size_t ora_chromaprint_fingerprint(const int16_t *pcm, size_t num_values, int ch
 uint32_t ora_simhash32(const uint32_t *data, size_t n);
 
 /* The stages of the pipeline one by one, with libchromaprint's constructor parameters, so that its own unit-test
- * vectors (tests/test_chroma.cpp, test_chroma_filter.cpp, test_chroma_normalizer.cpp, test_quantizer.cpp) can be
+ * vectors (tests/test_utils.cpp, test_chroma.cpp, test_chroma_filter.cpp, test_chroma_normalizer.cpp, test_quantizer.cpp) can be
  * replayed against exactly the code ora_chromaprint_fingerprint runs. */
+void ora_prepare_hamming_window(double *w, int size, double scale);
 void ora_chroma_prepare_notes(int min_freq, int max_freq, int frame_size, int sample_rate, signed char *notes,
                               double *notes_frac, int *min_index, int *max_index);
 void ora_chroma_consume(const signed char *notes, const double *notes_frac, int min_index, int max_index,

@@ -74,6 +74,8 @@ def lib():
     L.ora_chromaprint_fingerprint.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
                                               C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     L.ora_chromaprint_fingerprint.restype = C.c_size_t
+    L.ora_prepare_hamming_window.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.ora_prepare_hamming_window.restype = None
     L.ora_chroma_prepare_notes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p]
     L.ora_chroma_prepare_notes.restype = None
@@ -216,6 +218,12 @@ def fingerprint(pcm: np.ndarray, channels: int = 1, debug: bool = False):
 
 
 # ---- the pipeline's stages one by one (what libchromaprint's unit tests exercise) --------------------------------
+def hamming_window(size: int, scale: float = 1.0) -> List[float]:
+    w = (C.c_double * size)()
+    lib().ora_prepare_hamming_window(w, size, C.c_double(scale))
+    return list(w)
+
+
 def chroma_features(min_freq: int, max_freq: int, frame_size: int, sample_rate: int, frame: Sequence[float],
                     interpolate: bool = False) -> List[float]:
     """Chroma(min_freq, max_freq, frame_size, sample_rate).Consume(frame) -> 12 pitch-class energies."""

@@ -397,12 +397,14 @@ def test_optimised_cpu_scan_reports_the_table_walks_runs():
 
 def test_oracle_stages_reproduce_chromaprints_unit_test_vectors():
     """libchromaprint's own unit tests hold known answers for the stages of the pipeline taken one at a time: the
-    bin -> pitch-class map (with and without interpolation: the six-digit expectations fix base frequency, rounding
+    Hamming window (denominator size - 1), the bin -> pitch-class map (with and without interpolation: the six-digit expectations fix base frequency, rounding
     and class origin of Chroma::PrepareNotes), the temporal FIR (which coefficient meets the oldest row), the
     Euclidean normaliser with its 0.01 threshold, and the quantiser's `<` at the thresholds.  The oracle's stage
     functions -- the same ones ora_chromaprint_fingerprint runs -- must reproduce every one of them."""
     import json
     g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "chromaprint_unit_vectors.json")))
+    h = g["hamming_window"]
+    assert np.allclose(O.hamming_window(h["size"]), h["expected"], rtol=0, atol=h["tolerance"])
     c = g["chroma"]
     k = c["constructor"]
     for case in c["cases"]:
