@@ -164,7 +164,7 @@ def main() -> None:
     cmp = capi.Comparator([f"episode-{k:04d}.wav" for k in range(n)])
     cmp.handle()
     n_pairs = lib.num_pairs()
-    cap = 1 << 16
+    cap = max(1 << 16, 4 * n_pairs)          # run-list capacity: every pair of a library with one shared intro matches
     windows = [len(e.pcm) // 2 for e in eps]
     kept = [capi.lib().needle_hip_fingerprint_num_kept(w, 2) for w in windows]
 
@@ -178,11 +178,11 @@ def main() -> None:
     if not distributed:
         d_runs, d_count = capi.DeviceBuffer(cap * capi.RUN_DTYPE.itemsize), capi.DeviceBuffer(4)
 
-        host_ms = {"enqueue": 0.0, "wait_runs": 0.0, "epilogue": 0.0}
+        host_ms = {"enqueue": 0.0, "enqueue_analyze": 0.0, "enqueue_search": 0.0, "wait_runs": 0.0, "epilogue": 0.0}
         # Jobs are pipelined two deep: job k's run list is downloaded asynchronously into pinned memory and its
         # host epilogue runs while job k+1's kernels execute.  Every job (analyze, search, download, epilogue)
         # completes inside the timed region; flush() finishes the one still in flight.
-        max_runs = 4096
+        max_runs = max(4096, 2 * n_pairs)        # what the asynchronous download fetches without a second trip
         bufs = [(capi.DeviceBuffer(cap * capi.RUN_DTYPE.itemsize), capi.DeviceBuffer(4)) for _ in range(2)]
         pending = []
         seq = [0]
@@ -207,10 +207,14 @@ def main() -> None:
             t0 = time.perf_counter()
             d_runs, d_count = bufs[slot]
             lib.analyze(0, n, sync=False)
+            ta = time.perf_counter()
             lib.search(cmp, 0, n_pairs, d_runs.ptr, cap, d_count.ptr, sync=False)
+            ts = time.perf_counter()
             lib.fetch_runs_begin(slot, d_runs.ptr, d_count.ptr, max_runs)
             if collect:
                 host_ms["enqueue"] += 1e3 * (time.perf_counter() - t0)
+                host_ms["enqueue_analyze"] += 1e3 * (ta - t0)
+                host_ms["enqueue_search"] += 1e3 * (ts - ta)
             if pending:
                 finish(pending.pop(), collect)                   # previous job's epilogue overlaps this job's kernels
             pending.append(slot)

@@ -1,6 +1,8 @@
 // needle::audio::Comparator (needle/src/audio/comparator.rs) with the O(n*m) table sweeps replaced by
 // the GPU diagonal scan (search.hip).  Everything that depends on order — the reverse table walk,
 // BinaryHeap pushes, candidate numbering, tie-breaks — is reproduced on the host from the run list.
+#include <chrono>
+#include <cmath>
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
@@ -12,6 +14,58 @@
 #include "needle_core.h"
 
 namespace needle {
+
+namespace {
+struct EpilogueTrace {  // NEEDLE_HIP_TRACE=1: phase times of the host epilogue on stderr
+  const bool on = std::getenv("NEEDLE_HIP_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char *what, size_t items) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[needle_hip] epilogue %s (%zu): %.2f ms\n", what, items,
+                 std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+
+unsigned host_workers(uint64_t work) {  // NEEDLE_HOST_THREADS=1 forces the sequential path
+  unsigned hw = usable_cpus();
+  if (const char *e = std::getenv("NEEDLE_HOST_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));
+  return (work < (1u << 22) || hw <= 1) ? 1u : std::min(hw, 64u);
+}
+
+// f(begin, end) over [0, n) in chunks of `grain`, on `workers` threads (this one included)
+template <class F>
+void parallel_chunks(size_t n, size_t grain, unsigned workers, F f) {
+  if (workers <= 1 || n <= grain) {
+    if (n) f((size_t)0, n);
+    return;
+  }
+  std::atomic<size_t> next{0};
+  auto body = [&]() {
+    for (size_t b = next.fetch_add(grain); b < n; b = next.fetch_add(grain)) f(b, std::min(n, b + grain));
+  };
+  std::vector<std::thread> pool;
+  for (unsigned w = 1; w < workers; w++) pool.emplace_back(body);
+  body();
+  for (std::thread &t : pool) t.join();
+}
+
+// distinct_matches (:434-454) as a count: links[a] = #{b : popcount(h[a] ^ h[b]) < bound}, a itself included.
+// The relation is symmetric, so this equals the size of the set the reference builds for a.  Written as a dense
+// c x c loop over a contiguous array so that the compiler vectorises it for whatever the host CPU offers.
+__attribute__((target_clones("avx512vpopcntdq", "avx2", "default")))
+void count_links(const uint32_t *h, size_t c, uint32_t bound, uint32_t *links) {
+  for (size_t a = 0; a < c; a++) {
+    const uint32_t ha = h[a];
+    uint32_t count = 0;
+    for (size_t b = 0; b < c; b++) count += (uint32_t)__builtin_popcount(ha ^ h[b]) < bound ? 1u : 0u;
+    links[a] = count;
+  }
+}
+
+}  // namespace
+
 
 // chromaprint-rust simhash::simhash32: per bit, +1 for every set bit, -1 for every clear bit over the
 // slice; output bit set iff the tally is > 0.  Counting set bits is enough: 2*ones > n.
@@ -33,14 +87,18 @@ uint32_t simhash32(const uint32_t *data, size_t n) {
 size_t pair_count(size_t n) { return n < 2 ? 0 : n * (n - 1) / 2; }
 
 void pair_at(size_t n, size_t index, size_t *pi, size_t *pj) {
-  // pairs (i, j), i < j, enumerated i-major (comparator.rs:537-545)
-  size_t i = 0;
-  while (index >= n - 1 - i) {
-    index -= n - 1 - i;
-    i++;
-  }
+  // pairs (i, j), i < j, enumerated i-major (comparator.rs:537-545): row i starts at i (2n - i - 1) / 2.  The
+  // root of that quadratic gives the row up to rounding; the two loops make it exact (a library has ~n^2 / 2
+  // pairs and this is called for each, so it must not walk the rows).
+  auto row_start = [n](size_t i) { return i * (2 * n - i - 1) / 2; };
+  const double b = 2.0 * (double)n - 1.0;
+  const double disc = b * b - 8.0 * (double)index;
+  size_t i = disc > 0.0 ? (size_t)((b - std::sqrt(disc)) / 2.0) : 0;
+  if (i + 2 > n) i = n >= 2 ? n - 2 : 0;
+  while (i > 0 && row_start(i) > index) i--;
+  while (i + 2 < n && row_start(i + 1) <= index) i++;
   *pi = i;
-  *pj = i + 1 + index;
+  *pj = i + 1 + (index - row_start(i));
 }
 
 Comparator Comparator::from_files(std::vector<std::string> videos) {
@@ -145,19 +203,42 @@ void Comparator::entries_from_runs(const NeedleHipRun *runs, size_t num_runs, co
   }
 }
 
-Status Comparator::best_matches(size_t num_videos, const std::vector<std::vector<HeapEntry>> &pair_entries,
-                                bool display, bool use_skip_files, bool write_skip_files,
+Status Comparator::best_matches(size_t num_videos, const PairEntries &pair_entries, bool display,
+                                bool use_skip_files, bool write_skip_files,
                                 std::vector<VideoResult> *per_video) const {
   per_video->assign(num_videos, {});
-  // info_map (:583-588): for every non-empty pair, (pair, as source) for i and (pair, as dest) for j
-  std::vector<std::vector<std::pair<size_t, bool>>> info_map(num_videos);
-  for (size_t p = 0; p < pair_entries.size(); p++) {
-    if (pair_entries[p].empty()) continue;  // :562
-    size_t i, j;
-    pair_at(num_videos, p, &i, &j);
-    info_map[i].push_back({p, true});
-    info_map[j].push_back({p, false});
+  // info_map (:583-588): for every non-empty pair, (pair, as source) for i and (pair, as dest) for j -- here as
+  // one array per kind with a start offset per video, filled in pair order
+  const size_t np = pair_entries.count.size();
+  std::vector<uint64_t> info_first(num_videos + 1, 0);
+  {
+    size_t i = 0, j = 1;
+    for (size_t p = 0; p < np; p++) {
+      if (pair_entries.count[p]) {
+        info_first[i + 1]++;
+        info_first[j + 1]++;
+      }
+      if (++j == num_videos) j = ++i + 1;
+    }
   }
+  for (size_t v = 0; v < num_videos; v++) info_first[v + 1] += info_first[v];
+  struct Info {
+    uint64_t pair;
+    bool is_source;
+  };
+  std::vector<Info> info(info_first[num_videos]);
+  {
+    std::vector<uint64_t> fill(info_first.begin(), info_first.end() - 1);
+    size_t i = 0, j = 1;
+    for (size_t p = 0; p < np; p++) {
+      if (pair_entries.count[p]) {
+        info[fill[i]++] = Info{p, true};
+        info[fill[j]++] = Info{p, false};
+      }
+      if (++j == num_videos) j = ++i + 1;
+    }
+  }
+  auto info_count = [&](size_t v) { return info_first[v + 1] - info_first[v]; };
   const uint32_t bound = hash_match_threshold_ + hash_match_threshold_ / 2;  // :441
   // The reference walks the videos in order: skip-file check, find_best_match, display, skip-file write
   // (:593-626).  Here the three kinds of work are separated so that find_best_match -- quadratic in a video's
@@ -183,27 +264,23 @@ Status Comparator::best_matches(size_t num_videos, const std::vector<std::vector
   std::vector<Status> status(num_videos);
   auto find_best = [&](size_t v) {
     std::vector<Candidate> cand;
-    for (const auto &[p, is_source] : info_map[v]) {
+    for (uint64_t q = info_first[v]; q < info_first[v + 1]; q++) {
+      const Info &in = info[q];
+      const HeapEntry *entries = pair_entries.entries.data() + pair_entries.first[in.pair];
       for (int pass = 0; pass < 2; pass++) {  // openings first, then endings (:414-431)
-        for (const HeapEntry &e : pair_entries[p]) {
+        for (uint32_t k = 0; k < pair_entries.count[in.pair]; k++) {
+          const HeapEntry &e = entries[k];
           if (e.is_opening != (pass == 0)) continue;
-          if (is_source)
+          if (in.is_source)
             cand.push_back({e.src_start, e.src_end, e.src_hash_duration, e.src_match_hash, e.is_opening});
           else
             cand.push_back({e.dst_start, e.dst_end, e.dst_hash_duration, e.dst_match_hash, e.is_opening});
         }
       }
     }
-    // distinct_matches (:434-454): symmetric relation, so the set size of i is its neighbour count
-    std::vector<uint32_t> links(cand.size(), 0);
-    for (size_t a = 0; a < cand.size(); a++) {
-      if (bound > 0) links[a]++;  // dist(a, a) = 0 < bound
-      for (size_t b = a + 1; b < cand.size(); b++)
-        if ((uint32_t)__builtin_popcount(cand[a].match_hash ^ cand[b].match_hash) < bound) {
-          links[a]++;
-          links[b]++;
-        }
-    }
+    std::vector<uint32_t> hashes(cand.size()), links(cand.size(), 0);
+    for (size_t k = 0; k < cand.size(); k++) hashes[k] = cand[k].match_hash;
+    count_links(hashes.data(), hashes.size(), bound, links.data());
 
     VideoResult &vr = (*per_video)[v];
     vr.has_result = true;  // Some(best) even if neither side is found (:514)
@@ -248,26 +325,16 @@ Status Comparator::best_matches(size_t num_videos, const std::vector<std::vector
   std::vector<size_t> todo;
   uint64_t work = 0;  // candidate pairs to compare
   for (size_t v = 0; v < num_videos; v++) {
-    if (skipped[v] || info_map[v].empty()) continue;
+    if (skipped[v] || info_count(v) == 0) continue;
     todo.push_back(v);
     uint64_t c = 0;
-    for (const auto &pi : info_map[v]) c += pair_entries[pi.first].size();
-    work += c * c / 2;
+    for (uint64_t q = info_first[v]; q < info_first[v + 1]; q++) c += pair_entries.count[info[q].pair];
+    work += c * c;
   }
-  unsigned hw = usable_cpus();
-  if (const char *e = std::getenv("NEEDLE_HOST_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));  // 1 = sequential
-  const unsigned workers = (work < (1u << 22) || hw == 1) ? 1u : (unsigned)std::min<uint64_t>({hw, 64, todo.size()});
-  if (workers <= 1) {
-    for (size_t v : todo) find_best(v);
-  } else {
-    std::atomic<size_t> next{0};
-    std::vector<std::thread> pool;
-    for (unsigned w = 0; w < workers; w++)
-      pool.emplace_back([&]() {
-        for (size_t k = next.fetch_add(1); k < todo.size(); k = next.fetch_add(1)) find_best(todo[k]);
-      });
-    for (std::thread &t : pool) t.join();
-  }
+  parallel_chunks(todo.size(), 1, (unsigned)std::min<size_t>(host_workers(work), std::max<size_t>(todo.size(), 1)),
+                  [&](size_t b, size_t e) {
+                    for (size_t k = b; k < e; k++) find_best(todo[k]);
+                  });
 
   for (size_t v = 0; v < num_videos; v++) {
     const std::string &path = v < videos_.size() ? videos_[v] : std::string();
@@ -276,7 +343,7 @@ Status Comparator::best_matches(size_t num_videos, const std::vector<std::vector
       if (display) std::printf("Skipping due to existing skip file...\n");
       continue;
     }
-    if (info_map[v].empty()) {
+    if (info_count(v) == 0) {
       if (display) std::printf(include_endings_ ? "No opening or ending found.\n" : "No opening found.\n");
       continue;
     }
@@ -362,32 +429,54 @@ Status Comparator::results_from_runs(const std::vector<const FrameHashesData *> 
   const size_t n = fh.size();
   const size_t regions = include_endings_ ? 2 : 1;
   const size_t np = pair_count(n);
-  // one sort puts the runs of each (pair, region) together (NeedleHipRun.problem = pair * regions + region) and,
-  // inside a group, in the reference's reverse table-walk order: src_end descending, then dst_end descending
-  std::vector<NeedleHipRun> sorted(runs.begin(), runs.end());
-  std::sort(sorted.begin(), sorted.end(), [](const NeedleHipRun &a, const NeedleHipRun &b) {
-    if (a.problem != b.problem) return a.problem < b.problem;
-    return a.src_end != b.src_end ? a.src_end > b.src_end : a.dst_end > b.dst_end;
-  });
-  std::vector<std::vector<HeapEntry>> pair_entries(np);
-  std::vector<HeapEntry> tmp;
-  for (size_t lo = 0; lo < sorted.size();) {
-    size_t hi = lo;
-    while (hi < sorted.size() && sorted[hi].problem == sorted[lo].problem) hi++;
-    const size_t problem = sorted[lo].problem;
-    if (problem < np * regions) {
-      const size_t p = problem / regions, r = problem % regions;
-      size_t i, j;
-      pair_at(n, p, &i, &j);
-      entries_from_runs(&sorted[lo], hi - lo, r == 0 ? fh[i]->opening : fh[i]->ending,
-                        r == 0 ? fh[j]->opening : fh[j]->ending, fh[i]->hash_duration, fh[j]->hash_duration, r == 0,
-                        &tmp);
-      // entries.extend(opening); entries.extend(ending) (:262-281): region 0 sorts before region 1
-      pair_entries[p].insert(pair_entries[p].end(), tmp.begin(), tmp.end());
-    }
-    lo = hi;
+  // Bucket the runs by problem (NeedleHipRun.problem = pair * regions + region) with a counting sort, then order
+  // each bucket the way the reference walks its table backwards: src_end descending, then dst_end descending.
+  EpilogueTrace trace;
+  const size_t buckets = np * regions;
+  std::vector<uint64_t> start(buckets + 1, 0);
+  for (const NeedleHipRun &r : runs)
+    if (r.problem < buckets) start[r.problem + 1]++;
+  for (size_t b = 0; b < buckets; b++) start[b + 1] += start[b];
+  std::vector<NeedleHipRun> sorted(start[buckets]);
+  {
+    std::vector<uint64_t> fill(start.begin(), start.end() - 1);
+    for (const NeedleHipRun &r : runs)
+      if (r.problem < buckets) sorted[fill[r.problem]++] = r;
   }
-  return best_matches(n, pair_entries, display, use_skip_files, write_skip_files, per_video);
+  trace.lap("bucket runs", sorted.size());
+  // Heap entries pair by pair (both regions of a pair by the same thread: entries.extend(opening);
+  // entries.extend(ending), :262-281), written where the pair's runs start: a run yields at most one entry.
+  PairEntries pair_entries;
+  pair_entries.entries.resize(sorted.size());
+  pair_entries.first.resize(np);
+  pair_entries.count.assign(np, 0);
+  parallel_chunks(np, 4096, host_workers((uint64_t)sorted.size() * 64), [&](size_t p0, size_t p1) {
+    std::vector<HeapEntry> tmp;
+    size_t i, j;
+    pair_at(n, p0, &i, &j);
+    for (size_t p = p0; p < p1; p++) {
+      uint64_t out = start[p * regions];
+      pair_entries.first[p] = out;
+      for (size_t r = 0; r < regions; r++) {
+        const uint64_t lo = start[p * regions + r], hi = start[p * regions + r + 1];
+        if (hi == lo) continue;
+        std::sort(sorted.begin() + lo, sorted.begin() + hi, [](const NeedleHipRun &a, const NeedleHipRun &b) {
+          return a.src_end != b.src_end ? a.src_end > b.src_end : a.dst_end > b.dst_end;
+        });
+        entries_from_runs(&sorted[lo], hi - lo, r == 0 ? fh[i]->opening : fh[i]->ending,
+                          r == 0 ? fh[j]->opening : fh[j]->ending, fh[i]->hash_duration, fh[j]->hash_duration,
+                          r == 0, &tmp);
+        std::copy(tmp.begin(), tmp.end(), pair_entries.entries.begin() + out);
+        out += tmp.size();
+      }
+      pair_entries.count[p] = (uint32_t)(out - pair_entries.first[p]);
+      if (++j == n) j = ++i + 1;
+    }
+  });
+  trace.lap("heap entries per pair", np);
+  Status s = best_matches(n, pair_entries, display, use_skip_files, write_skip_files, per_video);
+  trace.lap("best match per video", n);
+  return s;
 }
 
 Status Comparator::run(bool analyze, bool display, bool use_skip_files, bool write_skip_files, bool threading,

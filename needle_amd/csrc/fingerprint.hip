@@ -17,6 +17,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <thread>
 #include <cmath>
 #include <cstdlib>
@@ -386,9 +387,22 @@ __global__ __launch_bounds__(256) void classify_kernel(const double *__restrict_
 // workspace reused across calls (per device)
 struct FpWorkspace {
   DeviceBuffer<double> chroma, feat;
-  DeviceBuffer<FpStream> streams;
-  PinnedStage stage;
-  DescriptorUpload<FpStream> upload;
+  // Stream tables, one slot per chunk of a call: a job that is run again finds every chunk's table resident and
+  // uploads nothing (with a single slot the chunks of a large batch evict each other, and every upload then waits
+  // for the staging buffer behind the kernels already queued).
+  struct Descriptors {
+    DeviceBuffer<FpStream> streams;
+    PinnedStage stage;
+    DescriptorUpload<FpStream> upload;
+  };
+  static constexpr size_t kDescriptorSlots = 64;
+  std::vector<std::unique_ptr<Descriptors>> descriptors;
+  Descriptors &slot(size_t chunk) {
+    const size_t k = chunk % kDescriptorSlots;
+    if (descriptors.size() <= k) descriptors.resize(k + 1);
+    if (!descriptors[k]) descriptors[k] = std::make_unique<Descriptors>();
+    return *descriptors[k];
+  }
   bool lds_attr_set = false;  // the STFT kernel's 68 KiB of dynamic LDS needs an explicit opt-in
 };
 std::mutex g_ws_mu;
@@ -425,7 +439,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
   // Streams are processed in chunks so the f64 chroma/feature workspaces stay bounded (96 B/frame each).
   uint64_t kMaxFramesPerChunk = 8u << 20;  // workspace bound: 8 M frames = 0.8 GB of chroma + as much of features
   if (const char *e = getenv("NEEDLE_HIP_MAX_FRAMES_PER_CHUNK")) kMaxFramesPerChunk = (uint64_t)std::max(1, atoi(e));  // tests
-  size_t begin = 0;
+  size_t begin = 0, chunk = 0;
   while (begin < spans.size()) {
     std::vector<FpStream> meta;
     uint64_t frames = 0, rows = 0, kept = 0, pairs = 0;
@@ -456,7 +470,8 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
     if (frames > 0) {
       if (!(s = ws->chroma.reserve(frames * kBands)).ok()) return s;
       if (!(s = ws->feat.reserve(std::max<uint64_t>(rows, 1) * kBands)).ok()) return s;
-      if (!(s = ws->upload.put(&ws->streams, &ws->stage, meta, stream)).ok()) return s;
+      FpWorkspace::Descriptors &desc = ws->slot(chunk++);
+      if (!(s = desc.upload.put(&desc.streams, &desc.stage, meta, stream)).ok()) return s;
       const int n = (int)meta.size();
       if (!ws->lds_attr_set) {
         const void *variants[2] = {reinterpret_cast<const void *>(stft_chroma_kernel<1>),
@@ -473,7 +488,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
         const uint32_t grid = (uint32_t)((pairs + ppb - 1) / ppb);
         auto launch = [&](auto kernel) {
           hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm,
-                             ws->streams.ptr, n, tab.tw, tab.wcos, tab.wconst, tab.bin_slot, tab.class_start, ws->chroma.ptr,
+                             desc.streams.ptr, n, tab.tw, tab.wcos, tab.wconst, tab.bin_slot, tab.class_start, ws->chroma.ptr,
                              (uint32_t)pairs, ppb);
         };
         if (channels == 1) launch(stft_chroma_kernel<1>); else launch(stft_chroma_kernel<2>);
@@ -481,12 +496,12 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       if (rows > 0) {
         KernelTimer timer("fir_norm");
         hipLaunchKernelGGL(fir_norm_kernel, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, stream,
-                           ws->chroma.ptr, ws->streams.ptr, n, ws->feat.ptr, (uint32_t)rows);
+                           ws->chroma.ptr, desc.streams.ptr, n, ws->feat.ptr, (uint32_t)rows);
       }
       if (kept > 0) {
         KernelTimer timer("classify");
         hipLaunchKernelGGL(classify_kernel, dim3((uint32_t)((kept + 255) / 256)), dim3(256), 0, stream,
-                           ws->feat.ptr, ws->streams.ptr, n, tab.thr, step, d_items, (uint32_t)kept);
+                           ws->feat.ptr, desc.streams.ptr, n, tab.thr, step, d_items, (uint32_t)kept);
       }
       NEEDLE_HIP_TRY(hipGetLastError());
       if (d_chroma_dbg)
@@ -495,8 +510,8 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       if (d_feat_dbg && rows)
         NEEDLE_HIP_TRY(hipMemcpyAsync(d_feat_dbg, ws->feat.ptr, rows * kBands * sizeof(double),
                                       hipMemcpyDeviceToDevice, stream));
-      // the next chunk reuses the workspaces and the descriptor buffer
-      if (end < spans.size()) NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+      // the next chunk reuses the chroma / feature workspaces: safe without a host wait, the stream runs in order
+      // (and every chunk has its own descriptor slot)
     }
     begin = end;
   }

@@ -243,6 +243,7 @@ enum NeedleError needle_hip_library_search(NeedleHipLibrary *lib, const struct N
   const size_t np = pair_count(lib->n);
   if (!lib->have_pcm || first_pair > np || num_pairs > np - first_pair) return NeedleError_InvalidArgument;
   return guarded([&]() -> NeedleError {
+    const auto t_enter = std::chrono::steady_clock::now();
     const Comparator &cmp = comparator_of(comparator);
     if (cmp.include_endings() && !lib->endings)  // comparator.rs:271-273
       return report(Status::Make(NeedleError_Unknown, "no ending hash data present"));
@@ -278,8 +279,13 @@ enum NeedleError needle_hip_library_search(NeedleHipLibrary *lib, const struct N
                                             (uint32_t)(p * Rc + r)});
       }
     }
+    const auto t_built = std::chrono::steady_clock::now();
     Status s = gpu_hamming_runs_device(lib->arena, seqs.data(), seqs.size(), problems.data(), problems.size(),
                                        cmp.hash_match_threshold(), d_runs, capacity, d_count, sync);
+    if (getenv("NEEDLE_HIP_TRACE"))
+      std::fprintf(stderr, "[needle_hip] search enqueue: %zu problems built in %.2f ms, launched in %.2f ms\n",
+                   problems.size(), std::chrono::duration<double, std::milli>(t_built - t_enter).count(),
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_built).count());
     return s.ok() ? NeedleError_Ok : report(s);
   });
 }

@@ -129,9 +129,16 @@ class Comparator {
   Status results_from_runs(const std::vector<const FrameHashesData *> &frame_hashes,
                            const std::vector<NeedleHipRun> &runs, bool display, bool use_skip_files,
                            bool write_skip_files, std::vector<VideoResult> *per_video) const;
-  // :583-626 — per video best match from the per-pair entries (pairs in lexicographic order).
-  Status best_matches(size_t num_videos, const std::vector<std::vector<HeapEntry>> &pair_entries, bool display,
-                      bool use_skip_files, bool write_skip_files, std::vector<VideoResult> *per_video) const;
+  // Heap entries of every pair, pairs in lexicographic order, in one allocation: those of pair p are
+  // entries[first[p] .. first[p] + count[p]) (a library has ~n^2 / 2 pairs: no vector per pair).
+  struct PairEntries {
+    std::vector<HeapEntry> entries;
+    std::vector<uint64_t> first;
+    std::vector<uint32_t> count;
+  };
+  // :583-626 — per video best match from the per-pair entries.
+  Status best_matches(size_t num_videos, const PairEntries &pair_entries, bool display, bool use_skip_files,
+                      bool write_skip_files, std::vector<VideoResult> *per_video) const;
 
  private:
   std::vector<std::string> videos_;

@@ -369,3 +369,16 @@ def test_every_function_the_headers_declare_is_exported():
     assert len(cnames) >= 10
     for n in cnames:
         assert hasattr(CL, n), n
+
+
+def test_pair_index_map_matches_the_enumeration(tmp_path):
+    """comparator.rs:534-545 enumerates the pairs (i, j), i < j, i-major; the host code maps a pair index back to
+    (i, j) in closed form (a library has n^2 / 2 pairs and each needs it).  tests/cpp/pair_index_check.cpp compares
+    the map with the enumeration itself."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "needle_amd", "lib")
+    exe = str(tmp_path / "pair_index_check")
+    subprocess.run(["g++", "-O2", "-o", exe, os.path.join(root, "tests", "cpp", "pair_index_check.cpp"),
+                    "-L" + libdir, "-lneedle_capi", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "pair_at ok" in out.stdout, out.stdout + out.stderr
