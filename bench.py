@@ -186,6 +186,7 @@ def main() -> None:
         bufs = [(capi.DeviceBuffer(cap * capi.RUN_DTYPE.itemsize), capi.DeviceBuffer(4)) for _ in range(2)]
         pending = []
         seq = [0]
+        finished = [0]                           # epilogues counted in host_ms (the flushes add a few to the K steps)
 
         def finish(slot, collect):
             t0 = time.perf_counter()
@@ -200,6 +201,7 @@ def main() -> None:
             if collect:
                 host_ms["wait_runs"] += 1e3 * (t1 - t0)
                 host_ms["epilogue"] += 1e3 * (time.perf_counter() - t1)
+                finished[0] += 1
 
         def step(collect):
             slot = seq[0] & 1
@@ -357,7 +359,8 @@ def main() -> None:
             "kernel_ms_per_step": {k: round(v, 5) for k, v in avg.items()},
             "kernel_ms_note": f"{dominant}: HIP events inside the timed region; the others: {extra_steps} untimed "
                               "steps after it (events around every kernel slow a step by 3 %)",
-            "host_ms_per_step": ({k: round(v / args.steps, 4) for k, v in host_ms.items()} if not distributed else None),
+            "host_ms_per_step": ({k: round(v / (max(finished[0], 1) if k in ("wait_runs", "epilogue") else args.steps), 4)
+                                  for k, v in host_ms.items()} if not distributed else None),
             "runs_per_step": state["runs"],
             "detected": sum(1 for r in state["results"] if r is not None and r.opening is not None),
         }
