@@ -26,6 +26,7 @@ constexpr int kBandR = 7, kBandU = 3;          // band kernel: 7 diagonals per l
 constexpr int kBandB = 64 * kBandR;
 constexpr int kSampleW = 8;                     // sampled kernel: rows per aligned window
 constexpr int kSampleHead = 3;                  // rows of a window evaluated before the first early-out
+constexpr int kSparseMax = 6;                   // survivors of the head rows that are finished one diagonal at a time
 
 struct SearchProblem {
   uint32_t src_off, n;  // hash arena offset + length of the source sequence
@@ -213,14 +214,14 @@ __global__ __launch_bounds__(256) void hamming_runs_band_kernel(const uint32_t *
 //
 // Per evaluated cell: v_xor, v_bcnt, v_cmp (+ one scalar AND of lane masks); at the default 20 s minimum
 // (min_len 82, W 8, P 75) that is 3 VALU on at most 10.7 % of the cells -- typically 4 % (the first three rows of
-// each window) -- instead of 4 VALU on all of them.
+// each window, plus the few diagonals that survive them, finished one at a time) -- instead of 4 VALU on all of them.
 template <int R, int W>
 __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_t *__restrict__ hashes,
                                                                    const SearchProblem *__restrict__ problems,
                                                                    int num_problems, uint32_t threshold,
                                                                    NeedleHipRun *__restrict__ runs,
                                                                    uint32_t capacity, uint32_t *__restrict__ count,
-                                                                   int bands_per_wave) {
+                                                                   int bands_per_wave, int sparse_max) {
   constexpr int B = 64 * R;
   extern __shared__ uint32_t lds[];
   int lo = 0, hi = num_problems - 1;
@@ -288,10 +289,80 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
 #pragma unroll
       for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv ^ E[s + r]) <= threshold);
     }
-    bool any = false;
+    // exact resolution of one diagonal whose W window cells all match, by the whole wave (d is wave-uniform)
+    auto resolve = [&](const int d) {
+      const int ilo = d < 0 ? 1 - d : 1;
+      const int ihi = min(n - 1, m - 1 - d);
+      if (w0 < ilo || w0 + W - 1 > ihi) return;  // window not inside the table on this diagonal
+      // forwards from the window: first mismatching row after it (or ihi + 1)
+      int e = w0 + W;
+      bool ended = false;
+      const int fwd_limit = min(ihi, w0 + P + W - 1);  // last row of the NEXT aligned window
+      while (e <= fwd_limit) {
+        const int row = e + lane;
+        const bool bad = row <= fwd_limit && (uint32_t)__popc(lsrc[row] ^ ldst[B + row + d]) > threshold;
+        const unsigned long long mm = __ballot(bad);
+        if (mm) {
+          e += __ffsll((long long)mm) - 1;
+          ended = true;
+          break;
+        }
+        e += 64;
+      }
+      if (!ended) {
+        if (fwd_limit == w0 + P + W - 1) return;  // the run also covers the next window: it reports the run
+        e = ihi + 1;                                // the run reaches the table edge (comparator.rs:197)
+      }
+      const int b = e - 1;
+      // backwards from the window: last mismatching row before it (or ilo - 1)
+      int a = ilo;
+      int q = w0 - 1;
+      while (q >= ilo) {
+        const int row = q - lane;
+        const bool bad = row >= ilo && (uint32_t)__popc(lsrc[row] ^ ldst[B + row + d]) > threshold;
+        const unsigned long long mm = __ballot(bad);
+        if (mm) {
+          a = q - (__ffsll((long long)mm) - 1) + 1;
+          break;
+        }
+        q -= 64;
+      }
+      const int len = b - a + 1;
+      if (len >= min_len && lane == 0) {
+        const uint32_t slot = atomicAdd(count, 1u);
+        if (slot < capacity) runs[slot] = NeedleHipRun{(uint32_t)lo, (uint32_t)b, (uint32_t)(b + d), (uint32_t)len, 0u, 0u};
+      }
+    };
+
+    // Survivors of the head rows.  On unrelated random hashes there are none and the window ends here; real audio
+    // is self-similar (sustained notes: a diagonal that matched three rows running is likely to match the next
+    // one), a few of the wave's 64 R diagonals do survive, and walking the remaining rows for all of them would
+    // cost 64 R cells per row to test those few.  Up to sparse_max survivors are therefore finished one at a time,
+    // the W - kSampleHead remaining cells of a diagonal side by side in as many lanes; more than that (sustained
+    // sounds, silence) goes on row by row as before.  Both paths test exactly the same cells.
+    unsigned long long alive[R];
+    int survivors = 0;
 #pragma unroll
-    for (int r = 0; r < R; r++) any |= ok[r];
-    if (!__any(any)) continue;
+    for (int r = 0; r < R; r++) {
+      alive[r] = __ballot(ok[r]);
+      survivors += __popcll(alive[r]);
+    }
+    if (survivors == 0) continue;
+    if (survivors <= sparse_max) {
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        unsigned long long cand = alive[r];
+        while (cand) {
+          const int src_lane = __ffsll((long long)cand) - 1;
+          cand &= cand - 1;
+          const int d = D0 + src_lane * R + r;  // wave-uniform
+          const int row = w0 + kSampleHead + min(lane, W - kSampleHead - 1);  // lanes beyond the window repeat its last row
+          const bool bad = (uint32_t)__popc(lsrc[row] ^ ldst[B + row + d]) > threshold;
+          if (__ballot(bad) == 0) resolve(d);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int q = kSampleHead + R - 1; q < W + R - 1; q++) E[q] = ldst[B + w0 + d_l + q];
 #pragma unroll
@@ -300,11 +371,6 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
 #pragma unroll
       for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv ^ E[s + r]) <= threshold);
     }
-    any = false;
-#pragma unroll
-    for (int r = 0; r < R; r++) any |= ok[r];
-    if (!__any(any)) continue;
-
     // ---- candidates: resolved one at a time by the whole wave ----
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -312,48 +378,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
       while (cand) {
         const int src_lane = __ffsll((long long)cand) - 1;
         cand &= cand - 1;
-        const int d = D0 + src_lane * R + r;       // wave-uniform
-        const int ilo = d < 0 ? 1 - d : 1;
-        const int ihi = min(n - 1, m - 1 - d);
-        if (w0 < ilo || w0 + W - 1 > ihi) continue;  // window not inside the table on this diagonal
-        // forwards from the window: first mismatching row after it (or ihi + 1)
-        int e = w0 + W;
-        bool ended = false;
-        const int fwd_limit = min(ihi, w0 + P + W - 1);  // last row of the NEXT aligned window
-        while (e <= fwd_limit) {
-          const int row = e + lane;
-          const bool bad = row <= fwd_limit && (uint32_t)__popc(lsrc[row] ^ ldst[B + row + d]) > threshold;
-          const unsigned long long mm = __ballot(bad);
-          if (mm) {
-            e += __ffsll((long long)mm) - 1;
-            ended = true;
-            break;
-          }
-          e += 64;
-        }
-        if (!ended) {
-          if (fwd_limit == w0 + P + W - 1) continue;  // the run also covers the next window: it reports the run
-          e = ihi + 1;                                  // the run reaches the table edge (comparator.rs:197)
-        }
-        const int b = e - 1;
-        // backwards from the window: last mismatching row before it (or ilo - 1)
-        int a = ilo;
-        int q = w0 - 1;
-        while (q >= ilo) {
-          const int row = q - lane;
-          const bool bad = row >= ilo && (uint32_t)__popc(lsrc[row] ^ ldst[B + row + d]) > threshold;
-          const unsigned long long mm = __ballot(bad);
-          if (mm) {
-            a = q - (__ffsll((long long)mm) - 1) + 1;
-            break;
-          }
-          q -= 64;
-        }
-        const int len = b - a + 1;
-        if (len >= min_len && lane == 0) {
-          const uint32_t slot = atomicAdd(count, 1u);
-          if (slot < capacity) runs[slot] = NeedleHipRun{(uint32_t)lo, (uint32_t)b, (uint32_t)(b + d), (uint32_t)len, 0u, 0u};
-        }
+        resolve(D0 + src_lane * R + r);
       }
     }
   }
@@ -510,10 +535,13 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
     }
     {
       KernelTimer timer("hamming_runs");
-      if (sampled)
+      if (sampled) {
+        int sparse_max = kSparseMax;
+        if (const char *e = getenv("NEEDLE_HIP_SPARSE_MAX")) sparse_max = std::max(0, atoi(e));  // tests, tuning: 0 = row by row
         hipLaunchKernelGGL((hamming_runs_sampled_kernel<kBandR, kSampleW>), dim3((uint32_t)blocks), dim3(256),
                            lds_bytes, stream, d_hashes, ws->problems.ptr, (int)meta.size(), threshold, d_runs,
-                           capacity, d_count, bands_per_wave);
+                           capacity, d_count, bands_per_wave, sparse_max);
+      }
       else if (fast)
         hipLaunchKernelGGL((hamming_runs_band_kernel<kBandR, kBandU>), dim3((uint32_t)blocks), dim3(256), lds_bytes,
                            stream, d_hashes, ws->problems.ptr, (int)meta.size(), threshold, d_runs, capacity, d_count);

@@ -124,18 +124,24 @@ def test_hamming_runs_equal_reference_dp(n, m):
     assert got == _oracle_runs(src, dst, thr, min_len)
 
 
-@pytest.fixture(params=["sampled", "band", "generic"])
+@pytest.fixture(params=["sampled", "sampled-rows", "sampled-sparse", "band", "generic"])
 def search_mode(request):
     """The launcher picks the aligned-window kernel for min_len >= 23, the band kernel for >= 21 and the
     one-lane-per-diagonal kernel otherwise; the environment switches force the slower ones so every kernel is
-    checked on the same inputs."""
-    old = {k: os.environ.pop(k, None) for k in ("NEEDLE_HIP_BAND_SEARCH", "NEEDLE_HIP_GENERIC_SEARCH")}
+    checked on the same inputs -- and the aligned-window kernel with the survivors of a window's head rows always
+    walked row by row (NEEDLE_HIP_SPARSE_MAX=0) or always finished one diagonal at a time (1000)."""
+    keys = ("NEEDLE_HIP_BAND_SEARCH", "NEEDLE_HIP_GENERIC_SEARCH", "NEEDLE_HIP_SPARSE_MAX")
+    old = {k: os.environ.pop(k, None) for k in keys}
     if request.param == "band":
         os.environ["NEEDLE_HIP_BAND_SEARCH"] = "1"
     elif request.param == "generic":
         os.environ["NEEDLE_HIP_GENERIC_SEARCH"] = "1"
+    elif request.param == "sampled-rows":
+        os.environ["NEEDLE_HIP_SPARSE_MAX"] = "0"
+    elif request.param == "sampled-sparse":
+        os.environ["NEEDLE_HIP_SPARSE_MAX"] = "1000"
     yield request.param
-    for k in ("NEEDLE_HIP_BAND_SEARCH", "NEEDLE_HIP_GENERIC_SEARCH"):
+    for k in keys:
         os.environ.pop(k, None)
         if old[k] is not None:
             os.environ[k] = old[k]
@@ -774,13 +780,17 @@ def test_two_simulated_ranks_on_one_device_equal_single_library(n, world):
         [eps[n - 1].pcm[: lens[n - 1] // 2]], 1, hd)[0].opening]
 
 
-@pytest.mark.parametrize("bands_per_wave", [1, 2, 3, 8])
-def test_sampled_kernel_on_sustained_hashes_and_multi_band_workgroups(bands_per_wave, monkeypatch):
+@pytest.mark.parametrize("bands_per_wave,sparse_max", [(1, None), (2, "0"), (3, "1000"), (8, "2"), (1, "1"), (2, None)])
+def test_sampled_kernel_on_sustained_hashes_and_multi_band_workgroups(bands_per_wave, sparse_max, monkeypatch):
     """Hashes that repeat for a few frames, as sustained notes produce, give short chance runs on many diagonals:
     windows survive the early-out far more often than on random hashes and candidates that fail the length test
     get resolved.  Checked against the oracle's table-free scan for every pair of 14 sequences, with one band
-    per wave (small launches) and several (large launches: one workgroup walks many bands of its pair)."""
+    per wave (small launches) and several (large launches: one workgroup walks many bands of its pair), and with
+    the survivors of a window's head rows finished one diagonal at a time (the default up to 6 of them), never
+    (0: row by row) or always (1000)."""
     monkeypatch.setenv("NEEDLE_HIP_BANDS_PER_WAVE", str(bands_per_wave))
+    if sparse_max is not None:
+        monkeypatch.setenv("NEEDLE_HIP_SPARSE_MAX", sparse_max)
     rng = np.random.default_rng(100 + bands_per_wave)
     palette = rng.integers(0, 2 ** 32, 40, dtype=np.uint64).astype(np.uint32)     # few distinct "notes"
     seqs = []
