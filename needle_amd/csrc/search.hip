@@ -262,10 +262,20 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
   const int P = min_len - W + 1;  // >= W: the host selects this kernel only when min_len >= 2W - 1
   // a workgroup stages the destination once and its four waves walk bands_per_wave bands each (large launches:
   // one workgroup per pair instead of one per four bands, so the staging is not repeated)
+  // Bands near the corners of the table have few rows, those around the main diagonal all of them.  A workgroup
+  // therefore takes bands STRIDED across the table (slot q of workgroup b: band q nb + b, nb = workgroups of this
+  // pair), so that every workgroup carries the same mix of short and long bands -- with consecutive bands per
+  // workgroup the heavy middle workgroups of every pair land on the same CUs of a round-robin dispatch -- and the
+  // slot a wave starts with rotates with the pair, so that no SIMD always gets the long ones.
+  const int slots = 4 * bands_per_wave;
+  const int total_bands = (n + m - 3 + B - 1) / B;
+  const int nb = (total_bands + slots - 1) / slots;
+  const int b_in_pair = (int)(blockIdx.x - pr.block_base);
   for (int round = 0; round < bands_per_wave; round++) {
-  const int band = ((int)(blockIdx.x - pr.block_base) * bands_per_wave + round) * 4 + wave;
+  const int q = (round * 4 + wave + lo) % slots;
+  const int band = q * nb + b_in_pair;
   const int D0 = band * B - (n - 2);
-  if (D0 > m - 2) break;
+  if (band >= total_bands || D0 > m - 2) continue;
   const int i_start = max(1, 2 - D0 - B);
   const int i_end = min(n - 1, m - 1 - D0);
   const int d_l = D0 + lane * R;
@@ -280,14 +290,18 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
     uint32_t E[W + R - 1];
 #pragma unroll
     for (int q = 0; q < kSampleHead + R - 1; q++) E[q] = ldst[B + w0 + d_l + q];
+    // the window's W source hashes: wave-uniform, fetched together through the scalar cache (one latency for the
+    // head rows, the sparse finish and the remaining rows alike)
+    uint32_t sv[W];
+#pragma unroll
+    for (int s = 0; s < W; s++) sv[s] = src[w0 + s];
     bool ok[R];
 #pragma unroll
     for (int r = 0; r < R; r++) ok[r] = true;
 #pragma unroll
     for (int s = 0; s < kSampleHead; s++) {
-      const uint32_t sv = src[w0 + s];
 #pragma unroll
-      for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv ^ E[s + r]) <= threshold);
+      for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv[s] ^ E[s + r]) <= threshold);
     }
     // exact resolution of one diagonal whose W window cells all match, by the whole wave (d is wave-uniform)
     auto resolve = [&](const int d) {
@@ -349,6 +363,9 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
     }
     if (survivors == 0) continue;
     if (survivors <= sparse_max) {
+      uint32_t sv_tail = sv[W - 1];  // this lane's row of the window's remaining rows
+#pragma unroll
+      for (int s = W - 2; s >= kSampleHead; s--) sv_tail = lane == s - kSampleHead ? sv[s] : sv_tail;
 #pragma unroll
       for (int r = 0; r < R; r++) {
         unsigned long long cand = alive[r];
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
           cand &= cand - 1;
           const int d = D0 + src_lane * R + r;  // wave-uniform
           const int row = w0 + kSampleHead + min(lane, W - kSampleHead - 1);  // lanes beyond the window repeat its last row
-          const bool bad = (uint32_t)__popc(lsrc[row] ^ ldst[B + row + d]) > threshold;
+          const bool bad = (uint32_t)__popc(sv_tail ^ ldst[B + row + d]) > threshold;
           if (__ballot(bad) == 0) resolve(d);
         }
       }
@@ -367,9 +384,8 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
     for (int q = kSampleHead + R - 1; q < W + R - 1; q++) E[q] = ldst[B + w0 + d_l + q];
 #pragma unroll
     for (int s = kSampleHead; s < W; s++) {
-      const uint32_t sv = src[w0 + s];
 #pragma unroll
-      for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv ^ E[s + r]) <= threshold);
+      for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv[s] ^ E[s + r]) <= threshold);
     }
     // ---- candidates: resolved one at a time by the whole wave ----
 #pragma unroll
