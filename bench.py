@@ -4,7 +4,7 @@
 metric  : episode-pairs/sec (analyze+search) = N(N-1)/2 / wall(analyze N episodes + search all pairs +
           per-video best match), N = 28 synthetic 24-min episodes (BASELINE.json configs[1]).
 step    : one complete pass of the hot path over the library: fingerprint every episode's opening window
-          (stft_chroma, fir_norm, classify kernels), scan every pair (hamming_runs kernel), copy the run list
+          (stft_chroma and features_classify kernels), scan every pair (hamming_runs kernel), copy the run list
           and the hash arena back, run the order-sensitive host epilogue (duration validity, simhash32,
           BinaryHeap order, find_best_match).  PCM is resident in HBM before the timed region starts.
 N > 1   : one process per GPU (torch.distributed, backend nccl = RCCL).  The SAME 28-episode job is sharded:
@@ -168,7 +168,7 @@ def main() -> None:
     windows = [len(e.pcm) // 2 for e in eps]
     kept = [capi.lib().needle_hip_fingerprint_num_kept(w, 2) for w in windows]
 
-    kernel_names = ["stft_chroma", "fir_norm", "classify", "hamming_runs", "simhash_runs"]
+    kernel_names = ["stft_chroma", "features_classify", "hamming_runs", "simhash_runs"]
     kernel_ms = {k: 0.0 for k in kernel_names}      # timed region: the dominant kernel only (see below)
     warm_ms = {k: 0.0 for k in kernel_names}        # warm-up: all kernels, to find the dominant one
     extra_ms = {k: 0.0 for k in kernel_names}       # untimed steps after the timed region: all kernels (breakdown)

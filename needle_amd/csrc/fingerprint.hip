@@ -41,7 +41,7 @@ struct FpStream {
   uint32_t kept;
   uint32_t kept_base;
   uint32_t pair_base;   // prefix of ceil(frames / 2): the STFT kernel transforms two frames per FFT
-  uint32_t pad;
+  uint32_t tile_base;   // prefix of ceil(kept / items per tile): tiles of features_classify_kernel
 };
 
 // ---- constant tables, generated on the host in double and uploaded once per device --------------------
@@ -335,16 +335,8 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   fold_finish(prev);
 }
 
-// ---- kernel 2: temporal FIR + L2 normalise, one thread per output row -------------------------------------
-__global__ __launch_bounds__(256) void fir_norm_kernel(const double *__restrict__ chroma,
-                                                       const FpStream *__restrict__ streams, int num_streams,
-                                                       double *__restrict__ feat, uint32_t total_rows) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= total_rows) return;
-  const int si = find_stream<&FpStream::fir_base>(streams, num_streams, g);
-  const FpStream st = streams[si];
-  const uint32_t r = g - st.fir_base;
-  const double *in = chroma + ((uint64_t)st.frame_base + r) * kBands;
+// One feature row: 5-tap temporal FIR over chroma rows in[0..4] + L2 normalise (zero if the norm is < 0.01).
+__device__ __forceinline__ void feature_row(const double *__restrict__ in, double *out) {
   const double coef[5] = {0.25, 0.75, 1.0, 0.75, 0.25};
   double v[kBands];
   double squares = 0.0;
@@ -357,7 +349,6 @@ __global__ __launch_bounds__(256) void fir_norm_kernel(const double *__restrict_
     squares += acc * acc;
   }
   const double norm = squares > 0.0 ? sqrt(squares) : 0.0;
-  double *out = feat + (uint64_t)g * kBands;
   if (norm < 0.01) {
 #pragma unroll
     for (int c = 0; c < kBands; c++) out[c] = 0.0;
@@ -365,6 +356,50 @@ __global__ __launch_bounds__(256) void fir_norm_kernel(const double *__restrict_
 #pragma unroll
     for (int c = 0; c < kBands; c++) out[c] = v[c] / norm;
   }
+}
+
+// ---- kernel 2: temporal FIR + L2 normalise, one thread per output row -------------------------------------
+// (kernels 2 and 3 run separately only when a caller asks for the intermediate features; otherwise kernel 2+3)
+__global__ __launch_bounds__(256) void fir_norm_kernel(const double *__restrict__ chroma,
+                                                       const FpStream *__restrict__ streams, int num_streams,
+                                                       double *__restrict__ feat, uint32_t total_rows) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= total_rows) return;
+  const int si = find_stream<&FpStream::fir_base>(streams, num_streams, g);
+  const FpStream st = streams[si];
+  const uint32_t r = g - st.fir_base;
+  feature_row(chroma + ((uint64_t)st.frame_base + r) * kBands, feat + (uint64_t)g * kBands);
+}
+
+// ---- kernel 2+3: features of a tile in LDS, then its items -------------------------------------------------------
+// A wave owns a tile of up to 64 consecutive kept items of one stream: it computes the (items - 1) step + 16
+// feature rows the tile's windows cover into its own LDS region (each row once; neighbouring tiles repeat only the
+// 15-row halo), then every lane classifies its window out of LDS.  The features never go to HBM and one dependent
+// launch disappears.  Row pitch 13: with step 2 a lane's window starts 26 doubles after its neighbour's, which
+// spreads the lanes over all banks (pitch 12 would put every fourth lane on the same ones).
+constexpr int kTileRowsMax = 63 * 2 + 16;  // 64 items at the default step 2
+constexpr int kFeatPitch = 13;
+__global__ __launch_bounds__(256) void features_classify_kernel(const double *__restrict__ chroma,
+                                                                const FpStream *__restrict__ streams, int num_streams,
+                                                                const core::ClassifierThresholds *__restrict__ thr,
+                                                                uint32_t step, uint32_t items_per_tile,
+                                                                uint32_t *__restrict__ items, uint32_t total_tiles) {
+  __shared__ double tiles[4][kTileRowsMax * kFeatPitch];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t g = blockIdx.x * 4 + wave;
+  if (g >= total_tiles) return;  // wave-uniform; the waves of a workgroup never wait for each other
+  const int si = find_stream<&FpStream::tile_base>(streams, num_streams, g);
+  const FpStream st = streams[si];
+  const uint32_t k0 = (g - st.tile_base) * items_per_tile;
+  const uint32_t count = min(items_per_tile, st.kept - k0);
+  const uint32_t x0 = k0 * step;  // raw item index = first feature row of the tile
+  const uint32_t rows = (count - 1) * step + 16;
+  double *mine = tiles[wave];
+  const double *in = chroma + ((uint64_t)st.frame_base + x0) * kBands;
+  for (uint32_t r = lane; r < rows; r += 64) feature_row(in + (uint64_t)r * kBands, mine + r * kFeatPitch);
+  wave_lds_fence();
+  if (lane < count)
+    items[st.item_off + k0 + lane] = core::classify_window<kFeatPitch>(mine + lane * step * kFeatPitch, thr);
 }
 
 // ---- kernel 3: 16 classifiers over a 16x12 window, one thread per kept item ----------------------------------
@@ -442,7 +477,9 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
   size_t begin = 0, chunk = 0;
   while (begin < spans.size()) {
     std::vector<FpStream> meta;
-    uint64_t frames = 0, rows = 0, kept = 0, pairs = 0;
+    uint64_t frames = 0, rows = 0, kept = 0, pairs = 0, tiles = 0;
+    // items per tile of the fused feature + classify kernel: as many (up to 64) as its LDS rows cover
+    const uint32_t items_per_tile = (uint32_t)std::min<uint64_t>(64, (uint64_t)(kTileRowsMax - 16) / step + 1);
     size_t end = begin;
     while (end < spans.size()) {
       const size_t samples = spans[end].num_values / (size_t)channels;
@@ -459,7 +496,8 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       m.kept = (uint32_t)num_kept(samples, step);
       m.kept_base = (uint32_t)kept;
       m.pair_base = (uint32_t)pairs;
-      m.pad = 0;
+      m.tile_base = (uint32_t)tiles;
+      tiles += (m.kept + items_per_tile - 1) / items_per_tile;
       pairs += (m.frames + 1) / 2;
       frames += m.frames;
       rows += m.fir_rows;
@@ -493,15 +531,22 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
         };
         if (channels == 1) launch(stft_chroma_kernel<1>); else launch(stft_chroma_kernel<2>);
       }
-      if (rows > 0) {
-        KernelTimer timer("fir_norm");
-        hipLaunchKernelGGL(fir_norm_kernel, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, stream,
-                           ws->chroma.ptr, desc.streams.ptr, n, ws->feat.ptr, (uint32_t)rows);
-      }
-      if (kept > 0) {
-        KernelTimer timer("classify");
-        hipLaunchKernelGGL(classify_kernel, dim3((uint32_t)((kept + 255) / 256)), dim3(256), 0, stream,
-                           ws->feat.ptr, desc.streams.ptr, n, tab.thr, step, d_items, (uint32_t)kept);
+      const bool separate = d_feat_dbg != nullptr || getenv("NEEDLE_HIP_SEPARATE_CLASSIFY") != nullptr;
+      if (separate) {  // a caller wants the features themselves (tests): kernels 2 and 3 one after the other
+        if (rows > 0) {
+          KernelTimer timer("fir_norm");
+          hipLaunchKernelGGL(fir_norm_kernel, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, stream,
+                             ws->chroma.ptr, desc.streams.ptr, n, ws->feat.ptr, (uint32_t)rows);
+        }
+        if (kept > 0) {
+          KernelTimer timer("classify");
+          hipLaunchKernelGGL(classify_kernel, dim3((uint32_t)((kept + 255) / 256)), dim3(256), 0, stream,
+                             ws->feat.ptr, desc.streams.ptr, n, tab.thr, step, d_items, (uint32_t)kept);
+        }
+      } else if (tiles > 0) {
+        KernelTimer timer("features_classify");
+        hipLaunchKernelGGL(features_classify_kernel, dim3((uint32_t)((tiles + 3) / 4)), dim3(256), 0, stream,
+                           ws->chroma.ptr, desc.streams.ptr, n, tab.thr, step, items_per_tile, d_items, (uint32_t)tiles);
       }
       NEEDLE_HIP_TRY(hipGetLastError());
       if (d_chroma_dbg)

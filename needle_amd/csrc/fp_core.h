@@ -289,24 +289,26 @@ template <int R, int C>
 struct CellStep<R, C, 16> {
   static NEEDLE_HD void run(double, double *, double *) {}
 };
-template <int R, int C>
+template <int R, int C, int PITCH>
 struct WindowStep {
   static NEEDLE_HD void run(const double *w, double *a, double *b) {
-    CellStep<R, C, 0>::run(w[R * 12 + C], a, b);
-    WindowStep<(C == 11) ? R + 1 : R, (C == 11) ? 0 : C + 1>::run(w, a, b);
+    CellStep<R, C, 0>::run(w[R * PITCH + C], a, b);
+    WindowStep<(C == 11) ? R + 1 : R, (C == 11) ? 0 : C + 1, PITCH>::run(w, a, b);
   }
 };
-template <>
-struct WindowStep<16, 0> {
+template <int PITCH>
+struct WindowStep<16, 0, PITCH> {
   static NEEDLE_HD void run(const double *, double *, double *) {}
 };
 
 // One raw fingerprint item from 16 consecutive feature rows (w[16][12], row-major).
+// PITCH = doubles between consecutive rows (12 = packed).
+template <int PITCH = 12>
 NEEDLE_HD uint32_t classify_window(const double *w, const ClassifierThresholds *thr) {
   double a[16], b[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) a[i] = b[i] = 0.0;
-  WindowStep<0, 0>::run(w, a, b);
+  WindowStep<0, 0, PITCH>::run(w, a, b);
   uint32_t bits = 0;
 #pragma unroll
   for (int i = 0; i < 16; i++) {

@@ -9,7 +9,8 @@ import os
 import sys
 from collections import defaultdict
 
-KERNELS = {"stft_chroma": "stft_chroma_kernel", "fir_norm": "fir_norm_kernel", "classify": "classify_kernel",
+KERNELS = {"stft_chroma": "stft_chroma_kernel", "fir_norm": "fir_norm_kernel", "features_classify": "features_classify_kernel",
+           "classify": "classify_kernel",
            "hamming_runs_sampled": "hamming_runs_sampled_kernel", "hamming_runs_band": "hamming_runs_band_kernel", "hamming_runs": "hamming_runs_kernel",
            "simhash_runs": "simhash_runs_kernel"}
 
