@@ -1,12 +1,12 @@
 // GPU fingerprinter: the chromaprint Context replacement behind
 // needle/src/audio/analyzer.rs:176-300 (start/feed/finish/get_fingerprint_raw), batched over streams.
 //
-//   stft_chroma : s16 PCM -> Hamming window -> 4096-pt real FFT (f64, LDS Stockham) -> |X|^2 over bins
-//                 10..1307 -> 12 pitch-class energies per frame            [frames][12] f64
-//   fir_norm    : 5-tap temporal FIR {.25,.75,1,.75,.25} + L2 normalise (zero if norm < 0.01)
-//                                                                          [frames-4][12] f64
-//   classify    : 16 Haar-like filters over a 16x12 window, log-ratio quantised to 2 bits, Gray coded,
-//                 packed MSB first -> u32 per kept item (items 0, step, 2*step, ...)
+//   stft_chroma       : s16 PCM -> Hamming window -> two real frames per 4096-pt complex FFT (f64, in place in
+//                       LDS) -> |X|^2 over bins 10..1307 -> 12 pitch-class energies per frame   [frames][12] f64
+//   features_classify : 5-tap temporal FIR {.25,.75,1,.75,.25} + L2 normalise (zero if norm < 0.01) into LDS,
+//                       then 16 Haar-like filters over a 16x12 window, log-ratio quantised to 2 bits, Gray
+//                       coded, packed MSB first -> u32 per kept item (items 0, step, 2*step, ...)
+//   (fir_norm + classify: the same two steps as separate kernels, for callers that want the features)
 //
 // HBM traffic that matters is the PCM read (2 B/sample, each sample touched by 3 overlapping frames:
 // re-reads are served by L2) and 96 B/frame of chroma; everything else stays on chip.
