@@ -1,14 +1,9 @@
 // needle::audio::Analyzer at and above the PCM boundary (needle/src/audio/analyzer.rs).
 #include <algorithm>
-#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
-#include <functional>
-#include <memory>
-#include <mutex>
-#include <thread>
 
 #include "needle_core.h"
 
