@@ -212,6 +212,8 @@ Status upload_through_ring(const std::vector<Segment> &segs, const PcmReader &re
   Status s = ring.ensure(upload_slab_bytes());
   if (!s.ok()) return s;
 
+  long long fail_at = -1;
+  if (const char *e = getenv("NEEDLE_HIP_TEST_FAIL_READ_AT")) fail_at = atoll(e);
   std::mutex mu;
   std::condition_variable cv;
   std::vector<uint8_t> filled(N, 0);  // 1 = slab holds the segment, 2 = the reader failed
@@ -231,7 +233,10 @@ Status upload_through_ring(const std::vector<Segment> &segs, const PcmReader &re
       }
       Status rs;
       try {  // an exception must not leave a reader thread: the C ABI reports errors as codes
-        rs = read(segs[seg].stream, segs[seg].first, segs[seg].count, ring.slab(seg));
+        if ((long long)seg == fail_at)  // tests: a read error in the middle of a transfer
+          rs = Status::Make(NeedleError_IOError, "IO error: injected read failure");
+        else
+          rs = read(segs[seg].stream, segs[seg].first, segs[seg].count, ring.slab(seg));
       } catch (const std::exception &e) {
         rs = Status::Make(NeedleError_Unknown, std::string("PCM reader failed: ") + e.what());
       } catch (...) {

@@ -1040,3 +1040,27 @@ def test_file_analyzer_truncated_and_unreadable_files(tmp_path):
     open(bad, "wb").write(b"not a wave file at all" * 10)
     with pytest.raises(capi.NeedleError):
         capi.Analyzer.from_files([bad]).run(0.3)
+
+
+@pytest.mark.timeout(120)
+def test_upload_ring_survives_a_failing_reader(tmp_path, monkeypatch):
+    """A read error in the middle of a streamed upload (injected at a chosen segment) ends the call with an error
+    code -- readers, uploader and ring all wind down -- and the next call works and gives the right hashes: first,
+    last and a middle segment, with slabs small enough that the ring wraps many times."""
+    eps = synth.make_library(4, 60.0, 10.0)
+    paths = []
+    for k, e in enumerate(eps):
+        p = str(tmp_path / f"e{k}.wav")
+        synth.write_wav(p, e.pcm)
+        paths.append(p)
+    want = [fh.opening_data()[0].tolist() for fh in capi.Analyzer.from_files(paths).run(0.3)]
+    monkeypatch.setenv("NEEDLE_HIP_UPLOAD_SLAB_BYTES", "8192")
+    total_segments = sum(-(-(len(e.pcm) // 2 * 2) // 8192) for e in eps)
+    for fail_at in (0, 37, total_segments - 1):
+        monkeypatch.setenv("NEEDLE_HIP_TEST_FAIL_READ_AT", str(fail_at))
+        with pytest.raises(capi.NeedleError) as err:
+            capi.Analyzer.from_files(paths).run(0.3)
+        assert err.value.name == "IOError"
+        monkeypatch.delenv("NEEDLE_HIP_TEST_FAIL_READ_AT")
+        got = [fh.opening_data()[0].tolist() for fh in capi.Analyzer.from_files(paths).run(0.3)]
+        assert got == want
