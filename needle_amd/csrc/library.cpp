@@ -57,6 +57,10 @@ struct NeedleHipLibrary {
   std::vector<std::vector<HashTs>> ts_cache;  // un-seeked timestamps by kept length
   std::vector<uint32_t> min_len;              // per row, for the durations below
   ns_t min_len_for[2] = {~0ull, ~0ull};
+  // the pair table of the last search, reused while (first pair, pair count, regions, min_len) stay the same: a
+  // library has ~n^2 / 2 pairs and a job that is repeated should not rebuild millions of descriptors
+  std::vector<NeedleHipProblem> problems;
+  size_t problems_for[3] = {~(size_t)0, 0, 0};
   std::vector<FrameHashesData> shells;        // per-video timestamps for the epilogue (hashes stay in HBM)
   // double-buffered asynchronous run-list download (needle_hip_library_fetch_runs_begin / _end)
   struct Fetch {
@@ -264,20 +268,30 @@ enum NeedleError needle_hip_library_search(NeedleHipLibrary *lib, const struct N
       }
       lib->min_len_for[0] = cmp.min_opening_duration();
       lib->min_len_for[1] = cmp.min_ending_duration();
+      lib->problems_for[0] = ~(size_t)0;
     }
-    std::vector<NeedleHipProblem> problems;
-    problems.reserve(num_pairs * Rc);
-    for (size_t p = first_pair; p < first_pair + num_pairs; p++) {
-      size_t i, j;
-      pair_at(lib->n, p, &i, &j);
-      for (size_t r = 0; r < Rc; r++) {
-        if (r == 1 && (lib->win[i * R + 1].kept == 0 || lib->win[j * R + 1].kept == 0))  // comparator.rs:271-273
-          return report(Status::Make(NeedleError_Unknown, "no ending hash data present"));
-        const uint32_t a = lib->min_len[i * R + r], b = lib->min_len[j * R + r];
-        if (a == 0 || b == 0) continue;
-        problems.push_back(NeedleHipProblem{(uint32_t)(i * R + r), (uint32_t)(j * R + r), std::max(a, b),
-                                            (uint32_t)(p * Rc + r)});
+    std::vector<NeedleHipProblem> &problems = lib->problems;
+    const bool cached = lib->problems_for[0] == first_pair && lib->problems_for[1] == num_pairs && lib->problems_for[2] == Rc;
+    if (!cached) {
+      lib->problems_for[0] = ~(size_t)0;  // not valid until it is complete
+      problems.clear();
+      problems.reserve(num_pairs * Rc);
+      size_t i = 0, j = 0;
+      if (num_pairs) pair_at(lib->n, first_pair, &i, &j);
+      for (size_t p = first_pair; p < first_pair + num_pairs; p++) {
+        for (size_t r = 0; r < Rc; r++) {
+          if (r == 1 && (lib->win[i * R + 1].kept == 0 || lib->win[j * R + 1].kept == 0))  // comparator.rs:271-273
+            return report(Status::Make(NeedleError_Unknown, "no ending hash data present"));
+          const uint32_t a = lib->min_len[i * R + r], b = lib->min_len[j * R + r];
+          if (a == 0 || b == 0) continue;
+          problems.push_back(NeedleHipProblem{(uint32_t)(i * R + r), (uint32_t)(j * R + r), std::max(a, b),
+                                              (uint32_t)(p * Rc + r)});
+        }
+        if (++j == lib->n) j = ++i + 1;  // next pair in i-major order
       }
+      lib->problems_for[0] = first_pair;
+      lib->problems_for[1] = num_pairs;
+      lib->problems_for[2] = Rc;
     }
     const auto t_built = std::chrono::steady_clock::now();
     Status s = gpu_hamming_runs_device(lib->arena, seqs.data(), seqs.size(), problems.data(), problems.size(),

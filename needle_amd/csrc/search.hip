@@ -463,38 +463,30 @@ __global__ __launch_bounds__(256) void simhash_runs_kernel(const uint32_t *__res
   }
 }
 
-struct SearchWorkspace {
-  DeviceBuffer<SearchProblem> problems;
-  PinnedStage stage;
-  DescriptorUpload<SearchProblem> upload;
-  bool lds_attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in, per device
+// What a launch needs besides its inputs: the device descriptors, the grid and the kernel choice.  Kept with the
+// inputs it was derived from, so that a job that is run again (a library has ~n^2 / 2 pairs) rebuilds nothing.
+struct SearchPlan {
+  std::vector<NeedleHipSeq> seqs;          // inputs ...
+  std::vector<NeedleHipProblem> problems;
+  int mode[3] = {0, 0, 0};                 // ... and the environment switches that steer the choice
+  std::vector<SearchProblem> meta;         // derived
+  uint64_t blocks = 0;
+  size_t lds_bytes = 0;
+  bool sampled = false, fast = false;
+  int bands_per_wave = 1;
+  bool valid = false;
+  bool matches(const NeedleHipSeq *s, size_t ns, const NeedleHipProblem *p, size_t np, const int *m) const {
+    return valid && seqs.size() == ns && problems.size() == np && std::memcmp(mode, m, sizeof(mode)) == 0 &&
+           std::memcmp(seqs.data(), s, ns * sizeof(NeedleHipSeq)) == 0 &&
+           std::memcmp(problems.data(), p, np * sizeof(NeedleHipProblem)) == 0;
+  }
 };
-std::mutex g_ws_mu;
-std::map<int, SearchWorkspace *> g_ws;
 
-SearchWorkspace *workspace() {
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  std::lock_guard<std::mutex> lock(g_ws_mu);
-  auto it = g_ws.find(dev);
-  if (it != g_ws.end()) return it->second;
-  SearchWorkspace *w = new SearchWorkspace();
-  g_ws[dev] = w;
-  return w;
-}
-
-
-}  // namespace
-
-Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
-                               const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
-                               NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync) {
-  std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
-  Status s = ensure_device();
-  if (!s.ok()) return s;
-  hipStream_t stream = library_stream();
-  NEEDLE_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
-  std::vector<SearchProblem> meta;
+Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProblem *problems, size_t num_problems,
+                  const int *mode, SearchPlan *plan) {
+  plan->valid = false;
+  std::vector<SearchProblem> &meta = plan->meta;
+  meta.clear();
   meta.reserve(num_problems);
   uint64_t blocks = 0;
   size_t max_lds = 0;
@@ -529,8 +521,8 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
       smallest = std::min(smallest, m.min_len);
       max_m = std::max<size_t>(max_m, m.m);
     }
-    const bool generic_only = getenv("NEEDLE_HIP_GENERIC_SEARCH") != nullptr;
-    const bool sampled = !generic_only && smallest >= (uint32_t)(2 * kSampleW - 1 + 8) && !getenv("NEEDLE_HIP_BAND_SEARCH");
+    const bool generic_only = mode[0] != 0;
+    const bool sampled = !generic_only && smallest >= (uint32_t)(2 * kSampleW - 1 + 8) && mode[1] == 0;
     const bool fast = !generic_only && !sampled && smallest >= (uint32_t)(kBandR * kBandU);
     size_t lds_bytes = max_lds;
     int bands_per_wave = 1;
@@ -543,7 +535,7 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
       bands_per_wave = 1;
       if (sampled)
         while (bands_per_wave < 8 && total_bands / (4 * (uint64_t)bands_per_wave * 2) >= 16384) bands_per_wave *= 2;
-      if (const char *e = getenv("NEEDLE_HIP_BANDS_PER_WAVE")) bands_per_wave = std::max(1, atoi(e));  // tests, tuning
+      if (mode[2] > 0) bands_per_wave = mode[2];  // NEEDLE_HIP_BANDS_PER_WAVE: tests, tuning
       for (SearchProblem &m : meta) {
         m.block_base = (uint32_t)fb;
         const uint64_t diags = (uint64_t)m.n + m.m - 3;
@@ -558,8 +550,67 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
     if (lds_bytes > 160 * 1024)
       return Status::Make(NeedleError_InvalidArgument,
                           "hamming_runs: a sequence pair exceeds the 160 KiB LDS staging limit (~40000 hashes)");
-    SearchWorkspace *ws = workspace();
-    if (!(s = ws->upload.put(&ws->problems, &ws->stage, meta, stream)).ok()) return s;
+    plan->sampled = sampled;
+    plan->fast = fast;
+    plan->bands_per_wave = bands_per_wave;
+    plan->lds_bytes = lds_bytes;
+  }
+  plan->blocks = blocks;
+  plan->seqs.assign(seqs, seqs + num_seqs);
+  plan->problems.assign(problems, problems + num_problems);
+  std::memcpy(plan->mode, mode, sizeof(plan->mode));
+  plan->valid = true;
+  return Status::Ok();
+}
+
+struct SearchWorkspace {
+  DeviceBuffer<SearchProblem> problems;
+  PinnedStage stage;
+  DescriptorUpload<SearchProblem> upload;
+  SearchPlan plan;            // of the last launch
+  bool lds_attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in, per device
+};
+std::mutex g_ws_mu;
+std::map<int, SearchWorkspace *> g_ws;
+
+SearchWorkspace *workspace() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_ws_mu);
+  auto it = g_ws.find(dev);
+  if (it != g_ws.end()) return it->second;
+  SearchWorkspace *w = new SearchWorkspace();
+  g_ws[dev] = w;
+  return w;
+}
+
+
+}  // namespace
+
+Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
+                               const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
+                               NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync) {
+  std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
+  Status s = ensure_device();
+  if (!s.ok()) return s;
+  hipStream_t stream = library_stream();
+  NEEDLE_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
+  const int mode[3] = {getenv("NEEDLE_HIP_GENERIC_SEARCH") != nullptr, getenv("NEEDLE_HIP_BAND_SEARCH") != nullptr,
+                       getenv("NEEDLE_HIP_BANDS_PER_WAVE") ? std::max(1, atoi(getenv("NEEDLE_HIP_BANDS_PER_WAVE"))) : 0};
+  SearchWorkspace *ws = workspace();
+  SearchPlan &plan = ws->plan;
+  const bool reuse = plan.matches(seqs, num_seqs, problems, num_problems, mode);
+  if (!reuse && !(s = build_plan(seqs, num_seqs, problems, num_problems, mode, &plan)).ok()) return s;
+  const std::vector<SearchProblem> &meta = plan.meta;
+  const uint64_t blocks = plan.blocks;
+  const size_t lds_bytes = plan.lds_bytes;
+  const bool sampled = plan.sampled, fast = plan.fast;
+  const int bands_per_wave = plan.bands_per_wave;
+  if (!meta.empty()) {
+    // same inputs as last time and the table still where it was put: nothing to compare or upload
+    if (!(reuse && ws->upload.resident_at == ws->problems.ptr && ws->problems.ptr) &&
+        !(s = ws->upload.put(&ws->problems, &ws->stage, meta, stream)).ok())
+      return s;
     if (lds_bytes > 64 * 1024 && !ws->lds_attr_set) {
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
