@@ -182,10 +182,13 @@ def main() -> None:
         # Jobs are pipelined two deep: job k's run list is downloaded asynchronously into pinned memory and its
         # host epilogue runs while job k+1's kernels execute.  Every job (analyze, search, download, epilogue)
         # completes inside the timed region; flush() finishes the one still in flight.
-        max_runs = max(4096, 2 * n_pairs)        # what the asynchronous download fetches without a second trip
+        max_runs = max(4096, cap if n_pairs > 2048 else 0)   # what the asynchronous download fetches: at library scale the
+                                                             # whole buffer (a second, synchronous trip would wait for the NEXT job too)
         bufs = [(capi.DeviceBuffer(cap * capi.RUN_DTYPE.itemsize), capi.DeviceBuffer(4)) for _ in range(2)]
         pending = []
         seq = [0]
+        trace_host = os.environ.get("NEEDLE_BENCH_TRACE") is not None   # host-side timeline of the job pipeline on stderr
+        t_origin = time.perf_counter()
         finished = [0]                           # epilogues counted in host_ms (the flushes add a few to the K steps)
 
         def finish(slot, collect):
@@ -198,6 +201,9 @@ def main() -> None:
             t1 = time.perf_counter()
             state["results"] = lib.finalize(cmp, runs)
             state["runs"] = found
+            if trace_host:
+                print(f"[bench] finish slot {slot}: wait {1e3 * (t0 - t_origin):9.2f} -> {1e3 * (t1 - t_origin):9.2f}, "
+                      f"epilogue -> {1e3 * (time.perf_counter() - t_origin):9.2f} ms", file=sys.stderr)
             if collect:
                 host_ms["wait_runs"] += 1e3 * (t1 - t0)
                 host_ms["epilogue"] += 1e3 * (time.perf_counter() - t1)
@@ -213,6 +219,9 @@ def main() -> None:
             lib.search(cmp, 0, n_pairs, d_runs.ptr, cap, d_count.ptr, sync=False)
             ts = time.perf_counter()
             lib.fetch_runs_begin(slot, d_runs.ptr, d_count.ptr, max_runs)
+            if trace_host:
+                print(f"[bench] enqueue slot {slot}: {1e3 * (t0 - t_origin):9.2f} -> {1e3 * (time.perf_counter() - t_origin):9.2f} ms",
+                      file=sys.stderr)
             if collect:
                 host_ms["enqueue"] += 1e3 * (time.perf_counter() - t0)
                 host_ms["enqueue_analyze"] += 1e3 * (ta - t0)

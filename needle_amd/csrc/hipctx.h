@@ -30,6 +30,7 @@ std::recursive_mutex &gpu_mutex();
 // Fails loudly (NeedleError_Unknown "no HIP device") when no GPU is usable: there is no CPU path.
 Status ensure_device();
 hipStream_t library_stream();
+hipStream_t download_stream();  // result downloads, ordered behind the library stream with events
 
 template <typename T>
 struct DeviceBuffer {

@@ -110,6 +110,27 @@ void set_kernel_timing(const char *kernels) {
   timing_selection().set(kernels);
 }
 
+// Downloads of results go here, behind an event of the library stream: a copy enqueued on the library stream itself
+// was observed (ROCm 7.2) to complete only after the kernels enqueued BEHIND it, i.e. after the next job, which
+// serialised a job's host epilogue with the following job's device work.
+hipStream_t download_stream() {
+  static std::map<int, hipStream_t> streams;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = streams.find(dev);
+  if (it != streams.end()) return it->second;
+  hipStream_t s = nullptr;
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+  }
+  streams[dev] = s;
+  return s;
+}
+
 KernelTimer::KernelTimer(const char *n) : name(n) {
   hipStream_t s = library_stream();
   std::lock_guard<std::mutex> lock(g_mu);

@@ -66,13 +66,15 @@ struct NeedleHipLibrary {
   struct Fetch {
     void *host = nullptr;  // pinned: u32 count, then max_runs NeedleHipRun
     uint32_t max_runs = 0;
-    hipEvent_t done = nullptr;
+    hipEvent_t ready = nullptr, done = nullptr;  // search enqueued (library stream) / copies finished (download stream)
+    const NeedleHipRun *d_runs = nullptr;        // what the pending download reads
     bool pending = false;
   } fetch[2];
   ~NeedleHipLibrary() {
     for (Fetch &f : fetch) {
       if (f.host) (void)hipHostFree(f.host);
       if (f.done) (void)hipEventDestroy(f.done);
+      if (f.ready) (void)hipEventDestroy(f.ready);
     }
   }
 
@@ -293,6 +295,10 @@ enum NeedleError needle_hip_library_search(NeedleHipLibrary *lib, const struct N
       lib->problems_for[1] = num_pairs;
       lib->problems_for[2] = Rc;
     }
+    // a download that still reads this run buffer (on the download stream) has to finish before it is overwritten
+    for (NeedleHipLibrary::Fetch &f : lib->fetch)
+      if (f.pending && f.d_runs == d_runs && hipStreamWaitEvent(library_stream(), f.done, 0) != hipSuccess)
+        return report(Status::Make(NeedleError_Unknown, "stream wait failed"));
     const auto t_built = std::chrono::steady_clock::now();
     Status s = gpu_hamming_runs_device(lib->arena, seqs.data(), seqs.size(), problems.data(), problems.size(),
                                        cmp.hash_match_threshold(), d_runs, capacity, d_count, sync);
@@ -321,12 +327,17 @@ enum NeedleError needle_hip_library_fetch_runs_begin(NeedleHipLibrary *lib, int 
     }
     if (!f.done && hipEventCreateWithFlags(&f.done, hipEventDisableTiming) != hipSuccess)
       return report(Status::Make(NeedleError_Unknown, "event creation failed"));
-    hipStream_t stream = library_stream();
-    if (hipMemcpyAsync(f.host, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+    if (!f.ready && hipEventCreateWithFlags(&f.ready, hipEventDisableTiming) != hipSuccess)
+      return report(Status::Make(NeedleError_Unknown, "event creation failed"));
+    // the copies run on the download stream, behind the search that was just enqueued on the library stream
+    hipStream_t stream = library_stream(), down = download_stream();
+    if (hipEventRecord(f.ready, stream) != hipSuccess || hipStreamWaitEvent(down, f.ready, 0) != hipSuccess ||
+        hipMemcpyAsync(f.host, d_count, sizeof(uint32_t), hipMemcpyDeviceToHost, down) != hipSuccess ||
         hipMemcpyAsync(static_cast<char *>(f.host) + 16, d_runs, (size_t)max_runs * sizeof(NeedleHipRun),
-                       hipMemcpyDeviceToHost, stream) != hipSuccess ||
-        hipEventRecord(f.done, stream) != hipSuccess)
+                       hipMemcpyDeviceToHost, down) != hipSuccess ||
+        hipEventRecord(f.done, down) != hipSuccess)
       return report(Status::Make(NeedleError_Unknown, "asynchronous run download failed"));
+    f.d_runs = d_runs;
     f.pending = true;
     return NeedleError_Ok;
   });
