@@ -3,32 +3,42 @@
 
 metric  : episode-pairs/sec (analyze+search) = N(N-1)/2 / wall(analyze N episodes + search all pairs +
           per-video best match), N = 28 synthetic 24-min episodes (BASELINE.json configs[1]).
-step    : one complete pass of the hot path over the library: fingerprint every episode's opening window
-          (stft_chroma and features_classify kernels), scan every pair (hamming_runs kernel), copy the run list
-          and the hash arena back, run the order-sensitive host epilogue (duration validity, simhash32,
-          BinaryHeap order, find_best_match).  PCM is resident in HBM before the timed region starts.
-N > 1   : one process per GPU (torch.distributed, backend nccl = RCCL).  The SAME 28-episode job is sharded:
-          episodes in contiguous blocks, one all-gather of hash rows, pairs in contiguous ranges, one
-          all-gather of run lists, epilogue on rank 0 ("strong" scaling, BASELINE.json configs[3]).
+step    : one complete job of the hot path over the library, through the C ABI (needle_hip_library_job_begin /
+          _end): fingerprint every episode's opening window (stft_chroma and features_classify kernels), scan every
+          pair (hamming_runs kernel), hash the runs (simhash_runs), download the run list, run the order-sensitive
+          host epilogue (duration validity, BinaryHeap order, find_best_match).  Two jobs are in flight (job k's
+          epilogue overlaps job k+1's kernels); every job completes inside the timed region.
+          `value` is measured with the PCM RESIDENT IN HBM before the timed region starts (the bench contract);
+          the same job from caller-owned pinned host PCM, upload overlapped with compute, is `end_to_end`.
+--gpus N: one process per GPU.  Launched by torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this
+          process is one rank; launched plainly (`python bench.py --gpus N`) it spawns the N rank processes itself,
+          before touching any GPU.  The SAME 28-episode job is sharded inside libneedle_capi.so (BASELINE.json
+          configs[3]): episodes in contiguous blocks, one RCCL all-gather of hash rows, pairs in contiguous ranges,
+          one RCCL all-gather of run lists, epilogue on every rank ("strong" scaling).  No torch anywhere: the
+          communicator id travels through a file rendezvous (needle_amd/rendezvous.py).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed live with HIP events on the
-library's stream inside the timed region (the other kernels are timed in a few untimed steps after it); `cpu_baseline` times the oracle (the C restatement of the reference's CPU path, full
-DP table per pair, one task per episode / pair over all host cores) on rank 0 at N = 1.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed live with HIP events on the library's
+stream inside the timed region (the other kernels are timed in a few untimed steps after it); `roofline_search` is
+the scan kernel against the integer-VALU ceiling measured in the same run; `cpu_baseline` times the oracle (the C
+restatement of the reference's CPU path, full DP table per pair, one task per episode / pair over the usable host
+cores) on rank 0 at N = 1; `search_only` is BASELINE.json configs[2] (280 x 24 min from .needle.dat files).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+F64_VALU_PEAK_TFLOPS = 78.6    # vector f64 = half the 157.3 TFLOP/s f32 vector rate of MI355X_MICROARCH.md (no faster f64 MFMA)
 RATE = 11025
 
 
@@ -38,9 +48,6 @@ def algorithmic_bytes(kernel: str, windows, kept, n_pairs: int, n_runs: int) -> 
         n = sum(kept) / max(len(kept), 1)
         return n_pairs * 4.0 * 2.0 * n + 12.0 * n_runs
     return float(sum(2 * s + 4 * h for s, h in zip(windows, kept)))
-
-
-F64_VALU_PEAK_TFLOPS = 78.6    # vector f64 = half the 157.3 TFLOP/s f32 vector rate of MI355X_MICROARCH.md (no faster f64 MFMA)
 
 
 def stft_flops(windows) -> float:
@@ -71,10 +78,21 @@ def usable_cpus() -> int:
     return n
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(eps, results_gpu, hashes_gpu):
     """The oracle on the host cores (rank 0, N = 1 only): same episodes, same pairs, reference cost
     structure.  Bounded: the whole 28-episode job when the core count makes it ~<= 30 s, else a prefix of
     the pair list, scaled.  Also cross-checks the GPU's hashes and results against it."""
+    import numpy as np
     from oracle import oracle as O
     threads = usable_cpus()
     hd = O.duration_from_secs_f32(0.3)
@@ -109,9 +127,10 @@ def cpu_baseline(eps, results_gpu, hashes_gpu):
         parity = parity and got == want
     return {
         "value": round(value, 3), "unit": "episode-pairs/s", "cores": threads, "kind": "port",
-        "sample": f"oracle (C restatement of analyzer.rs/comparator.rs + chromaprint, not the Rust binary): "
+        "cpu_model": cpu_model(),
+        "sample": f"oracle (C restatement of analyzer.rs/comparator.rs + chromaprint in f64, not the Rust binary): "
                   f"analyze all {n} episodes in {t_analyze:.2f} s, search {sample_pairs}/{pairs_total} pairs in "
-                  f"{t_search:.2f} s (scaled to all pairs), {threads} threads",
+                  f"{t_search:.2f} s (scaled to all pairs), {threads} threads, PCM in host memory",
         "analyze_s": round(t_analyze, 3), "search_s_scaled": round(t_search_full, 3),
         "gpu_matches_oracle": bool(parity),
         "optimised_cpu_variant": {"value": round(pairs_total / (t_analyze + t_opt), 3), "unit": "episode-pairs/s",
@@ -119,6 +138,147 @@ def cpu_baseline(eps, results_gpu, hashes_gpu):
                                   "what": "same analyze stage + table-free diagonal scan of all pairs (min run 82), "
                                           f"{threads} threads, without the per-video epilogue"},
     }
+
+
+def end_to_end(capi, eps, cmp, n_pairs, reps=6):
+    """The same job from caller-owned host PCM (what a decoder hands over): needle_hip_library_stream_pcm uploads the
+    opening windows on an upload stream and fingerprints them group by group as they land, then search + epilogue.
+    Measured from pinned memory (read in place by the copy engine) and from pageable numpy arrays (ring of pinned
+    slabs filled by host threads).  PCIe-inclusive; never `value`."""
+    n = len(eps)
+    lens = [len(e.pcm) for e in eps]
+    window_bytes = sum(2 * (v // 2) for v in lens)
+    out = {}
+    pinned = [capi.PinnedArray(v) for v in lens]
+    for p, e in zip(pinned, eps):
+        p.array[:] = e.pcm
+    for label, arrays in (("pinned", [p.array for p in pinned]), ("pageable", [e.pcm for e in eps])):
+        lib = capi.Library(n)
+        jobs, uploads = [], []
+        res = None
+        for rep in range(reps + 2):
+            capi.synchronize()
+            t0 = time.perf_counter()
+            lib.stream_pcm(arrays, lens)
+            t1 = time.perf_counter()
+            lib.job_begin(cmp, 0)
+            res, _ = lib.job_end(cmp, 0)
+            t2 = time.perf_counter()
+            if rep >= 2:
+                jobs.append(t2 - t0)
+                uploads.append(t1 - t0)
+        ms = 1e3 * sum(jobs) / len(jobs)
+        out[label] = {"ms_per_job": round(ms, 3), "best_ms": round(1e3 * min(jobs), 3),
+                      "pairs_per_s": round(n_pairs / (ms * 1e-3), 1),
+                      "h2d_gbs": round(window_bytes / (sum(uploads) / len(uploads)) / 1e9, 2),
+                      "detected": sum(1 for r in res if r is not None and r.opening is not None)}
+        del lib
+    out["bytes_uploaded_per_job"] = window_bytes
+    out["what"] = ("needle_hip_library_stream_pcm (upload on its own stream, fingerprint kernels per ~32 MiB group "
+                   "behind events) + job_begin/_end (search, download, epilogue); one job at a time, wall clock")
+    return out
+
+
+def search_only(capi, synth, episodes, minutes, reps=5):
+    """BASELINE.json configs[2]: `episodes` x 24-min episodes as real .needle.dat files (written once by this
+    analyzer from synthetic audio), then needle_audio_comparator_run(analyze=false) timed from disk: file reads,
+    upload of the hashes, scan + simhash kernels, download, epilogue."""
+    t_prep = time.perf_counter()
+    half = minutes * 60.0 / 2
+    tmp = tempfile.mkdtemp(prefix="needle_bench_search_")
+    paths = []
+    batch = 28
+    for b0 in range(0, episodes, batch):
+        ks = range(b0, min(episodes, b0 + batch))
+        # only the opening half of each episode is ever hashed: synthesise that half (shared intro inside it)
+        eps = [synth.make_episode(k, half, 90.0 if half > 400 else half / 4) for k in ks]
+        batch_paths = [os.path.join(tmp, f"episode-{k:04d}.wav") for k in ks]
+        paths += batch_paths
+        # the product's own writer: Analyzer::run_pcm with the whole (half-)stream as the opening window,
+        # persist = True -> <video>.needle.dat next to each video path
+        capi.Analyzer.from_files(batch_paths).with_opening_search_percentage(1.0).run_pcm(
+            [e.pcm for e in eps], channels=1, persist=True)
+    prep_s = time.perf_counter() - t_prep
+    cmp = capi.Comparator(paths)
+    capi.set_kernel_timing("hamming_runs,simhash_runs")
+    walls, scan, simh = [], [], []
+    for rep in range(reps + 1):
+        t0 = time.perf_counter()
+        cmp.run(analyze=False, display=False)
+        dt = time.perf_counter() - t0
+        if rep:
+            walls.append(dt)
+            scan.append(capi.last_kernel_ms("hamming_runs"))
+            simh.append(capi.last_kernel_ms("simhash_runs"))
+    capi.set_kernel_timing(None)
+    for p in paths:
+        try:
+            os.unlink(os.path.splitext(p)[0] + ".needle.dat")
+        except OSError:
+            pass
+    try:
+        os.rmdir(tmp)
+    except OSError:
+        pass
+    pairs = episodes * (episodes - 1) // 2
+    n_h = capi.lib().needle_hip_fingerprint_num_kept(int(round(half * RATE)), 2)
+    wall = sum(walls) / len(walls)
+    return {"episodes": episodes, "pairs": pairs, "hashes_per_episode": int(n_h),
+            "wall_ms": round(1e3 * wall, 3), "pairs_per_s": round(pairs / wall, 1),
+            "scan_kernel_ms": round(sum(scan) / len(scan), 4), "simhash_kernel_ms": round(sum(simh) / len(simh), 4),
+            "table_cells": float(pairs) * n_h * n_h, "prepare_s": round(prep_s, 2),
+            "what": "needle_audio_comparator_run(analyze=false) over .needle.dat files in the page cache: read + parse, "
+                    "H2D of hashes, scan, simhash, D2H of runs, host epilogue; wall clock per call"}
+
+
+# ---- launcher: `python bench.py --gpus N` without a launcher's environment --------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n: int, timeout_s: float) -> int:
+    """Starts the N rank processes (this process never touches a GPU), rank 0 on our stdout.  A launch that does not
+    finish in time (a collective that never completes) is killed by PID and repeated once over the host-staged
+    transport, which needs nothing from the interconnect."""
+    for attempt in range(2):
+        env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if attempt:
+            env["NEEDLE_HIP_COMM"] = "host"
+        procs = []
+        for rank in range(n):
+            renv = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=renv,
+                                          stdout=None if rank == 0 else sys.stderr))
+        deadline = time.monotonic() + timeout_s
+        codes = [None] * n
+        while any(c is None for c in codes) and time.monotonic() < deadline:
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = p.poll()
+            if any(c not in (None, 0) for c in codes):
+                break
+            time.sleep(0.05)
+        failed = any(c not in (None, 0) for c in codes)
+        hung = any(c is None for c in codes)
+        if hung or failed:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+        if not hung and not failed:
+            return 0
+        print(f"[bench] launch attempt {attempt}: {'timed out' if hung and not failed else 'a rank failed'}"
+              f"{'; retrying over the host-staged transport' if attempt == 0 and env.get('NEEDLE_HIP_COMM') != 'host' else ''}",
+              file=sys.stderr)
+        if os.environ.get("NEEDLE_HIP_COMM") == "host":
+            break
+    return 1
 
 
 def main() -> None:
@@ -130,42 +290,44 @@ def main() -> None:
     ap.add_argument("--minutes", type=float, default=24.0)
     ap.add_argument("--intro-seconds", type=float, default=90.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-dist", action="store_true", help="use the torch.distributed path even at N=1")
+    ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / search_only / roofline_search")
+    ap.add_argument("--search-only-episodes", type=int, default=280)
+    ap.add_argument("--force-comm", action="store_true", help="create a 1-rank communicator even at N=1")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, args.launch_timeout))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or args.force_dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-    torch = dist = None
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29513")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        import torch  # noqa: F811  (loads its HIP runtime first; libneedle_capi.so binds to the same one)
-        import torch.distributed as dist  # noqa: F811
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    from needle_amd import capi, synth
-    from needle_amd import dist as ndist
+    import numpy as np
+    from needle_amd import capi, rendezvous, synth
 
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the needle path has no CPU fallback")
-    capi.set_device(local_rank if distributed else 0)
+    rdzv = None
+    if world > 1 or args.force_comm:
+        rdzv = rendezvous.init_comm(capi, rank, world, local_rank % capi.device_count())
+    else:
+        capi.set_device(0)
 
     n = args.episodes
-    eps = synth.make_library(n, args.minutes * 60.0, args.intro_seconds)
-    first, count = ndist.shard(n, world, rank)
+    total_samples = int(round(args.minutes * 60.0 * RATE))
+    first, count = capi.comm_shard(n, world, rank)
+    # every rank needs every length (metadata); only its own block's PCM
+    mine = {k: synth.make_episode(k, args.minutes * 60.0, args.intro_seconds) for k in range(first, first + count)}
+    if world == 1:
+        eps = [mine[k] for k in range(n)]
     lib = capi.Library(n)
-    lib.set_pcm([e.pcm if first <= k < first + count else None for k, e in enumerate(eps)],
-                [len(e.pcm) for e in eps])
+    lib.set_pcm([mine[k].pcm if k in mine else None for k in range(n)], [total_samples] * n)
     cmp = capi.Comparator([f"episode-{k:04d}.wav" for k in range(n)])
     cmp.handle()
     n_pairs = lib.num_pairs()
-    cap = max(1 << 16, 4 * n_pairs)          # run-list capacity: every pair of a library with one shared intro matches
-    windows = [len(e.pcm) // 2 for e in eps]
+    windows = [total_samples // 2] * n
     kept = [capi.lib().needle_hip_fingerprint_num_kept(w, 2) for w in windows]
 
     kernel_names = ["stft_chroma", "features_classify", "hamming_runs", "simhash_runs"]
@@ -174,154 +336,67 @@ def main() -> None:
     extra_ms = {k: 0.0 for k in kernel_names}       # untimed steps after the timed region: all kernels (breakdown)
     timed, acc = [list(kernel_names)], [warm_ms]
     state = {"runs": 0, "results": None}
+    host_ms = {"enqueue": 0.0, "wait_and_epilogue": 0.0}
+    finished = [0]
+    pending = []
+    seq = [0]
 
-    if not distributed:
-        d_runs, d_count = capi.DeviceBuffer(cap * capi.RUN_DTYPE.itemsize), capi.DeviceBuffer(4)
+    # Jobs are pipelined two deep: job k's run list is downloaded asynchronously into pinned memory and its host
+    # epilogue runs while job k+1's kernels execute.  Every job (analyze, [gather], search, [gather], download,
+    # epilogue) completes inside the timed region; flush() finishes the one still in flight.
+    def finish(slot, collect):
+        t0 = time.perf_counter()
+        state["results"], state["runs"] = lib.job_end(cmp, slot)
+        if collect:
+            host_ms["wait_and_epilogue"] += 1e3 * (time.perf_counter() - t0)
+            finished[0] += 1
 
-        host_ms = {"enqueue": 0.0, "enqueue_analyze": 0.0, "enqueue_search": 0.0, "wait_runs": 0.0, "epilogue": 0.0}
-        # Jobs are pipelined two deep: job k's run list is downloaded asynchronously into pinned memory and its
-        # host epilogue runs while job k+1's kernels execute.  Every job (analyze, search, download, epilogue)
-        # completes inside the timed region; flush() finishes the one still in flight.
-        max_runs = max(4096, cap if n_pairs > 2048 else 0)   # what the asynchronous download fetches: at library scale the
-                                                             # whole buffer (a second, synchronous trip would wait for the NEXT job too)
-        bufs = [(capi.DeviceBuffer(cap * capi.RUN_DTYPE.itemsize), capi.DeviceBuffer(4)) for _ in range(2)]
-        pending = []
-        seq = [0]
-        trace_host = os.environ.get("NEEDLE_BENCH_TRACE") is not None   # host-side timeline of the job pipeline on stderr
-        t_origin = time.perf_counter()
-        finished = [0]                           # epilogues counted in host_ms (the flushes add a few to the K steps)
+    def step(collect):
+        slot = seq[0] & 1
+        seq[0] += 1
+        t0 = time.perf_counter()
+        lib.job_begin(cmp, slot)
+        if collect:
+            host_ms["enqueue"] += 1e3 * (time.perf_counter() - t0)
+        if pending:
+            finish(pending.pop(), collect)                   # previous job's epilogue overlaps this job's kernels
+        pending.append(slot)
+        for k in timed[0]:                                   # events of the job before: already complete
+            acc[0][k] += max(capi.last_kernel_ms(k), 0.0)
 
-        def finish(slot, collect):
-            t0 = time.perf_counter()
-            runs, found = lib.fetch_runs_end(slot, max_runs)
-            if found > max_runs:                                 # rare: fetch the whole list synchronously
-                if found > cap:
-                    raise SystemExit("run list overflow")
-                runs = bufs[slot][0].to_host(capi.RUN_DTYPE, found)
-            t1 = time.perf_counter()
-            state["results"] = lib.finalize(cmp, runs)
-            state["runs"] = found
-            if trace_host:
-                print(f"[bench] finish slot {slot}: wait {1e3 * (t0 - t_origin):9.2f} -> {1e3 * (t1 - t_origin):9.2f}, "
-                      f"epilogue -> {1e3 * (time.perf_counter() - t_origin):9.2f} ms", file=sys.stderr)
-            if collect:
-                host_ms["wait_runs"] += 1e3 * (t1 - t0)
-                host_ms["epilogue"] += 1e3 * (time.perf_counter() - t1)
-                finished[0] += 1
+    def barrier():
+        while pending:
+            finish(pending.pop(), True)
+        capi.synchronize()
+        capi.comm_barrier()
 
-        def step(collect):
-            slot = seq[0] & 1
-            seq[0] += 1
-            t0 = time.perf_counter()
-            d_runs, d_count = bufs[slot]
-            lib.analyze(0, n, sync=False)
-            ta = time.perf_counter()
-            lib.search(cmp, 0, n_pairs, d_runs.ptr, cap, d_count.ptr, sync=False)
-            ts = time.perf_counter()
-            lib.fetch_runs_begin(slot, d_runs.ptr, d_count.ptr, max_runs)
-            if trace_host:
-                print(f"[bench] enqueue slot {slot}: {1e3 * (t0 - t_origin):9.2f} -> {1e3 * (time.perf_counter() - t_origin):9.2f} ms",
-                      file=sys.stderr)
-            if collect:
-                host_ms["enqueue"] += 1e3 * (time.perf_counter() - t0)
-                host_ms["enqueue_analyze"] += 1e3 * (ta - t0)
-                host_ms["enqueue_search"] += 1e3 * (ts - ta)
-            if pending:
-                finish(pending.pop(), collect)                   # previous job's epilogue overlaps this job's kernels
-            pending.append(slot)
-            for k in timed[0]:                                   # events of the job before: already complete
-                acc[0][k] += max(capi.last_kernel_ms(k), 0.0)
-
-        def flush():
-            while pending:
-                finish(pending.pop(), True)
-
-        def barrier():
-            flush()
-            capi.synchronize()
-    else:
-        b = ndist.block(n, world)
-        _, stride = lib.hash_arena()
-        arena = torch.zeros((b * world, stride), dtype=torch.int32, device="cuda")
-        lib.use_hash_arena(arena.data_ptr(), b * world, stride)
-        t_runs = torch.zeros((cap, capi.RUN_WORDS), dtype=torch.int32, device="cuda")
-        t_count = torch.zeros(1, dtype=torch.int32, device="cuda")
-
-        # torch's "current stream" becomes the library's own stream: the staging copies and the collectives'
-        # stream dependencies are then ordered against the library's kernels by the stream itself, and the only
-        # host wait of a job is the download of the gathered run list
-        torch.cuda.set_stream(torch.cuda.ExternalStream(capi.stream_ptr(), device=torch.device("cuda", local_rank)))
-
-        def sync():
-            pass
-
-        def full_sync():
-            capi.synchronize()
-            torch.cuda.synchronize()
-
-        def search_pairs(pfirst, pcount):
-            lib.search(cmp, pfirst, pcount, t_runs.data_ptr(), cap, t_count.data_ptr(), sync=False)
-            return t_runs, t_count          # gathered with one fixed-size collective (ndist.gather_runs_slab)
-
-        def finalize(runs_np):
-            runs = np.ascontiguousarray(runs_np.astype(np.int32)).view(capi.RUN_DTYPE).reshape(-1)
-            state["runs"] = len(runs)
-            return lib.finalize(cmp, runs)
-
-        # communicator set-up (RCCL creates its channels lazily on first use): two throw-away collectives of the
-        # job's own shapes, so that it never lands in a timed step however short the warm-up is
-        warm = torch.zeros((b * world, stride), dtype=torch.int32, device="cuda")
-        for _ in range(2):
-            ndist.gather_rows(warm, world, rank)
-        dist.barrier()
-        torch.cuda.synchronize()
-        del warm
-        gather = ndist.SlabGather(t_runs, world)
-        row_block = torch.zeros((b, stride), dtype=torch.int32, device="cuda")
-        pipe = ndist.JobPipeline(n, world, rank, arena, lambda f, c: lib.analyze(f, c, sync=False), search_pairs,
-                                 finalize, gather, row_block, side_stream=torch.cuda.Stream(priority=-1))
-
-        def step(collect, prefetch=True):
-            res = pipe.step(prefetch)
-            if rank == 0:
-                state["results"] = res
-            for k in timed[0]:
-                acc[0][k] += max(capi.last_kernel_ms(k), 0.0)
-
-        def barrier():
-            full_sync()
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    # N > 1: a step enqueues the NEXT job's fingerprinting before it waits for its own run list, except on the
-    # last step of a phase, so the timed region holds exactly `steps` analyses and `steps` searches
-    ahead = (lambda i, total: {"prefetch": i + 1 < total}) if distributed else (lambda i, total: {})
     # HIP events around every kernel cost 3 % of a step (one more packet between dependent dispatches each), so
     # the timed region carries them for the dominant kernel only -- the one `roofline` is about, found in the
     # warm-up where all kernels are timed; the other kernels' times come from a few untimed steps afterwards.
     capi.set_kernel_timing("all")
     for i in range(args.warmup):
-        step(False, **ahead(i, args.warmup))
+        step(False)
     barrier()
     dominant = max(warm_ms, key=warm_ms.get) if any(v > 0 for v in warm_ms.values()) else "stft_chroma"
+    if world > 1:                                            # every rank times the same kernel: rank 0 decides
+        dominant = kernel_names[int(capi.comm_all_gather(np.array([kernel_names.index(dominant)], dtype=np.int32))[0, 0])]
     timed[0], acc[0] = [dominant], kernel_ms
     capi.set_kernel_timing(dominant)
+    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(True, **ahead(i, args.steps))
+        step(True)
     barrier()
     elapsed = time.perf_counter() - t0
     extra_steps = min(args.steps, 10)
     timed[0], acc[0] = list(kernel_names), extra_ms
     capi.set_kernel_timing("all")
     for i in range(extra_steps + 1):                 # a step reads the events of the job before it
-        step(False, **ahead(i, extra_steps + 1))
+        step(False)
     barrier()
     capi.set_kernel_timing(None)
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if world > 1:
+        elapsed = float(capi.comm_all_gather(np.array([elapsed], dtype=np.float64)).max())
 
     if rank == 0:
         ms_per_step = 1000.0 * elapsed / args.steps
@@ -329,16 +404,16 @@ def main() -> None:
         avg = {k: extra_ms[k] / max(extra_steps, 1) for k in kernel_names}
         avg[dominant] = kernel_ms[dominant] / args.steps         # live, inside the timed region
         # per-launch work of THIS rank's launch of the dominant kernel
-        if dominant == "hamming_runs":
-            _, pcount = ndist.shard(n_pairs, world, 0)
-            abytes = algorithmic_bytes(dominant, windows, kept, pcount, state["runs"])
+        _, pcount = capi.comm_shard(n_pairs, world, 0)
+        f0, c0 = capi.comm_shard(n, world, 0)
+        if dominant in ("hamming_runs", "simhash_runs"):
+            abytes = algorithmic_bytes("hamming_runs", windows, kept, pcount, state["runs"] // world)
         else:
-            f0, c0 = ndist.shard(n, world, 0)
             abytes = algorithmic_bytes(dominant, windows[f0:f0 + c0], kept[f0:f0 + c0], 0, 0)
         achieved = abytes / (avg[dominant] * 1e-3) / 1e9 if avg[dominant] > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes/launch from rocprofv3 PMC passes
-        if os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes/launch from rocprofv3 PMC passes (N = 1 launch shape)
+        if os.path.exists(tpath) and world == 1:
             try:
                 traffic = json.load(open(tpath)).get(dominant)
             except Exception:
@@ -354,32 +429,60 @@ def main() -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{n} episodes x {args.minutes:g} min synthetic mono s16 PCM @ 11025 Hz, "
+            "config": {"workload": f"{n} episodes x {args.minutes:g} min synthetic mono s16 PCM @ 11025 Hz, PCM RESIDENT IN HBM "
+                                   f"before the timed region (host->device copy excluded: see end_to_end), "
                                    f"{args.intro_seconds:g} s shared intro, opening window 50 %, hash 0.3 s, "
                                    f"threshold 10, min opening 20 s; analyze+search, {n_pairs} pairs "
                                    f"(BASELINE.json configs[1]; configs[3] sharding when n_gpus > 1)",
                        "episodes": n, "pairs": n_pairs, "hashes_per_episode": kept[0],
-                       "parallelism": "1 gpu" if world == 1 else f"{world} ranks: episode blocks + pair ranges, "
-                                                                "2 all-gathers (RCCL)"},
+                       "parallelism": "1 gpu" if world == 1 else
+                       f"{world} ranks, one process per GPU: episode blocks + pair ranges, 2 all-gathers per job "
+                       f"inside libneedle_capi.so ({capi.comm_backend()})",
+                       "comm": capi.comm_backend()},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(abytes),
                          "avg_launch_ms": round(avg[dominant], 5), "compute": compute},
             "kernel_ms_per_step": {k: round(v, 5) for k, v in avg.items()},
-            "kernel_ms_note": f"{dominant}: HIP events inside the timed region; the others: {extra_steps} untimed "
-                              "steps after it (events around every kernel slow a step by 3 %)",
-            "host_ms_per_step": ({k: round(v / (max(finished[0], 1) if k in ("wait_runs", "epilogue") else args.steps), 4)
-                                  for k, v in host_ms.items()} if not distributed else None),
+            "kernel_ms_note": f"rank 0's launches; {dominant}: HIP events inside the timed region; the others: {extra_steps} "
+                              "untimed steps after it (events around every kernel slow a step by 3 %)",
+            "host_ms_per_step": {"enqueue": round(host_ms["enqueue"] / args.steps, 4),
+                                 "wait_and_epilogue": round(host_ms["wait_and_epilogue"] / max(finished[0], 1), 4)},
             "runs_per_step": state["runs"],
             "detected": sum(1 for r in state["results"] if r is not None and r.opening is not None),
         }
+        if not args.no_extras:
+            try:
+                ceiling = capi.int_valu_ceiling()
+                cells = float(pcount) * kept[0] * kept[0]
+                scan_ms = avg["hamming_runs"]
+                out["roofline_search"] = {
+                    "bound": "int valu", "kernel": "hamming_runs", "unit": "table cells/s",
+                    "achieved": round(cells / (scan_ms * 1e-3), 1) if scan_ms > 0 else None, "peak": round(ceiling, 1),
+                    "frac": round(cells / (scan_ms * 1e-3) / ceiling, 4) if scan_ms > 0 else None,
+                    "cells_per_launch": cells, "avg_launch_ms": round(scan_ms, 5),
+                    "note": "peak = needle_hip_int_valu_ceiling(), measured in this run: every cell of the reference's "
+                            "table evaluated with xor/popcount/compare/select on registers.  achieved = cells of the "
+                            "table COVERED per second; the aligned-window scan proves most cells irrelevant without "
+                            "evaluating them (a run of >= min_len must cover an aligned 8-row window), so frac > 1 "
+                            "means algorithmic skipping, not a faster ALU"}
+            except capi.NeedleError as e:
+                out["roofline_search"] = {"error": str(e)}
+        if world == 1 and not args.no_extras:
+            out["end_to_end"] = end_to_end(capi, eps, cmp, n_pairs)
+            so = search_only(capi, synth, args.search_only_episodes, 24.0)
+            if "roofline_search" in out and "peak" in out["roofline_search"]:
+                so["cells_per_s"] = round(so["table_cells"] / (so["scan_kernel_ms"] * 1e-3), 1)
+                so["frac_of_int_valu_ceiling"] = round(so["cells_per_s"] / out["roofline_search"]["peak"], 4)
+            out["search_only"] = so
         if world == 1 and not args.no_cpu_baseline:
             hashes = [lib.frame_hashes(v).opening_data()[0] for v in range(n)]
             out["cpu_baseline"] = cpu_baseline(eps, state["results"], hashes)
         print(json.dumps(out), flush=True)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rdzv is not None:
+        capi.comm_barrier()
+        capi.comm_finalize()
+        rdzv.close()
 
 
 if __name__ == "__main__":

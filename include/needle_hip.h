@@ -40,6 +40,9 @@ enum NeedleError needle_hip_free(void *device_ptr);
 enum NeedleError needle_hip_memcpy_h2d(void *device_dst, const void *host_src, size_t bytes);
 enum NeedleError needle_hip_memcpy_d2h(void *host_dst, const void *device_src, size_t bytes);
 void needle_hip_host_free(void *ptr); /* frees arrays this library malloc'd for the caller */
+/* Pinned (page-locked) host memory for PCM the caller wants uploaded at the full PCIe rate without staging. */
+enum NeedleError needle_hip_host_alloc(void **host_ptr, size_t bytes);
+enum NeedleError needle_hip_host_alloc_free(void *host_ptr);
 
 /* GPU timing of the most recent COMPLETED launch of a kernel (it never waits behind queued work unless no
  * launch has finished yet), measured with HIP events on the
@@ -50,6 +53,10 @@ double needle_hip_last_kernel_ms(const char *kernel);
  * Default: none (each event record is one more packet between dependent dispatches: timing all five kernels of
  * a 28 x 24 min job costs 3 % of its time), unless the environment variable NEEDLE_HIP_KERNEL_TIMING is set. */
 void needle_hip_set_kernel_timing(const char *kernels);
+/* Diagnostic for the search roofline: table cells per second this device sustains on the scan's
+ * per-cell instruction sequence (xor, popcount, compare, select) with operands in registers -- the integer-VALU
+ * ceiling a brute-force evaluation of every cell of comparator.rs:176-187 cannot exceed.  Takes ~10 ms. */
+enum NeedleError needle_hip_int_valu_ceiling(double *cells_per_second);
 
 /* ---- fingerprint: the chromaprint Context replacement -------------------------------------------
  * Replaces chromaprint::Context::{start,feed,finish,get_fingerprint_raw,get_delay,get_item_duration,
@@ -177,6 +184,16 @@ enum NeedleError needle_hip_comparator_run_with_frame_hashes(const struct Needle
                                                              bool use_skip_files, bool write_skip_files,
                                                              NeedleHipSearchResult *results);
 
+/* The host half of that call on its own: the order-sensitive epilogue (reverse-walk order, duration validity,
+ * BinaryHeap array order, find_best_match; comparator.rs:191-249,405-515,583-626) from a COMPLETE run list of all
+ * pairs (NeedleHipRun.problem = pair index * regions + region, regions = 2 with endings) to the results of videos
+ * [first_video, first_video + video_count); the other slots are left empty.  No device work: this is what every rank
+ * of a multi-GPU job runs for its own block of videos after the run lists have been all-gathered. */
+enum NeedleError needle_hip_comparator_results_from_runs(const struct NeedleAudioComparator *comparator,
+                                                         const FrameHashes *const *frame_hashes, size_t num_videos,
+                                                         const NeedleHipRun *runs, size_t num_runs, size_t first_video,
+                                                         size_t video_count, NeedleHipSearchResult *results);
+
 /* ---- Library: an HBM-resident analyze+search job, shardable across GPUs ----------------------------
  * One object per process/GPU describing ALL videos of a job.  PCM of the videos this rank owns is
  * uploaded once and stays in HBM; hashes live in a padded device arena [video * rows_per_video][stride] so a
@@ -195,6 +212,16 @@ size_t needle_hip_library_rows_per_video(const NeedleHipLibrary *library);
  * videos this rank does not own.  Crops to the opening window and uploads. */
 enum NeedleError needle_hip_library_set_pcm(NeedleHipLibrary *library, const int16_t *const *pcm,
                                             const size_t *num_values, int channels);
+/* The streaming form ("analyze streamed from host-pinned PCM", BASELINE.json configs[4]): the search windows of the
+ * videos with a non-NULL pointer are copied to the device in order on an upload stream and fingerprinted group by
+ * group (~32 MiB of PCM each) on the library stream as they land, straight into their arena rows; nothing of the PCM
+ * stays in HBM beyond a 2 GiB staging arena, and the kernels of all but the last group run underneath the copies.
+ * Pinned host memory (needle_hip_host_alloc, or anything hipHostRegister'ed) is read in place by the copy engine;
+ * pageable memory goes through a ring of pinned slabs filled by host threads.  On return the caller's buffers are
+ * free; the last kernels may still be running (stream order: search / job_begin may follow at once).  Replaces
+ * set_pcm + analyze; job_begin then skips its analyze step. */
+enum NeedleError needle_hip_library_stream_pcm(NeedleHipLibrary *library, const int16_t *const *pcm,
+                                               const size_t *num_values, int channels);
 /* Fingerprint videos [first, first+count) into their arena rows (GPU only, no host copy). */
 enum NeedleError needle_hip_library_analyze(NeedleHipLibrary *library, size_t first, size_t count, bool sync);
 /* Arena geometry: device pointer to u32[num_videos * rows_per_video][stride]. */
@@ -206,7 +233,9 @@ enum NeedleError needle_hip_library_use_hash_arena(NeedleHipLibrary *library, ui
                                                    size_t stride);
 size_t needle_hip_library_num_pairs(const NeedleHipLibrary *library);
 /* Runs of pairs [first_pair, first_pair+num_pairs) into caller-provided device buffers
- * (NeedleHipRun.problem = global pair index). */
+ * (NeedleHipRun.problem = global pair index * comparator regions + region).  A sequence must fit the scan's LDS
+ * staging: at most ~39 000 hashes per search window in the default kernels (2.7 h of audio at step 1, 5.3 h at the
+ * default step 2); longer windows fail with NeedleError_InvalidArgument. */
 enum NeedleError needle_hip_library_search(NeedleHipLibrary *library, const struct NeedleAudioComparator *comparator,
                                            size_t first_pair, size_t num_pairs, NeedleHipRun *d_runs,
                                            uint32_t capacity, uint32_t *d_count, bool sync);
@@ -227,6 +256,47 @@ enum NeedleError needle_hip_library_finalize(NeedleHipLibrary *library, const st
                                              NeedleHipSearchResult *results);
 /* Copies one video's FrameHashes out of the library after analyze (+gather). */
 enum NeedleError needle_hip_library_frame_hashes(NeedleHipLibrary *library, size_t index, FrameHashes **output);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI --------------------------------------------------
+ * The reference parallelises inside one process with rayon when `threading` is set: over videos in
+ * Analyzer::run (analyzer.rs:437-445) and over pairs in Comparator::run_with_frame_hashes
+ * (comparator.rs:549-564).  Across the GPUs of a node the same two fan-outs are: videos in contiguous blocks
+ * per rank, pairs in contiguous ranges of the lexicographic pair list per rank, and two all-gathers between
+ * them (hash rows after analyze, run lists after search) -- all inside this library, on its own streams, with
+ * librccl loaded on demand (no link-time dependency; no torch).  A process is one rank and drives one device:
+ *
+ *   rank 0: needle_hip_comm_create_id(id); hand the 128 bytes to the other ranks by any means (file, socket, MPI)
+ *   all   : needle_hip_set_device(local_rank); needle_hip_comm_init(id, rank, world_size);
+ *           library_new / set_pcm (PCM pointers for the videos of needle_hip_comm_shard(n, ...) only, NULL for
+ *           the rest) / job_begin / job_end ...; needle_hip_comm_finalize()
+ *
+ * Results are identical for every world size: the run set is a union over disjoint pair ranges and the epilogue
+ * orders it.  NEEDLE_HIP_COMM=host selects a host-staged transport over POSIX shared memory instead of RCCL (ranks of
+ * one node, any device assignment, e.g. two ranks on one GPU) -- for exercising the N-rank path where RCCL cannot run
+ * and as a fallback; it moves data only and is not a compute fallback. */
+#define NEEDLE_HIP_COMM_ID_BYTES 128
+enum NeedleError needle_hip_comm_create_id(uint8_t id[NEEDLE_HIP_COMM_ID_BYTES]);
+enum NeedleError needle_hip_comm_init(const uint8_t id[NEEDLE_HIP_COMM_ID_BYTES], int rank, int world_size); /* collective */
+void needle_hip_comm_finalize(void);
+int needle_hip_comm_rank(void);             /* 0 without a communicator */
+int needle_hip_comm_world_size(void);       /* 1 without a communicator */
+const char *needle_hip_comm_backend(void);  /* "none", "rccl", "host" */
+enum NeedleError needle_hip_comm_barrier(void);
+/* Host buffers: rank r's `bytes_per_rank` bytes land at recv + r * bytes_per_rank on every rank. */
+enum NeedleError needle_hip_comm_all_gather_host(const void *send, void *recv, size_t bytes_per_rank);
+/* The sharding plan: `units` (videos, pairs) in world_size contiguous blocks of ceil(units / world_size). */
+void needle_hip_comm_shard(size_t units, int world_size, int rank, size_t *first, size_t *count);
+
+/* One analyze+search job of the library across the communicator (or on one GPU without one), in two halves so
+ * that two jobs can be in flight (slot 0 / 1): _begin enqueues this rank's fingerprinting, the all-gather of hash
+ * rows, the scan of this rank's pair range, the all-gather of run lists and their download, and returns at once;
+ * _end waits for that download, runs the per-video epilogue (find_best_match, comparator.rs:583-626; sharded by video
+ * across ranks with one more all-gather once it is large enough to pay for it) and fills results[num_videos] on
+ * every rank.  *num_runs (optional): runs found over all pairs. */
+enum NeedleError needle_hip_library_job_begin(NeedleHipLibrary *library, const struct NeedleAudioComparator *comparator,
+                                              int slot);
+enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *library, const struct NeedleAudioComparator *comparator,
+                                            int slot, NeedleHipSearchResult *results, size_t *num_runs);
 
 #ifdef __cplusplus
 }

@@ -85,7 +85,13 @@ NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_library_set_pcm", "needle_hip_library_analyze",
     "needle_hip_library_hash_arena", "needle_hip_library_use_hash_arena", "needle_hip_library_num_pairs", "needle_hip_library_search",
     "needle_hip_library_fetch_runs_begin", "needle_hip_library_fetch_runs_end",
-    "needle_hip_library_finalize", "needle_hip_library_frame_hashes"]
+    "needle_hip_library_finalize", "needle_hip_library_frame_hashes",
+    "needle_hip_comm_create_id", "needle_hip_comm_init", "needle_hip_comm_finalize", "needle_hip_comm_rank",
+    "needle_hip_comm_world_size", "needle_hip_comm_backend", "needle_hip_comm_barrier",
+    "needle_hip_comm_all_gather_host", "needle_hip_comm_shard", "needle_hip_library_job_begin",
+    "needle_hip_library_job_end", "needle_hip_library_stream_pcm", "needle_hip_host_alloc",
+    "needle_hip_host_alloc_free", "needle_hip_int_valu_ceiling",
+    "needle_hip_comparator_results_from_runs"]
 
 _LIB = None
 
@@ -166,6 +172,8 @@ def lib():
     L.needle_hip_analyzer_run_pcm.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.c_int, C.c_int, f32, b]
     L.needle_hip_comparator_run_with_frame_hashes.argtypes = [vp, C.POINTER(vp), sz, b, b, b,
                                                               C.POINTER(CSearchResult)]
+    L.needle_hip_comparator_results_from_runs.argtypes = [vp, C.POINTER(vp), sz, vp, sz, sz, sz,
+                                                          C.POINTER(CSearchResult)]
     L.needle_hip_library_new.argtypes = [sz, f32, f32, C.POINTER(vp)]
     L.needle_hip_library_free.argtypes = [vp]
     L.needle_hip_library_free.restype = None
@@ -183,6 +191,18 @@ def lib():
     L.needle_hip_library_fetch_runs_end.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(u32)]
     L.needle_hip_library_finalize.argtypes = [vp, vp, vp, sz, C.POINTER(CSearchResult)]
     L.needle_hip_library_frame_hashes.argtypes = [vp, sz, C.POINTER(vp)]
+    L.needle_hip_comm_create_id.argtypes = [vp]
+    L.needle_hip_comm_init.argtypes = [vp, C.c_int, C.c_int]
+    L.needle_hip_comm_finalize.restype = None
+    L.needle_hip_comm_backend.restype = C.c_char_p
+    L.needle_hip_comm_all_gather_host.argtypes = [vp, vp, sz]
+    L.needle_hip_comm_shard.argtypes = [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]
+    L.needle_hip_comm_shard.restype = None
+    L.needle_hip_library_stream_pcm.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.c_int]
+    L.needle_hip_host_alloc.argtypes = [C.POINTER(vp), sz]
+    L.needle_hip_host_alloc_free.argtypes = [vp]
+    L.needle_hip_library_job_begin.argtypes = [vp, vp, C.c_int]
+    L.needle_hip_library_job_end.argtypes = [vp, vp, C.c_int, C.POINTER(CSearchResult), C.POINTER(sz)]
     _LIB = L
     return L
 
@@ -218,6 +238,14 @@ def stream_ptr() -> int:
     if not p:
         raise RuntimeError("no HIP device: the library has no stream")
     return int(p)
+
+
+def int_valu_ceiling() -> float:
+    """Measured cells/s of the scan's 4-instruction cell on registers (needle_hip_int_valu_ceiling)."""
+    v = C.c_double(0.0)
+    lib().needle_hip_int_valu_ceiling.argtypes = [C.POINTER(C.c_double)]
+    check(lib().needle_hip_int_valu_ceiling(C.byref(v)))
+    return v.value
 
 
 def last_kernel_ms(name: str) -> float:
@@ -451,6 +479,18 @@ class Comparator:
                                                                 write_skip_files, res))
         return _results(res, n)
 
+    def results_from_runs(self, frame_hashes: Sequence[FrameHashes], runs: np.ndarray, first_video: int = 0,
+                          video_count: Optional[int] = None) -> List[Optional[SearchResult]]:
+        """The host epilogue alone (needle_hip_comparator_results_from_runs): no device work."""
+        n = len(frame_hashes)
+        runs = np.ascontiguousarray(runs, dtype=RUN_DTYPE)
+        arr = (C.c_void_p * max(n, 1))(*[f._h for f in frame_hashes])
+        res = (CSearchResult * max(n, 1))()
+        check(lib().needle_hip_comparator_results_from_runs(
+            self._h or self.handle(), arr, n, runs.ctypes.data, runs.size, first_video,
+            n - first_video if video_count is None else video_count, res))
+        return _results(res, n)
+
     def run(self, analyze: bool, display: bool = False, use_skip_files: bool = False,
             write_skip_files: bool = False, threading: bool = True) -> None:   # comparator.rs:637 / lib.rs:612
         h = self.handle()
@@ -522,6 +562,56 @@ def hamming_runs(seqs: Sequence[np.ndarray], problems: Sequence[Tuple[int, int, 
     return out
 
 
+# ---- communicator: one process per GPU (include/needle_hip.h, "multi-GPU") --------------------------------------
+COMM_ID_BYTES = 128
+
+
+def comm_create_id() -> bytes:
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    check(lib().needle_hip_comm_create_id(buf))
+    return bytes(buf)
+
+
+def comm_init(comm_id: bytes, rank: int, world: int) -> None:
+    assert len(comm_id) == COMM_ID_BYTES
+    buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(comm_id)
+    check(lib().needle_hip_comm_init(buf, rank, world))
+
+
+def comm_finalize() -> None:
+    lib().needle_hip_comm_finalize()
+
+
+def comm_rank() -> int:
+    return lib().needle_hip_comm_rank()
+
+
+def comm_world_size() -> int:
+    return lib().needle_hip_comm_world_size()
+
+
+def comm_backend() -> str:
+    return lib().needle_hip_comm_backend().decode()
+
+
+def comm_barrier() -> None:
+    check(lib().needle_hip_comm_barrier())
+
+
+def comm_all_gather(local: np.ndarray) -> np.ndarray:
+    """All-gather of equal-sized host arrays: returns [world, *local.shape]."""
+    local = np.ascontiguousarray(local)
+    out = np.zeros((comm_world_size(),) + local.shape, dtype=local.dtype)
+    check(lib().needle_hip_comm_all_gather_host(local.ctypes.data, out.ctypes.data, local.nbytes))
+    return out
+
+
+def comm_shard(units: int, world: int, rank: int) -> Tuple[int, int]:
+    first, count = C.c_size_t(0), C.c_size_t(0)
+    lib().needle_hip_comm_shard(units, world, rank, C.byref(first), C.byref(count))
+    return first.value, count.value
+
+
 # ---- HBM-resident library (bench / multi-GPU) -----------------------------------------------------------------
 class Library:
     """NeedleHipLibrary: PCM resident in HBM, padded device hash arena, pair-sharded search."""
@@ -545,6 +635,13 @@ class Library:
         ptrs = (C.c_void_p * self.n)(*[None if a is None else a.ctypes.data for a in arrs])
         lens = (C.c_size_t * self.n)(*list(num_values))
         check(lib().needle_hip_library_set_pcm(self._h, ptrs, lens, channels))
+
+    def stream_pcm(self, pcm: Sequence[Optional[np.ndarray]], num_values: Sequence[int], channels: int = 1) -> None:
+        """Upload + fingerprint overlapped, PCM not kept (needle_hip_library_stream_pcm)."""
+        arrs = [None if p is None else np.ascontiguousarray(p, dtype=np.int16) for p in pcm]
+        ptrs = (C.c_void_p * self.n)(*[None if a is None else a.ctypes.data for a in arrs])
+        lens = (C.c_size_t * self.n)(*list(num_values))
+        check(lib().needle_hip_library_stream_pcm(self._h, ptrs, lens, channels))
 
     def analyze(self, first: int = 0, count: Optional[int] = None, sync: bool = True) -> None:
         check(lib().needle_hip_library_analyze(self._h, first, self.n - first if count is None else count, sync))
@@ -592,10 +689,37 @@ class Library:
         check(lib().needle_hip_library_frame_hashes(self._h, index, C.byref(out)))
         return FrameHashes(out.value, True)
 
+    def job_begin(self, comparator: Comparator, slot: int = 0) -> None:
+        """Enqueues one analyze+search job of this rank's share (all of it without a communicator)."""
+        check(lib().needle_hip_library_job_begin(self._h, comparator._h or comparator.handle(), slot))
+
+    def job_end(self, comparator: Comparator, slot: int = 0) -> Tuple[List[Optional[SearchResult]], int]:
+        """(results for all videos -- the same on every rank, runs found over all pairs)."""
+        res = (CSearchResult * self.n)()
+        found = C.c_size_t(0)
+        check(lib().needle_hip_library_job_end(self._h, comparator._h or comparator.handle(), slot, res, C.byref(found)))
+        return _results(res, self.n), found.value
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().needle_hip_library_free(self._h)
             self._h = None
+
+
+class PinnedArray:
+    """An int16 numpy array over page-locked host memory (needle_hip_host_alloc): PCM the copy engine reads in place."""
+
+    def __init__(self, count: int):
+        p = C.c_void_p()
+        check(lib().needle_hip_host_alloc(C.byref(p), max(count, 1) * 2))
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array((C.c_int16 * max(count, 1)).from_address(self.ptr))[:count]
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            lib().needle_hip_host_alloc_free(self.ptr)
+            self.ptr = None
 
 
 class DeviceBuffer:

@@ -385,6 +385,30 @@ enum NeedleError needle_hip_memcpy_d2h(void *host_dst, const void *device_src, s
 
 void needle_hip_host_free(void *ptr) { std::free(ptr); }
 
+enum NeedleError needle_hip_host_alloc(void **host_ptr, size_t bytes) {
+  if (!host_ptr) return NeedleError_NullArgument;
+  return guarded([&]() -> NeedleError {
+    Status s = ensure_device();
+    if (!s.ok()) return report(s);
+    if (hipHostMalloc(host_ptr, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+      return report(Status::Make(NeedleError_Unknown, "pinned allocation of " + std::to_string(bytes) + " bytes failed"));
+    return NeedleError_Ok;
+  });
+}
+
+enum NeedleError needle_hip_host_alloc_free(void *host_ptr) {
+  if (host_ptr && hipHostFree(host_ptr) != hipSuccess) return report(Status::Make(NeedleError_Unknown, "hipHostFree failed"));
+  return NeedleError_Ok;
+}
+
+enum NeedleError needle_hip_int_valu_ceiling(double *cells_per_second) {
+  if (!cells_per_second) return NeedleError_NullArgument;
+  return guarded([&]() -> NeedleError {
+    Status s = gpu_int_valu_ceiling(cells_per_second);
+    return s.ok() ? NeedleError_Ok : report(s);
+  });
+}
+
 double needle_hip_last_kernel_ms(const char *kernel) { return kernel ? kernel_ms(kernel) : -1.0; }
 void needle_hip_set_kernel_timing(const char *kernels) { set_kernel_timing(kernels); }
 
@@ -630,6 +654,27 @@ enum NeedleError needle_hip_comparator_run_with_frame_hashes(const struct Needle
     }
     std::vector<VideoResult> res;
     Status s = comparator->inner.run_with_frame_hashes(fh, display, use_skip_files, write_skip_files, true, &res);
+    if (!s.ok()) return report(s);
+    for (size_t i = 0; i < num_videos; i++) fill_result(res[i], &results[i]);
+    return NeedleError_Ok;
+  });
+}
+
+enum NeedleError needle_hip_comparator_results_from_runs(const struct NeedleAudioComparator *comparator,
+                                                         const FrameHashes *const *frame_hashes, size_t num_videos,
+                                                         const NeedleHipRun *runs, size_t num_runs, size_t first_video,
+                                                         size_t video_count, NeedleHipSearchResult *results) {
+  if (!comparator || !frame_hashes || !results || (!runs && num_runs)) return NeedleError_NullArgument;
+  if (first_video > num_videos || video_count > num_videos - first_video) return NeedleError_InvalidArgument;
+  return guarded([&]() -> NeedleError {
+    std::vector<const FrameHashesData *> fh(num_videos);
+    for (size_t i = 0; i < num_videos; i++) {
+      if (!frame_hashes[i]) return NeedleError_NullArgument;
+      fh[i] = &frame_hashes[i]->d;
+    }
+    std::vector<VideoResult> res;
+    Status s = comparator->inner.results_from_runs(fh, runs, num_runs, false, false, false, &res, first_video,
+                                                   first_video + video_count);
     if (!s.ok()) return report(s);
     for (size_t i = 0; i < num_videos; i++) fill_result(res[i], &results[i]);
     return NeedleError_Ok;

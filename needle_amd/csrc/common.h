@@ -9,6 +9,8 @@
 
 #include "../../include/needle_hip.h"
 
+struct ihipStream_t;  // hipStream_t = ihipStream_t * (hip_runtime_api.h), without pulling HIP into host-only files
+
 namespace needle {
 
 // ---- errors -------------------------------------------------------------------------------------------
@@ -115,7 +117,14 @@ struct StreamSpan {
 
 Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan> &streams, int channels,
                               uint32_t step, uint32_t *d_items, bool sync, double *d_chroma_dbg = nullptr,
-                              double *d_feat_dbg = nullptr);
+                              double *d_feat_dbg = nullptr, size_t descriptor_slot = 0);
+// Host PCM -> kept items in DEVICE memory (d_items + item_off[i]), uploads and kernels overlapped: the streams are
+// uploaded in order on the upload stream and fingerprinted group by group (about NEEDLE_HIP_LAUNCH_GROUP_BYTES of
+// PCM each) on the library stream as they land.  The PCM is not kept.  On return every copy out of host memory has
+// executed; the kernels may still be running (library stream order).
+Status gpu_fingerprint_streamed_device(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
+                                       int channels, uint32_t step, uint32_t *d_items,
+                                       const std::vector<uint64_t> &item_off);
 // `rate` != 11025 routes the streams through the device resampler first (resample.hip).
 Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
                             int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items,
@@ -124,14 +133,19 @@ Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::
 // pinned host memory): up to `readers` threads call it concurrently for different segments while earlier segments
 // are on their way to the device.  Host memory stays a fixed ring of slabs whatever the streams' lengths.
 using PcmReader = std::function<Status(size_t stream, uint64_t first_value, uint64_t num_values, int16_t *dst)>;
-// The upload alone (hipctx.hip): stream i goes to d_pcm + dev_off[i] (offsets in values, multiples of 8).  On
-// return the copies have executed.
+// The upload alone (hipctx.hip): stream i goes to d_pcm + dev_off[i] (offsets in values, multiples of 8), copied on
+// `stream` (NULL: the library stream).  On return the copies have executed.  `issued` (optional) is called on the
+// issuing thread right after the last copy of a stream has been enqueued, streams in order (zero-length streams of
+// the ring path are skipped): the caller's place to queue work behind an event of `stream`.
+using StreamIssued = std::function<Status(size_t stream_index)>;
 Status gpu_upload_pcm_streamed(const std::vector<size_t> &num_values, const std::vector<uint64_t> &dev_off,
-                               const PcmReader &read, unsigned readers, int16_t *d_pcm);
-// Same from host pointers; enqueues plain asynchronous copies when the total is small (then nothing has executed
-// on return, as with hipMemcpyAsync).
+                               const PcmReader &read, unsigned readers, int16_t *d_pcm, ::ihipStream_t *stream = nullptr,
+                               const StreamIssued &issued = nullptr);
+// Same from host pointers.  Pinned host memory is copied in place and small totals go as plain asynchronous copies
+// (in both cases nothing need have executed on return, as with hipMemcpyAsync); large pageable totals go through the ring.
 Status gpu_upload_pcm(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
-                      const std::vector<uint64_t> &dev_off, int16_t *d_pcm);
+                      const std::vector<uint64_t> &dev_off, int16_t *d_pcm, ::ihipStream_t *stream = nullptr,
+                      const StreamIssued &issued = nullptr);
 Status gpu_fingerprint_streamed(const std::vector<size_t> &num_values, const PcmReader &read, unsigned readers,
                                 int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items,
                                 int rate = kSampleRate);
@@ -141,6 +155,9 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
 Status gpu_hamming_runs_host(const uint32_t *hashes, size_t num_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
                              const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
                              std::vector<NeedleHipRun> *runs);
+
+// Diagnostic (search.hip): cells/s of the band scan's 4-instruction cell on registers only, measured on this device.
+Status gpu_int_valu_ceiling(double *cells_per_second);
 
 // ---- resampler front-end (resample.hip) -------------------------------------------------------------------
 struct ResampleSpan {

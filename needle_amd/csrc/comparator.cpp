@@ -205,8 +205,11 @@ void Comparator::entries_from_runs(const NeedleHipRun *runs, size_t num_runs, co
 
 Status Comparator::best_matches(size_t num_videos, const PairEntries &pair_entries, bool display,
                                 bool use_skip_files, bool write_skip_files,
-                                std::vector<VideoResult> *per_video) const {
+                                std::vector<VideoResult> *per_video, size_t v0, size_t v1) const {
   per_video->assign(num_videos, {});
+  v1 = std::min(v1, num_videos);
+  v0 = std::min(v0, v1);
+  auto mine = [&](size_t v) { return v >= v0 && v < v1; };
   // info_map (:583-588): for every non-empty pair, (pair, as source) for i and (pair, as dest) for j -- here as
   // one array per kind with a start offset per video, filled in pair order
   const size_t np = pair_entries.count.size();
@@ -215,8 +218,8 @@ Status Comparator::best_matches(size_t num_videos, const PairEntries &pair_entri
     size_t i = 0, j = 1;
     for (size_t p = 0; p < np; p++) {
       if (pair_entries.count[p]) {
-        info_first[i + 1]++;
-        info_first[j + 1]++;
+        if (mine(i)) info_first[i + 1]++;
+        if (mine(j)) info_first[j + 1]++;
       }
       if (++j == num_videos) j = ++i + 1;
     }
@@ -232,8 +235,8 @@ Status Comparator::best_matches(size_t num_videos, const PairEntries &pair_entri
     size_t i = 0, j = 1;
     for (size_t p = 0; p < np; p++) {
       if (pair_entries.count[p]) {
-        info[fill[i]++] = Info{p, true};
-        info[fill[j]++] = Info{p, false};
+        if (mine(i)) info[fill[i]++] = Info{p, true};
+        if (mine(j)) info[fill[j]++] = Info{p, false};
       }
       if (++j == num_videos) j = ++i + 1;
     }
@@ -241,25 +244,11 @@ Status Comparator::best_matches(size_t num_videos, const PairEntries &pair_entri
   auto info_count = [&](size_t v) { return info_first[v + 1] - info_first[v]; };
   const uint32_t bound = hash_match_threshold_ + hash_match_threshold_ / 2;  // :441
   // The reference walks the videos in order: skip-file check, find_best_match, display, skip-file write
-  // (:593-626).  Here the three kinds of work are separated so that find_best_match -- quadratic in a video's
-  // candidate count, i.e. the dominant host cost at library scale -- runs for all videos on host threads, while
-  // everything with side effects stays sequential and in the reference's order.
-  std::vector<char> skipped(num_videos, 0);
-  if (use_skip_files) {  // :600-605, check_skip_file :310-327
-    for (size_t v = 0; v < num_videos; v++) {
-      const std::string &path = v < videos_.size() ? videos_[v] : std::string();
-      const std::string skip = with_extension(path, SKIP_FILE_NAME);
-      std::ifstream probe(skip);
-      if (!probe) continue;
-      std::string md5, stored;
-      Status s = header_md5(path, &md5);
-      if (!s.ok()) return s;
-      s = read_skip_file_md5(skip, &stored);
-      if (!s.ok()) return s;
-      skipped[v] = stored == md5;
-    }
-  }
-
+  // (:593-626).  find_best_match -- quadratic in a video's candidate count, i.e. the dominant host cost at
+  // library scale -- has no side effects, so it runs first for all videos on host threads; everything with side
+  // effects (the skip-file check included: a skip file written for video k is seen by a later video with the same
+  // path, and an unreadable one must not hide the output of the videos before it) then happens video by video in
+  // the reference's order.
   // find_best_match (:405-515) of one video
   std::vector<Status> status(num_videos);
   auto find_best = [&](size_t v) {
@@ -324,8 +313,8 @@ Status Comparator::best_matches(size_t num_videos, const PairEntries &pair_entri
   };
   std::vector<size_t> todo;
   uint64_t work = 0;  // candidate pairs to compare
-  for (size_t v = 0; v < num_videos; v++) {
-    if (skipped[v] || info_count(v) == 0) continue;
+  for (size_t v = v0; v < v1; v++) {
+    if (info_count(v) == 0) continue;
     todo.push_back(v);
     uint64_t c = 0;
     for (uint64_t q = info_first[v]; q < info_first[v + 1]; q++) c += pair_entries.count[info[q].pair];
@@ -336,12 +325,24 @@ Status Comparator::best_matches(size_t num_videos, const PairEntries &pair_entri
                     for (size_t k = b; k < e; k++) find_best(todo[k]);
                   });
 
-  for (size_t v = 0; v < num_videos; v++) {
+  for (size_t v = v0; v < v1; v++) {
     const std::string &path = v < videos_.size() ? videos_[v] : std::string();
     if (display) std::printf("\n%s\n\n", path.c_str());  // :595-597
-    if (skipped[v]) {
-      if (display) std::printf("Skipping due to existing skip file...\n");
-      continue;
+    if (use_skip_files) {  // :600-605, check_skip_file :310-327
+      const std::string skip = with_extension(path, SKIP_FILE_NAME);
+      std::ifstream probe(skip);
+      if (probe) {
+        std::string md5, stored;
+        Status s = header_md5(path, &md5);
+        if (!s.ok()) return s;
+        s = read_skip_file_md5(skip, &stored);
+        if (!s.ok()) return s;
+        if (stored == md5) {
+          (*per_video)[v] = VideoResult{};
+          if (display) std::printf("Skipping due to existing skip file...\n");
+          continue;
+        }
+      }
     }
     if (info_count(v) == 0) {
       if (display) std::printf(include_endings_ ? "No opening or ending found.\n" : "No opening found.\n");
@@ -402,6 +403,9 @@ Status Comparator::run_with_frame_hashes(const std::vector<const FrameHashesData
     }
   }
   const size_t np = pair_count(n);
+  // offsets into the arena and problem tags are 32-bit on the device (NeedleHipSeq.offset, NeedleHipProblem.tag)
+  if (arena.size() > UINT32_MAX || np * regions > UINT32_MAX)
+    return Status::Make(NeedleError_InvalidArgument, "library too large for one search call: more than 2^32 hashes or sequence pairs");
   std::vector<NeedleHipProblem> problems;
   for (size_t p = 0; p < np; p++) {
     size_t i, j;
@@ -420,28 +424,43 @@ Status Comparator::run_with_frame_hashes(const std::vector<const FrameHashesData
   Status s = gpu_hamming_runs_host(arena.data(), arena.size(), seqs.data(), seqs.size(), problems.data(),
                                    problems.size(), hash_match_threshold_, &runs);
   if (!s.ok()) return s;
-  return results_from_runs(fh, runs, display, use_skip_files, write_skip_files, per_video);
+  return results_from_runs(fh, runs.data(), runs.size(), display, use_skip_files, write_skip_files, per_video);
 }
 
 Status Comparator::results_from_runs(const std::vector<const FrameHashesData *> &fh,
-                                     const std::vector<NeedleHipRun> &runs, bool display, bool use_skip_files,
-                                     bool write_skip_files, std::vector<VideoResult> *per_video) const {
+                                     const NeedleHipRun *runs, size_t num_runs, bool display, bool use_skip_files,
+                                     bool write_skip_files, std::vector<VideoResult> *per_video, size_t v0,
+                                     size_t v1) const {
   const size_t n = fh.size();
   const size_t regions = include_endings_ ? 2 : 1;
   const size_t np = pair_count(n);
+  v1 = std::min(v1, n);
+  v0 = std::min(v0, v1);
+  // A rank that owns videos [v0, v1) needs the pairs with at least one end in that block, nothing else.
+  const bool partial = v0 > 0 || v1 < n;
+  std::vector<uint8_t> relevant;
+  if (partial) {
+    relevant.assign(np, 0);
+    size_t i = 0, j = 1;
+    for (size_t p = 0; p < np; p++) {
+      relevant[p] = (i >= v0 && i < v1) || (j >= v0 && j < v1);
+      if (++j == n) j = ++i + 1;
+    }
+  }
+  auto wanted = [&](uint32_t problem) { return problem < np * regions && (!partial || relevant[problem / regions]); };
   // Bucket the runs by problem (NeedleHipRun.problem = pair * regions + region) with a counting sort, then order
   // each bucket the way the reference walks its table backwards: src_end descending, then dst_end descending.
   EpilogueTrace trace;
   const size_t buckets = np * regions;
   std::vector<uint64_t> start(buckets + 1, 0);
-  for (const NeedleHipRun &r : runs)
-    if (r.problem < buckets) start[r.problem + 1]++;
+  for (size_t q = 0; q < num_runs; q++)
+    if (wanted(runs[q].problem)) start[runs[q].problem + 1]++;
   for (size_t b = 0; b < buckets; b++) start[b + 1] += start[b];
   std::vector<NeedleHipRun> sorted(start[buckets]);
   {
     std::vector<uint64_t> fill(start.begin(), start.end() - 1);
-    for (const NeedleHipRun &r : runs)
-      if (r.problem < buckets) sorted[fill[r.problem]++] = r;
+    for (size_t q = 0; q < num_runs; q++)
+      if (wanted(runs[q].problem)) sorted[fill[runs[q].problem]++] = runs[q];
   }
   trace.lap("bucket runs", sorted.size());
   // Heap entries pair by pair (both regions of a pair by the same thread: entries.extend(opening);
@@ -474,8 +493,8 @@ Status Comparator::results_from_runs(const std::vector<const FrameHashesData *> 
     }
   });
   trace.lap("heap entries per pair", np);
-  Status s = best_matches(n, pair_entries, display, use_skip_files, write_skip_files, per_video);
-  trace.lap("best match per video", n);
+  Status s = best_matches(n, pair_entries, display, use_skip_files, write_skip_files, per_video, v0, v1);
+  trace.lap("best match per video", v1 - v0);
   return s;
 }
 

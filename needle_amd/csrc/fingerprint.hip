@@ -466,7 +466,7 @@ FpWorkspace *workspace() {
 
 Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan> &spans, int channels,
                               uint32_t step, uint32_t *d_items, bool sync, double *d_chroma_dbg,
-                              double *d_feat_dbg) {
+                              double *d_feat_dbg, size_t descriptor_slot) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   if (channels != 1 && channels != 2)
     return Status::Make(NeedleError_InvalidArgument, "fingerprint: channels must be 1 or 2");
@@ -482,7 +482,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
   // Streams are processed in chunks so the f64 chroma/feature workspaces stay bounded (96 B/frame each).
   uint64_t kMaxFramesPerChunk = 8u << 20;  // workspace bound: 8 M frames = 0.8 GB of chroma + as much of features
   if (const char *e = getenv("NEEDLE_HIP_MAX_FRAMES_PER_CHUNK")) kMaxFramesPerChunk = (uint64_t)std::max(1, atoi(e));  // tests
-  size_t begin = 0, chunk = 0;
+  size_t begin = 0, chunk = descriptor_slot;
   while (begin < spans.size()) {
     std::vector<FpStream> meta;
     uint64_t frames = 0, rows = 0, kept = 0, pairs = 0, tiles = 0;
@@ -592,13 +592,37 @@ HostEntryWorkspace *host_entry_workspace() {
   return w;
 }
 
-// Plans device batches over the streams, has `upload` put each batch's PCM at in_off[] of the device arena, runs
-// (resampler +) fingerprinter and scatters the kept items.
+// Plans device batches over the streams and, inside a batch, overlaps the host -> device copies with the kernels:
+// `upload` copies the batch's streams in order on the upload stream and reports each stream as its last copy is
+// enqueued; every time about `group_bytes` of PCM have been enqueued, an event is recorded behind them and the
+// (resampler +) fingerprinter of those streams is launched on the library stream behind that event.  The copy
+// engine therefore never waits for kernels and the kernels of all but the last group are hidden under the copies
+// that follow.  Items go to the host (`items`) or stay on the device (`d_items_out` + `item_off_out`).
 using BatchUpload = std::function<Status(size_t begin, size_t end, const std::vector<uint64_t> &in_off, int16_t *d_pcm,
-                                         hipStream_t stream)>;
+                                         hipStream_t stream, const StreamIssued &issued)>;
+
+struct OverlapEvents {  // per device, reused by every call (guarded by gpu_mutex())
+  hipEvent_t landed = nullptr, batch_done = nullptr, entry = nullptr;
+};
+OverlapEvents *overlap_events() {
+  static std::mutex mu;
+  static std::map<int, OverlapEvents *> all;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  OverlapEvents *&e = all[dev];
+  if (!e) {
+    e = new OverlapEvents();
+    (void)hipEventCreateWithFlags(&e->landed, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&e->batch_done, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&e->entry, hipEventDisableTiming);
+  }
+  return e;
+}
 
 Status fingerprint_in_batches(const std::vector<size_t> &num_values, int channels, uint32_t step,
-                              std::vector<std::vector<uint32_t>> *items, int rate, const BatchUpload &upload) {
+                              std::vector<std::vector<uint32_t>> *items, int rate, const BatchUpload &upload,
+                              uint32_t *d_items_out = nullptr, const std::vector<uint64_t> *item_off_out = nullptr) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   Status s = ensure_device();
   if (!s.ok()) return s;
@@ -607,15 +631,19 @@ Status fingerprint_in_batches(const std::vector<size_t> &num_values, int channel
   if (step == 0) return Status::Make(NeedleError_InvalidArgument, "fingerprint: step must be >= 1");
   const bool resample = rate != kSampleRate;
   const size_t n = num_values.size();
-  items->assign(n, {});
+  if (items) items->assign(n, {});
   // Batches bounded by bytes so the device arena stays modest for huge libraries.
   uint64_t kMaxBatchValues = 1ull << 30;  // 2 GiB of s16
   if (const char *e = getenv("NEEDLE_HIP_MAX_BATCH_VALUES")) kMaxBatchValues = (uint64_t)std::max(1ll, atoll(e));  // tests
-  hipStream_t stream = library_stream();
+  uint64_t group_values = (32ull << 20) / sizeof(int16_t);
+  if (const char *e = getenv("NEEDLE_HIP_LAUNCH_GROUP_BYTES")) group_values = (uint64_t)std::max(2ll, atoll(e)) / sizeof(int16_t);
+  hipStream_t stream = library_stream(), up = upload_stream();
+  OverlapEvents *ev = overlap_events();
   HostEntryWorkspace *ws = host_entry_workspace();  // grow-only arenas, guarded by gpu_mutex()
   DeviceBuffer<int16_t> &d_pcm = ws->d_pcm, &d_mono = ws->d_mono;
   DeviceBuffer<uint32_t> &d_items = ws->d_items;
-  size_t begin = 0;
+  size_t begin = 0, descriptor_slot = 0;
+  bool first_batch = true;
   while (begin < n) {
     std::vector<StreamSpan> spans;        // what the fingerprinter reads (11025 Hz; mono if resampled)
     std::vector<ResampleSpan> rspans;     // what the resampler reads, when the input rate differs
@@ -626,13 +654,14 @@ Status fingerprint_in_batches(const std::vector<size_t> &num_values, int channel
       if (!spans.empty() && values + num_values[end] > kMaxBatchValues) break;
       const size_t in_samples = num_values[end] / (size_t)channels;
       const size_t out_samples = resample ? resample_out_len(in_samples, rate) : in_samples;
+      const uint64_t item_off = d_items_out ? (*item_off_out)[end] : kept;
       in_off.push_back(values);
       if (resample) {
         rspans.push_back(ResampleSpan{values, in_samples, mono});
-        spans.push_back(StreamSpan{mono, out_samples, kept});
+        spans.push_back(StreamSpan{mono, out_samples, item_off});
         mono += (out_samples + 1) & ~(uint64_t)1;
       } else {
-        spans.push_back(StreamSpan{values, num_values[end], kept});
+        spans.push_back(StreamSpan{values, num_values[end], item_off});
       }
       values += (num_values[end] + 7) & ~(uint64_t)7;  // keep every stream 16-byte aligned in the arena
       kept += num_kept(out_samples, step);
@@ -642,38 +671,63 @@ Status fingerprint_in_batches(const std::vector<size_t> &num_values, int channel
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
       if (!trace) return;
-      (void)hipStreamSynchronize(stream);
       const auto now = std::chrono::steady_clock::now();
       std::fprintf(stderr, "[needle_hip] fingerprint_host %s: %.2f ms\n", what,
                    std::chrono::duration<double, std::milli>(now - t0).count());
       t0 = now;
     };
     if (!(s = d_pcm.reserve(std::max<uint64_t>(values, 1))).ok()) return s;
-    if (!(s = d_items.reserve(std::max<uint64_t>(kept, 1))).ok()) return s;
+    if (!d_items_out && !(s = d_items.reserve(std::max<uint64_t>(kept, 1))).ok()) return s;
+    if (resample && !(s = d_mono.reserve(std::max<uint64_t>(mono, 1))).ok()) return s;
+    uint32_t *const d_out = d_items_out ? d_items_out : d_items.ptr;
     lap("device allocations");
-    if (!(s = upload(begin, end, in_off, d_pcm.ptr, stream)).ok()) return s;
-    lap("upload");
-    if (resample) {  // decode-rate PCM -> mono 11025 Hz, on the device, then straight into the fingerprinter
-      if (!(s = d_mono.reserve(std::max<uint64_t>(mono, 1))).ok()) return s;
-      s = gpu_resample_device(d_pcm.ptr, rspans, channels, rate, d_mono.ptr, false);
-      if (!s.ok()) return s;
-      s = gpu_fingerprint_device(d_mono.ptr, spans, 1, step, d_items.ptr, false);
-    } else {
-      s = gpu_fingerprint_device(d_pcm.ptr, spans, channels, step, d_items.ptr, false);
+    // the copies must not overtake kernels that still read the PCM arena: those of the previous batch, or of an
+    // earlier call on the library stream
+    NEEDLE_HIP_TRY(hipEventRecord(first_batch ? ev->entry : ev->batch_done, stream));
+    NEEDLE_HIP_TRY(hipStreamWaitEvent(up, first_batch ? ev->entry : ev->batch_done, 0));
+    first_batch = false;
+    size_t launched = 0;       // streams of this batch whose kernels have been enqueued
+    uint64_t pending_values = 0;
+    auto launch_group = [&](size_t upto) -> Status {  // streams [launched, upto) of the batch have been enqueued on `up`
+      if (upto <= launched) return Status::Ok();
+      NEEDLE_HIP_TRY(hipEventRecord(ev->landed, up));
+      NEEDLE_HIP_TRY(hipStreamWaitEvent(stream, ev->landed, 0));
+      const std::vector<StreamSpan> group(spans.begin() + launched, spans.begin() + upto);
+      Status gs;
+      if (resample) {  // decode-rate PCM -> mono 11025 Hz, on the device, then straight into the fingerprinter
+        const std::vector<ResampleSpan> rgroup(rspans.begin() + launched, rspans.begin() + upto);
+        gs = gpu_resample_device(d_pcm.ptr, rgroup, channels, rate, d_mono.ptr, false);
+        if (gs.ok()) gs = gpu_fingerprint_device(d_mono.ptr, group, 1, step, d_out, false, nullptr, nullptr, descriptor_slot++);
+      } else {
+        gs = gpu_fingerprint_device(d_pcm.ptr, group, channels, step, d_out, false, nullptr, nullptr, descriptor_slot++);
+      }
+      launched = upto;
+      pending_values = 0;
+      return gs;
+    };
+    const StreamIssued issued = [&](size_t i) -> Status {  // i: index inside the batch
+      pending_values += num_values[begin + i];
+      if (pending_values >= group_values) return launch_group(i + 1);
+      return Status::Ok();
+    };
+    if (!(s = upload(begin, end, in_off, d_pcm.ptr, up, issued)).ok()) return s;
+    if (!(s = launch_group(end - begin)).ok()) return s;
+    lap("upload + kernel launches");
+    if (items) {
+      std::vector<uint32_t> host(std::max<uint64_t>(kept, 1));
+      NEEDLE_HIP_TRY(hipMemcpyAsync(host.data(), d_items.ptr, kept * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+      for (size_t i = begin; i < end; i++) {
+        const size_t in_samples = num_values[i] / (size_t)channels;
+        const size_t k = num_kept(resample ? resample_out_len(in_samples, rate) : in_samples, step);
+        (*items)[i].assign(host.begin() + spans[i - begin].item_off, host.begin() + spans[i - begin].item_off + k);
+      }
+      lap("download + scatter");
     }
-    if (!s.ok()) return s;
-    lap("kernels");
-    std::vector<uint32_t> host(std::max<uint64_t>(kept, 1));
-    NEEDLE_HIP_TRY(hipMemcpyAsync(host.data(), d_items.ptr, kept * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
-    for (size_t i = begin; i < end; i++) {
-      const size_t in_samples = num_values[i] / (size_t)channels;
-      const size_t k = num_kept(resample ? resample_out_len(in_samples, rate) : in_samples, step);
-      (*items)[i].assign(host.begin() + spans[i - begin].item_off, host.begin() + spans[i - begin].item_off + k);
-    }
-    lap("download + scatter");
     begin = end;
   }
+  // every copy out of host memory has executed when this returns (the callers' buffers and the slab ring are free)
+  NEEDLE_HIP_TRY(hipStreamSynchronize(up));
   return Status::Ok();
 }
 
@@ -685,9 +739,11 @@ Status gpu_fingerprint_host(const std::vector<const int16_t *> &pcm, const std::
     return Status::Make(NeedleError_InvalidArgument, "fingerprint: one length per stream is required");
   return fingerprint_in_batches(
       num_values, channels, step, items, rate,
-      [&](size_t begin, size_t end, const std::vector<uint64_t> &in_off, int16_t *d_pcm, hipStream_t) -> Status {
+      [&](size_t begin, size_t end, const std::vector<uint64_t> &in_off, int16_t *d_pcm, hipStream_t up,
+          const StreamIssued &issued) -> Status {
         return gpu_upload_pcm(std::vector<const int16_t *>(pcm.begin() + begin, pcm.begin() + end),
-                              std::vector<size_t>(num_values.begin() + begin, num_values.begin() + end), in_off, d_pcm);
+                              std::vector<size_t>(num_values.begin() + begin, num_values.begin() + end), in_off, d_pcm, up,
+                              issued);
       });
 }
 
@@ -695,13 +751,30 @@ Status gpu_fingerprint_streamed(const std::vector<size_t> &num_values, const Pcm
                                 int channels, uint32_t step, std::vector<std::vector<uint32_t>> *items, int rate) {
   return fingerprint_in_batches(
       num_values, channels, step, items, rate,
-      [&](size_t begin, size_t end, const std::vector<uint64_t> &in_off, int16_t *d_pcm, hipStream_t) -> Status {
+      [&](size_t begin, size_t end, const std::vector<uint64_t> &in_off, int16_t *d_pcm, hipStream_t up,
+          const StreamIssued &issued) -> Status {
         const PcmReader shifted = [&](size_t stream, uint64_t first, uint64_t count, int16_t *dst) {
           return read(begin + stream, first, count, dst);
         };
         return gpu_upload_pcm_streamed(std::vector<size_t>(num_values.begin() + begin, num_values.begin() + end), in_off,
-                                       shifted, readers, d_pcm);
+                                       shifted, readers, d_pcm, up, issued);
       });
+}
+
+Status gpu_fingerprint_streamed_device(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
+                                       int channels, uint32_t step, uint32_t *d_items,
+                                       const std::vector<uint64_t> &item_off) {
+  if (pcm.size() != num_values.size() || item_off.size() != num_values.size())
+    return Status::Make(NeedleError_InvalidArgument, "fingerprint: one length and one item offset per stream are required");
+  return fingerprint_in_batches(
+      num_values, channels, step, nullptr, kSampleRate,
+      [&](size_t begin, size_t end, const std::vector<uint64_t> &in_off, int16_t *d_pcm, hipStream_t up,
+          const StreamIssued &issued) -> Status {
+        return gpu_upload_pcm(std::vector<const int16_t *>(pcm.begin() + begin, pcm.begin() + end),
+                              std::vector<size_t>(num_values.begin() + begin, num_values.begin() + end), in_off, d_pcm, up,
+                              issued);
+      },
+      d_items, &item_off);
 }
 
 }  // namespace needle

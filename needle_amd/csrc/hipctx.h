@@ -31,6 +31,7 @@ std::recursive_mutex &gpu_mutex();
 Status ensure_device();
 hipStream_t library_stream();
 hipStream_t download_stream();  // result downloads, ordered behind the library stream with events
+hipStream_t upload_stream();    // PCM uploads of the streaming analyzer; kernels follow on the library stream behind events
 
 template <typename T>
 struct DeviceBuffer {

@@ -131,6 +131,21 @@ hipStream_t download_stream() {
   return s;
 }
 
+// Host -> device PCM copies of the streaming analyzer go here, so that the fingerprint kernels of the streams that
+// have landed (library stream, behind an event) run underneath the copies of the streams that follow.
+hipStream_t upload_stream() {
+  static std::map<int, hipStream_t> streams;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = streams.find(dev);
+  if (it != streams.end()) return it->second;
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+  streams[dev] = s;
+  return s;
+}
+
 KernelTimer::KernelTimer(const char *n) : name(n) {
   hipStream_t s = library_stream();
   std::lock_guard<std::mutex> lock(g_mu);
@@ -225,7 +240,7 @@ size_t upload_slab_bytes() {
 }
 
 Status upload_through_ring(const std::vector<Segment> &segs, const PcmReader &read, unsigned readers, int16_t *d_pcm,
-                           hipStream_t stream) {
+                           hipStream_t stream, const StreamIssued &issued_cb) {
   SlabRing &ring = *slab_ring();  // guarded by gpu_mutex(), which the callers hold
   constexpr size_t K = SlabRing::kSlabs;
   const size_t N = segs.size();
@@ -319,6 +334,14 @@ Status upload_through_ring(const std::vector<Segment> &segs, const PcmReader &re
       result = Status::Make(NeedleError_Unknown, std::string("PCM upload failed: ") + hipGetErrorString(e));
       break;
     }
+    // the last segment of a stream is on its way: the caller may queue work behind it (an event on `stream`)
+    if (issued_cb && (issued + 1 == N || segs[issued + 1].stream != g.stream)) {
+      result = issued_cb(g.stream);
+      if (!result.ok()) {
+        issued++;
+        break;
+      }
+    }
   }
   {
     std::lock_guard<std::mutex> lock(mu);
@@ -343,7 +366,8 @@ Status upload_through_ring(const std::vector<Segment> &segs, const PcmReader &re
 }  // namespace
 
 Status gpu_upload_pcm_streamed(const std::vector<size_t> &num_values, const std::vector<uint64_t> &dev_off,
-                               const PcmReader &read, unsigned readers, int16_t *d_pcm) {
+                               const PcmReader &read, unsigned readers, int16_t *d_pcm, hipStream_t stream,
+                               const StreamIssued &issued_cb) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   Status s = ensure_device();
   if (!s.ok()) return s;
@@ -352,36 +376,52 @@ Status gpu_upload_pcm_streamed(const std::vector<size_t> &num_values, const std:
   for (size_t i = 0; i < num_values.size(); i++)
     for (uint64_t at = 0; at < num_values[i]; at += slab_values)
       segs.push_back(Segment{i, at, std::min<uint64_t>(slab_values, num_values[i] - at), dev_off[i] + at});
-  return upload_through_ring(segs, read, readers, d_pcm, library_stream());
+  return upload_through_ring(segs, read, readers, d_pcm, stream ? stream : library_stream(), issued_cb);
 }
 
 // PCM that already sits in (pageable) host memory: small uploads go as plain asynchronous copies, large ones
 // through the ring with a few threads doing the copy into pinned memory -- the runtime's own staging of a
 // pageable source reaches about half the PCIe rate.
 Status gpu_upload_pcm(const std::vector<const int16_t *> &pcm, const std::vector<size_t> &num_values,
-                      const std::vector<uint64_t> &dev_off, int16_t *d_pcm) {
+                      const std::vector<uint64_t> &dev_off, int16_t *d_pcm, hipStream_t stream,
+                      const StreamIssued &issued_cb) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   Status s = ensure_device();
   if (!s.ok()) return s;
+  if (!stream) stream = library_stream();
   uint64_t total = 0;
   for (size_t v : num_values) total += v;
   size_t threshold = 16u << 20;
   if (const char *e = getenv("NEEDLE_HIP_RING_UPLOAD_MIN_BYTES")) threshold = (size_t)std::max(0ll, atoll(e));
-  if (total * sizeof(int16_t) < threshold) {
-    hipStream_t stream = library_stream();
-    for (size_t i = 0; i < pcm.size(); i++)
+  // Caller-owned PINNED memory (hipHostMalloc / hipHostRegister, e.g. needle_hip_host_alloc): the copy engine reads
+  // it in place, no staging.
+  bool pinned = total > 0 && getenv("NEEDLE_HIP_NO_DIRECT_UPLOAD") == nullptr;
+  for (size_t i = 0; pinned && i < pcm.size(); i++) {
+    if (!num_values[i]) continue;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, pcm[i]) != hipSuccess) {
+      (void)hipGetLastError();
+      pinned = false;
+    } else if (attr.type != hipMemoryTypeHost) {
+      pinned = false;
+    }
+  }
+  if (pinned || total * sizeof(int16_t) < threshold) {
+    for (size_t i = 0; i < pcm.size(); i++) {
       if (num_values[i])
         NEEDLE_HIP_TRY(hipMemcpyAsync(d_pcm + dev_off[i], pcm[i], num_values[i] * sizeof(int16_t),
                                       hipMemcpyHostToDevice, stream));
+      if (issued_cb && !(s = issued_cb(i)).ok()) return s;
+    }
     return Status::Ok();
   }
-  const PcmReader read = [&](size_t stream, uint64_t first, uint64_t count, int16_t *dst) {
-    std::memcpy(dst, pcm[stream] + first, count * sizeof(int16_t));
+  const PcmReader read = [&](size_t stream_index, uint64_t first, uint64_t count, int16_t *dst) {
+    std::memcpy(dst, pcm[stream_index] + first, count * sizeof(int16_t));
     return Status::Ok();
   };
   unsigned threads = std::min(usable_cpus(), 16u);
   if (const char *e = getenv("NEEDLE_HIP_UPLOAD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
-  return gpu_upload_pcm_streamed(num_values, dev_off, read, threads, d_pcm);
+  return gpu_upload_pcm_streamed(num_values, dev_off, read, threads, d_pcm, stream, issued_cb);
 }
 
 }  // namespace needle

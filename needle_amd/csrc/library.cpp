@@ -17,6 +17,7 @@
 #include <cstring>
 #include <new>
 
+#include "comm.h"
 #include "hipctx.h"
 #include "needle_core.h"
 
@@ -48,7 +49,8 @@ struct NeedleHipLibrary {
   ns_t hash_duration = 0;
   uint32_t step = 0;
   int channels = 1;
-  bool have_pcm = false;
+  bool have_pcm = false;      // windows and arena are set up (set_pcm or stream_pcm)
+  bool pcm_resident = false;  // set_pcm: the PCM stays in HBM and analyze can be repeated
   std::vector<Window> win;  // [video * regions() + region]
   size_t stride = 0;
   DeviceBuffer<int16_t> d_pcm;
@@ -68,18 +70,56 @@ struct NeedleHipLibrary {
     uint32_t max_runs = 0;
     hipEvent_t ready = nullptr, done = nullptr;  // search enqueued (library stream) / copies finished (download stream)
     const NeedleHipRun *d_runs = nullptr;        // what the pending download reads
+    const uint32_t *d_count = nullptr;
     bool pending = false;
   } fetch[2];
+  // One slot of the job pipeline (needle_hip_library_job_begin / _end): the run slabs of all ranks, device side and
+  // pinned host side.  Rank r's slab = 32-byte header (word 0: runs found) + slab_runs runs; the scan writes straight
+  // into this rank's slab and the all-gather fills in the others in place.
+  struct Job {
+    DeviceBuffer<uint8_t> d_slabs;
+    uint32_t slab_runs = 0, head_runs = 0;
+    int world = 0;
+    void *host = nullptr;
+    size_t host_bytes = 0;
+    hipEvent_t searched = nullptr, done = nullptr;
+    bool pending = false;
+    std::vector<NeedleHipRun> merged;
+    size_t slab_bytes() const { return kSlabHeader + (size_t)slab_runs * sizeof(NeedleHipRun); }
+    size_t head_bytes() const { return kSlabHeader + (size_t)head_runs * sizeof(NeedleHipRun); }
+  } job[2];
+  static constexpr size_t kSlabHeader = 32;
+  uint32_t slab_runs = 0;      // per-rank run capacity of the next job (grows on overflow)
+  uint32_t last_max_count = 0;  // largest per-rank run count of the last finished job: sizes the one-trip download
+  size_t arena_rows = 0;       // rows the arena was allocated with (world * block * regions)
   ~NeedleHipLibrary() {
     for (Fetch &f : fetch) {
       if (f.host) (void)hipHostFree(f.host);
       if (f.done) (void)hipEventDestroy(f.done);
       if (f.ready) (void)hipEventDestroy(f.ready);
     }
+    for (Job &j : job) {
+      if (j.host) (void)hipHostFree(j.host);
+      if (j.done) (void)hipEventDestroy(j.done);
+      if (j.searched) (void)hipEventDestroy(j.searched);
+    }
   }
 
   size_t regions() const { return endings ? 2 : 1; }
   size_t rows() const { return n * regions(); }
+  // with a communicator the arena holds world blocks of ceil(n / world) videos, so that a plain all-gather of
+  // equal-sized row blocks fills it (the rows past n * regions are padding nobody reads)
+  size_t padded_rows() const { return shard_block(n, comm_world()) * (size_t)comm_world() * regions(); }
+  void ensure_shells() {  // per-video timestamps for the epilogue: the runs carry their simhashes, hashes stay in HBM
+    if (shells.size() == n) return;
+    shells.assign(n, {});
+    const size_t R = regions();
+    for (size_t v = 0; v < n; v++) {
+      shells[v].opening = window_timestamps(win[v * R]);
+      if (endings) shells[v].ending = window_timestamps(win[v * R + 1]);
+      shells[v].hash_duration = hash_duration;
+    }
+  }
 
   const std::vector<HashTs> &timestamps(uint32_t k) {
     if (ts_cache.size() <= k) ts_cache.resize(k + 1);
@@ -142,64 +182,114 @@ enum NeedleError needle_hip_library_include_endings(NeedleHipLibrary *lib, float
   return NeedleError_Ok;
 }
 
+}  // extern "C"
+
+namespace {
+// Search windows of every video (analyzer.rs:378,390) from the stream lengths, arena geometry, and -- for the videos
+// whose PCM this rank holds -- where each window starts in the caller's buffer.  `resident`: the windows get offsets
+// into the device PCM arena (set_pcm); otherwise nothing of the PCM is kept (stream_pcm).
+Status plan_windows(NeedleHipLibrary *lib, const int16_t *const *pcm, const size_t *num_values, int channels, bool resident,
+                    std::vector<const int16_t *> *src, std::vector<size_t> *len, std::vector<uint64_t> *dst,
+                    std::vector<uint64_t> *rows_of_src, uint64_t *total_values) {
+  Status s = ensure_device();
+  if (!s.ok()) return s;
+  lib->channels = channels;
+  const size_t R = lib->regions();
+  lib->win.assign(lib->rows(), Window{});
+  uint64_t total = 0;
+  uint32_t max_kept = 0;
+  std::vector<size_t> first_sample(lib->rows(), 0);
+  for (size_t v = 0; v < lib->n; v++) {
+    const size_t samples = num_values[v] / (size_t)channels;
+    size_t open_samples = 0, end_first = 0;
+    ns_t seek = 0;
+    s = Analyzer::windows(samples, kSampleRate, lib->opening_pct, lib->ending_pct, &open_samples, &end_first, &seek);
+    if (!s.ok()) return s;
+    for (size_t r = 0; r < R; r++) {
+      Window &w = lib->win[v * R + r];
+      const size_t count = r == 0 ? open_samples : samples - end_first;
+      first_sample[v * R + r] = r == 0 ? 0 : end_first;
+      w.values = count * (size_t)channels;
+      w.kept = (uint32_t)num_kept(count, lib->step);
+      w.seek = r == 0 ? 0 : seek;
+      max_kept = std::max(max_kept, w.kept);
+      if (pcm[v] && resident) {
+        w.pcm_off = total;
+        total += (w.values + 1) & ~(uint64_t)1;
+      }
+    }
+  }
+  size_t stride = ((size_t)max_kept + 63) & ~(size_t)63;  // rows start 256-byte aligned
+  if (stride == 0) stride = 64;
+  const size_t arena_rows = std::max(lib->rows(), lib->padded_rows());
+  // NeedleHipSeq.offset and NeedleHipProblem.tag are 32-bit on the device
+  if ((uint64_t)arena_rows * stride > UINT32_MAX || (uint64_t)pair_count(lib->n) * R > UINT32_MAX)
+    return Status::Make(NeedleError_InvalidArgument, "library too large for one job: more than 2^32 arena hashes or sequence pairs");
+  const bool own_arena = lib->arena == lib->d_arena.ptr;
+  if (!lib->arena || (own_arena && (stride != lib->stride || arena_rows != lib->arena_rows))) {
+    if (!(s = lib->d_arena.reserve(arena_rows * stride)).ok()) return s;
+    lib->arena = lib->d_arena.ptr;
+    lib->arena_rows = arena_rows;
+    lib->stride = stride;
+    if (hipMemsetAsync(lib->arena, 0, arena_rows * stride * sizeof(uint32_t), library_stream()) != hipSuccess)
+      return Status::Make(NeedleError_Unknown, "hipMemset failed");
+  } else if (!own_arena && (stride > lib->stride || arena_rows > lib->arena_rows)) {
+    return Status::Make(NeedleError_InvalidArgument, "the adopted hash arena is too small for these videos");
+  }
+  for (size_t v = 0; v < lib->n; v++) {
+    for (size_t r = 0; r < R; r++) {
+      const Window &w = lib->win[v * R + r];
+      if (!pcm[v] || !w.values) continue;
+      src->push_back(pcm[v] + first_sample[v * R + r] * (size_t)channels);
+      len->push_back(w.values);
+      if (dst) dst->push_back(w.pcm_off);
+      if (rows_of_src) rows_of_src->push_back(v * R + r);
+    }
+  }
+  if (total_values) *total_values = total;
+  lib->min_len.clear();
+  lib->shells.clear();
+  lib->problems_for[0] = ~(size_t)0;
+  return Status::Ok();
+}
+}  // namespace
+
+extern "C" {
+
 enum NeedleError needle_hip_library_set_pcm(NeedleHipLibrary *lib, const int16_t *const *pcm, const size_t *num_values,
                                             int channels) {
   if (!lib || !pcm || !num_values) return NeedleError_NullArgument;
   if (channels != 1 && channels != 2) return NeedleError_InvalidArgument;
   return guarded([&]() -> NeedleError {
-    Status s = ensure_device();
-    if (!s.ok()) return report(s);
-    lib->channels = channels;
-    const size_t R = lib->regions();
-    lib->win.assign(lib->rows(), Window{});
-    uint64_t total = 0;
-    uint32_t max_kept = 0;
-    std::vector<size_t> first_sample(lib->rows(), 0);
-    for (size_t v = 0; v < lib->n; v++) {
-      const size_t samples = num_values[v] / (size_t)channels;
-      size_t open_samples = 0, end_first = 0;
-      ns_t seek = 0;
-      s = Analyzer::windows(samples, kSampleRate, lib->opening_pct, lib->ending_pct, &open_samples, &end_first, &seek);
-      if (!s.ok()) return report(s);
-      for (size_t r = 0; r < R; r++) {
-        Window &w = lib->win[v * R + r];
-        const size_t count = r == 0 ? open_samples : samples - end_first;
-        first_sample[v * R + r] = r == 0 ? 0 : end_first;
-        w.values = count * (size_t)channels;
-        w.kept = (uint32_t)num_kept(count, lib->step);
-        w.seek = r == 0 ? 0 : seek;
-        max_kept = std::max(max_kept, w.kept);
-        if (pcm[v]) {
-          w.pcm_off = total;
-          total += (w.values + 1) & ~(uint64_t)1;
-        }
-      }
-    }
-    lib->stride = ((size_t)max_kept + 63) & ~(size_t)63;  // rows start 256-byte aligned
-    if (lib->stride == 0) lib->stride = 64;
-    if (!(s = lib->d_pcm.reserve(std::max<uint64_t>(total, 1))).ok()) return report(s);
-    if (!(s = lib->d_arena.reserve(lib->rows() * lib->stride)).ok()) return report(s);
-    hipStream_t stream = library_stream();
-    lib->arena = lib->d_arena.ptr;
-    if (hipMemsetAsync(lib->arena, 0, lib->rows() * lib->stride * sizeof(uint32_t), stream) != hipSuccess)
-      return report(Status::Make(NeedleError_Unknown, "hipMemset failed"));
     std::vector<const int16_t *> src;
     std::vector<size_t> len;
     std::vector<uint64_t> dst;
-    for (size_t v = 0; v < lib->n; v++) {
-      for (size_t r = 0; r < R; r++) {
-        const Window &w = lib->win[v * R + r];
-        if (!pcm[v] || !w.values) continue;
-        src.push_back(pcm[v] + first_sample[v * R + r] * (size_t)channels);
-        len.push_back(w.values);
-        dst.push_back(w.pcm_off);
-      }
-    }
+    uint64_t total = 0;
+    Status s = plan_windows(lib, pcm, num_values, channels, true, &src, &len, &dst, nullptr, &total);
+    if (!s.ok()) return report(s);
+    if (!(s = lib->d_pcm.reserve(std::max<uint64_t>(total, 1))).ok()) return report(s);
     if (!(s = gpu_upload_pcm(src, len, dst, lib->d_pcm.ptr)).ok()) return report(s);
-    if (hipStreamSynchronize(stream) != hipSuccess) return report(Status::Make(NeedleError_Unknown, "PCM upload failed"));
+    if (hipStreamSynchronize(library_stream()) != hipSuccess) return report(Status::Make(NeedleError_Unknown, "PCM upload failed"));
     lib->have_pcm = true;
-    lib->min_len.clear();
-    lib->shells.clear();
+    lib->pcm_resident = true;
+    return NeedleError_Ok;
+  });
+}
+
+enum NeedleError needle_hip_library_stream_pcm(NeedleHipLibrary *lib, const int16_t *const *pcm, const size_t *num_values,
+                                               int channels) {
+  if (!lib || !pcm || !num_values) return NeedleError_NullArgument;
+  if (channels != 1 && channels != 2) return NeedleError_InvalidArgument;
+  return guarded([&]() -> NeedleError {
+    std::vector<const int16_t *> src;
+    std::vector<size_t> len;
+    std::vector<uint64_t> rows;
+    Status s = plan_windows(lib, pcm, num_values, channels, false, &src, &len, nullptr, &rows, nullptr);
+    if (!s.ok()) return report(s);
+    for (uint64_t &r : rows) r *= lib->stride;  // kept items of a window go straight to its arena row
+    if (!(s = gpu_fingerprint_streamed_device(src, len, channels, lib->step, lib->arena, rows)).ok()) return report(s);
+    lib->have_pcm = true;
+    lib->pcm_resident = false;
     return NeedleError_Ok;
   });
 }
@@ -234,7 +324,9 @@ size_t needle_hip_library_rows_per_video(const NeedleHipLibrary *lib) { return l
 enum NeedleError needle_hip_library_use_hash_arena(NeedleHipLibrary *lib, uint32_t *d_arena, size_t rows, size_t stride) {
   if (!lib || !d_arena) return NeedleError_NullArgument;
   if (!lib->have_pcm || rows < lib->rows() || stride < lib->stride) return NeedleError_InvalidArgument;
+  if ((uint64_t)rows * stride > UINT32_MAX) return NeedleError_InvalidArgument;
   lib->arena = d_arena;
+  lib->arena_rows = rows;
   lib->stride = stride;
   lib->d_arena.release();
   return NeedleError_Ok;
@@ -297,7 +389,8 @@ enum NeedleError needle_hip_library_search(NeedleHipLibrary *lib, const struct N
     }
     // a download that still reads this run buffer (on the download stream) has to finish before it is overwritten
     for (NeedleHipLibrary::Fetch &f : lib->fetch)
-      if (f.pending && f.d_runs == d_runs && hipStreamWaitEvent(library_stream(), f.done, 0) != hipSuccess)
+      if (f.pending && (f.d_runs == d_runs || f.d_count == d_count) &&
+          hipStreamWaitEvent(library_stream(), f.done, 0) != hipSuccess)
         return report(Status::Make(NeedleError_Unknown, "stream wait failed"));
     const auto t_built = std::chrono::steady_clock::now();
     Status s = gpu_hamming_runs_device(lib->arena, seqs.data(), seqs.size(), problems.data(), problems.size(),
@@ -338,6 +431,7 @@ enum NeedleError needle_hip_library_fetch_runs_begin(NeedleHipLibrary *lib, int 
         hipEventRecord(f.done, down) != hipSuccess)
       return report(Status::Make(NeedleError_Unknown, "asynchronous run download failed"));
     f.d_runs = d_runs;
+    f.d_count = d_count;
     f.pending = true;
     return NeedleError_Ok;
   });
@@ -364,22 +458,12 @@ enum NeedleError needle_hip_library_finalize(NeedleHipLibrary *lib, const struct
   if (!lib->have_pcm) return NeedleError_InvalidArgument;
   return guarded([&]() -> NeedleError {
     const Comparator &cmp = comparator_of(comparator);
-    // the epilogue needs timestamps only: the runs carry their simhashes, so the hash arena stays in HBM
-    if (lib->shells.size() != lib->n) {
-      lib->shells.assign(lib->n, {});
-      const size_t R = lib->regions();
-      for (size_t v = 0; v < lib->n; v++) {
-        lib->shells[v].opening = lib->window_timestamps(lib->win[v * R]);
-        if (lib->endings) lib->shells[v].ending = lib->window_timestamps(lib->win[v * R + 1]);
-        lib->shells[v].hash_duration = lib->hash_duration;
-      }
-    }
+    lib->ensure_shells();
     std::vector<const FrameHashesData *> fh;
     for (const FrameHashesData &d : lib->shells) fh.push_back(&d);
-    std::vector<NeedleHipRun> run_vec(runs, runs + num_runs);
     std::vector<VideoResult> res;
     const auto t0 = std::chrono::steady_clock::now();
-    Status s = cmp.results_from_runs(fh, run_vec, false, false, false, &res);
+    Status s = cmp.results_from_runs(fh, runs, num_runs, false, false, false, &res);
     if (getenv("NEEDLE_HIP_TRACE"))
       std::fprintf(stderr, "[needle_hip] epilogue %zu runs: %.1f us\n", num_runs,
                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
@@ -410,6 +494,250 @@ enum NeedleError needle_hip_library_frame_hashes(NeedleHipLibrary *lib, size_t i
     }
     fh.hash_duration = lib->hash_duration;
     *output = make_frame_hashes(std::move(fh));
+    return NeedleError_Ok;
+  });
+}
+
+}  // extern "C"
+
+// ---- the whole job, across the communicator ------------------------------------------------------------------------
+namespace {
+
+uint32_t round_up4(uint64_t v) { return (uint32_t)std::min<uint64_t>((v + 3) & ~(uint64_t)3, 0xfffffffcu); }
+
+Status job_buffers(NeedleHipLibrary *lib, NeedleHipLibrary::Job &j, int world) {
+  if (!j.searched) NEEDLE_HIP_TRY(hipEventCreateWithFlags(&j.searched, hipEventDisableTiming));
+  if (!j.done) NEEDLE_HIP_TRY(hipEventCreateWithFlags(&j.done, hipEventDisableTiming));
+  if (j.slab_runs != lib->slab_runs || j.world != world) {
+    j.slab_runs = lib->slab_runs;
+    j.world = world;
+    j.d_slabs.release();
+    Status s = j.d_slabs.reserve(j.slab_bytes() * (size_t)world);
+    if (!s.ok()) return s;
+  }
+  // the one-trip download: everything the last job needed plus a margin, the whole slab while that is small
+  uint32_t head = lib->last_max_count ? round_up4((uint64_t)lib->last_max_count + lib->last_max_count / 8 + 64) : 4096u;
+  head = std::min(head, j.slab_runs);
+  if (j.slab_bytes() * (size_t)world <= (1u << 20)) head = j.slab_runs;
+  j.head_runs = head;
+  const size_t want = j.head_bytes() * (size_t)world;
+  if (want > j.host_bytes) {
+    if (j.host) (void)hipHostFree(j.host);
+    j.host = nullptr;
+    j.host_bytes = 0;
+    NEEDLE_HIP_TRY(hipHostMalloc(&j.host, want + want / 4, hipHostMallocDefault));
+    j.host_bytes = want + want / 4;
+  }
+  return Status::Ok();
+}
+
+// scan of this rank's pair range into its slab, gather of the slabs, download of their heads: all asynchronous
+NeedleError job_search_and_gather(NeedleHipLibrary *lib, const NeedleAudioComparator *comparator, NeedleHipLibrary::Job &j) {
+  const int world = comm_world(), rank = comm_rank();
+  size_t pfirst = 0, pcount = 0;
+  shard_range(pair_count(lib->n), world, rank, &pfirst, &pcount);
+  uint8_t *mine = j.d_slabs.ptr + (size_t)rank * j.slab_bytes();
+  NeedleError e = needle_hip_library_search(lib, comparator, pfirst, pcount,
+                                            reinterpret_cast<NeedleHipRun *>(mine + NeedleHipLibrary::kSlabHeader), j.slab_runs,
+                                            reinterpret_cast<uint32_t *>(mine), false);
+  if (e != NeedleError_Ok) return e;
+  hipStream_t stream = library_stream(), down = download_stream();
+  if (hipEventRecord(j.searched, stream) != hipSuccess || hipStreamWaitEvent(down, j.searched, 0) != hipSuccess)
+    return report(Status::Make(NeedleError_Unknown, "stream ordering failed"));
+  Status s = comm_all_gather(kSide, mine, j.d_slabs.ptr, j.slab_bytes(), down);
+  if (!s.ok()) return report(s);
+  if (hipMemcpy2DAsync(j.host, j.head_bytes(), j.d_slabs.ptr, j.slab_bytes(), j.head_bytes(), (size_t)world,
+                       hipMemcpyDeviceToHost, down) != hipSuccess ||
+      hipEventRecord(j.done, down) != hipSuccess)
+    return report(Status::Make(NeedleError_Unknown, "asynchronous run download failed"));
+  return NeedleError_Ok;
+}
+
+bool shard_epilogue(size_t total_runs) {
+  // Sharding the per-video epilogue costs one more (small) collective; it pays once the epilogue is milliseconds.
+  if (const char *e = getenv("NEEDLE_HIP_SHARD_EPILOGUE")) return atoi(e) != 0;
+  return total_runs >= (1u << 17);
+}
+
+}  // namespace
+
+extern "C" {
+
+int needle_hip_comm_rank(void) { return comm_rank(); }
+int needle_hip_comm_world_size(void) { return comm_world(); }
+const char *needle_hip_comm_backend(void) { return comm_backend(); }
+
+enum NeedleError needle_hip_comm_create_id(uint8_t id[NEEDLE_HIP_COMM_ID_BYTES]) {
+  if (!id) return NeedleError_NullArgument;
+  return guarded([&]() -> NeedleError {
+    Status s = comm_create_id(id);
+    return s.ok() ? NeedleError_Ok : report(s);
+  });
+}
+
+enum NeedleError needle_hip_comm_init(const uint8_t id[NEEDLE_HIP_COMM_ID_BYTES], int rank, int world_size) {
+  if (!id) return NeedleError_NullArgument;
+  return guarded([&]() -> NeedleError {
+    Status s = comm_init(id, rank, world_size);
+    return s.ok() ? NeedleError_Ok : report(s);
+  });
+}
+
+void needle_hip_comm_finalize(void) { comm_finalize(); }
+
+enum NeedleError needle_hip_comm_barrier(void) {
+  return guarded([&]() -> NeedleError {
+    Status s = comm_barrier();
+    return s.ok() ? NeedleError_Ok : report(s);
+  });
+}
+
+enum NeedleError needle_hip_comm_all_gather_host(const void *send, void *recv, size_t bytes_per_rank) {
+  if ((!send || !recv) && bytes_per_rank) return NeedleError_NullArgument;
+  return guarded([&]() -> NeedleError {
+    Status s = comm_all_gather_host(send, recv, bytes_per_rank);
+    return s.ok() ? NeedleError_Ok : report(s);
+  });
+}
+
+void needle_hip_comm_shard(size_t units, int world_size, int rank, size_t *first, size_t *count) {
+  size_t f = 0, c = 0;
+  if (world_size >= 1 && rank >= 0 && rank < world_size) shard_range(units, world_size, rank, &f, &c);
+  if (first) *first = f;
+  if (count) *count = c;
+}
+
+enum NeedleError needle_hip_library_job_begin(NeedleHipLibrary *lib, const struct NeedleAudioComparator *comparator, int slot) {
+  if (!lib || !comparator) return NeedleError_NullArgument;
+  if (slot < 0 || slot > 1 || !lib->have_pcm) return NeedleError_InvalidArgument;
+  return guarded([&]() -> NeedleError {
+    NeedleHipLibrary::Job &j = lib->job[slot];
+    if (j.pending) return report(Status::Make(NeedleError_InvalidArgument, "job slot still pending"));
+    const int world = comm_world(), rank = comm_rank();
+    if (lib->arena_rows < lib->padded_rows())
+      return report(Status::Make(NeedleError_InvalidArgument,
+                                 "the hash arena predates the communicator: call needle_hip_library_set_pcm after needle_hip_comm_init"));
+    // 1. fingerprint this rank's block of videos into its arena rows (analyzer.rs:437-445 across GPUs)
+    size_t first = 0, count = 0;
+    shard_range(lib->n, world, rank, &first, &count);
+    // (after needle_hip_library_stream_pcm the rows are already there: the PCM was fingerprinted as it was uploaded)
+    NeedleError e = count && lib->pcm_resident ? needle_hip_library_analyze(lib, first, count, false) : NeedleError_Ok;
+    if (e != NeedleError_Ok) return e;
+    // 2. every rank gets every hash row: one in-place all-gather of equal row blocks, in stream order
+    if (comm_get()) {
+      const size_t block_bytes = shard_block(lib->n, world) * lib->regions() * lib->stride * sizeof(uint32_t);
+      Status s = comm_all_gather(kData, reinterpret_cast<const uint8_t *>(lib->arena) + (size_t)rank * block_bytes, lib->arena,
+                                 block_bytes, library_stream());
+      if (!s.ok()) return report(s);
+    }
+    // 3. + 4. scan this rank's pair range (comparator.rs:549-564 across GPUs), gather the run lists
+    if (lib->slab_runs == 0 && getenv("NEEDLE_HIP_SLAB_RUNS"))  // tests: a slab that overflows
+      lib->slab_runs = round_up4((uint64_t)std::max(4, atoi(getenv("NEEDLE_HIP_SLAB_RUNS"))));
+    if (lib->slab_runs == 0)
+      lib->slab_runs = round_up4(std::max<uint64_t>(1024, 4 * (uint64_t)shard_block(pair_count(lib->n), world) * lib->regions()));
+    Status s = job_buffers(lib, j, world);
+    if (!s.ok()) return report(s);
+    if ((e = job_search_and_gather(lib, comparator, j)) != NeedleError_Ok) return e;
+    j.pending = true;
+    return NeedleError_Ok;
+  });
+}
+
+enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct NeedleAudioComparator *comparator, int slot,
+                                            NeedleHipSearchResult *results, size_t *num_runs) {
+  if (!lib || !comparator || !results) return NeedleError_NullArgument;
+  if (slot < 0 || slot > 1 || !lib->job[slot].pending) return NeedleError_InvalidArgument;
+  return guarded([&]() -> NeedleError {
+    NeedleHipLibrary::Job &j = lib->job[slot];
+    const int world = comm_world(), rank = comm_rank();
+    const Comparator &cmp = comparator_of(comparator);
+    std::vector<uint32_t> counts((size_t)world);
+    for (;;) {
+      if (hipEventSynchronize(j.done) != hipSuccess) return report(Status::Make(NeedleError_Unknown, "run download failed"));
+      uint32_t most = 0;
+      for (int r = 0; r < world; r++) {
+        counts[r] = *reinterpret_cast<const uint32_t *>(static_cast<const char *>(j.host) + (size_t)r * j.head_bytes());
+        most = std::max(most, counts[r]);
+      }
+      if (most <= j.slab_runs) {
+        lib->last_max_count = most;
+        break;
+      }
+      // Some rank found more runs than a slab holds (every rank sees the same counts, so every rank takes this
+      // branch): grow and repeat the scan of this job -- the scan is deterministic and the arena still holds the
+      // hashes, whether or not the next job's analyze has run in between (same PCM, same rows).
+      lib->slab_runs = round_up4((uint64_t)most + most / 4 + 64);
+      lib->last_max_count = most;
+      Status s = job_buffers(lib, j, world);
+      if (!s.ok()) return report(s);
+      NeedleError e = job_search_and_gather(lib, comparator, j);
+      if (e != NeedleError_Ok) return e;
+    }
+    j.pending = false;
+    // run list of all ranks: heads from the pinned buffer, tails (rare: the first job of a library) straight from HBM
+    size_t total = 0;
+    for (int r = 0; r < world; r++) total += counts[r];
+    j.merged.resize(total);
+    size_t at = 0;
+    bool tails = false;
+    for (int r = 0; r < world; r++) {
+      const uint32_t head = std::min(counts[r], j.head_runs);
+      std::memcpy(j.merged.data() + at, static_cast<const char *>(j.host) + (size_t)r * j.head_bytes() + NeedleHipLibrary::kSlabHeader,
+                  (size_t)head * sizeof(NeedleHipRun));
+      if (counts[r] > head) {
+        tails = true;
+        if (hipMemcpyAsync(j.merged.data() + at + head,
+                           j.d_slabs.ptr + (size_t)r * j.slab_bytes() + NeedleHipLibrary::kSlabHeader + (size_t)head * sizeof(NeedleHipRun),
+                           (size_t)(counts[r] - head) * sizeof(NeedleHipRun), hipMemcpyDeviceToHost, download_stream()) != hipSuccess)
+          return report(Status::Make(NeedleError_Unknown, "run download failed"));
+      }
+      at += counts[r];
+    }
+    if (tails && hipStreamSynchronize(download_stream()) != hipSuccess)
+      return report(Status::Make(NeedleError_Unknown, "run download failed"));
+    if (num_runs) *num_runs = total;
+
+    // 5. the order-sensitive per-video epilogue (comparator.rs:583-626): every rank for all videos while that is
+    // cheaper than another collective, otherwise each rank for its own block of videos + one all-gather of results
+    lib->ensure_shells();
+    std::vector<const FrameHashesData *> fh;
+    for (const FrameHashesData &d : lib->shells) fh.push_back(&d);
+    std::vector<VideoResult> res;
+    const bool sharded = world > 1 && shard_epilogue(total);
+    size_t v0 = 0, vcount = lib->n;
+    if (sharded) shard_range(lib->n, world, rank, &v0, &vcount);
+    const auto t0 = std::chrono::steady_clock::now();
+    Status s = cmp.results_from_runs(fh, j.merged.data(), total, false, false, false, &res, v0, v0 + vcount);
+    if (getenv("NEEDLE_HIP_TRACE"))
+      std::fprintf(stderr, "[needle_hip] rank %d epilogue %zu runs, videos [%zu, %zu): %.1f us\n", rank, total, v0, v0 + vcount,
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    // an error on one rank must not leave the others waiting in the collective below: it travels with the results
+    if (!sharded) {
+      if (!s.ok()) return report(s);
+      for (size_t v = 0; v < lib->n; v++) fill_c_result(res[v], &results[v]);
+      return NeedleError_Ok;
+    }
+    const size_t b = shard_block(lib->n, world);
+    struct Block {
+      uint64_t failed;
+    };
+    const size_t block_bytes = sizeof(Block) + b * sizeof(NeedleHipSearchResult);
+    std::vector<uint8_t> mine(block_bytes, 0), all(block_bytes * (size_t)world, 0);
+    reinterpret_cast<Block *>(mine.data())->failed = s.ok() ? 0 : 1;
+    if (s.ok())
+      for (size_t k = 0; k < vcount; k++)
+        fill_c_result(res[v0 + k], reinterpret_cast<NeedleHipSearchResult *>(mine.data() + sizeof(Block)) + k);
+    Status g = comm_all_gather_host(mine.data(), all.data(), block_bytes);
+    if (!s.ok()) return report(s);
+    if (!g.ok()) return report(g);
+    for (int r = 0; r < world; r++) {
+      const uint8_t *blk = all.data() + (size_t)r * block_bytes;
+      if (reinterpret_cast<const Block *>(blk)->failed)
+        return report(Status::Make(NeedleError_Unknown, "the epilogue failed on rank " + std::to_string(r)));
+      size_t f = 0, c = 0;
+      shard_range(lib->n, world, r, &f, &c);
+      std::memcpy(results + f, blk + sizeof(Block), c * sizeof(NeedleHipSearchResult));
+    }
     return NeedleError_Ok;
   });
 }

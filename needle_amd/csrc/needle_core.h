@@ -126,9 +126,11 @@ class Comparator {
   ns_t min_opening_duration() const { return min_opening_duration_; }
   ns_t min_ending_duration() const { return min_ending_duration_; }
   // Run list of ALL pairs (NeedleHipRun.problem = pair_index * regions + region) -> per-video results.
-  Status results_from_runs(const std::vector<const FrameHashesData *> &frame_hashes,
-                           const std::vector<NeedleHipRun> &runs, bool display, bool use_skip_files,
-                           bool write_skip_files, std::vector<VideoResult> *per_video) const;
+  // [v0, v1): the videos whose results are wanted (a rank's block in a multi-GPU job; the other slots of
+  // per_video stay empty and only the pairs that touch the block are worked on).
+  Status results_from_runs(const std::vector<const FrameHashesData *> &frame_hashes, const NeedleHipRun *runs,
+                           size_t num_runs, bool display, bool use_skip_files, bool write_skip_files,
+                           std::vector<VideoResult> *per_video, size_t v0 = 0, size_t v1 = ~(size_t)0) const;
   // Heap entries of every pair, pairs in lexicographic order, in one allocation: those of pair p are
   // entries[first[p] .. first[p] + count[p]) (a library has ~n^2 / 2 pairs: no vector per pair).
   struct PairEntries {
@@ -138,7 +140,8 @@ class Comparator {
   };
   // :583-626 — per video best match from the per-pair entries.
   Status best_matches(size_t num_videos, const PairEntries &pair_entries, bool display, bool use_skip_files,
-                      bool write_skip_files, std::vector<VideoResult> *per_video) const;
+                      bool write_skip_files, std::vector<VideoResult> *per_video, size_t v0 = 0,
+                      size_t v1 = ~(size_t)0) const;
 
  private:
   std::vector<std::string> videos_;

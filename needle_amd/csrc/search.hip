@@ -682,4 +682,70 @@ Status gpu_hamming_runs_host(const uint32_t *hashes, size_t num_hashes, const Ne
   return Status::Make(NeedleError_Unknown, "hamming_runs: run list did not fit after resize");
 }
 
+// ---- diagnostic: the integer-VALU ceiling of the scan's per-cell work on THIS device ------------------------------
+// "calibrate with a popcount micro-benchmark on the box and use the measured ceiling as the
+// denominator".  A cell here is exactly the four instructions of the band scan's inner loop -- v_xor_b32,
+// v_bcnt_u32_b32, v_cmp, v_cndmask -- on registers only, no memory, eight independent cells per lane and row, at the
+// occupancy that gives the highest rate.
+namespace {
+template <int R>
+__global__ __launch_bounds__(256) void valu_ceiling_kernel(uint32_t *out, int rows, uint32_t threshold, uint32_t seed) {
+  uint32_t W[R];
+  int Z[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    W[r] = seed * (threadIdx.x + 1) * (r + 3) + blockIdx.x;
+    Z[r] = -1;
+  }
+  uint32_t sv = __builtin_amdgcn_readfirstlane(seed ^ blockIdx.x);
+  for (int i = 0; i < rows; i++) {
+    sv = sv * 1664525u + 1013904223u;  // scalar update: stands in for the s_load'ed source hash of the row
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const uint32_t c = (uint32_t)__popc(sv ^ W[r]);
+      Z[r] = (c <= threshold) ? Z[r] : i;
+    }
+  }
+  uint32_t acc = 0;
+#pragma unroll
+  for (int r = 0; r < R; r++) acc += (uint32_t)Z[r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+}  // namespace
+
+Status gpu_int_valu_ceiling(double *cells_per_second) {
+  std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
+  Status s = ensure_device();
+  if (!s.ok()) return s;
+  constexpr int R = 8;
+  const int rows = 20000;
+  int cus = 256;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  hipStream_t stream = library_stream();
+  DeviceBuffer<uint32_t> out;
+  if (!(s = out.reserve((size_t)cus * 8 * 256)).ok()) return s;
+  hipEvent_t a = nullptr, b = nullptr;
+  NEEDLE_HIP_TRY(hipEventCreate(&a));
+  NEEDLE_HIP_TRY(hipEventCreate(&b));
+  double best = 0.0;
+  for (int blocks_per_cu : {2, 4, 8}) {
+    const int grid = cus * blocks_per_cu;
+    hipLaunchKernelGGL(valu_ceiling_kernel<R>, dim3(grid), dim3(256), 0, stream, out.ptr, 100, 10u, 12345u);  // warm-up
+    (void)hipEventRecord(a, stream);
+    hipLaunchKernelGGL(valu_ceiling_kernel<R>, dim3(grid), dim3(256), 0, stream, out.ptr, rows, 10u, 12345u);
+    (void)hipEventRecord(b, stream);
+    if (hipEventSynchronize(b) != hipSuccess) break;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) == hipSuccess && ms > 0.f)
+      best = std::max(best, (double)grid * 256 * R * rows / (ms * 1e-3));
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  if (best <= 0.0) return Status::Make(NeedleError_Unknown, "integer-VALU ceiling measurement failed");
+  *cells_per_second = best;
+  return Status::Ok();
+}
+
 }  // namespace needle

@@ -1,0 +1,198 @@
+"""GPU tests (-m gpu) of the job pipeline, the streaming analyzer and the N-rank path of libneedle_capi.so
+(include/needle_hip.h: needle_hip_library_job_begin/_end, needle_hip_library_stream_pcm, needle_hip_comm_*).
+
+The oracle is the checker throughout.  Multi-rank runs are real processes (tests/comm_worker.py gpu): over the
+host-staged transport with every rank on device 0 (any box), over RCCL with one rank (any box: the calls go through
+ncclAllGather) and over RCCL with 2 / 4 / 8 ranks where that many devices exist (skipped below)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from needle_amd import capi, synth
+from oracle import oracle as O
+from tests.test_comm_cpu import launch
+
+pytestmark = pytest.mark.gpu
+NS = O.NS
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert capi.device_count() > 0, "GPU tests need a HIP device (the product has no CPU fallback)"
+
+
+def _oracle(eps, min_opening=10, endings=False):
+    hd = O.duration_from_secs_f32(0.3)
+    if not endings:
+        ref = O.analyze_batch([e.pcm[: len(e.pcm) // 2] for e in eps], 1, hd)
+    else:
+        ref = []
+        for e in eps:
+            dur = O.duration_from_secs_f64(len(e.pcm) * (1.0 / 11025.0))
+            n_open = O.duration_mul_f32(dur, 0.5) * 11025 // NS
+            seek = O.duration_mul_f32(dur, float(np.float32(1.0) - np.float32(0.25)))
+            first = seek * 11025 // NS
+            op = O.step_and_timestamp(O.fingerprint(e.pcm[:n_open]), hd)
+            en = O.step_and_timestamp(O.fingerprint(e.pcm[first:]), hd, seek_to_ns=seek)
+            ref.append(O.FrameHashes(op, en, hd, ""))
+    want = O.run_with_frame_hashes(O.Comparator(include_endings=endings, min_opening_duration=min_opening * NS,
+                                                min_ending_duration=min_opening * NS), ref)
+    return ref, [None if r is None else [None if r.opening is None else list(r.opening),
+                                         None if r.ending is None else list(r.ending)] for r in want]
+
+
+def _as_json(rs):
+    return [None if r is None else [None if r.opening is None else list(r.opening),
+                                    None if r.ending is None else list(r.ending)] for r in rs]
+
+
+@pytest.fixture(scope="module")
+def lib7():
+    return synth.make_library(7, 90.0, 20.0)
+
+
+@pytest.mark.parametrize("slab_runs", [None, 4])
+def test_job_api_single_rank_equals_oracle(lib7, monkeypatch, slab_runs):
+    """job_begin / job_end without a communicator: two jobs in flight, results = the oracle's; a 4-run slab forces
+    the overflow -> grow -> rescan path on the first job."""
+    if slab_runs:
+        monkeypatch.setenv("NEEDLE_HIP_SLAB_RUNS", str(slab_runs))
+    n = len(lib7)
+    lib = capi.Library(n)
+    lib.set_pcm([e.pcm for e in lib7], [len(e.pcm) for e in lib7])
+    cmp = capi.Comparator([f"ep{k}.wav" for k in range(n)], min_opening_duration=10)
+    ref, want = _oracle(lib7)
+    lib.job_begin(cmp, 0)
+    lib.job_begin(cmp, 1)
+    with pytest.raises(capi.NeedleError):
+        lib.job_begin(cmp, 1)                                  # slot still pending
+    r0, k0 = lib.job_end(cmp, 0)
+    lib.job_begin(cmp, 0)
+    r1, k1 = lib.job_end(cmp, 1)
+    r2, k2 = lib.job_end(cmp, 0)
+    assert _as_json(r0) == _as_json(r1) == _as_json(r2) == want
+    assert k0 == k1 == k2 >= n * (n - 1) // 2
+    for v in range(n):
+        assert lib.frame_hashes(v).opening_data()[0].tolist() == [h for h, _ in ref[v].opening]
+
+
+@pytest.mark.parametrize("source", ["pinned", "pageable-ring", "pageable-small"])
+def test_stream_pcm_equals_resident_analyze_and_oracle(lib7, monkeypatch, source):
+    """needle_hip_library_stream_pcm: uploads overlapped with per-group fingerprint launches, several launch groups
+    and several device batches, from pinned memory (read in place), through the slab ring, and as plain copies."""
+    monkeypatch.setenv("NEEDLE_HIP_LAUNCH_GROUP_BYTES", str(1_500_000))       # ~1.5 streams per group
+    monkeypatch.setenv("NEEDLE_HIP_MAX_BATCH_VALUES", str(2_000_000))         # ~4 streams per device batch
+    if source == "pageable-ring":
+        monkeypatch.setenv("NEEDLE_HIP_RING_UPLOAD_MIN_BYTES", "0")
+        monkeypatch.setenv("NEEDLE_HIP_UPLOAD_SLAB_BYTES", str(300_000))
+    n = len(lib7)
+    lens = [len(e.pcm) for e in lib7]
+    keep = [capi.PinnedArray(v) for v in lens] if source == "pinned" else None
+    if keep:
+        for p, e in zip(keep, lib7):
+            p.array[:] = e.pcm
+    arrays = [p.array for p in keep] if keep else [e.pcm for e in lib7]
+    ref, want = _oracle(lib7)
+    cmp = capi.Comparator([f"ep{k}.wav" for k in range(n)], min_opening_duration=10)
+    lib = capi.Library(n)
+    for rep in range(2):                                       # a second pass reuses arena and staging buffers
+        lib.stream_pcm(arrays, lens)
+        lib.job_begin(cmp, 0)
+        res, _ = lib.job_end(cmp, 0)
+        assert _as_json(res) == want
+        for v in range(n):
+            assert lib.frame_hashes(v).opening_data()[0].tolist() == [h for h, _ in ref[v].opening], (source, rep, v)
+    with pytest.raises(capi.NeedleError):
+        lib.analyze(0, n)                                      # nothing resident to analyze again
+
+
+def test_stream_pcm_with_endings_and_ragged_lengths():
+    eps = [synth.make_episode(k, 100.0 + 7.0 * k, 22.0, 21.0) for k in range(4)]
+    lens = [len(e.pcm) for e in eps]
+    ref, want = _oracle(eps, min_opening=10, endings=True)
+    lib = capi.Library(4).include_endings()
+    lib.stream_pcm([e.pcm for e in eps], lens)
+    cmp = capi.Comparator([f"ep{k}.wav" for k in range(4)], min_opening_duration=10, min_ending_duration=10,
+                          include_endings=True)
+    lib.job_begin(cmp, 0)
+    res, _ = lib.job_end(cmp, 0)
+    assert _as_json(res) == want
+    for v in range(4):
+        fh = lib.frame_hashes(v)
+        assert fh.opening_data()[0].tolist() == [h for h, _ in ref[v].opening]
+        assert fh.ending_data()[0].tolist() == [h for h, _ in ref[v].ending]
+        assert fh.ending_data()[1].tolist() == [t for _, t in ref[v].ending]
+
+
+def _check_ranks(got, lib, want, ref, world, backend):
+    n = len(lib)
+    for g in got:
+        assert g["backend"] == backend and g["world"] == world
+        for job in g["jobs"]:
+            assert job["results"] == want
+            assert job["runs"] == got[0]["jobs"][0]["runs"] >= n * (n - 1) // 2
+        for v in range(n):
+            assert g["hashes"][v] == [h for h, _ in ref[v].opening]     # rows fingerprinted by other ranks included
+
+
+@pytest.mark.parametrize("world,shard_epilogue,slab_runs", [(2, "0", None), (2, "1", None), (3, "1", 4), (2, "0", 4)])
+def test_ranks_over_host_transport_on_one_gpu(lib7, tmp_path, world, shard_epilogue, slab_runs):
+    """The complete N-rank path of the library -- own-block analyze, all-gather of rows, own pair range, all-gather of
+    run slabs, (sharded) epilogue, all-gather of results, two jobs in flight -- between real processes that share
+    device 0, over the host-staged transport.  (3, 7): blocks of 3, 3, 1."""
+    ref, want = _oracle(lib7)
+    env = {"NEEDLE_HIP_COMM": "host", "NEEDLE_HIP_SHARD_EPILOGUE": shard_epilogue}
+    if slab_runs:
+        env["NEEDLE_HIP_SLAB_RUNS"] = str(slab_runs)
+    got = launch("gpu", world, str(tmp_path / "r"), [len(lib7), 90.0], extra_env=env, local_ranks=[0] * world)
+    _check_ranks(got, lib7, want, ref, world, "host")
+
+
+def test_ranks_with_endings_over_host_transport(tmp_path):
+    eps = [synth.make_episode(k, 90.0, 20.0) for k in range(5)]          # what comm_worker.py synthesises
+    ref, want = _oracle(eps, endings=True)
+    got = launch("gpu", 2, str(tmp_path / "e"), [5, 90.0], local_ranks=[0, 0],
+                 extra_env={"NEEDLE_HIP_COMM": "host", "NEEDLE_HIP_SHARD_EPILOGUE": "1", "NEEDLE_TEST_ENDINGS": "1"})
+    for g in got:
+        for job in g["jobs"]:
+            assert job["results"] == want
+
+
+def test_rccl_communicator_with_one_rank(lib7, tmp_path):
+    """librccl loaded on demand, ncclCommInitRank, and -- forced -- every collective of a job through ncclAllGather
+    with a single rank: the RCCL call path on a one-GPU box."""
+    ref, want = _oracle(lib7)
+    got = launch("gpu", 1, str(tmp_path / "c"), [len(lib7), 90.0],
+                 extra_env={"NEEDLE_HIP_COMM_FORCE_COLLECTIVES": "1", "NEEDLE_HIP_SHARD_EPILOGUE": "1"})
+    _check_ranks(got, lib7, want, ref, 1, "rccl")
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rccl_ranks_bit_identical_results(lib7, tmp_path, world):
+    """G in {2, 4, 8} over RCCL / xGMI, one process per GPU: results identical to one rank's and to the oracle's."""
+    if capi.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {capi.device_count()}")
+    ref, want = _oracle(lib7)
+    for shard in ("0", "1"):
+        got = launch("gpu", world, str(tmp_path / f"g{world}_{shard}"), [len(lib7), 90.0],
+                     extra_env={"NEEDLE_HIP_SHARD_EPILOGUE": shard})
+        _check_ranks(got, lib7, want, ref, world, "rccl")
+
+
+def test_bench_gpus_flag_spawns_the_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2` with no launcher environment starts two rank processes and reports n_gpus = 2
+    (here both on device 0 over the host-staged transport; on a multi-GPU box the default transport is RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["NEEDLE_HIP_COMM"] = "host"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--episodes", "5", "--minutes", "2",
+                          "--intro-seconds", "30", "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["comm"] == "host" and line["detected"] == 5
+    assert line["steps"] == 3 and line["value"] > 0
