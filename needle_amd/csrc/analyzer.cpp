@@ -161,7 +161,12 @@ Status Analyzer::run(ns_t hash_duration, bool persist, bool threading, std::vect
   out->assign(n, {});
   std::vector<std::string> md5s(n);
   std::vector<Pending> pending;
-  for (size_t i = 0; i < n; i++) {
+  // The reference's sequential map (:447-451) has analysed and persisted every video in front of the one that fails
+  // (run_single persists as it goes, :414-417).  The GPU batch wants all windows up front, so a video that cannot
+  // be probed ends the list there: the videos before it are analysed and persisted as usual, then its error is
+  // returned.  A re-run of a large library therefore keeps its progress.
+  Status deferred;
+  auto probe_video = [&](size_t i) -> Status {
     // run_single :339-348
     Status s = header_md5(videos_[i], &md5s[i]);
     if (!s.ok()) return s;
@@ -177,7 +182,7 @@ Status Analyzer::run(ns_t hash_duration, bool persist, bool threading, std::vect
           std::printf("Skipping analysis for %s...\n", videos_[i].c_str());
           std::fflush(stdout);  // println! is line buffered
           (*out)[i] = std::move(existing);
-          continue;
+          return Status::Ok();
         }
       }
     }
@@ -191,6 +196,11 @@ Status Analyzer::run(ns_t hash_duration, bool persist, bool threading, std::vect
                 &p.opening_frames, &p.ending_first, &p.seek);
     if (!s.ok()) return s;
     pending.push_back(p);
+    return Status::Ok();
+  };
+  for (size_t i = 0; i < n; i++) {
+    deferred = probe_video(i);
+    if (!deferred.ok()) break;
   }
 
   trace.lap("md5 + cache check + WAV headers", n);
@@ -236,7 +246,7 @@ Status Analyzer::run(ns_t hash_duration, bool persist, bool threading, std::vect
     }
     trace.lap("timestamps + persist", group.size());
   }
-  return Status::Ok();
+  return deferred;
 }
 
 }  // namespace needle

@@ -54,7 +54,13 @@ void parallel_chunks(size_t n, size_t grain, unsigned workers, F f) {
 // distinct_matches (:434-454) as a count: links[a] = #{b : popcount(h[a] ^ h[b]) < bound}, a itself included.
 // The relation is symmetric, so this equals the size of the set the reference builds for a.  Written as a dense
 // c x c loop over a contiguous array so that the compiler vectorises it for whatever the host CPU offers.
+#if defined(__SANITIZE_THREAD__)
+// no clones: an ifunc resolver runs before the ThreadSanitizer runtime is up and crashes the process at load
+#elif defined(__clang__)
 __attribute__((target_clones("avx512vpopcntdq", "avx2", "default")))
+#else  // g++ (the sanitizer builds) names the AVX-512 VPOPCNTDQ clone by architecture
+__attribute__((target_clones("arch=icelake-server", "avx2", "default")))
+#endif
 void count_links(const uint32_t *h, size_t c, uint32_t bound, uint32_t *links) {
   for (size_t a = 0; a < c; a++) {
     const uint32_t ha = h[a];

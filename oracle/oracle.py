@@ -61,7 +61,7 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(_HERE, "liboracle.so")
+    path = os.environ.get("NEEDLE_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")   # another build of the checker (ASan)
     if not os.path.exists(path):
         build()
     L = C.CDLL(path)

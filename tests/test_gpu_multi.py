@@ -196,3 +196,42 @@ def test_bench_gpus_flag_spawns_the_ranks_itself(tmp_path):
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["comm"] == "host" and line["detected"] == 5
     assert line["steps"] == 3 and line["value"] > 0
+
+
+def test_analyzer_keeps_progress_in_front_of_a_bad_file(tmp_path):
+    """analyzer.rs:414-417,447-451: the reference's sequential map has analysed AND persisted every video in front of
+    the one that fails.  Here: two good files, one that is not RIFF/WAVE, one more good file -> the call fails with the
+    bad file's error, the first two .needle.dat files exist and are complete, the fourth is untouched."""
+    eps = synth.make_library(3, 60.0, 15.0)
+    paths = [str(tmp_path / f"ep{k}.wav") for k in range(4)]
+    for p, e in zip([paths[0], paths[1], paths[3]], eps):
+        synth.write_wav(p, e.pcm)
+    open(paths[2], "wb").write(b"definitely not a wave file" * 20)
+    with pytest.raises(capi.NeedleError):
+        capi.Analyzer.from_files(paths).run(0.3, persist=True)
+    hd = O.duration_from_secs_f32(0.3)
+    for k in (0, 1):
+        fh = capi.FrameHashes.from_path(os.path.splitext(paths[k])[0] + ".needle.dat")
+        want = O.analyze_batch([eps[k].pcm[: len(eps[k].pcm) // 2]], 1, hd)[0]
+        assert fh.opening_data()[0].tolist() == [h for h, _ in want.opening]
+    assert not os.path.exists(os.path.splitext(paths[3])[0] + ".needle.dat")
+
+
+def test_skip_files_are_checked_video_by_video_in_order(tmp_path, capfd):
+    """comparator.rs:593-626 interleaves check, best match, display and skip-file write per video.  The same path
+    twice in the list: the second occurrence is skipped because the first one's skip file has just been written."""
+    eps = synth.make_library(2, 90.0, 20.0)
+    a, b = str(tmp_path / "a.wav"), str(tmp_path / "b.wav")
+    synth.write_wav(a, eps[0].pcm)
+    synth.write_wav(b, eps[1].pcm)
+    paths = [a, b, a]
+    capi.Analyzer.from_files([a, b]).run(0.3, persist=True)
+    capfd.readouterr()
+    cmp = capi.Comparator(paths, min_opening_duration=10)
+    cmp.run(analyze=False, display=True, use_skip_files=True, write_skip_files=True)
+    out = capfd.readouterr().out
+    blocks = out.strip().split("\n\n")
+    assert out.count("Skipping due to existing skip file...") == 1
+    assert out.rstrip().endswith("Skipping due to existing skip file...")
+    assert out.count("* Opening - ") == 2 and len(blocks) >= 3
+    assert os.path.exists(os.path.splitext(a)[0] + ".needle.skip.json")
