@@ -36,6 +36,11 @@ pub struct FrameHashes {
 }
 
 #[repr(C)]
+pub struct NeedleHipLibrary {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct NeedleHipSearchResult {
     pub has_result: bool,
@@ -141,4 +146,52 @@ extern "C" {
     pub fn needle_hip_frame_hashes_md5(frame_hashes: *const FrameHashes) -> *const c_char;
     pub fn needle_hip_frame_hashes_read(path: *const c_char, output: *mut *mut FrameHashes) -> NeedleError;
     pub fn needle_hip_frame_hashes_write(frame_hashes: *const FrameHashes, path: *const c_char) -> NeedleError;
+    // ---- multi-GPU: one process per GPU, RCCL inside the library (include/needle_hip.h "multi-GPU") ----
+    pub fn needle_hip_comm_create_id(id: *mut u8) -> NeedleError; // NEEDLE_HIP_COMM_ID_BYTES = 128
+    pub fn needle_hip_comm_init(id: *const u8, rank: c_int, world_size: c_int) -> NeedleError;
+    pub fn needle_hip_comm_finalize();
+    pub fn needle_hip_comm_rank() -> c_int;
+    pub fn needle_hip_comm_world_size() -> c_int;
+    pub fn needle_hip_comm_barrier() -> NeedleError;
+    pub fn needle_hip_comm_all_gather_host(send: *const c_void, recv: *mut c_void, bytes_per_rank: usize) -> NeedleError;
+    pub fn needle_hip_comm_shard(units: usize, world_size: c_int, rank: c_int, first: *mut usize, count: *mut usize);
+    pub fn needle_hip_library_new(
+        num_videos: usize,
+        opening_search_percentage: f32,
+        hash_duration: f32,
+        output: *mut *mut NeedleHipLibrary,
+    ) -> NeedleError;
+    pub fn needle_hip_library_free(library: *mut NeedleHipLibrary);
+    pub fn needle_hip_library_include_endings(library: *mut NeedleHipLibrary, ending_search_percentage: f32) -> NeedleError;
+    pub fn needle_hip_library_set_pcm(
+        library: *mut NeedleHipLibrary,
+        pcm: *const *const i16,
+        num_values: *const usize,
+        channels: c_int,
+    ) -> NeedleError;
+    pub fn needle_hip_library_stream_pcm(
+        library: *mut NeedleHipLibrary,
+        pcm: *const *const i16,
+        num_values: *const usize,
+        channels: c_int,
+    ) -> NeedleError;
+    pub fn needle_hip_library_job_begin(
+        library: *mut NeedleHipLibrary,
+        comparator: *const NeedleAudioComparator,
+        slot: c_int,
+    ) -> NeedleError;
+    pub fn needle_hip_library_job_end(
+        library: *mut NeedleHipLibrary,
+        comparator: *const NeedleAudioComparator,
+        slot: c_int,
+        results: *mut NeedleHipSearchResult,
+        num_runs: *mut usize,
+    ) -> NeedleError;
+    pub fn needle_hip_library_frame_hashes(
+        library: *mut NeedleHipLibrary,
+        index: usize,
+        output: *mut *mut FrameHashes,
+    ) -> NeedleError;
+    pub fn needle_hip_host_alloc(host_ptr: *mut *mut c_void, bytes: usize) -> NeedleError;
+    pub fn needle_hip_host_alloc_free(host_ptr: *mut c_void) -> NeedleError;
 }

@@ -433,3 +433,99 @@ pub fn device_count() -> Result<i32> {
 pub fn frame_hash_path(video: impl AsRef<Path>) -> PathBuf {
     video.as_ref().with_extension("needle.dat")
 }
+
+/// One process per GPU (include/needle_hip.h, "multi-GPU").  What upstream does with rayon inside one process
+/// (analyzer.rs:437-445 over videos, comparator.rs:549-564 over pairs) is spread over the ranks of a communicator
+/// inside libneedle_capi.so: RCCL all-gathers on the library's own streams, no host round trips inside a job.
+pub mod multi_gpu {
+    use super::{check, ffi, Comparator, Result, SearchResult};
+    use std::os::raw::c_int;
+    use std::time::Duration;
+
+    pub const COMM_ID_BYTES: usize = 128;
+
+    /// Rank 0: the id every other rank needs (hand it over by file, socket, MPI ...).
+    pub fn create_id() -> Result<[u8; COMM_ID_BYTES]> {
+        let mut id = [0u8; COMM_ID_BYTES];
+        unsafe { check(ffi::needle_hip_comm_create_id(id.as_mut_ptr()))? };
+        Ok(id)
+    }
+
+    /// Collective over all ranks; binds `device` to this process first.
+    pub fn init(id: &[u8; COMM_ID_BYTES], rank: usize, world_size: usize, device: usize) -> Result<()> {
+        unsafe {
+            check(ffi::needle_hip_set_device(device as c_int))?;
+            check(ffi::needle_hip_comm_init(id.as_ptr(), rank as c_int, world_size as c_int))
+        }
+    }
+
+    pub fn finalize() {
+        unsafe { ffi::needle_hip_comm_finalize() }
+    }
+
+    /// The videos (or pairs) `rank` owns: `[first, first + count)`.
+    pub fn shard(units: usize, world_size: usize, rank: usize) -> (usize, usize) {
+        let (mut first, mut count) = (0usize, 0usize);
+        unsafe { ffi::needle_hip_comm_shard(units, world_size as c_int, rank as c_int, &mut first, &mut count) };
+        (first, count)
+    }
+
+    /// An analyze + search job over ALL videos of a library, this rank holding the PCM of its own block only.
+    pub struct Library {
+        raw: *mut ffi::NeedleHipLibrary,
+        num_videos: usize,
+    }
+
+    impl Library {
+        pub fn new(num_videos: usize, opening_search_percentage: f32, hash_duration: Duration) -> Result<Self> {
+            let mut raw = std::ptr::null_mut();
+            unsafe {
+                check(ffi::needle_hip_library_new(num_videos, opening_search_percentage, hash_duration.as_secs_f32(), &mut raw))?
+            };
+            Ok(Library { raw, num_videos })
+        }
+
+        /// `pcm[v]` is `None` for the videos another rank owns; `num_values[v]` is known to every rank.
+        /// `resident`: keep the PCM in HBM (repeatable analyze) instead of streaming it through.
+        pub fn load_pcm(&mut self, pcm: &[Option<&[i16]>], num_values: &[usize], channels: usize, resident: bool) -> Result<()> {
+            assert!(pcm.len() == self.num_videos && num_values.len() == self.num_videos);
+            let ptrs: Vec<*const i16> = pcm.iter().map(|p| p.map_or(std::ptr::null(), |s| s.as_ptr())).collect();
+            unsafe {
+                if resident {
+                    check(ffi::needle_hip_library_set_pcm(self.raw, ptrs.as_ptr(), num_values.as_ptr(), channels as c_int))
+                } else {
+                    check(ffi::needle_hip_library_stream_pcm(self.raw, ptrs.as_ptr(), num_values.as_ptr(), channels as c_int))
+                }
+            }
+        }
+
+        /// `Comparator::run_with_frame_hashes` across the communicator: the same `Vec<Option<SearchResult>>` on every rank.
+        pub fn run<P: AsRef<std::path::Path>>(&mut self, comparator: &Comparator<P>) -> Result<Vec<Option<SearchResult>>> {
+            let handle = comparator.handle()?;
+            let mut results = vec![ffi::NeedleHipSearchResult::default(); self.num_videos];
+            let status = unsafe {
+                check(ffi::needle_hip_library_job_begin(self.raw, handle, 0)).and_then(|_| {
+                    check(ffi::needle_hip_library_job_end(self.raw, handle, 0, results.as_mut_ptr(), std::ptr::null_mut()))
+                })
+            };
+            unsafe { ffi::needle_audio_comparator_free(handle) };
+            status?;
+            let span = |a: u64, b: u64| (Duration::from_nanos(a), Duration::from_nanos(b));
+            Ok(results
+                .into_iter()
+                .map(|r| {
+                    r.has_result.then(|| SearchResult {
+                        opening: r.has_opening.then(|| span(r.opening_start_ns, r.opening_end_ns)),
+                        ending: r.has_ending.then(|| span(r.ending_start_ns, r.ending_end_ns)),
+                    })
+                })
+                .collect())
+        }
+    }
+
+    impl Drop for Library {
+        fn drop(&mut self) {
+            unsafe { ffi::needle_hip_library_free(self.raw) }
+        }
+    }
+}
