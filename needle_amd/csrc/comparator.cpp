@@ -396,6 +396,7 @@ Status Comparator::run_with_frame_hashes(const std::vector<const FrameHashesData
                                          std::vector<VideoResult> *per_video) const {
   const size_t n = fh.size();
   const size_t regions = include_endings_ ? 2 : 1;
+  EpilogueTrace trace;
   // hash arena: [video][region] sequences back to back
   std::vector<uint32_t> arena;
   std::vector<NeedleHipSeq> seqs(n * regions);
@@ -425,11 +426,13 @@ Status Comparator::run_with_frame_hashes(const std::vector<const FrameHashesData
                                           (uint32_t)(p * regions + r)});
     }
   }
+  trace.lap("arena + pair table", problems.size());
   std::vector<NeedleHipRun> runs;
   // an empty problem list still goes through the device entry point: there is no CPU path to fall to
   Status s = gpu_hamming_runs_host(arena.data(), arena.size(), seqs.data(), seqs.size(), problems.data(),
                                    problems.size(), hash_match_threshold_, &runs);
   if (!s.ok()) return s;
+  trace.lap("upload + scan + simhash + download", runs.size());
   return results_from_runs(fh, runs.data(), runs.size(), display, use_skip_files, write_skip_files, per_video);
 }
 
@@ -507,11 +510,20 @@ Status Comparator::results_from_runs(const std::vector<const FrameHashesData *> 
 Status Comparator::run(bool analyze, bool display, bool use_skip_files, bool write_skip_files, bool threading,
                        std::vector<VideoResult> *per_video) const {
   std::vector<FrameHashesData> data(videos_.size());
+  EpilogueTrace trace;
   if (!analyze) {
-    for (size_t v = 0; v < videos_.size(); v++) {  // FrameHashes::from_video(video, false), data.rs:124-128
-      Status s = frame_hashes_read(with_extension(videos_[v], FRAME_HASH_DATA_FILE_NAME), &data[v]);
+    // FrameHashes::from_video(video, false), data.rs:124-128, for every video.  The reads are independent; with
+    // `threading` they go to host threads (a library is thousands of small files), and the error reported is the
+    // one the sequential walk would have hit first.
+    std::vector<Status> status(videos_.size());
+    unsigned workers = threading ? std::min(usable_cpus(), 16u) : 1u;
+    if (const char *e = std::getenv("NEEDLE_HOST_THREADS")) workers = (unsigned)std::max(1, std::atoi(e));
+    parallel_chunks(videos_.size(), 16, videos_.size() >= 64 ? workers : 1u, [&](size_t b, size_t e) {
+      for (size_t v = b; v < e; v++)
+        status[v] = frame_hashes_read(with_extension(videos_[v], FRAME_HASH_DATA_FILE_NAME), &data[v]);
+    });
+    for (const Status &s : status)
       if (!s.ok()) return s;
-    }
   } else {
     // data.rs:134-136: default Analyzer (no endings), force, 0.3 s, not persisted — here as one GPU batch
     Analyzer a = Analyzer::from_files(videos_, false, true);
@@ -520,6 +532,7 @@ Status Comparator::run(bool analyze, bool display, bool use_skip_files, bool wri
     Status s = a.run(hd, false, threading, &data);
     if (!s.ok()) return s;
   }
+  trace.lap(analyze ? "analyze" : "read .needle.dat files", videos_.size());
   std::vector<const FrameHashesData *> ptrs;
   for (const FrameHashesData &d : data) ptrs.push_back(&d);
   return run_with_frame_hashes(ptrs, display, use_skip_files, write_skip_files, threading, per_video);

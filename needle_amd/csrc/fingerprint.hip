@@ -529,7 +529,21 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       }
       {
         KernelTimer timer("stft_chroma");
+        // Pairs per workgroup.  The device holds `slots` workgroups at a time (2 per CU).  A launch of more than
+        // about two rounds of workgroups balances itself (workgroups retire at different times and the dispatcher
+        // backfills: measured, a "whole rounds" choice of the size changed 7- and 14-episode launches by < 2 %), so
+        // long launches keep kPairsPerBlock.  A SHORT launch -- one rank's share of a sharded job, a single file --
+        // is cut so that every slot gets one workgroup: 4 episodes x 24 min = 11 626 pairs run as 506 workgroups of
+        // 23 pairs (0.153 ms) instead of 727 of 16 (0.162 ms); one episode as 485 workgroups of 6 instead of 182 of 16.
         uint32_t ppb = kPairsPerBlock;
+        {
+          int cus = 256, dev = 0;
+          (void)hipGetDevice(&dev);
+          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+          const uint64_t slots = 2ull * (uint64_t)std::max(cus, 1);
+          if ((pairs + kPairsPerBlock - 1) / kPairsPerBlock < 2 * slots)
+            ppb = (uint32_t)std::min<uint64_t>(40, std::max<uint64_t>(4, (pairs + slots - 1) / slots));
+        }
         if (const char *e = getenv("NEEDLE_STFT_PAIRS")) ppb = (uint32_t)std::max(1, atoi(e));
         const uint32_t grid = (uint32_t)(((pairs + ppb - 1) / ppb + 7) / 8 * 8);  // multiple of 8: see the XCD mapping
         auto launch = [&](auto kernel) {

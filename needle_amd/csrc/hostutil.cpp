@@ -313,10 +313,23 @@ Status frame_hashes_write(const std::string &path, const FrameHashesData &fh) {
 }
 
 Status frame_hashes_read(const std::string &path, FrameHashesData *out) {
-  std::ifstream f(path, std::ios::binary);
-  if (!f)  // data.rs:106-108
+  // the whole file with one read (a library has one of these per video: an iostream iterator costs more than the parse)
+  const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+  if (fd < 0)  // data.rs:106-108
     return Status::Make(NeedleError_FrameHashDataNotFound, "frame hash data not found at: \"" + path + "\"");
-  std::string buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  std::string buf;
+  struct stat st;
+  if (::fstat(fd, &st) == 0 && st.st_size > 0) buf.resize((size_t)st.st_size);
+  size_t got = 0;
+  for (;;) {
+    if (got == buf.size()) buf.resize(buf.size() + 65536);  // not a regular file, or it grew: keep reading
+    const ssize_t k = ::read(fd, &buf[got], buf.size() - got);
+    if (k < 0 && errno == EINTR) continue;
+    if (k <= 0) break;
+    got += (size_t)k;
+  }
+  ::close(fd);
+  buf.resize(got);
   Reader r(buf);
   const uint32_t version = r.get<uint32_t>();
   if (!r.bad && version != 0) r.bad = true;  // unknown variant index is a bincode error

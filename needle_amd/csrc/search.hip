@@ -657,12 +657,26 @@ Status gpu_hamming_runs_host(const uint32_t *hashes, size_t num_hashes, const Ne
     if ((uint64_t)seqs[i].offset + seqs[i].len > num_hashes)
       return Status::Make(NeedleError_InvalidArgument, "hamming_runs: sequence outside the hash arena");
   hipStream_t stream = library_stream();
-  DeviceBuffer<uint32_t> d_hashes, d_count;
-  DeviceBuffer<NeedleHipRun> d_runs;
+  // grow-only device buffers kept per device (guarded by gpu_mutex()): a search-only call over a library pays for
+  // its copies and kernels, not for hipMalloc / hipFree
+  struct HostCallBuffers {
+    DeviceBuffer<uint32_t> d_hashes, d_count;
+    DeviceBuffer<NeedleHipRun> d_runs;
+  };
+  static std::map<int, HostCallBuffers *> all;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  HostCallBuffers *&hb = all[dev];
+  if (!hb) hb = new HostCallBuffers();
+  DeviceBuffer<uint32_t> &d_hashes = hb->d_hashes, &d_count = hb->d_count;
+  DeviceBuffer<NeedleHipRun> &d_runs = hb->d_runs;
   if (!(s = d_hashes.reserve(std::max<size_t>(num_hashes, 1))).ok()) return s;
   if (!(s = d_count.reserve(1)).ok()) return s;
   NEEDLE_HIP_TRY(hipMemcpyAsync(d_hashes.ptr, hashes, num_hashes * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-  uint32_t capacity = 1u << 16;
+  // run-list capacity: what the buffer already holds from earlier calls, or a few runs per pair (a library whose
+  // episodes share an intro has at least one per pair); a list that still does not fit costs a second, exact pass
+  uint32_t capacity = (uint32_t)std::min<uint64_t>(
+      0x7fffffffu, std::max<uint64_t>({(uint64_t)1 << 16, (uint64_t)d_runs.count, 3 * (uint64_t)num_problems}));
   for (int attempt = 0; attempt < 2; attempt++) {
     if (!(s = d_runs.reserve(capacity)).ok()) return s;
     s = gpu_hamming_runs_device(d_hashes.ptr, seqs, num_seqs, problems, num_problems, threshold, d_runs.ptr,

@@ -362,13 +362,21 @@ def test_config2_full_size_parity(lib28):
     got = lib.finalize(cmp, runs)
     want = O.run_with_frame_hashes(O.Comparator(), ref, threads=threads)
     _same_results(got, want)
+    # Ground truth.  GPU vs oracle is 0 ns (above); against the PLANTED edges the reference's own semantics are
+    # offset: a hash is stamped 2.6 s + 0.123 s * item (its clock runs 0.65 % slow against the real 123.81 ms hop),
+    # covers 2.72 s of audio and matches with <= 10 differing bits.  Measured on this library (28 episodes, intro
+    # offsets 17 s .. 6 min): start - planted start in [-1.60, +1.08] s (mean -0.06), end - planted end in
+    # [-0.89, +1.22] s (mean +0.19).  The bound below is that distribution with a little headroom, not a tolerance
+    # of the implementation.
+    d_start, d_end = [], []
     for r, e in zip(got, lib28):
         assert r is not None and r.opening is not None
-        start, end = r.opening[0] / 1e9, r.opening[1] / 1e9
-        # ground truth: the reference's own result sits within one analysis span (2.7 s: a hash covers 2.6 s of
-        # audio and tolerates 10 differing bits, so runs begin/end up to a span away from the planted edges)
-        assert abs(start - e.intro_off / 11025) < 3.0
-        assert abs(end - (e.intro_off + e.intro_len) / 11025) < 3.0
+        d_start.append(r.opening[0] / 1e9 - e.intro_off / 11025)
+        d_end.append(r.opening[1] / 1e9 - (e.intro_off + e.intro_len) / 11025)
+    print(f"opening start - planted: min {min(d_start):+.3f} mean {sum(d_start) / n:+.3f} max {max(d_start):+.3f} s; "
+          f"end - planted: min {min(d_end):+.3f} mean {sum(d_end) / n:+.3f} max {max(d_end):+.3f} s")
+    assert -1.75 < min(d_start) and max(d_start) < 1.25
+    assert -1.0 < min(d_end) and max(d_end) < 1.4
     # sharded search (two "ranks" splitting the pair list) gives the same run set
     half = lib.num_pairs() // 2
     parts = []
