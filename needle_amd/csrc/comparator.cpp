@@ -414,9 +414,8 @@ Status Comparator::run_with_frame_hashes(const std::vector<const FrameHashesData
   if (arena.size() > UINT32_MAX || np * regions > UINT32_MAX)
     return Status::Make(NeedleError_InvalidArgument, "library too large for one search call: more than 2^32 hashes or sequence pairs");
   std::vector<NeedleHipProblem> problems;
-  for (size_t p = 0; p < np; p++) {
-    size_t i, j;
-    pair_at(n, p, &i, &j);
+  problems.reserve(np * regions);
+  for (size_t p = 0, i = 0, j = 1; p < np; p++) {  // (i, j) in the reference's i-major order (:537-545)
     if (include_endings_ && (fh[i]->ending.empty() || fh[j]->ending.empty()))  // :271-273; the caller unwrap()s
       return Status::Make(NeedleError_Unknown, "no ending hash data present");
     for (size_t r = 0; r < regions; r++) {
@@ -425,6 +424,7 @@ Status Comparator::run_with_frame_hashes(const std::vector<const FrameHashesData
       problems.push_back(NeedleHipProblem{(uint32_t)(i * regions + r), (uint32_t)(j * regions + r), std::max(a, b),
                                           (uint32_t)(p * regions + r)});
     }
+    if (++j == n) j = ++i + 1;
   }
   trace.lap("arena + pair table", problems.size());
   std::vector<NeedleHipRun> runs;
