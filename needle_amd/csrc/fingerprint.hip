@@ -12,6 +12,7 @@
 // re-reads are served by L2) and 96 B/frame of chroma; everything else stays on chip.
 #include "fp_core.h"
 #include "hipctx.h"
+#include "stft_kernel.h"
 
 #include <algorithm>
 #include <chrono>
@@ -31,27 +32,14 @@ using core::cd;
 
 namespace {
 
-struct FpStream {
-  uint64_t pcm_off;     // s16 values
-  uint64_t item_off;    // where this stream's kept items go in d_items
-  uint32_t frames;
-  uint32_t frame_base;  // prefix of frames
-  uint32_t fir_rows;    // frames - 4 (or 0)
-  uint32_t fir_base;
-  uint32_t kept;
-  uint32_t kept_base;
-  uint32_t pair_base;   // prefix of ceil(frames / 2): the STFT kernel transforms two frames per FFT
-  uint32_t tile_base;   // prefix of ceil(kept / items per tile): tiles of features_classify_kernel
-};
 
 // ---- constant tables, generated on the host in double and uploaded once per device --------------------
 struct FpTables {
   cd *tw = nullptr;                 // [4096] e^{-2 pi i k/4096}
-  uint16_t *bin_slot = nullptr;     // [kNumBins] position of bin (kMinBin + i) in the class-sorted order
+  uint16_t *bin_slot = nullptr;     // [kNumBins] slot in the LDS image of the power pair of bin (kMinBin + i)
   double *wcos = nullptr;           // [512] cos(theta (i - 256)), theta = 2 pi / 4095: window recurrence seeds
   core::WindowConst wconst;         // fp_core.h window_step
-  uint16_t *class_bins = nullptr;   // [kNumBins] spectrum bins grouped by pitch class
-  uint32_t *class_start = nullptr;  // [13]
+  uint32_t *fold_tab = nullptr;     // [12 * 16] fold thread -> first slot | positions << 16 (fp_core.h PowerLayout)
   core::ClassifierThresholds *thr = nullptr;
 };
 
@@ -89,259 +77,44 @@ Status get_tables(FpTables *out) {
   wconst.k2 = (double)(2.0L * cosl(256.0L * theta));
   wconst.a = core::kPairInputScale * (0.54 / 32767.0);
   wconst.b = core::kPairInputScale * (0.46 / 32767.0);
-  // chromaprint Chroma::PrepareNotes: bin -> pitch class
-  std::vector<std::vector<uint16_t>> by_class(kBands);
+  // chromaprint Chroma::PrepareNotes: bin -> pitch class; then where each bin's power pair lives in the LDS image
+  // and what each fold lane reads (fp_core.h build_power_layout)
+  std::vector<uint8_t> class_of_bin(core::kNumBins);
   for (int i = core::kMinBin; i < core::kMaxBin; i++) {
     double freq = (double)i * kSampleRate / kFrameSize;
     double octave = std::log(freq / (440.0 / 16.0)) / std::log(2.0);
     double note = kBands * (octave - std::floor(octave));
-    by_class[(int)(signed char)note].push_back((uint16_t)i);
+    class_of_bin[i - core::kMinBin] = (uint8_t)(int)(signed char)note;
   }
-  std::vector<uint16_t> bins;
-  std::vector<uint32_t> start(kBands + 1, 0);
-  for (int c = 0; c < kBands; c++) {
-    start[c] = (uint32_t)bins.size();
-    bins.insert(bins.end(), by_class[c].begin(), by_class[c].end());
-  }
-  start[kBands] = (uint32_t)bins.size();
+  auto layout = std::make_unique<core::PowerLayout>();
+  if (!core::build_power_layout(class_of_bin.data(), layout.get()))
+    return Status::Make(NeedleError_Unknown, "pitch classes do not fit the fold's power layout");
   core::ClassifierThresholds thr;
   for (int i = 0; i < 16; i++)
     for (int j = 0; j < 3; j++) thr.e[i][j] = std::exp(kThresholds[i][j]);
 
-  std::vector<uint16_t> bin_slot(core::kNumBins);
-  for (size_t pos = 0; pos < bins.size(); pos++)  // where the bin's power goes in the LDS image (frame A)
-    bin_slot[bins[pos] - core::kMinBin] = (uint16_t)core::dif_power_slot((int)pos);
-  for (int c = 0; c < kBands; c++)
-    if (start[c + 1] - start[c] > (uint32_t)(core::kClassLanes * core::kClassLaneMax))
-      return Status::Make(NeedleError_Unknown, "pitch class larger than the fold's lane budget");
   FpTables t;
-  NEEDLE_HIP_TRY(hipMalloc((void **)&t.bin_slot, bin_slot.size() * sizeof(uint16_t)));
-  NEEDLE_HIP_TRY(hipMemcpy(t.bin_slot, bin_slot.data(), bin_slot.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  NEEDLE_HIP_TRY(hipMalloc((void **)&t.bin_slot, sizeof(layout->bin_slot)));
+  NEEDLE_HIP_TRY(hipMemcpy(t.bin_slot, layout->bin_slot, sizeof(layout->bin_slot), hipMemcpyHostToDevice));
+  NEEDLE_HIP_TRY(hipMalloc((void **)&t.fold_tab, sizeof(layout->fold)));
+  NEEDLE_HIP_TRY(hipMemcpy(t.fold_tab, layout->fold, sizeof(layout->fold), hipMemcpyHostToDevice));
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.tw, tw.size() * sizeof(cd)));
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.wcos, wcos.size() * sizeof(double)));
   t.wconst = wconst;
-  NEEDLE_HIP_TRY(hipMalloc((void **)&t.class_bins, bins.size() * sizeof(uint16_t)));
-  NEEDLE_HIP_TRY(hipMalloc((void **)&t.class_start, start.size() * sizeof(uint32_t)));
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.thr, sizeof(thr)));
   NEEDLE_HIP_TRY(hipMemcpy(t.tw, tw.data(), tw.size() * sizeof(cd), hipMemcpyHostToDevice));
   NEEDLE_HIP_TRY(hipMemcpy(t.wcos, wcos.data(), wcos.size() * sizeof(double), hipMemcpyHostToDevice));
-  NEEDLE_HIP_TRY(hipMemcpy(t.class_bins, bins.data(), bins.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-  NEEDLE_HIP_TRY(hipMemcpy(t.class_start, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   NEEDLE_HIP_TRY(hipMemcpy(t.thr, &thr, sizeof(thr), hipMemcpyHostToDevice));
   g_tables[dev] = t;
   *out = t;
   return Status::Ok();
 }
 
-// index of the stream whose [base, next base) range holds g; `base` is a field of FpStream
-template <uint32_t FpStream::*BASE>
-__device__ __forceinline__ int find_stream(const FpStream *streams, int n, uint32_t g) {
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (streams[mid].*BASE <= g) lo = mid; else hi = mid - 1;
-  }
-  return lo;
-}
-
-// ---- kernel 1: one 256-thread workgroup per PAIR of consecutive frames ---------------------------------------
-// z = frameA + i*frameB through one 4096-point complex FFT (fp_core.h, radix 16 x 3, padded LDS), split into
-// the two real spectra, |X|^2 over bins 10..1307 folded into 12 pitch classes per frame.  A workgroup walks
-// kPairsPerBlock CONSECUTIVE pairs of one region of the batch, so the 3x overlap between neighbouring frames
-// (hop 1365 of 4096) is re-read from this XCD's L2 rather than from HBM.
-constexpr int kPairsPerBlock = 16;  // default; NEEDLE_STFT_PAIRS overrides for tuning
-
-// LDS-only workgroup barrier: waits for this wave's LDS traffic, not for its outstanding global loads
-// (__syncthreads() would also drain vmcnt and with it the prefetch of the next pair's PCM).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// Orders this wave's LDS writes before its later LDS reads for the compiler; the hardware executes one wave's LDS
-// operations in order, so lanes of the same wave see each other's data without a workgroup barrier.
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// x from another lane of the row, by a DPP control word (no LDS round trip, unlike __shfl_xor)
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double x) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-
-struct PairSrc {
-  const int16_t *a, *b;  // first value of frame A / frame B (B = A when the stream has an odd frame count)
-  uint64_t row;          // chroma row of frame A
-  bool has_b;
-};
-
-template <int CH>
-__global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__restrict__ pcm,
-                                                             const FpStream *__restrict__ streams, int num_streams,
-                                                             const cd *__restrict__ tw,
-                                                             const double *__restrict__ wcos, core::WindowConst wconst,
-                                                             const uint16_t *__restrict__ bin_slot,
-                                                             const uint32_t *__restrict__ class_start,
-                                                             double *__restrict__ chroma, uint32_t total_pairs,
-                                                             uint32_t pairs_per_block) {
-  extern __shared__ cd lds[];  // core::kLds2Slots complex slots
-  using raw_t = typename std::conditional<CH == 1, int16_t, int>::type;  // one sample, or one packed L|R pair
-  const int t = threadIdx.x;
-  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x & 7) and each XCD has its own L2.  Neighbouring
-  // stretches of the timeline share 2731 of their samples (the frame overlap), so each XCD gets one contiguous
-  // eighth of the timeline: the workgroups that run side by side on an XCD are then neighbours in time and the
-  // overlap is re-read from that XCD's L2 (the grid is a multiple of 8).  Measured: fabric fetches per launch
-  // 482 MB either way for 445 MB of PCM -- the boundary overlap of a plain mapping is only 28 MB and was mostly
-  // caught by the memory-side cache already -- and no change in kernel time; kept because it is never worse.
-  const uint32_t per_xcd = gridDim.x >> 3;
-  const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  const uint32_t first = logical * pairs_per_block;
-  const uint32_t last = min(total_pairs, first + pairs_per_block);
-  if (first >= last) return;
-  const cd base0 = tw[t], base1 = tw[16 * (t & 15)];  // W_4096^t, W_4096^{16 n0}: loop-invariant twiddle bases
-
-  // ---- loop invariants of this thread, packed so they cost few registers --------------------------------------
-  // where the powers of its six bins (register j of stage 2) go in the class-sorted LDS image
-  uint32_t slot_pk[core::kBinsPerThread / 2];
-#pragma unroll
-  for (int j = 0; j < core::kBinsPerThread; j++) {
-    const int kf = core::dif_bin_of(t, j);
-    const uint32_t idx = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : core::kPowerTrashSlot;
-    slot_pk[j >> 1] = (j & 1) ? (slot_pk[j >> 1] | (idx << 16)) : idx;
-  }
-  if (t == 0) lds[core::kPowerZeroSlot] = cd{0.0, 0.0};  // first read after the loop's barriers
-  // its share of the pitch-class fold: 12 classes x 16 lanes (one DPP row per class), each lane both frames
-  const bool folds = t < kBands * core::kClassLanes;
-  const int fold_c = t >> 4, fold_l = t & 15;
-  const uint32_t fold_bounds = folds ? (class_start[fold_c] | (class_start[fold_c + 1] << 16)) : 0;
-
-  // ---- the stream (region of the batch) the current pair belongs to; consecutive pairs rarely change it ------
-  int si = find_stream<&FpStream::pair_base>(streams, num_streams, first);
-  FpStream st = streams[si];
-  uint32_t st_end = st.pair_base + (st.frames + 1) / 2;
-  auto locate = [&](uint32_t g) {  // g must not decrease between calls
-    while (g >= st_end) {
-      st = streams[++si];
-      st_end = st.pair_base + (st.frames + 1) / 2;
-    }
-    const uint32_t fa = 2 * (g - st.pair_base);
-    PairSrc p;
-    p.has_b = fa + 1 < st.frames;
-    p.a = pcm + st.pcm_off + (uint64_t)fa * kHop * CH;
-    p.b = p.has_b ? p.a + kHop * CH : p.a;  // no frame B: read A again, zeroed after conversion
-    p.row = (uint64_t)st.frame_base + fa;
-    return p;
-  };
-  using reg_t = int;  // one 16-bit sample sign-extended by the load, or one packed L|R pair
-  reg_t ra[16], rb[16];
-  // PCM of both frames: issued one pair ahead, while the previous pair's powers are still being produced (the
-  // spectrum registers are dead by then).  The window comes from a recurrence (fp_core.h window_step), seeded per
-  // thread with cos(theta (t - 256)) and cos(theta t).
-  const double wseed_prev = wcos[t], wseed = wcos[t + 256];
-  auto issue_loads = [&](const PairSrc &p) {
-    const raw_t *qa = reinterpret_cast<const raw_t *>(p.a), *qb = reinterpret_cast<const raw_t *>(p.b);
-    // an opaque copy of the thread index keeps these loads (and their addresses) in the loop; laundering the
-    // POINTER would do that too but loses its address space: flat loads, which count in lgkmcnt and so stall
-    // every LDS-only barrier
-    int tt = t;
-    asm volatile("" : "+v"(tt));
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      ra[k] = (reg_t)qa[tt + 256 * k];
-      rb[k] = (reg_t)qb[tt + 256 * k];
-    }
-  };
-  // The pitch-class fold of a pair runs one pair late, between the next pair's sample conversion and its first
-  // butterflies: the LDS reads are issued, the conversion hides their latency, then 8 lanes per class add up.
-  cd fv[core::kClassLaneMax];
-  auto fold_issue = [&]() {
-    if (folds) {
-      uint32_t fb = fold_bounds;
-      asm volatile("" : "+v"(fb));  // recompute the addresses per pair rather than keep them in registers
-      core::class_lane_load(lds, (int)(fb & 0xffffu), (int)(fb >> 16), fold_l, fv);
-    }
-  };
-  auto fold_finish = [&](const PairSrc &p) {
-    if (folds) {
-      cd acc = core::class_lane_add(fv);
-      // fixed-order tree over the class's 16 lanes (fp_core.h class_tree_partner)
-      acc = cd{acc.x + dpp_f64<0xB1>(acc.x), acc.y + dpp_f64<0xB1>(acc.y)};    // quad_perm [1,0,3,2]
-      acc = cd{acc.x + dpp_f64<0x4E>(acc.x), acc.y + dpp_f64<0x4E>(acc.y)};    // quad_perm [2,3,0,1]
-      acc = cd{acc.x + dpp_f64<0x141>(acc.x), acc.y + dpp_f64<0x141>(acc.y)};  // row_half_mirror
-      acc = cd{acc.x + dpp_f64<0x140>(acc.x), acc.y + dpp_f64<0x140>(acc.y)};  // row_mirror
-      if (fold_l == 0) {
-        chroma[p.row * kBands + fold_c] = acc.x;
-        if (p.has_b) chroma[(p.row + 1) * kBands + fold_c] = acc.y;
-      }
-    }
-  };
-  PairSrc cur = locate(first), prev = cur;
-  issue_loads(cur);
-
-  for (uint32_t g = first; g < last; g++) {
-    // all per-thread address arithmetic is redone per pair from this opaque copy of the thread index: kept
-    // loop-invariant by the compiler it costs more registers than the kernel has (spills to scratch)
-    int tt = t;
-    asm volatile("" : "+v"(tt));
-    if (g != first) fold_issue();
-    cd r[16];
-    double wc = wseed, wc_prev = wseed_prev;
-    asm volatile("" : "+v"(wc), "+v"(wc_prev));  // per pair: the 16 window values are not kept across the loop
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      int sa, sb;
-      if (CH == 1) {
-        sa = ra[k];
-        sb = rb[k];
-      } else {  // AudioProcessor::LoadStereo: (L + R) / 2, C truncation
-        sa = ((int)(int16_t)ra[k] + (ra[k] >> 16)) / 2;
-        sb = ((int)(int16_t)rb[k] + (rb[k] >> 16)) / 2;
-      }
-      const double w = core::window_step(wconst, &wc, &wc_prev);
-      r[k] = cd{(double)sa * w, (double)sb * w};
-    }
-    if (!cur.has_b) {  // odd frame count: the stream's last pair has no frame B (uniform branch)
-#pragma unroll
-      for (int k = 0; k < 16; k++) r[k].y = 0.0;
-    }
-    if (g != first) fold_finish(prev);
-    // in-place decimation-in-frequency stages; which exchanges need a workgroup barrier: fp_core.h
-    core::fft16(r);
-    lds_barrier();                // every thread has read its share of the previous pair's powers
-    core::dif0_store(tt, base0, lds, r);
-    lds_barrier();
-    core::dif1(tt, base1, lds, r);
-    wave_lds_fence();             // stage 1 -> 2 stays inside 16 consecutive lanes
-    core::dif2(tt, lds, r);       // r[out16(j)] = Z[bin (t>>4) + 16 (t&15) + 256 j]
-    core::dif2_publish(tt, lds, r);  // own slots; only the partner values Z[N - k] other threads need
-    lds_barrier();
-
-    uint32_t spk[core::kBinsPerThread / 2];
-#pragma unroll
-    for (int j = 0; j < core::kBinsPerThread / 2; j++) {
-      spk[j] = slot_pk[j];
-      asm volatile("" : "+v"(spk[j]));  // unpack per pair: unpacked copies kept across the loop would spill
-    }
-#pragma unroll
-    for (int j = 0; j < core::kBinsPerThread; j++) {
-      const uint32_t idx = (spk[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-      double pa, pb;
-      core::dif_bin_power_any(tt, j, lds, r, &pa, &pb);
-      // class-sorted power pairs into dead slots (fp_core.h dif_power_slot): no barrier after the partner reads;
-      // bins outside 10..1307 land in a slot nobody reads
-      lds[idx] = cd{pa, pb};
-    }
-    const PairSrc nxt = locate(min(g + 1, last - 1));  // last pair: harmless re-read
-    issue_loads(nxt);
-    lds_barrier();                // the power image is complete
-    prev = cur;
-    cur = nxt;
-  }
-  fold_issue();
-  fold_finish(prev);
-}
+using stft::FpStream;
+using stft::find_stream;
+using stft::stft_chroma_kernel;
+using stft::wave_lds_fence;
+using stft::kPairsPerBlock;
 
 // One feature row: 5-tap temporal FIR over chroma rows in[0..4] + L2 normalise (zero if the norm is < 0.01).
 __device__ __forceinline__ void feature_row(const double *__restrict__ in, double *out) {
@@ -548,7 +321,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
         const uint32_t grid = (uint32_t)(((pairs + ppb - 1) / ppb + 7) / 8 * 8);  // multiple of 8: see the XCD mapping
         auto launch = [&](auto kernel) {
           hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm,
-                             desc.streams.ptr, n, tab.tw, tab.wcos, tab.wconst, tab.bin_slot, tab.class_start, ws->chroma.ptr,
+                             desc.streams.ptr, n, tab.tw, tab.wcos, tab.wconst, tab.bin_slot, tab.fold_tab, ws->chroma.ptr,
                              (uint32_t)pairs, ppb);
         };
         if (channels == 1) launch(stft_chroma_kernel<1>); else launch(stft_chroma_kernel<2>);

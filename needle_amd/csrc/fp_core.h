@@ -56,30 +56,70 @@ NEEDLE_HD void bfly4(cd &a0, cd &a1, cd &a2, cd &a3) {
 // register holding X[j].
 NEEDLE_HD int out16(int j) { return 4 * (j & 3) + (j >> 2); }
 
-NEEDLE_HD void fft16(cd *a) {
-  const double c = 0.92387953251128673848, s = 0.38268343236508977173, h = 0.70710678118654752440;
-  // step 1: 4-point DFTs over n1 for each n2 (x[4 n1 + n2]); result y[n2][k1] -> a[4 k1 + n2]
-#pragma unroll
-  for (int n2 = 0; n2 < 4; n2++) bfly4(a[n2], a[4 + n2], a[8 + n2], a[12 + n2]);
-  // step 2: twiddles W_16^{n2 k1}
-  {
-    cd v;
-    v = a[4 * 1 + 1]; a[4 * 1 + 1] = cd{v.x * c + v.y * s, v.y * c - v.x * s};            // W^1 = (c, -s)
-    v = a[4 * 2 + 1]; a[4 * 2 + 1] = cd{(v.x + v.y) * h, (v.y - v.x) * h};                // W^2 = (h, -h)
-    v = a[4 * 3 + 1]; a[4 * 3 + 1] = cd{v.x * s + v.y * c, v.y * s - v.x * c};            // W^3 = (s, -c)
-    v = a[4 * 1 + 2]; a[4 * 1 + 2] = cd{(v.x + v.y) * h, (v.y - v.x) * h};                // W^2
-    v = a[4 * 2 + 2]; a[4 * 2 + 2] = cd{v.y, -v.x};                                        // W^4 = -i
-    v = a[4 * 3 + 2]; a[4 * 3 + 2] = cd{(v.y - v.x) * h, -(v.x + v.y) * h};               // W^6 = (-h, -h)
-    v = a[4 * 1 + 3]; a[4 * 1 + 3] = cd{v.x * s + v.y * c, v.y * s - v.x * c};            // W^3
-    v = a[4 * 2 + 3]; a[4 * 2 + 3] = cd{(v.y - v.x) * h, -(v.x + v.y) * h};               // W^6
-    v = a[4 * 3 + 3]; a[4 * 3 + 3] = cd{-(v.x * c) - v.y * s, v.x * s - v.y * c};          // W^9 = (-c, s)
-  }
-  // step 3: 4-point DFTs over n2 for each k1
-#pragma unroll
-  for (int k1 = 0; k1 < 4; k1++) bfly4(a[4 * k1], a[4 * k1 + 1], a[4 * k1 + 2], a[4 * k1 + 3]);
+NEEDLE_HD double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// Last layer of the 16-point transform for one k1: bfly4 over (b0, w1 b1, w2 b2, w3 b3) with the constant
+// twiddles folded into fused multiply-adds.  The caller passes E0 = b0 + w2 b2, E1 = b0 - w2 b2 and, for the odd
+// pair, v = u1 + rho u3, v' = u1 - rho u3 where w1 b1 = g u1 and w3 b3 = g rho u3: then E2 = g v, E3 = -i g v'
+// are never formed, the four outputs are E0 +- g v and E1 +- g (-i v') (8 FMAs in place of 8 adds).
+NEEDLE_HD void bfly4_tail(cd E0, cd E1, cd v, cd vp, double g, cd &o0, cd &o1, cd &o2, cd &o3) {
+  o0 = cd{fmad(g, v.x, E0.x), fmad(g, v.y, E0.y)};
+  o2 = cd{fmad(-g, v.x, E0.x), fmad(-g, v.y, E0.y)};
+  o1 = cd{fmad(g, vp.y, E1.x), fmad(-g, vp.x, E1.y)};
+  o3 = cd{fmad(-g, vp.y, E1.x), fmad(g, vp.x, E1.y)};
 }
 
-// One complex slot as a single 128-bit LDS read (slots are 16-byte aligned); stores stay paired 64-bit.
+// The transform in two parts, so that a caller can start storing the outputs of one k1 while the next is computed:
+// fft16_head = step 1 (4-point DFTs over n1 for each n2; y[n2][k1] -> a[4 k1 + n2]); fft16_tail<K1> = the twiddles
+// W_16^{n2 K1} and the 4-point DFT over n2, leaving X[K1 + 4 k2] in a[4 K1 + k2].
+// W_16^1 = (c, -s), W_16^2 = (h, -h), W_16^3 = (s, -c), W_16^6 = (-h, -h), W_16^9 = (-c, s); t8 = s / c = tan(pi/8),
+// ct8 = c / s.  A twiddle w = g (1, tau) costs two FMAs for u = (1, tau) x and its scale g rides on the FMAs of the
+// following additions: 144 instructions per transform instead of 168.
+NEEDLE_HD void fft16_head(cd *a) {
+#pragma unroll
+  for (int n2 = 0; n2 < 4; n2++) bfly4(a[n2], a[4 + n2], a[8 + n2], a[12 + n2]);
+}
+template <int K1>
+NEEDLE_HD void fft16_tail(cd *a) {
+  const double c = 0.92387953251128673848, s = 0.38268343236508977173, h = 0.70710678118654752440;
+  const double t8 = 0.41421356237309504880, ct8 = 2.41421356237309504880;
+  if (K1 == 0) {
+    bfly4(a[0], a[1], a[2], a[3]);
+  } else if (K1 == 1) {  // w = (1, W1, W2, W3)
+    const cd b0 = a[4], b1 = a[5], b2 = a[6], b3 = a[7];
+    const cd u2 = cd{b2.x + b2.y, b2.y - b2.x};  // W2 b2 = h u2
+    const cd E0 = cd{fmad(h, u2.x, b0.x), fmad(h, u2.y, b0.y)}, E1 = cd{fmad(-h, u2.x, b0.x), fmad(-h, u2.y, b0.y)};
+    const cd u1 = cd{fmad(t8, b1.y, b1.x), fmad(-t8, b1.x, b1.y)};    // W1 b1 = c u1
+    const cd u3 = cd{fmad(ct8, b3.y, b3.x), fmad(-ct8, b3.x, b3.y)};  // W3 b3 = s u3 = c t8 u3
+    const cd v = cd{fmad(t8, u3.x, u1.x), fmad(t8, u3.y, u1.y)}, vp = cd{fmad(-t8, u3.x, u1.x), fmad(-t8, u3.y, u1.y)};
+    bfly4_tail(E0, E1, v, vp, c, a[4], a[5], a[6], a[7]);
+  } else if (K1 == 2) {  // w = (1, W2, W4, W6)
+    const cd b0 = a[8], b1 = a[9], b2 = a[10], b3 = a[11];
+    const cd E0 = cd{b0.x + b2.y, b0.y - b2.x}, E1 = cd{b0.x - b2.y, b0.y + b2.x};  // W4 = -i
+    const cd u1 = cd{b1.x + b1.y, b1.y - b1.x};  // W2 b1 = h u1
+    const cd n3 = cd{b3.x - b3.y, b3.x + b3.y};  // W6 b3 = -h n3
+    const cd v = cd{u1.x - n3.x, u1.y - n3.y}, vp = cd{u1.x + n3.x, u1.y + n3.y};
+    bfly4_tail(E0, E1, v, vp, h, a[8], a[9], a[10], a[11]);
+  } else {  // K1 == 3: w = (1, W3, W6, W9)
+    const cd b0 = a[12], b1 = a[13], b2 = a[14], b3 = a[15];
+    const cd n2 = cd{b2.x - b2.y, b2.x + b2.y};  // W6 b2 = -h n2
+    const cd E0 = cd{fmad(-h, n2.x, b0.x), fmad(-h, n2.y, b0.y)}, E1 = cd{fmad(h, n2.x, b0.x), fmad(h, n2.y, b0.y)};
+    const cd u1 = cd{fmad(ct8, b1.y, b1.x), fmad(-ct8, b1.x, b1.y)};  // W3 b1 = s u1
+    const cd u3 = cd{fmad(t8, b3.y, b3.x), fmad(-t8, b3.x, b3.y)};    // W9 b3 = -c u3 = -s ct8 u3
+    const cd v = cd{fmad(-ct8, u3.x, u1.x), fmad(-ct8, u3.y, u1.y)}, vp = cd{fmad(ct8, u3.x, u1.x), fmad(ct8, u3.y, u1.y)};
+    bfly4_tail(E0, E1, v, vp, s, a[12], a[13], a[14], a[15]);
+  }
+}
+NEEDLE_HD void fft16(cd *a) {
+  fft16_head(a);
+  fft16_tail<0>(a);
+  fft16_tail<1>(a);
+  fft16_tail<2>(a);
+  fft16_tail<3>(a);
+}
+
+// One complex slot as a single 128-bit LDS access (slots are 16-byte aligned).  128-bit accesses take a 16-bit
+// immediate byte offset, so every slot of the form base + constant costs no address arithmetic.
 NEEDLE_HD cd lds_get(const cd *lds, int slot) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef double v2d __attribute__((ext_vector_type(2), aligned(16)));
@@ -89,35 +129,86 @@ NEEDLE_HD cd lds_get(const cd *lds, int slot) {
   return lds[slot];
 #endif
 }
+NEEDLE_HD void lds_put(cd *lds, int slot, cd v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef double v2d __attribute__((ext_vector_type(2), aligned(16)));
+  *reinterpret_cast<v2d *>(lds + slot) = v2d{v.x, v.y};
+#else
+  lds[slot] = v;
+#endif
+}
+// the same by BYTE offset from the start of the image (offsets kept packed in registers, already scaled):
+// pack_slots puts two 13-bit slots, each times 16, into one word; slot_bytes<0/1> takes them out again
+NEEDLE_HD uint32_t pack_slots(uint32_t a, uint32_t b) { return (a << 4) | (b << 17); }
+template <int WHICH>
+NEEDLE_HD uint32_t slot_bytes(uint32_t packed) { return WHICH == 0 ? (packed & 0x1fff0u) : ((packed >> 13) & 0x1fff0u); }
+NEEDLE_HD void lds_put_bytes(cd *lds, uint32_t byte_off, cd v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef double v2d __attribute__((ext_vector_type(2), aligned(16)));
+  *reinterpret_cast<v2d *>(reinterpret_cast<char *>(lds) + byte_off) = v2d{v.x, v.y};
+#else
+  lds[byte_off / sizeof(cd)] = v;
+#endif
+}
 
 // ================================================================================================
 // Schedule of the 4096-point transform: decimation in frequency IN PLACE.  With n = 256 n2 + 16 n1 + n0,
-//   stage 0 (thread t = 16 n1 + n0) transforms digit n2:  slots t + 256 k      -> same slots, * W_4096^{t j}
-//   stage 1 (thread t = 16 b  + n0) transforms digit n1:  slots 256 b + n0 + 16 k -> same slots, * W_4096^{16 n0 j}
-//   stage 2 (thread t = 16 b  + c ) transforms digit n0:  slots 16 t + k
-// so X[k0 + 16 k1 + 256 k2] ends in slot 256 k0 + 16 k1 + k2, i.e. in register j = k2 of thread t = 16 k0 + k1.
-// Every thread reads and writes the SAME slots within a stage, so only two exchanges need a workgroup barrier:
+//   stage 0 (thread t = 16 n1 + n0)      transforms digit n2:  slots t + 256 k          -> same slots, * W_4096^{t j}
+//   stage 1 (thread t = 16 g + n0)       transforms digit n1:  slots 256 b + n0 + 16 k  -> same slots, * W_4096^{16 n0 j}
+//   stage 2 (thread t = 16 g + c)        transforms digit n0:  slots 16 (16 b + c) + k
+// where b = group_k0(g) is a fixed permutation of the sixteen 16-lane groups (below), so X[b + 16 c + 256 k2] ends in
+// slot 256 b + 16 c + k2, i.e. in register j = k2 of the thread with group_k0(t >> 4) = b, t & 15 = c.
+// Every thread reads and writes the SAME slots within a stage, so only ONE exchange of the transform needs a
+// workgroup barrier:
 //   stage 0 -> 1  crosses waves (barrier);
-//   stage 1 -> 2  stays inside the 16 consecutive lanes b = t >> 4 (slots [256 b, 256 b + 256)): LDS operations of
+//   stage 1 -> 2  stays inside the 16 consecutive lanes g = t >> 4 (slots [256 b, 256 b + 256)): LDS operations of
 //                 one wave execute in order, no barrier;
 //   stage 2 -> publish: a thread overwrites only slots it alone has read, no barrier;
-//   publish -> partner reads crosses waves (barrier).
+//   publish -> partner reads: the partner Z[N - k] of a bin with low digit b lives in the group with low digit
+//                 16 - b, and the permutation puts b and 16 - b in the SAME WAVE: no barrier either;
+//   power stores: every wave keeps the powers of its own bins in dead slots of its own rows (power layout below), so
+//                 no other wave's stage-2 inputs can be overwritten: no barrier before them.
 // The last stage only publishes the six registers (j = 10..15) that other threads need as partners Z[N - k] of the
-// bins 10..1307; the bins themselves (j = 0..5) never leave the registers.  The class-sorted powers then go to the
-// slots of registers j = 0..7 (dif_power_index), which are dead by then and disjoint from the partner slots, so the
-// partner reads and the power stores need no barrier between them either.
+// bins 10..1307; the bins themselves (j = 0..5) never leave the registers.
 // ================================================================================================
+// Low digits b of the four waves: {1, 2, 15, 14}, {3, 4, 13, 12}, {5, 6, 11, 10}, {7, 8, 9, 0}: b and (16 - b) & 15
+// together, and each wave's rows 16 b + c form two runs of 32 consecutive rows (one of 48 + one of 16 in the last).
+NEEDLE_HD int group_k0(int g) { return (int)((0x0987AB65CD43EF21ull >> (4 * g)) & 15u); }
+NEEDLE_HD int thread_k0(int t) { return group_k0(t >> 4); }
+NEEDLE_HD int wave_of_k0(int b) {  // the wave (t >> 6) that owns low digit b
+  return (b == 1 || b == 2 || b == 15 || b == 14) ? 0 : (b == 3 || b == 4 || b == 13 || b == 12) ? 1
+       : (b == 5 || b == 6 || b == 11 || b == 10) ? 2 : 3;
+}
+
 NEEDLE_HD int dif_slot_of_bin(int kf) { return 256 * (kf & 15) + 16 * ((kf >> 4) & 15) + (kf >> 8); }
-NEEDLE_HD int dif_bin_of(int t, int j) { return (t >> 4) + 16 * (t & 15) + 256 * j; }
+NEEDLE_HD int dif_bin_of(int t, int j) { return thread_k0(t) + 16 * (t & 15) + 256 * j; }
+
+// Padded slots of a thread's 16 values in each stage are ONE per-thread base plus a compile-time constant:
+//   stage 0  pidx(t + 256 j)                 = dif0_base(t) + 272 j
+//   stage 1  pidx(256 b + n0 + 16 k)         = dif1_base(t) + 17 k
+//   stage 2  pidx(16 (16 b + c) + k)         = dif2_base(t) + k
+//   partner  pidx(slot of bin N - (K + 256 j)) = dif_partner_base(t) + 15 - j   (K = dif_bin_of(t, 0))
+NEEDLE_HD int dif0_base(int t) { return t + (t >> 4); }
+NEEDLE_HD int dif1_base(int t) { return 272 * thread_k0(t) + (t & 15); }
+NEEDLE_HD int dif2_base(int t) { return 17 * (16 * thread_k0(t) + (t & 15)); }
+// N - (K + 256 j) = (256 - K) + 256 (15 - j) for K != 0: low byte K' = 256 - K, register 15 - j of the thread that
+// owns K'.  K = 0: bins 256 j, partners 256 (16 - j) = slot 16 - j; j = 0 (bin 0, discarded) then reads the pad
+// slot 16.
+NEEDLE_HD int dif_partner_base(int t) {
+  const int K = thread_k0(t) + 16 * (t & 15);
+  const int Kp = (256 - K) & 255;
+  return K == 0 ? 1 : 272 * (Kp & 15) + 17 * (Kp >> 4);
+}
 
 // stage 0: r holds the inputs x[t + 256 k]; leaves the stage's outputs in the same slots.  Split in two so the
 // kernel can keep the register-only half ahead of the barrier that frees the LDS image of the previous pair.
 NEEDLE_HD void dif0_store(int t, cd base0, cd *lds, const cd *r) {
-  lds[pidx(t)] = r[out16(0)];
+  const int o = dif0_base(t);
+  lds_put(lds, o, r[out16(0)]);
   cd w = base0;
 #pragma unroll
   for (int j = 1; j < 16; j++) {
-    lds[pidx(t + 256 * j)] = cmulf(r[out16(j)], w);
+    lds_put(lds, o + 272 * j, cmulf(r[out16(j)], w));
     if (j < 15) w = cmulf(w, base0);
   }
 }
@@ -128,30 +219,99 @@ NEEDLE_HD void dif0(int t, cd base0, cd *lds, cd *r) {
 
 // stage 1, in place; base1 = W_4096^{16 (t & 15)}
 NEEDLE_HD void dif1(int t, cd base1, cd *lds, cd *r) {
-  const int o = 256 * (t >> 4) + (t & 15);
+  const int o = dif1_base(t);
 #pragma unroll
-  for (int k = 0; k < 16; k++) r[k] = lds_get(lds, pidx(o + 16 * k));
+  for (int k = 0; k < 16; k++) r[k] = lds_get(lds, o + 17 * k);
   fft16(r);
-  lds[pidx(o)] = r[out16(0)];
+  lds_put(lds, o, r[out16(0)]);
   cd w = base1;
 #pragma unroll
   for (int j = 1; j < 16; j++) {
-    lds[pidx(o + 16 * j)] = cmulf(r[out16(j)], w);
+    lds_put(lds, o + 17 * j, cmulf(r[out16(j)], w));
     if (j < 15) w = cmulf(w, base1);
   }
 }
 
+// The same two stages with the stores of one k1 (outputs j = k1, k1 + 4, k1 + 8, k1 + 12) issued as soon as its
+// tail is done, so that the LDS pipeline drains them under the arithmetic of the next tail.  pw[j] = base^j.
+NEEDLE_HD void twiddle_powers(cd base, cd *pw) {
+  pw[1] = base;
+#pragma unroll
+  for (int j = 2; j < 16; j++) pw[j] = cmulf(pw[j - 1], base);
+}
+template <int K1>
+NEEDLE_HD void dif_tail_store(int o, int pitch, const cd *pw, cd *lds, cd *r) {
+  fft16_tail<K1>(r);
+#pragma unroll
+  for (int k2 = 0; k2 < 4; k2++) {
+    const int j = K1 + 4 * k2;
+    lds_put(lds, o + pitch * j, j == 0 ? r[4 * K1 + k2] : cmulf(r[4 * K1 + k2], pw[j]));
+  }
+}
+NEEDLE_HD void dif0_streamed(int t, cd base0, cd *lds, cd *r) {
+  cd pw[16];
+  twiddle_powers(base0, pw);
+  const int o = dif0_base(t);
+  fft16_head(r);
+  dif_tail_store<0>(o, 272, pw, lds, r);
+  dif_tail_store<1>(o, 272, pw, lds, r);
+  dif_tail_store<2>(o, 272, pw, lds, r);
+  dif_tail_store<3>(o, 272, pw, lds, r);
+}
+NEEDLE_HD void dif1_streamed(int t, cd base1, cd *lds, cd *r) {
+  cd pw[16];
+  twiddle_powers(base1, pw);
+  const int o = dif1_base(t);
+#pragma unroll
+  for (int k = 0; k < 16; k++) r[k] = lds_get(lds, o + 17 * k);
+  fft16_head(r);
+  dif_tail_store<0>(o, 17, pw, lds, r);
+  dif_tail_store<1>(o, 17, pw, lds, r);
+  dif_tail_store<2>(o, 17, pw, lds, r);
+  dif_tail_store<3>(o, 17, pw, lds, r);
+}
+
 // stage 2: afterwards r[out16(j)] = Z[dif_bin_of(t, j)]
 NEEDLE_HD void dif2(int t, const cd *lds, cd *r) {
+  const int o = dif2_base(t);
 #pragma unroll
-  for (int k = 0; k < 16; k++) r[k] = lds_get(lds, pidx(16 * t + k));
+  for (int k = 0; k < 16; k++) r[k] = lds_get(lds, o + k);
   fft16(r);
 }
 
 // publish the registers other threads read as partners (bins >= 2789 live in j = 10..15), in place
 NEEDLE_HD void dif2_publish(int t, cd *lds, const cd *r) {
+  const int o = dif2_base(t);
 #pragma unroll
-  for (int j = 10; j < 16; j++) lds[pidx(16 * t + j)] = r[out16(j)];
+  for (int j = 10; j < 16; j++) lds_put(lds, o + j, r[out16(j)]);
+}
+
+// stage 2 with the publish stores issued tail by tail
+template <int K1>
+NEEDLE_HD void dif2_tail_publish(int o, cd *lds, cd *r) {
+  fft16_tail<K1>(r);
+#pragma unroll
+  for (int k2 = 2; k2 < 4; k2++) {
+    const int j = K1 + 4 * k2;
+    if (j >= 10) lds_put(lds, o + j, r[4 * K1 + k2]);
+  }
+}
+NEEDLE_HD void dif2_streamed(int t, cd *lds, cd *r) {
+  const int o = dif2_base(t);
+#pragma unroll
+  for (int k = 0; k < 16; k++) r[k] = lds_get(lds, o + k);
+  fft16_head(r);
+  dif2_tail_publish<0>(o, lds, r);
+  dif2_tail_publish<1>(o, lds, r);
+  dif2_tail_publish<2>(o, lds, r);
+  dif2_tail_publish<3>(o, lds, r);
+}
+
+// the partners Z[N - k] of this thread's bins in registers j = 0..kBinsPerThread-1, all reads issued together
+NEEDLE_HD void dif_partner_load(int t, const cd *lds, cd *y) {
+  const int o = dif_partner_base(t);
+#pragma unroll
+  for (int j = 0; j < kBinsPerThread; j++) y[j] = lds_get(lds, o + 15 - j);
 }
 
 // ---- Hamming window by recurrence -------------------------------------------------------------------------------
@@ -178,15 +338,17 @@ NEEDLE_HD double window_step(const WindowConst &wc, double *c, double *c_prev) {
 // two, so every intermediate is the unscaled one times 2^-1 exactly and the powers are bit-identical.
 constexpr double kPairInputScale = 0.5;
 
-// powers of this thread's bin in register j for the two frames (any bin 0 < k < 4096; bin 0 reads a slot that
-// holds something else, for callers that discard it)
-NEEDLE_HD void dif_bin_power_any(int t, int j, const cd *lds, const cd *r, double *pa, double *pb) {
-  const int kf = dif_bin_of(t, j);
-  const cd z = r[out16(j)], y = lds_get(lds, pidx(dif_slot_of_bin(kFft2N - kf)));
+// powers of one bin for the two frames from Z[k] and its partner Z[N - k]
+NEEDLE_HD void dif_power_of(cd z, cd y, double *pa, double *pb) {
   const double ar = z.x + y.x, ai = z.y - y.y;  // X_A
   const double br = z.y + y.y, bi = y.x - z.x;  // X_B
-  *pa = ar * ar + ai * ai;
-  *pb = br * br + bi * bi;
+  *pa = fmad(ar, ar, ai * ai);
+  *pb = fmad(br, br, bi * bi);
+}
+// powers of this thread's bin in register j (any bin 0 < k < 4096; bin 0 reads a slot that holds something else,
+// for callers that discard it)
+NEEDLE_HD void dif_bin_power_any(int t, int j, const cd *lds, const cd *r, double *pa, double *pb) {
+  dif_power_of(r[out16(j)], lds_get(lds, dif_partner_base(t) + 15 - j), pa, pb);
 }
 // the same, j = 0..5; false if the bin is outside 10..1307
 NEEDLE_HD bool dif_bin_power(int t, int j, const cd *lds, const cd *r, int *kf_out, double *pa, double *pb) {
@@ -197,28 +359,81 @@ NEEDLE_HD bool dif_bin_power(int t, int j, const cd *lds, const cd *r, int *kf_o
   return true;
 }
 
-// Class-sorted power image.  Position p (0..1297, the bins sorted by pitch class) holds the PAIR (power in frame
-// A, power in frame B) in one 16-byte slot: slot 17 (p >> 3) + (p & 7), i.e. registers j = 0..7 of thread
-// (p >> 3)'s stage-2 row (pidx(16 q + j) = 17 q + j), dead by then and disjoint from the partner slots.  One
-// 128-bit store per bin, and one 128-bit load gives a fold lane both frames' powers: LDS operations, not their
-// bytes, are what this kernel pays for.
+// Power image.  The PAIR (power in frame A, power in frame B) of a bin goes into one 16-byte slot of the wave that
+// owns the bin (one 128-bit store per bin, and one 128-bit load gives a fold lane both frames' powers: LDS
+// operations, not their bytes, are what this kernel pays for).  The slots are registers j = 0..7 of the wave's own
+// stage-2 rows (pidx(16 q + j) = 17 q + j), dead once the wave has read its stage-2 inputs and disjoint from the
+// partner slots j = 10..15 -- so no other wave's data is ever overwritten and the stores need no barrier.
+// Inside a wave the bins of pitch class c (segment (w, c), n bins in ascending order, position q = 0..n-1) form a
+// vertical strip: slot 17 (R + (q >> 2)) + C + (q & 3), a column group C in {0, 4} and consecutive rows from R.
+// Fold lane l of class c (16 lanes = one DPP row per class) takes segment w = l >> 2 and positions u, u + 4, ...
+// (u = l & 3): slots base + 17 i, one base and constants.  PowerLayout is built on the host (build_power_layout).
 constexpr int kClassLanes = 16;      // lanes that share one pitch class in the fold (one DPP row)
-constexpr int kClassLaneMax = 9;     // >= ceil(largest class / kClassLanes); checked where the tables are built
-NEEDLE_HD int dif_power_slot(int p) { return 17 * (p >> 3) + (p & 7); }
-// Two constant slots make the stores and the fold's loads branch-free.  kPowerZeroSlot: a pad slot (17 q + 16:
-// touched by no stage and no power) that holds (0, 0), read in place of positions outside a class.
-// kPowerTrashSlot: a row beyond the last position, where the powers of the bins outside 10..1307 go.
-constexpr int kPowerZeroSlot = 16, kPowerTrashSlot = 17 * 200;
+constexpr int kClassLaneMax = 10;    // >= rows of the tallest strip; checked by build_power_layout
+constexpr int kClassLaneMin = 4;     // <= positions of every fold lane; checked by build_power_layout
+// Two constant slots make the stores and the fold's loads branch-free, both PAD slots (17 q + 16: touched by no
+// stage).  kPowerZeroSlot holds (0, 0), read in place of positions beyond a lane's count; kPowerTrashSlot takes the
+// powers of the bins outside 10..1307 and is never read.
+constexpr int kPowerZeroSlot = 16, kPowerTrashSlot = 33;
 
-// One lane's share of a pitch class [b0, b1): positions b0 + l, b0 + l + 16, ... (every other row of the image:
-// slots 34 apart), both frames at once (x = frame A, y = frame B).  Split into the loads and the sums so the
-// kernel can put other work between them.
-NEEDLE_HD void class_lane_load(const cd *lds, int b0, int b1, int l, cd *v) {
-#pragma unroll
-  for (int i = 0; i < kClassLaneMax; i++) {
-    const int b = b0 + l + kClassLanes * i;
-    v[i] = lds_get(lds, b < b1 ? dif_power_slot(b) : kPowerZeroSlot);
+struct PowerLayout {
+  uint16_t bin_slot[kNumBins];   // slot in the LDS image of the power pair of bin kMinBin + i
+  uint32_t fold[12 * kClassLanes];  // fold thread 16 c + l: first slot | positions << 16
+};
+// class_of_bin[i] = pitch class of bin kMinBin + i.  Returns false if a strip does not fit (never for chromaprint's
+// tables; the caller turns it into an error).
+inline bool build_power_layout(const uint8_t *class_of_bin, PowerLayout *out) {
+  for (int f = 0; f < 12 * kClassLanes; f++) out->fold[f] = (uint32_t)kPowerZeroSlot;
+  for (int w = 0; w < 4; w++) {
+    // this wave's rows in ascending order, as runs of consecutive rows
+    int rows[64], nrows = 0;
+    for (int b = 0; b < 16; b++)
+      if (wave_of_k0(b) == w)
+        for (int c = 0; c < 16; c++) rows[nrows++] = 16 * b + c;
+    int next_row[2] = {0, 0};  // per column group: index into rows[] of the first free row
+    for (int c = 0; c < 12; c++) {
+      int bins[kNumBins], n = 0;
+      for (int k = kMinBin; k < kMaxBin; k++)
+        if (class_of_bin[k - kMinBin] == c && wave_of_k0(k & 15) == w) bins[n++] = k;
+      const int h = (n + 3) / 4;
+      if (h > kClassLaneMax) return false;
+      // first fit: a column group with h consecutive rows left inside one run
+      int R = -1, C = 0;
+      for (int cg = 0; cg < 2 && R < 0; cg++) {
+        int i = next_row[cg];
+        while (i + h <= nrows) {
+          bool run = true;
+          for (int d = 1; d < h; d++) run = run && rows[i + d] == rows[i] + d;
+          if (run) break;
+          i++;  // skip to the next run
+        }
+        if (i + h <= nrows) {
+          R = rows[i];
+          C = 4 * cg;
+          next_row[cg] = i + h;
+        }
+      }
+      if (R < 0) return false;
+      for (int q = 0; q < n; q++)
+        out->bin_slot[bins[q] - kMinBin] = (uint16_t)(17 * (R + (q >> 2)) + C + (q & 3));
+      for (int u = 0; u < 4; u++) {
+        const int count = n > u ? (n - u + 3) / 4 : 0;
+        if (count < kClassLaneMin) return false;
+        out->fold[16 * c + 4 * w + u] = (uint32_t)(17 * R + C + u) | ((uint32_t)count << 16);
+      }
+    }
   }
+  return true;
+}
+
+// One fold lane's share of its class: `count` positions from slot `base`, 17 slots apart, both frames at once (x =
+// frame A, y = frame B); reads beyond the count fetch the zero slot.  Split into the loads and the sums so the kernel
+// can put other work between them.
+NEEDLE_HD void class_lane_load(const cd *lds, uint32_t fold_entry, cd *v) {
+  const int base = (int)(fold_entry & 0xffffu), count = (int)(fold_entry >> 16);
+#pragma unroll
+  for (int i = 0; i < kClassLaneMax; i++)
+    v[i] = lds_get(lds, (i < kClassLaneMin || i < count) ? base + 17 * i : kPowerZeroSlot);
 }
 NEEDLE_HD cd class_lane_add(const cd *v) {
   cd acc = v[0];

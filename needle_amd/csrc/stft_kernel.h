@@ -1,0 +1,270 @@
+// stft_chroma_kernel: the dominant kernel of the analyze half, in a header of its own so that the product
+// (fingerprint.hip) and the timing laboratory (tools/stft_lab.hip) compile the SAME source.  LAB = 0 is the product;
+// non-zero LAB bits switch pieces off or change the schedule for measurements (results are then wrong on purpose).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <type_traits>
+
+#include "fp_core.h"
+
+namespace needle {
+namespace stft {
+
+using core::cd;
+constexpr int kHop = 1365, kBands = 12;
+
+struct FpStream {
+  uint64_t pcm_off;     // s16 values
+  uint64_t item_off;    // where this stream's kept items go in d_items
+  uint32_t frames;
+  uint32_t frame_base;  // prefix of frames
+  uint32_t fir_rows;    // frames - 4 (or 0)
+  uint32_t fir_base;
+  uint32_t kept;
+  uint32_t kept_base;
+  uint32_t pair_base;   // prefix of ceil(frames / 2): the STFT kernel transforms two frames per FFT
+  uint32_t tile_base;   // prefix of ceil(kept / items per tile): tiles of features_classify_kernel
+};
+
+// index of the stream whose [base, next base) range holds g; `base` is a field of FpStream
+template <uint32_t FpStream::*BASE>
+__device__ __forceinline__ int find_stream(const FpStream *streams, int n, uint32_t g) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (streams[mid].*BASE <= g) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// ---- kernel 1: one 256-thread workgroup per PAIR of consecutive frames ---------------------------------------
+// z = frameA + i*frameB through one 4096-point complex FFT (fp_core.h, radix 16 x 3, padded LDS), split into
+// the two real spectra, |X|^2 over bins 10..1307 folded into 12 pitch classes per frame.  A workgroup walks
+// kPairsPerBlock CONSECUTIVE pairs of one region of the batch, so the 3x overlap between neighbouring frames
+// (hop 1365 of 4096) is re-read from this XCD's L2 rather than from HBM.
+constexpr int kPairsPerBlock = 16;  // default; NEEDLE_STFT_PAIRS overrides for tuning
+
+// LDS-only workgroup barrier: waits for this wave's LDS traffic, not for its outstanding global loads
+// (__syncthreads() would also drain vmcnt and with it the prefetch of the next pair's PCM).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Orders this wave's LDS writes before its later LDS reads for the compiler; the hardware executes one wave's LDS
+// operations in order, so lanes of the same wave see each other's data without a workgroup barrier.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// x from another lane of the row, by a DPP control word (no LDS round trip, unlike __shfl_xor)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  // every lane of a row has a source under these controls; bound_ctrl spares the "old value" register and its move
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+struct PairSrc {
+  const int16_t *a, *b;  // first value of frame A / frame B (B = A when the stream has an odd frame count)
+  uint64_t row;          // chroma row of frame A
+  bool has_b;
+};
+
+// LAB bits (timing experiments only; 0 = product; results are wrong with any of bits 1..8 set):
+//   1  barrier 1 (previous pair's fold reads done -> stage-0 stores) -> none
+//   2  barrier 2 (stage-0 stores -> stage-1 reads) -> wave fence
+//   4  EXTRA workgroup barrier between the publish stores and the partner reads (the round-1 schedule had one)
+//   8  barrier 3 (power stores -> fold reads) -> wave fence
+//  16  round-1 order: all butterflies of a stage, then all its stores; barrier 1 after the first butterflies
+enum : int { kLabNoB1 = 1, kLabNoB2 = 2, kLabExtraB = 4, kLabNoB3 = 8, kLabSerial = 16 };
+
+template <int CH, int LAB = 0>
+__global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__restrict__ pcm,
+                                                             const FpStream *__restrict__ streams, int num_streams,
+                                                             const cd *__restrict__ tw,
+                                                             const double *__restrict__ wcos, core::WindowConst wconst,
+                                                             const uint16_t *__restrict__ bin_slot,
+                                                             const uint32_t *__restrict__ fold_tab,
+                                                             double *__restrict__ chroma, uint32_t total_pairs,
+                                                             uint32_t pairs_per_block) {
+  extern __shared__ cd lds[];  // core::kLds2Slots complex slots
+  using raw_t = typename std::conditional<CH == 1, int16_t, int>::type;  // one sample, or one packed L|R pair
+  const int t = threadIdx.x;
+  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x & 7) and each XCD has its own L2.  Neighbouring
+  // stretches of the timeline share 2731 of their samples (the frame overlap), so each XCD gets one contiguous
+  // eighth of the timeline: the workgroups that run side by side on an XCD are then neighbours in time and the
+  // overlap is re-read from that XCD's L2 (the grid is a multiple of 8).  Measured: fabric fetches per launch
+  // 482 MB either way for 445 MB of PCM -- the boundary overlap of a plain mapping is only 28 MB and was mostly
+  // caught by the memory-side cache already -- and no change in kernel time; kept because it is never worse.
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t first = logical * pairs_per_block;
+  const uint32_t last = min(total_pairs, first + pairs_per_block);
+  if (first >= last) return;
+  const cd base0 = tw[t], base1 = tw[16 * (t & 15)];  // W_4096^t, W_4096^{16 n0}: loop-invariant twiddle bases
+
+  // ---- loop invariants of this thread, packed so they cost few registers --------------------------------------
+  // where the powers of its six bins (register j of stage 2) go in the class-sorted LDS image
+  uint32_t slot_pk[core::kBinsPerThread / 2];
+#pragma unroll
+  for (int j = 0; j < core::kBinsPerThread; j += 2) {
+    uint32_t idx[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int kf = core::dif_bin_of(t, j + h);
+      idx[h] = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : (uint32_t)core::kPowerTrashSlot;
+    }
+    slot_pk[j >> 1] = core::pack_slots(idx[0], idx[1]);
+  }
+  if (t == 0) lds[core::kPowerZeroSlot] = cd{0.0, 0.0};  // first read after the loop's barriers
+  // its share of the pitch-class fold: 12 classes x 16 lanes (one DPP row per class), each lane both frames
+  const bool folds = t < kBands * core::kClassLanes;
+  const int fold_c = t >> 4, fold_l = t & 15;
+  const uint32_t fold_entry = folds ? fold_tab[t] : 0;  // fp_core.h PowerLayout: first slot | positions << 16
+
+  // ---- the stream (region of the batch) the current pair belongs to; consecutive pairs rarely change it ------
+  int si = find_stream<&FpStream::pair_base>(streams, num_streams, first);
+  FpStream st = streams[si];
+  uint32_t st_end = st.pair_base + (st.frames + 1) / 2;
+  auto locate = [&](uint32_t g) {  // g must not decrease between calls
+    while (g >= st_end) {
+      st = streams[++si];
+      st_end = st.pair_base + (st.frames + 1) / 2;
+    }
+    const uint32_t fa = 2 * (g - st.pair_base);
+    PairSrc p;
+    p.has_b = fa + 1 < st.frames;
+    p.a = pcm + st.pcm_off + (uint64_t)fa * kHop * CH;
+    p.b = p.has_b ? p.a + kHop * CH : p.a;  // no frame B: read A again, zeroed after conversion
+    p.row = (uint64_t)st.frame_base + fa;
+    return p;
+  };
+  using reg_t = int;  // one 16-bit sample sign-extended by the load, or one packed L|R pair
+  reg_t ra[16], rb[16];
+  // PCM of both frames: issued one pair ahead, while the previous pair's powers are still being produced (the
+  // spectrum registers are dead by then).  The window comes from a recurrence (fp_core.h window_step), seeded per
+  // thread with cos(theta (t - 256)) and cos(theta t).
+  const double wseed_prev = wcos[t], wseed = wcos[t + 256];
+  auto issue_loads = [&](const PairSrc &p) {
+    const raw_t *qa = reinterpret_cast<const raw_t *>(p.a), *qb = reinterpret_cast<const raw_t *>(p.b);
+    // an opaque copy of the thread index keeps these loads (and their addresses) in the loop; laundering the
+    // POINTER would do that too but loses its address space: flat loads, which count in lgkmcnt and so stall
+    // every LDS-only barrier
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      ra[k] = (reg_t)qa[tt + 256 * k];
+      rb[k] = (reg_t)qb[tt + 256 * k];
+    }
+  };
+  // The pitch-class fold of a pair runs one pair late, between the next pair's sample conversion and its first
+  // butterflies: the LDS reads are issued, the conversion hides their latency, then 8 lanes per class add up.
+  cd fv[core::kClassLaneMax];
+  auto fold_issue = [&]() {
+    if (folds) {
+      uint32_t fe = fold_entry;
+      asm volatile("" : "+v"(fe));  // recompute the addresses per pair rather than keep them in registers
+      core::class_lane_load(lds, fe, fv);
+    }
+  };
+  auto fold_finish = [&](const PairSrc &p) {
+    if (folds) {
+      cd acc = core::class_lane_add(fv);
+      // fixed-order tree over the class's 16 lanes (fp_core.h class_tree_partner)
+      acc = cd{acc.x + dpp_f64<0xB1>(acc.x), acc.y + dpp_f64<0xB1>(acc.y)};    // quad_perm [1,0,3,2]
+      acc = cd{acc.x + dpp_f64<0x4E>(acc.x), acc.y + dpp_f64<0x4E>(acc.y)};    // quad_perm [2,3,0,1]
+      acc = cd{acc.x + dpp_f64<0x141>(acc.x), acc.y + dpp_f64<0x141>(acc.y)};  // row_half_mirror
+      acc = cd{acc.x + dpp_f64<0x140>(acc.x), acc.y + dpp_f64<0x140>(acc.y)};  // row_mirror
+      if (fold_l == 0) {
+        chroma[p.row * kBands + fold_c] = acc.x;
+        if (p.has_b) chroma[(p.row + 1) * kBands + fold_c] = acc.y;
+      }
+    }
+  };
+  PairSrc cur = locate(first), prev = cur;
+  issue_loads(cur);
+
+  for (uint32_t g = first; g < last; g++) {
+    // all per-thread address arithmetic is redone per pair from this opaque copy of the thread index: kept
+    // loop-invariant by the compiler it costs more registers than the kernel has (spills to scratch)
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    if (g != first) fold_issue();
+    cd r[16];
+    double wc = wseed, wc_prev = wseed_prev;
+    asm volatile("" : "+v"(wc), "+v"(wc_prev));  // per pair: the 16 window values are not kept across the loop
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      int sa, sb;
+      if (CH == 1) {
+        sa = ra[k];
+        sb = rb[k];
+      } else {  // AudioProcessor::LoadStereo: (L + R) / 2, C truncation
+        sa = ((int)(int16_t)ra[k] + (ra[k] >> 16)) / 2;
+        sb = ((int)(int16_t)rb[k] + (rb[k] >> 16)) / 2;
+      }
+      const double w = core::window_step(wconst, &wc, &wc_prev);
+      r[k] = cd{(double)sa * w, (double)sb * w};
+    }
+    if (!cur.has_b) {  // odd frame count: the stream's last pair has no frame B (uniform branch)
+#pragma unroll
+      for (int k = 0; k < 16; k++) r[k].y = 0.0;
+    }
+    if (g != first) fold_finish(prev);
+    // In-place decimation-in-frequency stages; which exchanges need a workgroup barrier: fp_core.h.  The stores of
+    // a stage are issued tail by tail (fp_core.h dif_tail_store) so that the LDS pipeline, whose 128-bit stores cost
+    // 13 cycles each, drains them under the arithmetic that follows instead of in a burst in front of a barrier.
+    if (LAB & kLabSerial) {
+      core::fft16(r);
+      if (!(LAB & kLabNoB1)) lds_barrier();
+      core::dif0_store(tt, base0, lds, r);
+      if (!(LAB & kLabNoB2)) lds_barrier(); else wave_lds_fence();
+      core::dif1(tt, base1, lds, r);
+      wave_lds_fence();
+      core::dif2(tt, lds, r);
+      core::dif2_publish(tt, lds, r);
+    } else {
+      if (!(LAB & kLabNoB1)) lds_barrier();  // every thread has read its share of the previous pair's powers
+      core::dif0_streamed(tt, base0, lds, r);
+      if (!(LAB & kLabNoB2)) lds_barrier(); else wave_lds_fence();
+      core::dif1_streamed(tt, base1, lds, r);
+      wave_lds_fence();                // stage 1 -> 2 stays inside 16 consecutive lanes
+      core::dif2_streamed(tt, lds, r);  // r[out16(j)] = Z[bin b + 16 (t & 15) + 256 j]; publishes j = 10..15
+    }
+    // publish -> partner reads stays inside the wave (fp_core.h group_k0)
+    if (LAB & kLabExtraB) lds_barrier(); else wave_lds_fence();
+
+    // partners Z[N - k] of the six bins: one base + constants, all six reads in flight together
+    cd yp[core::kBinsPerThread];
+    core::dif_partner_load(tt, lds, yp);
+    uint32_t spk[core::kBinsPerThread / 2];
+#pragma unroll
+    for (int j = 0; j < core::kBinsPerThread / 2; j++) {
+      spk[j] = slot_pk[j];
+      asm volatile("" : "+v"(spk[j]));  // unpack per pair: unpacked copies kept across the loop would spill
+    }
+    double pwa[core::kBinsPerThread], pwb[core::kBinsPerThread];
+#pragma unroll
+    for (int j = 0; j < core::kBinsPerThread; j++) core::dif_power_of(r[core::out16(j)], yp[j], &pwa[j], &pwb[j]);
+    // power pairs into dead slots of this wave's own rows (fp_core.h PowerLayout): no barrier after the partner
+    // reads; bins outside 10..1307 land in a pad slot nobody reads
+#pragma unroll
+    for (int j = 0; j < core::kBinsPerThread; j++)
+      core::lds_put_bytes(lds, (j & 1) ? core::slot_bytes<1>(spk[j >> 1]) : core::slot_bytes<0>(spk[j >> 1]), cd{pwa[j], pwb[j]});
+    const PairSrc nxt = locate(min(g + 1, last - 1));  // last pair: harmless re-read
+    issue_loads(nxt);
+    if (!(LAB & kLabNoB3)) lds_barrier(); else wave_lds_fence();  // the power image is complete
+    prev = cur;
+    cur = nxt;
+  }
+  fold_issue();
+  fold_finish(prev);
+}
+
+}  // namespace stft
+}  // namespace needle

@@ -5,6 +5,7 @@
 // reachable from, libneedle_capi.so.
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -17,9 +18,7 @@ struct Tables {
   std::vector<cd> tw;
   std::vector<double> wcos;  // recurrence seeds, as the kernel's table
   WindowConst wconst;
-  std::vector<uint16_t> class_bins;
-  uint32_t class_start[13];
-  std::vector<uint16_t> bin_pos;  // bin - kMinBin -> position in the class-sorted list
+  PowerLayout layout;  // where each bin's power pair goes, what each fold lane reads
   ClassifierThresholds thr;
 };
 
@@ -46,20 +45,14 @@ const Tables &tables() {
   t.wconst.k2 = (double)(2.0L * cosl(256.0L * theta));
   t.wconst.a = kPairInputScale * (0.54 / 32767.0);
   t.wconst.b = kPairInputScale * (0.46 / 32767.0);
-  std::vector<std::vector<uint16_t>> by(12);
+  std::vector<uint8_t> class_of_bin(kNumBins);
   for (int i = kMinBin; i < kMaxBin; i++) {
     double freq = (double)i * 11025 / 4096;
     double octave = std::log(freq / (440.0 / 16.0)) / std::log(2.0);
     double note = 12 * (octave - std::floor(octave));
-    by[(int)(signed char)note].push_back((uint16_t)i);
+    class_of_bin[i - kMinBin] = (uint8_t)(int)(signed char)note;
   }
-  for (int c = 0; c < 12; c++) {
-    t.class_start[c] = (uint32_t)t.class_bins.size();
-    t.class_bins.insert(t.class_bins.end(), by[c].begin(), by[c].end());
-  }
-  t.class_start[12] = (uint32_t)t.class_bins.size();
-  t.bin_pos.resize(kNumBins);
-  for (size_t pos = 0; pos < t.class_bins.size(); pos++) t.bin_pos[t.class_bins[pos] - kMinBin] = (uint16_t)pos;
+  if (!build_power_layout(class_of_bin.data(), &t.layout)) std::abort();
   for (int i = 0; i < 16; i++)
     for (int j = 0; j < 3; j++) t.thr.e[i][j] = std::exp(kThr[i][j]);
   return t;
@@ -88,46 +81,69 @@ void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, do
       regs[t * 16 + k] = cd{(double)sample(fa, n) * w, (double)sample(fb, n) * w};
     }
   }
-  for (int t = 0; t < 256; t++) dif0(t, T.tw[t], lds.data(), &regs[t * 16]);
-  // stage 1 -> stage 2 -> publish run group by group (16 consecutive lanes), the other groups still untouched:
-  // this is the order the kernel is allowed to take without a workgroup barrier between these phases
-  for (int grp = 15; grp >= 0; grp--) {
-    for (int t = 16 * grp; t < 16 * grp + 16; t++) dif1(t, T.tw[16 * (t & 15)], lds.data(), &regs[t * 16]);
-    for (int t = 16 * grp; t < 16 * grp + 16; t++) {
-      dif2(t, lds.data(), &regs[t * 16]);
-      dif2_publish(t, lds.data(), &regs[t * 16]);
-    }
-  }
-  // partner reads and power stores interleaved thread by thread (no barrier between them in the kernel); walking
-  // the threads in both directions must give the same image if the stores never touch a live partner slot
-  std::vector<cd> snapshot = lds;
+  for (int t = 0; t < 256; t++) dif0_streamed(t, T.tw[t], lds.data(), &regs[t * 16]);
+  // ---- workgroup barrier (stage-0 stores -> stage-1 reads).  From here to the next barrier (power image complete)
+  // the kernel has only wave-level ordering: a wave may run through ALL of stage 1, stage 2, publish, partner reads
+  // and power stores while another has not started stage 1.  The waves are therefore run to completion one after the
+  // other, in both orders, and inside a wave the 16-lane groups run stage 1 -> stage 2 one group ahead of the next
+  // (the order a wave is allowed to take without a fence between them); the two images must be identical.
+  const std::vector<cd> after_stage0 = lds;
+  const std::vector<cd> regs0 = regs;
   std::vector<cd> image[2];
+  int seen_total = 0;
   for (int dir = 0; dir < 2; dir++) {
-    lds = snapshot;
+    lds = after_stage0;
+    regs = regs0;
     int seen = 0;
-    for (int i = 0; i < 256; i++) {
-      const int t = dir ? 255 - i : i;
-      for (int j = 0; j < 6; j++) {
-        int kf;
-        double a, b;
-        if (dif_bin_power(t, j, lds.data(), &regs[t * 16], &kf, &a, &b)) {
-          lds[dif_power_slot(T.bin_pos[kf - kMinBin])] = cd{a, b};
+    for (int wi = 0; wi < 4; wi++) {
+      const int w = dir ? 3 - wi : wi;
+      for (int grp = 3; grp >= 0; grp--) {
+        const int t0 = 64 * w + 16 * grp;
+        for (int t = t0; t < t0 + 16; t++) dif1_streamed(t, T.tw[16 * (t & 15)], lds.data(), &regs[t * 16]);
+        for (int t = t0; t < t0 + 16; t++) dif2_streamed(t, lds.data(), &regs[t * 16]);
+      }
+      // wave fence; partner reads and power stores interleaved thread by thread inside the wave, both directions
+      for (int i = 0; i < 64; i++) {
+        const int t = 64 * w + (dir ? 63 - i : i);
+        cd y[kBinsPerThread];
+        dif_partner_load(t, lds.data(), y);  // as the kernel: the six partner reads first, then the six stores
+        for (int j = 0; j < kBinsPerThread; j++) {
+          const int kf = dif_bin_of(t, j);
+          if (kf < kMinBin || kf >= kMaxBin) {
+            lds[kPowerTrashSlot] = cd{1e300, 1e300};  // what the kernel does with them: a slot nobody may read
+            continue;
+          }
+          if (dif_partner_base(t) + 15 - j != pidx(dif_slot_of_bin(kFft2N - kf))) { chroma_a[0] = -3.0; return; }
+          // the partner must have been published by THIS wave, and the power slot must be one of this wave's rows
+          if (wave_of_k0((kFft2N - kf) & 15) != w) { chroma_a[0] = -4.0; return; }
+          const int slot = T.layout.bin_slot[kf - kMinBin];
+          const int row = slot / 17, col = slot % 17;
+          if (wave_of_k0(row >> 4) != w || col > 7) { chroma_a[0] = -5.0; return; }
+          // the kernel keeps the slots packed two to a register, already scaled to bytes
+          if (slot_bytes<0>(pack_slots((uint32_t)slot, 4351u)) != (uint32_t)slot * sizeof(cd) ||
+              slot_bytes<1>(pack_slots(4351u, (uint32_t)slot)) != (uint32_t)slot * sizeof(cd)) { chroma_a[0] = -6.0; return; }
+          double a, b;
+          dif_power_of(regs[t * 16 + out16(j)], y[j], &a, &b);
+          lds[slot] = cd{a, b};
           seen++;
         }
       }
     }
     if (seen != kNumBins) { chroma_a[0] = -1.0; return; }  // every bin must be owned by exactly one (t, j)
+    seen_total += seen;
     image[dir] = lds;
   }
-  for (int p = 0; p < kNumBins; p++) {
-    const cd u = image[0][dif_power_slot(p)], v = image[1][dif_power_slot(p)];
+  for (int i = 0; i < kNumBins; i++) {
+    const int slot = T.layout.bin_slot[i];
+    const cd u = image[0][slot], v = image[1][slot];
     if (u.x != v.x || u.y != v.y) { chroma_a[0] = -2.0; return; }
   }
+  // ---- workgroup barrier (power image complete -> fold reads)
   for (int c = 0; c < 12; c++) {
     cd lane[kClassLanes];
     for (int l = 0; l < kClassLanes; l++) {
       cd v[kClassLaneMax];
-      class_lane_load(lds.data(), (int)T.class_start[c], (int)T.class_start[c + 1], l, v);
+      class_lane_load(lds.data(), T.layout.fold[16 * c + l], v);
       lane[l] = class_lane_add(v);
     }
     for (int step = 0; step < 4; step++) {
