@@ -40,7 +40,15 @@ constexpr int kBinsPerThread = 6;  // registers j = 0..5 of a thread hold every 
 // One LDS buffer of 4096 complex slots whose index is padded by one slot per 16 (pidx): the stride-16 and
 // stride-17 access patterns of the stages are then bank-conflict free for 16-byte elements.
 constexpr int kFft2N = 4096;
-constexpr int kLds2Slots = kFft2N + kFft2N / 16;  // padded complex slots
+constexpr int kFftSlots = kFft2N + kFft2N / 16;  // padded complex slots of the transform's image
+// Behind the image: one 16-byte slot per thread for loop invariants that would otherwise occupy (spilled) registers,
+// the constant zero and the trash slot of the power image.  A thread's OTHER private slot is its pad inside the image
+// (slot 17 t + 16, touched by no stage).
+constexpr int kThreadSlot0 = kFftSlots;                 // + t: packed power slots (3 words), fold entry (1 word)
+constexpr int kPowerZeroSlot = kThreadSlot0 + 256;      // holds (0, 0): read in place of positions beyond a lane's count
+constexpr int kPowerTrashSlot = kPowerZeroSlot + 1;     // takes the powers of the bins outside 10..1307, never read
+constexpr int kLds2Slots = kPowerTrashSlot + 1;         // 73 760 bytes: two workgroups per CU
+NEEDLE_HD int thread_pad_slot(int t) { return 17 * t + 16; }  // window recurrence seeds
 
 NEEDLE_HD int pidx(int i) { return i + (i >> 4); }
 
@@ -139,6 +147,28 @@ NEEDLE_HD void lds_put(cd *lds, int slot, cd v) {
 }
 // the same by BYTE offset from the start of the image (offsets kept packed in registers, already scaled):
 // pack_slots puts two 13-bit slots, each times 16, into one word; slot_bytes<0/1> takes them out again
+struct Words4 {
+  uint32_t w[4];
+};
+NEEDLE_HD Words4 lds_get_words(const cd *lds, int slot) {
+  Words4 r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef uint32_t v4u __attribute__((ext_vector_type(4), aligned(16)));
+  const v4u v = *reinterpret_cast<const v4u *>(lds + slot);
+  r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+#else
+  __builtin_memcpy(r.w, lds + slot, 16);
+#endif
+  return r;
+}
+NEEDLE_HD void lds_put_words(cd *lds, int slot, Words4 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef uint32_t v4u __attribute__((ext_vector_type(4), aligned(16)));
+  *reinterpret_cast<v4u *>(lds + slot) = v4u{v.w[0], v.w[1], v.w[2], v.w[3]};
+#else
+  __builtin_memcpy(lds + slot, v.w, 16);
+#endif
+}
 NEEDLE_HD uint32_t pack_slots(uint32_t a, uint32_t b) { return (a << 4) | (b << 17); }
 template <int WHICH>
 NEEDLE_HD uint32_t slot_bytes(uint32_t packed) { return WHICH == 0 ? (packed & 0x1fff0u) : ((packed >> 13) & 0x1fff0u); }
@@ -192,8 +222,8 @@ NEEDLE_HD int dif0_base(int t) { return t + (t >> 4); }
 NEEDLE_HD int dif1_base(int t) { return 272 * thread_k0(t) + (t & 15); }
 NEEDLE_HD int dif2_base(int t) { return 17 * (16 * thread_k0(t) + (t & 15)); }
 // N - (K + 256 j) = (256 - K) + 256 (15 - j) for K != 0: low byte K' = 256 - K, register 15 - j of the thread that
-// owns K'.  K = 0: bins 256 j, partners 256 (16 - j) = slot 16 - j; j = 0 (bin 0, discarded) then reads the pad
-// slot 16.
+// owns K'.  K = 0: bins 256 j, partners 256 (16 - j) = slot 16 - j; j = 0 (bin 0, discarded) then reads a pad
+// slot (16: some thread's private words, harmless).
 NEEDLE_HD int dif_partner_base(int t) {
   const int K = thread_k0(t) + 16 * (t & 15);
   const int Kp = (256 - K) & 255;
@@ -371,10 +401,8 @@ NEEDLE_HD bool dif_bin_power(int t, int j, const cd *lds, const cd *r, int *kf_o
 constexpr int kClassLanes = 16;      // lanes that share one pitch class in the fold (one DPP row)
 constexpr int kClassLaneMax = 10;    // >= rows of the tallest strip; checked by build_power_layout
 constexpr int kClassLaneMin = 4;     // <= positions of every fold lane; checked by build_power_layout
-// Two constant slots make the stores and the fold's loads branch-free, both PAD slots (17 q + 16: touched by no
-// stage).  kPowerZeroSlot holds (0, 0), read in place of positions beyond a lane's count; kPowerTrashSlot takes the
-// powers of the bins outside 10..1307 and is never read.
-constexpr int kPowerZeroSlot = 16, kPowerTrashSlot = 33;
+// Two constant slots (kPowerZeroSlot, kPowerTrashSlot, behind the image) make the stores and the fold's loads
+// branch-free.
 
 struct PowerLayout {
   uint16_t bin_slot[kNumBins];   // slot in the LDS image of the power pair of bin kMinBin + i

@@ -109,22 +109,28 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
 
   // ---- loop invariants of this thread, packed so they cost few registers --------------------------------------
   // where the powers of its six bins (register j of stage 2) go in the class-sorted LDS image
-  uint32_t slot_pk[core::kBinsPerThread / 2];
-#pragma unroll
-  for (int j = 0; j < core::kBinsPerThread; j += 2) {
-    uint32_t idx[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int kf = core::dif_bin_of(t, j + h);
-      idx[h] = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : (uint32_t)core::kPowerTrashSlot;
-    }
-    slot_pk[j >> 1] = core::pack_slots(idx[0], idx[1]);
-  }
-  if (t == 0) lds[core::kPowerZeroSlot] = cd{0.0, 0.0};  // first read after the loop's barriers
-  // its share of the pitch-class fold: 12 classes x 16 lanes (one DPP row per class), each lane both frames
+  // ---- loop invariants of this thread live in LDS (two private 16-byte slots, fp_core.h) and are read back once per
+  // pair: kept in registers they are spilled to scratch, whose reloads stall the top of every pair -----------------
   const bool folds = t < kBands * core::kClassLanes;
-  const int fold_c = t >> 4, fold_l = t & 15;
-  const uint32_t fold_entry = folds ? fold_tab[t] : 0;  // fp_core.h PowerLayout: first slot | positions << 16
+  {
+    core::Words4 inv;
+#pragma unroll
+    for (int j = 0; j < core::kBinsPerThread; j += 2) {  // where the powers of its six bins go in the power image
+      uint32_t idx[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int kf = core::dif_bin_of(t, j + h);
+        idx[h] = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : (uint32_t)core::kPowerTrashSlot;
+      }
+      inv.w[j >> 1] = core::pack_slots(idx[0], idx[1]);
+    }
+    // its share of the pitch-class fold: 12 classes x 16 lanes (one DPP row per class), each lane both frames
+    inv.w[3] = folds ? fold_tab[t] : 0;  // fp_core.h PowerLayout: first slot | positions << 16
+    core::lds_put_words(lds, core::kThreadSlot0 + t, inv);
+    // window recurrence (fp_core.h window_step), seeded per thread with cos(theta t) and cos(theta (t - 256))
+    core::lds_put(lds, core::thread_pad_slot(t), cd{wcos[t + 256], wcos[t]});
+    if (t == 0) core::lds_put(lds, core::kPowerZeroSlot, cd{0.0, 0.0});  // first read after the loop's barriers
+  }
 
   // ---- the stream (region of the batch) the current pair belongs to; consecutive pairs rarely change it ------
   int si = find_stream<&FpStream::pair_base>(streams, num_streams, first);
@@ -146,9 +152,7 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   using reg_t = int;  // one 16-bit sample sign-extended by the load, or one packed L|R pair
   reg_t ra[16], rb[16];
   // PCM of both frames: issued one pair ahead, while the previous pair's powers are still being produced (the
-  // spectrum registers are dead by then).  The window comes from a recurrence (fp_core.h window_step), seeded per
-  // thread with cos(theta (t - 256)) and cos(theta t).
-  const double wseed_prev = wcos[t], wseed = wcos[t + 256];
+  // spectrum registers are dead by then).
   auto issue_loads = [&](const PairSrc &p) {
     const raw_t *qa = reinterpret_cast<const raw_t *>(p.a), *qb = reinterpret_cast<const raw_t *>(p.b);
     // an opaque copy of the thread index keeps these loads (and their addresses) in the loop; laundering the
@@ -165,14 +169,10 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   // The pitch-class fold of a pair runs one pair late, between the next pair's sample conversion and its first
   // butterflies: the LDS reads are issued, the conversion hides their latency, then 8 lanes per class add up.
   cd fv[core::kClassLaneMax];
-  auto fold_issue = [&]() {
-    if (folds) {
-      uint32_t fe = fold_entry;
-      asm volatile("" : "+v"(fe));  // recompute the addresses per pair rather than keep them in registers
-      core::class_lane_load(lds, fe, fv);
-    }
+  auto fold_issue = [&](uint32_t fold_entry) {
+    if (folds) core::class_lane_load(lds, fold_entry, fv);
   };
-  auto fold_finish = [&](const PairSrc &p) {
+  auto fold_finish = [&](const PairSrc &p, int tt) {  // tt: the opaque copy of t (addresses are not loop invariants)
     if (folds) {
       cd acc = core::class_lane_add(fv);
       // fixed-order tree over the class's 16 lanes (fp_core.h class_tree_partner)
@@ -180,9 +180,11 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
       acc = cd{acc.x + dpp_f64<0x4E>(acc.x), acc.y + dpp_f64<0x4E>(acc.y)};    // quad_perm [2,3,0,1]
       acc = cd{acc.x + dpp_f64<0x141>(acc.x), acc.y + dpp_f64<0x141>(acc.y)};  // row_half_mirror
       acc = cd{acc.x + dpp_f64<0x140>(acc.x), acc.y + dpp_f64<0x140>(acc.y)};  // row_mirror
-      if (fold_l == 0) {
-        chroma[p.row * kBands + fold_c] = acc.x;
-        if (p.has_b) chroma[(p.row + 1) * kBands + fold_c] = acc.y;
+      if ((tt & 15) == 0) {
+        double *out = chroma + p.row * kBands;  // uniform base + a 32-bit lane offset
+        const uint32_t c = (uint32_t)tt >> 4;
+        out[c] = acc.x;
+        if (p.has_b) out[kBands + c] = acc.y;
       }
     }
   };
@@ -194,10 +196,10 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     // loop-invariant by the compiler it costs more registers than the kernel has (spills to scratch)
     int tt = t;
     asm volatile("" : "+v"(tt));
-    if (g != first) fold_issue();
+    const cd seeds = core::lds_get(lds, core::thread_pad_slot(tt));
+    if (g != first) fold_issue(core::lds_get_words(lds, core::kThreadSlot0 + tt).w[3]);
     cd r[16];
-    double wc = wseed, wc_prev = wseed_prev;
-    asm volatile("" : "+v"(wc), "+v"(wc_prev));  // per pair: the 16 window values are not kept across the loop
+    double wc = seeds.x, wc_prev = seeds.y;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       int sa, sb;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
 #pragma unroll
       for (int k = 0; k < 16; k++) r[k].y = 0.0;
     }
-    if (g != first) fold_finish(prev);
+    if (g != first) fold_finish(prev, tt);
     // In-place decimation-in-frequency stages; which exchanges need a workgroup barrier: fp_core.h.  The stores of
     // a stage are issued tail by tail (fp_core.h dif_tail_store) so that the LDS pipeline, whose 128-bit stores cost
     // 13 cycles each, drains them under the arithmetic that follows instead of in a burst in front of a barrier.
@@ -242,12 +244,7 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     // partners Z[N - k] of the six bins: one base + constants, all six reads in flight together
     cd yp[core::kBinsPerThread];
     core::dif_partner_load(tt, lds, yp);
-    uint32_t spk[core::kBinsPerThread / 2];
-#pragma unroll
-    for (int j = 0; j < core::kBinsPerThread / 2; j++) {
-      spk[j] = slot_pk[j];
-      asm volatile("" : "+v"(spk[j]));  // unpack per pair: unpacked copies kept across the loop would spill
-    }
+    const core::Words4 inv = core::lds_get_words(lds, core::kThreadSlot0 + tt);  // packed power slots
     double pwa[core::kBinsPerThread], pwb[core::kBinsPerThread];
 #pragma unroll
     for (int j = 0; j < core::kBinsPerThread; j++) core::dif_power_of(r[core::out16(j)], yp[j], &pwa[j], &pwb[j]);
@@ -255,15 +252,15 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     // reads; bins outside 10..1307 land in a pad slot nobody reads
 #pragma unroll
     for (int j = 0; j < core::kBinsPerThread; j++)
-      core::lds_put_bytes(lds, (j & 1) ? core::slot_bytes<1>(spk[j >> 1]) : core::slot_bytes<0>(spk[j >> 1]), cd{pwa[j], pwb[j]});
+      core::lds_put_bytes(lds, (j & 1) ? core::slot_bytes<1>(inv.w[j >> 1]) : core::slot_bytes<0>(inv.w[j >> 1]), cd{pwa[j], pwb[j]});
     const PairSrc nxt = locate(min(g + 1, last - 1));  // last pair: harmless re-read
     issue_loads(nxt);
     if (!(LAB & kLabNoB3)) lds_barrier(); else wave_lds_fence();  // the power image is complete
     prev = cur;
     cur = nxt;
   }
-  fold_issue();
-  fold_finish(prev);
+  fold_issue(core::lds_get_words(lds, core::kThreadSlot0 + t).w[3]);
+  fold_finish(prev, t);
 }
 
 }  // namespace stft

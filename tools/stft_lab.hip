@@ -91,58 +91,85 @@ static void setup(Lab &L) {
   CK(hipEventCreate(&L.b));
 }
 
-template <typename K>
-static void run(Lab &L, K kern, const char *name, bool check, uint32_t ppb = 16, size_t lds_bytes = 0) {
-  const size_t lds = lds_bytes ? lds_bytes : core::kLds2Slots * sizeof(cd);
-  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const uint32_t grid = (uint32_t)(((L.total_pairs + ppb - 1) / ppb + 7) / 8 * 8);
+// One variant: a launcher, its name, whether its chroma must equal the product's, its launch shape.
+struct Variant {
+  const char *name;
+  void (*launch)(Lab &, uint32_t grid, size_t lds, uint32_t ppb);
+  bool check;
+  uint32_t ppb;
+  size_t lds_bytes;
   std::vector<float> ms;
-  CK(hipMemset(L.d_chroma, 0, (size_t)L.eps * (L.frames + 1) * 12 * 8));
-  for (int rep = 0; rep < 8; rep++) {
-    CK(hipEventRecord(L.a));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, L.d_pcm, L.d_streams, L.eps, L.d_tw, L.d_wcos, L.wconst,
-                       L.d_bin_slot, L.d_fold_tab, L.d_chroma, L.total_pairs, ppb);
-    CK(hipEventRecord(L.b));
-    CK(hipEventSynchronize(L.b));
-    float t;
-    CK(hipEventElapsedTime(&t, L.a, L.b));
-    if (rep >= 2) ms.push_back(t);
-  }
-  CK(hipGetLastError());
-  std::sort(ms.begin(), ms.end());
   double diff = -1.0;
+};
+
+template <int LAB>
+static void launch_variant(Lab &L, uint32_t grid, size_t lds, uint32_t ppb) {
+  static bool attr = false;
+  static size_t attr_lds = 0;
+  auto kern = stft::stft_chroma_kernel<1, LAB>;
+  if (!attr || attr_lds != lds) {
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, L.d_pcm, L.d_streams, L.eps, L.d_tw, L.d_wcos, L.wconst,
+                     L.d_bin_slot, L.d_fold_tab, L.d_chroma, L.total_pairs, ppb);
+}
+
+static void time_once(Lab &L, Variant &v, bool record) {
+  const size_t lds = v.lds_bytes ? v.lds_bytes : core::kLds2Slots * sizeof(cd);
+  const uint32_t grid = (uint32_t)(((L.total_pairs + v.ppb - 1) / v.ppb + 7) / 8 * 8);
+  CK(hipEventRecord(L.a));
+  v.launch(L, grid, lds, v.ppb);
+  CK(hipEventRecord(L.b));
+  CK(hipEventSynchronize(L.b));
+  CK(hipGetLastError());
+  float t;
+  CK(hipEventElapsedTime(&t, L.a, L.b));
+  if (record) v.ms.push_back(t);
+}
+
+static void check_variant(Lab &L, Variant &v) {
+  CK(hipMemset(L.d_chroma, 0, (size_t)L.eps * (L.frames + 1) * 12 * 8));
+  time_once(L, v, false);
   std::vector<double> out((size_t)L.eps * L.frames * 12);
   CK(hipMemcpy(out.data(), L.d_chroma, out.size() * 8, hipMemcpyDeviceToHost));
-  if (L.ref.empty()) {
-    L.ref = out;
-  } else if (check) {
-    diff = 0.0;
-    for (size_t i = 0; i < out.size(); i++) diff = std::max(diff, std::fabs(out[i] - L.ref[i]) / std::max(std::fabs(L.ref[i]), 1e-300));
+  if (L.ref.empty()) L.ref = out;
+  if (v.check) {
+    v.diff = 0.0;
+    for (size_t i = 0; i < out.size(); i++) v.diff = std::max(v.diff, std::fabs(out[i] - L.ref[i]) / std::max(std::fabs(L.ref[i]), 1e-300));
   }
-  std::printf("%-56s ppb=%2u lds=%6zu  min %.4f  med %.4f ms", name, ppb, lds, ms.front(), ms[ms.size() / 2]);
-  if (diff >= 0.0) std::printf("   max rel diff vs product %.2e", diff);
-  std::printf("\n");
-  std::fflush(stdout);
 }
 
 int main(int argc, char **argv) {
   Lab L;
   setup(L);
   using namespace needle::stft;
-  const int rounds = argc > 1 ? std::atoi(argv[1]) : 2;
-  // warm-up: the first launches run at a lower clock
-  for (int i = 0; i < 4; i++) run(L, stft_chroma_kernel<1, 0>, "warm-up (product)", true);
-  for (int round = 0; round < rounds; round++) {
-    std::printf("---- round %d\n", round);
-    run(L, stft_chroma_kernel<1, 0>, "product", true);
-    run(L, stft_chroma_kernel<1, kLabSerial>, "round-1 order (stage butterflies, then its stores)", true);
-    run(L, stft_chroma_kernel<1, kLabExtraB>, "extra barrier between publish and partner reads", true);
-    run(L, stft_chroma_kernel<1, kLabSerial | kLabExtraB>, "round-1 order + extra barrier (the round-1 schedule)", true);
-    run(L, stft_chroma_kernel<1, 0>, "product, one workgroup per CU (100 KB of LDS)", true, 16, 100 * 1024);
-    run(L, stft_chroma_kernel<1, kLabNoB1>, "no barrier 1 (fold reads -> stage-0 stores)", false);
-    run(L, stft_chroma_kernel<1, kLabNoB2>, "no barrier 2 (stage-0 stores -> stage-1 reads)", false);
-    run(L, stft_chroma_kernel<1, kLabNoB3>, "no barrier 3 (power stores -> fold reads)", false);
-    run(L, stft_chroma_kernel<1, kLabNoB1 | kLabNoB2 | kLabNoB3>, "no workgroup barrier at all", false);
+  const int reps = argc > 1 ? std::atoi(argv[1]) : 40;
+  const size_t one_per_cu = 100 * 1024;
+  std::vector<Variant> vs = {
+      {"product", launch_variant<0>, true, 16, 0},
+      {"round-1 order (a stage's butterflies, then its stores)", launch_variant<kLabSerial>, true, 16, 0},
+      {"extra barrier between publish and partner reads", launch_variant<kLabExtraB>, true, 16, 0},
+      {"round-1 order + extra barrier (the round-1 schedule)", launch_variant<kLabSerial | kLabExtraB>, true, 16, 0},
+      {"product, one workgroup per CU (100 KB of LDS)", launch_variant<0>, true, 16, one_per_cu},
+      {"no barrier 1 (fold reads -> stage-0 stores)", launch_variant<kLabNoB1>, false, 16, 0},
+      {"no barrier 2 (stage-0 stores -> stage-1 reads)", launch_variant<kLabNoB2>, false, 16, 0},
+      {"no barrier 3 (power stores -> fold reads)", launch_variant<kLabNoB3>, false, 16, 0},
+      {"no workgroup barrier at all", launch_variant<kLabNoB1 | kLabNoB2 | kLabNoB3>, false, 16, 0},
+      {"product, 8 pairs per workgroup", launch_variant<0>, true, 8, 0},
+      {"product, 32 pairs per workgroup", launch_variant<0>, true, 32, 0},
+  };
+  for (int i = 0; i < 30; i++) time_once(L, vs[0], false);  // warm-up: the first launches run at a lower clock
+  for (Variant &v : vs) check_variant(L, v);
+  // the variants take turns, so that clock drift and neighbours on the node hit all of them alike
+  for (int r = 0; r < reps; r++)
+    for (Variant &v : vs) time_once(L, v, true);
+  for (Variant &v : vs) {
+    std::sort(v.ms.begin(), v.ms.end());
+    std::printf("%-58s ppb=%2u  min %.4f  q25 %.4f  med %.4f ms", v.name, v.ppb, v.ms.front(), v.ms[v.ms.size() / 4], v.ms[v.ms.size() / 2]);
+    if (v.diff >= 0.0) std::printf("   max rel diff vs product %.1e", v.diff);
+    std::printf("\n");
   }
   return 0;
 }
