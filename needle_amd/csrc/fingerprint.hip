@@ -35,10 +35,10 @@ namespace {
 
 // ---- constant tables, generated on the host in double and uploaded once per device --------------------
 struct FpTables {
-  double *tw_rows = nullptr;        // [256][2][30] twiddle constants of stages 1 and 2 per thread (fp_core.h)
+  cd *tw = nullptr;                 // [4096] e^{-2 pi i k/4096}
   uint16_t *bin_slot = nullptr;     // [kNumBins] slot in the LDS image of the power pair of bin (kMinBin + i)
   double *wcos = nullptr;           // [512] cos(theta (i - 256)), theta = 2 pi / 4095: window recurrence seeds
-  core::WindowConst wconst;         // fp_core.h window_seeds / window_col
+  core::WindowConst wconst;         // fp_core.h window_step
   uint32_t *fold_tab = nullptr;     // [12 * 16] fold thread -> first slot | positions << 16 (fp_core.h PowerLayout)
   core::ClassifierThresholds *thr = nullptr;
 };
@@ -73,7 +73,10 @@ Status get_tables(FpTables *out) {
   const long double theta = 2.0L * 3.14159265358979323846264338327950288L / 4095.0L;
   std::vector<double> wcos(512);
   for (int i = 0; i < 512; i++) wcos[i] = (double)cosl(theta * (long double)(i - 256));
-  const core::WindowConst wconst = core::make_window_const(theta, core::kPairInputScale);
+  core::WindowConst wconst;
+  wconst.k2 = (double)(2.0L * cosl(256.0L * theta));
+  wconst.a = core::kPairInputScale * (0.54 / 32767.0);
+  wconst.b = core::kPairInputScale * (0.46 / 32767.0);
   // chromaprint Chroma::PrepareNotes: bin -> pitch class; then where each bin's power pair lives in the LDS image
   // and what each fold lane reads (fp_core.h build_power_layout)
   std::vector<uint8_t> class_of_bin(core::kNumBins);
@@ -95,14 +98,11 @@ Status get_tables(FpTables *out) {
   NEEDLE_HIP_TRY(hipMemcpy(t.bin_slot, layout->bin_slot, sizeof(layout->bin_slot), hipMemcpyHostToDevice));
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.fold_tab, sizeof(layout->fold)));
   NEEDLE_HIP_TRY(hipMemcpy(t.fold_tab, layout->fold, sizeof(layout->fold), hipMemcpyHostToDevice));
-  std::vector<double> rows((size_t)core::kThreads * 2 * core::kTwRow);
-  for (int th = 0; th < core::kThreads; th++)
-    core::build_twiddle_rows(tw.data(), th, &rows[(size_t)th * 2 * core::kTwRow], &rows[(size_t)th * 2 * core::kTwRow + core::kTwRow]);
-  NEEDLE_HIP_TRY(hipMalloc((void **)&t.tw_rows, rows.size() * sizeof(double)));
+  NEEDLE_HIP_TRY(hipMalloc((void **)&t.tw, tw.size() * sizeof(cd)));
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.wcos, wcos.size() * sizeof(double)));
   t.wconst = wconst;
   NEEDLE_HIP_TRY(hipMalloc((void **)&t.thr, sizeof(thr)));
-  NEEDLE_HIP_TRY(hipMemcpy(t.tw_rows, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
+  NEEDLE_HIP_TRY(hipMemcpy(t.tw, tw.data(), tw.size() * sizeof(cd), hipMemcpyHostToDevice));
   NEEDLE_HIP_TRY(hipMemcpy(t.wcos, wcos.data(), wcos.size() * sizeof(double), hipMemcpyHostToDevice));
   NEEDLE_HIP_TRY(hipMemcpy(t.thr, &thr, sizeof(thr), hipMemcpyHostToDevice));
   g_tables[dev] = t;
@@ -321,8 +321,8 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
         const uint32_t grid = (uint32_t)(((pairs + ppb - 1) / ppb + 7) / 8 * 8);  // multiple of 8: see the XCD mapping
         auto launch = [&](auto kernel) {
           hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm,
-                             desc.streams.ptr, n, tab.tw_rows, tab.wcos, tab.wconst, tab.bin_slot, tab.fold_tab, ws->chroma.ptr,
-                             (uint32_t)pairs, ppb, (const cd *)nullptr);
+                             desc.streams.ptr, n, tab.tw, tab.wcos, tab.wconst, tab.bin_slot, tab.fold_tab, ws->chroma.ptr,
+                             (uint32_t)pairs, ppb);
         };
         if (channels == 1) launch(stft_chroma_kernel<1>); else launch(stft_chroma_kernel<2>);
       }

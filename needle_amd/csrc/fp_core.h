@@ -87,30 +87,45 @@ NEEDLE_HD void fft16_head(cd *a) {
 #pragma unroll
   for (int n2 = 0; n2 < 4; n2++) bfly4(a[n2], a[4 + n2], a[8 + n2], a[12 + n2]);
 }
-// `hook(i)`, i = 0..3, is called at four points of the tail: a caller uses it to issue one LDS store of the PREVIOUS
-// tail's outputs at each, which spaces the stores out under this tail's arithmetic.
+// `hook(i)`, i = 0..3, is called at four points of the tail: a caller can use it to issue one LDS store of the PREVIOUS
+// tail's outputs at each, which spaces the stores out under this tail's arithmetic.  PLAIN: the round-1 arithmetic
+// (constant twiddles multiplied out, then a 4-point DFT of additions: 168 instructions per transform), kept for
+// tools/stft_lab.hip.
 struct NoHook {
   NEEDLE_HD void operator()(int) const {}
 };
-template <int K1, typename HOOK = NoHook>
+template <int K1, typename HOOK = NoHook, bool PLAIN = false>
 NEEDLE_HD void fft16_tail(cd *a, HOOK hook = HOOK()) {
   const double c = 0.92387953251128673848, s = 0.38268343236508977173, h = 0.70710678118654752440;
   const double t8 = 0.41421356237309504880, ct8 = 2.41421356237309504880;
   cd E0, E1, v, vp;
-  double g;
-  if (K1 == 0) {  // no twiddles: v = b1 + b3, v' = b1 - b3, g = 1 (plain additions below)
-    const cd b0 = a[0], b1 = a[1], b2 = a[2], b3 = a[3];
+  double g = 1.0;
+  if (K1 == 0 || PLAIN) {  // no twiddles left: v = b1 + b3, v' = b1 - b3, plain additions below
+    cd b0 = a[4 * K1], b1 = a[4 * K1 + 1], b2 = a[4 * K1 + 2], b3 = a[4 * K1 + 3];
+    if (PLAIN && K1 == 1) {
+      b1 = cd{b1.x * c + b1.y * s, b1.y * c - b1.x * s};       // W1 = (c, -s)
+      b2 = cd{(b2.x + b2.y) * h, (b2.y - b2.x) * h};           // W2 = (h, -h)
+      b3 = cd{b3.x * s + b3.y * c, b3.y * s - b3.x * c};       // W3 = (s, -c)
+    } else if (PLAIN && K1 == 2) {
+      b1 = cd{(b1.x + b1.y) * h, (b1.y - b1.x) * h};           // W2
+      b2 = cd{b2.y, -b2.x};                                    // W4 = -i
+      b3 = cd{(b3.y - b3.x) * h, -(b3.x + b3.y) * h};          // W6 = (-h, -h)
+    } else if (PLAIN && K1 == 3) {
+      b1 = cd{b1.x * s + b1.y * c, b1.y * s - b1.x * c};       // W3
+      b2 = cd{(b2.y - b2.x) * h, -(b2.x + b2.y) * h};          // W6
+      b3 = cd{-(b3.x * c) - b3.y * s, b3.x * s - b3.y * c};    // W9 = (-c, s)
+    }
     E0 = cadd(b0, b2);
     E1 = csub(b0, b2);
     hook(0);
     v = cadd(b1, b3);
     vp = csub(b1, b3);
     hook(1);
-    a[0] = cadd(E0, v);
-    a[2] = csub(E0, v);
+    a[4 * K1] = cadd(E0, v);
+    a[4 * K1 + 2] = csub(E0, v);
     hook(2);
-    a[1] = cd{E1.x + vp.y, E1.y - vp.x};
-    a[3] = cd{E1.x - vp.y, E1.y + vp.x};
+    a[4 * K1 + 1] = cd{E1.x + vp.y, E1.y - vp.x};
+    a[4 * K1 + 3] = cd{E1.x - vp.y, E1.y + vp.x};
     hook(3);
     return;
   } else if (K1 == 1) {  // w = (1, W1, W2, W3)
@@ -267,93 +282,48 @@ NEEDLE_HD int dif_partner_base(int t) {
   return K == 0 ? 1 : 272 * (Kp & 15) + 17 * (Kp >> 4);
 }
 
-// ---- twiddles on the CONSUMER side, folded into the first layer -----------------------------------------------------
-// Decimation in frequency multiplies output j of a stage-0 butterfly by W^{t j} and output j of a stage-1 butterfly
-// by W^{16 n0 j}.  Seen from the thread that READS a value, input k of the stage-1 thread (b, n0) carries
-// W^{n0 b} (W^{16 b})^k and input k of the stage-2 thread (b, c) carries (W^{16 c})^k; moving the factor W^{n0 b} that
-// is common to all inputs of a stage-1 butterfly through to its outputs (the transform is linear) leaves
-//   stage 1, thread (b, n0):  input k times g1^k,  g1 = W_4096^{16 b}
-//   stage 2, thread (b, c):   input k times g2^k,  g2 = W_4096^{b + 16 c}
-// and NO multiplication on the producer side: a stage stores its butterfly outputs as they are.  Applied to the inputs
-// of the first layer (4-point DFTs over inputs n2, 4 + n2, 8 + n2, 12 + n2) a twiddle w = gamma (1, tau) costs two
-// FMAs for u = (1, tau) x; its scale rides on the FMAs that replace the layer's additions:
-//   A0 = w0 x0 (a full multiply; x0 itself in column 0),  E0/E1 = A0 +- gamma2 u2,
-//   e2 = gamma1 (u1 + rho u3), e3 = -i gamma1 (u1 - rho u3) with rho = gamma3 / gamma1, never formed: bfly4_tail.
-// 36 instructions per stage on top of the 64 additions instead of 60: 24 fewer per stage, and the stores of a stage
-// need no arithmetic.  gamma = cos is never exactly zero in the table (cosl of a rounded pi / 2), only tiny; tau and rho
-// are then huge and the products come out right to the last bits that matter (the error stays relative to |x|).
-// Per thread and stage 30 constants, built on the host (build_twiddle_rows) and loaded once per workgroup:
-//   column 0: tau2 gamma2 tau1 tau3 rho gamma1;  columns 1..3: w0.re w0.im tau2 gamma2 tau1 tau3 rho gamma1.
-constexpr int kTwRow = 30;
-inline void build_twiddle_row(const cd *tw4096, int m, double *row) {  // g = W_4096^m
-  int o = 0;
-  for (int n2 = 0; n2 < 4; n2++) {
-    const cd w0 = tw4096[(m * n2) & 4095], w1 = tw4096[(m * (4 + n2)) & 4095], w2 = tw4096[(m * (8 + n2)) & 4095],
-             w3 = tw4096[(m * (12 + n2)) & 4095];
-    if (n2 != 0) {
-      row[o++] = w0.x;
-      row[o++] = w0.y;
-    }
-    row[o++] = w2.y / w2.x;
-    row[o++] = w2.x;
-    row[o++] = w1.y / w1.x;
-    row[o++] = w3.y / w3.x;
-    row[o++] = w3.x / w1.x;
-    row[o++] = w1.x;
+// stage 0: r holds the inputs x[t + 256 k]; leaves the stage's outputs in the same slots.  Split in two so the
+// kernel can keep the register-only half ahead of the barrier that frees the LDS image of the previous pair.
+NEEDLE_HD void dif0_store(int t, cd base0, cd *lds, const cd *r) {
+  const int o = dif0_base(t);
+  lds_put(lds, o, r[out16(0)]);
+  cd w = base0;
+#pragma unroll
+  for (int j = 1; j < 16; j++) {
+    lds_put(lds, o + 272 * j, cmulf(r[out16(j)], w));
+    if (j < 15) w = cmulf(w, base0);
   }
 }
-// rows of thread t for stage 1 and stage 2
-inline void build_twiddle_rows(const cd *tw4096, int t, double *row1, double *row2) {
-  const int b = thread_k0(t), c = t & 15;
-  build_twiddle_row(tw4096, 16 * b, row1);
-  build_twiddle_row(tw4096, b + 16 * c, row2);
+NEEDLE_HD void dif0(int t, cd base0, cd *lds, cd *r) {
+  fft16(r);
+  dif0_store(t, base0, lds, r);
 }
 
-template <int N2>
-NEEDLE_HD void head_col_tw(cd *a, const double *row) {
-  const double *k = row + (N2 == 0 ? 0 : 6 + 8 * (N2 - 1));
-  const cd A0 = N2 == 0 ? a[0] : cmulf(a[N2], cd{k[0], k[1]});
-  const int o = N2 == 0 ? 0 : 2;
-  const double tau2 = k[o], g2 = k[o + 1], tau1 = k[o + 2], tau3 = k[o + 3], rho = k[o + 4], g1 = k[o + 5];
-  const cd x1 = a[4 + N2], x2 = a[8 + N2], x3 = a[12 + N2];
-  const cd u2 = cd{fmad(-tau2, x2.y, x2.x), fmad(tau2, x2.x, x2.y)};
-  const cd E0 = cd{fmad(g2, u2.x, A0.x), fmad(g2, u2.y, A0.y)}, E1 = cd{fmad(-g2, u2.x, A0.x), fmad(-g2, u2.y, A0.y)};
-  const cd u1 = cd{fmad(-tau1, x1.y, x1.x), fmad(tau1, x1.x, x1.y)};
-  const cd u3 = cd{fmad(-tau3, x3.y, x3.x), fmad(tau3, x3.x, x3.y)};
-  const cd v = cd{fmad(rho, u3.x, u1.x), fmad(rho, u3.y, u1.y)}, vp = cd{fmad(-rho, u3.x, u1.x), fmad(-rho, u3.y, u1.y)};
-  bfly4_tail(E0, E1, v, vp, g1, a[N2], a[4 + N2], a[8 + N2], a[12 + N2]);
-}
-NEEDLE_HD void fft16_head_tw(cd *a, const double *row) {
-  head_col_tw<0>(a, row);
-  head_col_tw<1>(a, row);
-  head_col_tw<2>(a, row);
-  head_col_tw<3>(a, row);
-}
-// First layer of stage 0: the inputs are (sample of frame A, sample of frame B) still WITHOUT the window; the real
-// window value of each input rides on the layer's FMAs the same way (4 multiplies + 8 FMAs + 8 additions per column
-// instead of 8 multiplies + 16 additions).
-template <int N2>
-NEEDLE_HD void head_col_win(cd *a, const double *w4, cd x0, cd x1, cd x2, cd x3) {
-  const cd A0 = cd{w4[0] * x0.x, w4[0] * x0.y};
-  const double w1 = w4[1], w2 = w4[2], w3 = w4[3];
-  const cd E0 = cd{fmad(w2, x2.x, A0.x), fmad(w2, x2.y, A0.y)}, E1 = cd{fmad(-w2, x2.x, A0.x), fmad(-w2, x2.y, A0.y)};
-  const cd p3 = cd{w3 * x3.x, w3 * x3.y};
-  const cd e2 = cd{fmad(w1, x1.x, p3.x), fmad(w1, x1.y, p3.y)}, d = cd{fmad(w1, x1.x, -p3.x), fmad(w1, x1.y, -p3.y)};
-  const cd e3 = cd{d.y, -d.x};
-  a[N2] = cadd(E0, e2);
-  a[4 + N2] = cadd(E1, e3);
-  a[8 + N2] = csub(E0, e2);
-  a[12 + N2] = csub(E1, e3);
+// stage 1, in place; base1 = W_4096^{16 (t & 15)}
+NEEDLE_HD void dif1(int t, cd base1, cd *lds, cd *r) {
+  const int o = dif1_base(t);
+#pragma unroll
+  for (int k = 0; k < 16; k++) r[k] = lds_get(lds, o + 17 * k);
+  fft16(r);
+  lds_put(lds, o, r[out16(0)]);
+  cd w = base1;
+#pragma unroll
+  for (int j = 1; j < 16; j++) {
+    lds_put(lds, o + 17 * j, cmulf(r[out16(j)], w));
+    if (j < 15) w = cmulf(w, base1);
+  }
 }
 
-// A stage = first layer, then the four tails; STREAM: the stores of one k1 (outputs j = k1, k1 + 4, k1 + 8, k1 + 12)
-// are issued as soon as its tail is done, so that the LDS pipeline drains them under the arithmetic of the next tail
-// (otherwise all stores follow all butterflies, the round-1 order kept for tools/stft_lab.hip).
-// STREAM = 2 (the product): the four stores of tail k1 are issued one at a time at four points of tail k1 + 1 (the
-// last tail's own four follow it), so the LDS pipeline sees one 13-cycle store per ~5 arithmetic instructions instead
-// of bursts of four.  STREAM = 1: each tail's stores right behind it.  STREAM = 0: all stores behind all butterflies.
-// pw (tools/stft_lab.hip only): output j is multiplied by pw[j] on its way out, the producer-side twiddles of the
-// schedule before the consumer-side ones (then the next stage's first layer is the plain fft16_head).
+// The same two stages with their stores streamed out under the butterflies instead of in a burst behind them.  pw[j] =
+// base^j.  MODE bit 0 (kStoreSpaced): the four stores of tail k1 (outputs j = k1, k1 + 4, k1 + 8, k1 + 12, each with
+// its twiddle multiply) go out one at a time at four points of tail k1 + 1, the last tail's own four behind it;
+// otherwise each tail's four follow it directly.  MODE bit 1 (kPlainFft): round-1 arithmetic in the tails.
+enum : int { kStoreSpaced = 1, kPlainFft = 2 };
+NEEDLE_HD void twiddle_powers(cd base, cd *pw) {
+  pw[1] = base;
+#pragma unroll
+  for (int j = 2; j < 16; j++) pw[j] = cmulf(pw[j - 1], base);
+}
 template <int K1>
 struct StoreHook {
   int o, pitch;
@@ -362,66 +332,80 @@ struct StoreHook {
   const cd *pw;
   NEEDLE_HD void operator()(int k2) const {
     const int j = K1 + 4 * k2;
-    lds_put(lds, o + pitch * j, (pw && j) ? cmulf(r[4 * K1 + k2], pw[j]) : r[4 * K1 + k2]);
+    lds_put(lds, o + pitch * j, j == 0 ? r[4 * K1 + k2] : cmulf(r[4 * K1 + k2], pw[j]));
   }
 };
-NEEDLE_HD void twiddle_powers(cd base, cd *pw) {
-  pw[0] = cd{1.0, 0.0};
-  pw[1] = base;
-#pragma unroll
-  for (int j = 2; j < 16; j++) pw[j] = cmulf(pw[j - 1], base);
-}
-template <int STREAM>
-NEEDLE_HD void dif_tails_store(int o, int pitch, cd *lds, cd *r, const cd *pw = nullptr) {
-  if (STREAM == 2) {
-    fft16_tail<0>(r);
-    fft16_tail<1>(r, StoreHook<0>{o, pitch, lds, r, pw});
-    fft16_tail<2>(r, StoreHook<1>{o, pitch, lds, r, pw});
-    fft16_tail<3>(r, StoreHook<2>{o, pitch, lds, r, pw});
+template <int MODE>
+NEEDLE_HD void dif_tails_store(int o, int pitch, const cd *pw, cd *lds, cd *r) {
+  constexpr bool P = (MODE & kPlainFft) != 0;
+  if (MODE & kStoreSpaced) {
+    fft16_tail<0, NoHook, P>(r);
+    fft16_tail<1, StoreHook<0>, P>(r, StoreHook<0>{o, pitch, lds, r, pw});
+    fft16_tail<2, StoreHook<1>, P>(r, StoreHook<1>{o, pitch, lds, r, pw});
+    fft16_tail<3, StoreHook<2>, P>(r, StoreHook<2>{o, pitch, lds, r, pw});
 #pragma unroll
     for (int k2 = 0; k2 < 4; k2++) StoreHook<3>{o, pitch, lds, r, pw}(k2);
-    return;
-  }
-  fft16_tail<0>(r);
-  if (STREAM == 1) for (int k2 = 0; k2 < 4; k2++) StoreHook<0>{o, pitch, lds, r, pw}(k2);
-  fft16_tail<1>(r);
-  if (STREAM == 1) for (int k2 = 0; k2 < 4; k2++) StoreHook<1>{o, pitch, lds, r, pw}(k2);
-  fft16_tail<2>(r);
-  if (STREAM == 1) for (int k2 = 0; k2 < 4; k2++) StoreHook<2>{o, pitch, lds, r, pw}(k2);
-  fft16_tail<3>(r);
-  if (STREAM == 1) for (int k2 = 0; k2 < 4; k2++) StoreHook<3>{o, pitch, lds, r, pw}(k2);
-  if (STREAM == 0) {
+  } else {
+    fft16_tail<0, NoHook, P>(r);
 #pragma unroll
-    for (int j = 0; j < 16; j++) lds_put(lds, o + pitch * j, (pw && j) ? cmulf(r[out16(j)], pw[j]) : r[out16(j)]);
+    for (int k2 = 0; k2 < 4; k2++) StoreHook<0>{o, pitch, lds, r, pw}(k2);
+    fft16_tail<1, NoHook, P>(r);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2++) StoreHook<1>{o, pitch, lds, r, pw}(k2);
+    fft16_tail<2, NoHook, P>(r);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2++) StoreHook<2>{o, pitch, lds, r, pw}(k2);
+    fft16_tail<3, NoHook, P>(r);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2++) StoreHook<3>{o, pitch, lds, r, pw}(k2);
   }
 }
-// stage 0 after its first layer (head_col_win, which the caller runs column by column as it converts the samples):
-// outputs to slots t + 256 j
-template <int STREAM = 2>
-NEEDLE_HD void dif0_tails(int t, cd *lds, cd *r, const cd *pw = nullptr) {
-  dif_tails_store<STREAM>(dif0_base(t), 272, lds, r, pw);
+template <int MODE = 0>
+NEEDLE_HD void dif0_streamed(int t, cd base0, cd *lds, cd *r) {
+  cd pw[16];
+  twiddle_powers(base0, pw);
+  fft16_head(r);
+  dif_tails_store<MODE>(dif0_base(t), 272, pw, lds, r);
 }
-// stage 1, in place; row1 = this thread's stage-1 constants
-template <int STREAM = 2>
-NEEDLE_HD void dif1(int t, const double *row1, cd *lds, cd *r, const cd *pw = nullptr) {
+template <int MODE = 0>
+NEEDLE_HD void dif1_streamed(int t, cd base1, cd *lds, cd *r) {
+  cd pw[16];
+  twiddle_powers(base1, pw);
   const int o = dif1_base(t);
 #pragma unroll
   for (int k = 0; k < 16; k++) r[k] = lds_get(lds, o + 17 * k);
-  if (pw) fft16_head(r); else fft16_head_tw(r, row1);
-  dif_tails_store<STREAM>(o, 17, lds, r, pw);
+  fft16_head(r);
+  dif_tails_store<MODE>(o, 17, pw, lds, r);
 }
-// stage 2: afterwards r[out16(j)] = Z[dif_bin_of(t, j)]; the registers other threads read as partners (bins >= 2789
-// live in j = 10..15) are published in place
-template <int STREAM = 2>
-NEEDLE_HD void dif2(int t, const double *row2, cd *lds, cd *r) {
+
+// stage 2: afterwards r[out16(j)] = Z[dif_bin_of(t, j)]
+NEEDLE_HD void dif2(int t, const cd *lds, cd *r) {
   const int o = dif2_base(t);
 #pragma unroll
   for (int k = 0; k < 16; k++) r[k] = lds_get(lds, o + k);
-  if (row2) fft16_head_tw(r, row2); else fft16_head(r);
-  fft16_tail<0>(r);
-  fft16_tail<1>(r);
-  if (STREAM) {  // j = 12, 13 (k2 = 3 of tails 0 and 1) under tail 2; j = 10, 14 under tail 3; j = 11, 15 behind it
-    struct Hook23 {
+  fft16(r);
+}
+
+// publish the registers other threads read as partners (bins >= 2789 live in j = 10..15), in place
+NEEDLE_HD void dif2_publish(int t, cd *lds, const cd *r) {
+  const int o = dif2_base(t);
+#pragma unroll
+  for (int j = 10; j < 16; j++) lds_put(lds, o + j, r[out16(j)]);
+}
+
+// stage 2 with the publish stores streamed out the same way (j = 12, 13 are outputs of tails 0 and 1, j = 10, 14 of
+// tail 2, j = 11, 15 of tail 3)
+template <int MODE = 0>
+NEEDLE_HD void dif2_streamed(int t, cd *lds, cd *r) {
+  constexpr bool P = (MODE & kPlainFft) != 0;
+  const int o = dif2_base(t);
+#pragma unroll
+  for (int k = 0; k < 16; k++) r[k] = lds_get(lds, o + k);
+  fft16_head(r);
+  fft16_tail<0, NoHook, P>(r);
+  fft16_tail<1, NoHook, P>(r);
+  if (MODE & kStoreSpaced) {
+    struct Hook2 {
       int o; cd *lds; const cd *r;
       NEEDLE_HD void operator()(int i) const {
         if (i == 1) lds_put(lds, o + 12, r[3]);
@@ -435,15 +419,19 @@ NEEDLE_HD void dif2(int t, const double *row2, cd *lds, cd *r) {
         if (i == 3) lds_put(lds, o + 14, r[11]);
       }
     };
-    fft16_tail<2>(r, Hook23{o, lds, r});
-    fft16_tail<3>(r, Hook3{o, lds, r});
+    fft16_tail<2, Hook2, P>(r, Hook2{o, lds, r});
+    fft16_tail<3, Hook3, P>(r, Hook3{o, lds, r});
     lds_put(lds, o + 11, r[14]);
     lds_put(lds, o + 15, r[15]);
   } else {
-    fft16_tail<2>(r);
-    fft16_tail<3>(r);
-#pragma unroll
-    for (int j = 10; j < 16; j++) lds_put(lds, o + j, r[out16(j)]);
+    lds_put(lds, o + 12, r[3]);
+    lds_put(lds, o + 13, r[7]);
+    fft16_tail<2, NoHook, P>(r);
+    lds_put(lds, o + 10, r[10]);
+    lds_put(lds, o + 14, r[11]);
+    fft16_tail<3, NoHook, P>(r);
+    lds_put(lds, o + 11, r[14]);
+    lds_put(lds, o + 15, r[15]);
   }
 }
 
@@ -456,45 +444,21 @@ NEEDLE_HD void dif_partner_load(int t, const cd *lds, cd *y) {
 
 // ---- Hamming window by recurrence -------------------------------------------------------------------------------
 // chromaprint's window is w[n] = (0.54 - 0.46 cos(theta n)) / 32767, theta = 2 pi / 4095.  A thread needs it at
-// n = t + 256 k, k = 0..15.  With c_k = cos(theta (t + 256 k)): c_{k+s} = 2 cos(256 s theta) c_k - c_{k-s}, one fused
-// multiply-add per value, and one more for A - B cos: two instructions per sample instead of an 8-byte load per
-// sample from a 32 KB table that every workgroup re-read for every frame pair (measured: 6 % of the kernel).  The first
-// layer of stage 0 consumes the inputs column by column (k = n2, n2 + 4, n2 + 8, n2 + 12), so the recurrence runs in
-// two levels: from the per-thread seeds (c_0, c_-1) six steps of stride 1 give c_1..c_3 and c_-2..c_-4, then each column
-// takes three steps of stride 4 -- the sixteen values are never alive together.  The recurrence stays within 1e-14
-// (relative) of the table values.
+// n = t + 256 k, k = 0..15: cos(theta (t + 256 (k + 1))) = 2 cos(256 theta) cos(theta (t + 256 k)) -
+// cos(theta (t + 256 (k - 1))), one fused multiply-add per step from two per-thread starting values, and one more
+// for A - B cos: two instructions per sample instead of an 8-byte load per sample from a 32 KB table that every
+// workgroup re-read for every frame pair (measured: 6 % of the kernel).  Over 16 steps the recurrence stays
+// within 8e-15 (relative) of the table values.
 struct WindowConst {
-  double k1;    // 2 cos(256 theta)
-  double k4;    // 2 cos(1024 theta)
+  double k2;    // 2 cos(256 theta)
   double a, b;  // w = a - b cos(theta n); both carry kPairInputScale / 32767
 };
-inline WindowConst make_window_const(long double theta, double scale) {
-  WindowConst wc;
-  wc.k1 = (double)(2.0L * cosl(256.0L * theta));
-  wc.k4 = (double)(2.0L * cosl(1024.0L * theta));
-  wc.a = scale * (0.54 / 32767.0);
-  wc.b = scale * (0.46 / 32767.0);
-  return wc;
-}
-// cs[i] = c_i (i = 0..3), cm[i] = c_{i-4} from the seeds c_0, c_-1
-NEEDLE_HD void window_seeds(const WindowConst &wc, double c0, double cm1, double *cs, double *cm) {
-  cs[0] = c0;
-  cm[3] = cm1;
-  cs[1] = fmad(wc.k1, cs[0], -cm[3]);
-  cs[2] = fmad(wc.k1, cs[1], -cs[0]);
-  cs[3] = fmad(wc.k1, cs[2], -cs[1]);
-  cm[2] = fmad(wc.k1, cm[3], -cs[0]);
-  cm[1] = fmad(wc.k1, cm[2], -cm[3]);
-  cm[0] = fmad(wc.k1, cm[1], -cm[2]);
-}
-// the window at k = N2, N2 + 4, N2 + 8, N2 + 12
-template <int N2>
-NEEDLE_HD void window_col(const WindowConst &wc, const double *cs, const double *cm, double *w4) {
-  const double c0 = cs[N2], c4 = fmad(wc.k4, c0, -cm[N2]), c8 = fmad(wc.k4, c4, -c0), c12 = fmad(wc.k4, c8, -c4);
-  w4[0] = fmad(-wc.b, c0, wc.a);
-  w4[1] = fmad(-wc.b, c4, wc.a);
-  w4[2] = fmad(-wc.b, c8, wc.a);
-  w4[3] = fmad(-wc.b, c12, wc.a);
+NEEDLE_HD double window_step(const WindowConst &wc, double *c, double *c_prev) {
+  const double w = __builtin_fma(-wc.b, *c, wc.a);
+  const double next = __builtin_fma(wc.k2, *c, -*c_prev);
+  *c_prev = *c;
+  *c = next;
+  return w;
 }
 
 // The transform's inputs carry this factor (it is folded into the window table), so that the split of Z into the
@@ -591,11 +555,15 @@ inline bool build_power_layout(const uint8_t *class_of_bin, PowerLayout *out) {
 // One fold lane's share of its class: `count` positions from slot `base`, 17 slots apart, both frames at once (x =
 // frame A, y = frame B); reads beyond the count fetch the zero slot.  Split into the loads and the sums so the kernel
 // can put other work between them.
-NEEDLE_HD void class_lane_load(const cd *lds, uint32_t fold_entry, cd *v) {
+template <int FROM, int TO>
+NEEDLE_HD void class_lane_load_part(const cd *lds, uint32_t fold_entry, cd *v) {  // v[i - FROM], i = FROM..TO-1
   const int base = (int)(fold_entry & 0xffffu), count = (int)(fold_entry >> 16);
 #pragma unroll
-  for (int i = 0; i < kClassLaneMax; i++)
-    v[i] = lds_get(lds, (i < kClassLaneMin || i < count) ? base + 17 * i : kPowerZeroSlot);
+  for (int i = FROM; i < TO; i++)
+    v[i - FROM] = lds_get(lds, (i < kClassLaneMin || i < count) ? base + 17 * i : kPowerZeroSlot);
+}
+NEEDLE_HD void class_lane_load(const cd *lds, uint32_t fold_entry, cd *v) {
+  class_lane_load_part<0, kClassLaneMax>(lds, fold_entry, v);
 }
 NEEDLE_HD cd class_lane_add(const cd *v) {
   cd acc = v[0];

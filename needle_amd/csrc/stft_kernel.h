@@ -80,20 +80,19 @@ struct PairSrc {
 //   4  EXTRA workgroup barrier between the publish stores and the partner reads (the round-1 schedule had one)
 //   8  barrier 3 (power stores -> fold reads) -> wave fence
 //  16  round-1 order: all butterflies of a stage, then all its stores; barrier 1 after the first butterflies
-//  32  each tail's four stores right behind it (bursts of four) instead of spaced under the next tail
-//  64  twiddles on the producer side (outputs multiplied by running powers of W^t / W^{16 n0} before they are stored;
-//      the round-1 arithmetic) instead of folded into the consumer's first layer; needs the `tw` table
-enum : int { kLabNoB1 = 1, kLabNoB2 = 2, kLabExtraB = 4, kLabNoB3 = 8, kLabSerial = 16, kLabBursts = 32, kLabOutTw = 64 };
+//  32  the stores of a tail spaced out under the next tail (fp_core.h kStoreSpaced) instead of right behind their own
+//  64  round-1 arithmetic in the 16-point transforms (168 instead of 144 instructions each)
+enum : int { kLabNoB1 = 1, kLabNoB2 = 2, kLabExtraB = 4, kLabNoB3 = 8, kLabSerial = 16, kLabSpaced = 32, kLabPlainFft = 64 };
 
 template <int CH, int LAB = 0>
 __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__restrict__ pcm,
                                                              const FpStream *__restrict__ streams, int num_streams,
-                                                             const double *__restrict__ tw_rows,
+                                                             const cd *__restrict__ tw,
                                                              const double *__restrict__ wcos, core::WindowConst wconst,
                                                              const uint16_t *__restrict__ bin_slot,
                                                              const uint32_t *__restrict__ fold_tab,
                                                              double *__restrict__ chroma, uint32_t total_pairs,
-                                                             uint32_t pairs_per_block, const cd *__restrict__ tw = nullptr) {
+                                                             uint32_t pairs_per_block) {
   extern __shared__ cd lds[];  // core::kLds2Slots complex slots
   using raw_t = typename std::conditional<CH == 1, int16_t, int>::type;  // one sample, or one packed L|R pair
   const int t = threadIdx.x;
@@ -108,20 +107,7 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   const uint32_t first = logical * pairs_per_block;
   const uint32_t last = min(total_pairs, first + pairs_per_block);
   if (first >= last) return;
-  // this thread's twiddle constants for stages 1 and 2 (fp_core.h build_twiddle_rows): 60 loop-invariant doubles, the
-  // bulk of the register budget
-  double row1[core::kTwRow], row2[core::kTwRow];
-  cd pw0[16], pw1[16];  // LAB & kLabOutTw only
-  if (LAB & kLabOutTw) {
-    core::twiddle_powers(tw[t], pw0);
-    core::twiddle_powers(tw[16 * (t & 15)], pw1);
-  } else {
-#pragma unroll
-    for (int i = 0; i < core::kTwRow; i++) {
-      row1[i] = tw_rows[(size_t)t * 2 * core::kTwRow + i];
-      row2[i] = tw_rows[(size_t)t * 2 * core::kTwRow + core::kTwRow + i];
-    }
-  }
+  const cd base0 = tw[t], base1 = tw[16 * (t & 15)];  // W_4096^t, W_4096^{16 n0}: loop-invariant twiddle bases
 
   // ---- loop invariants of this thread, packed so they cost few registers --------------------------------------
   // where the powers of its six bins (register j of stage 2) go in the class-sorted LDS image
@@ -142,10 +128,9 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     }
     // its share of the pitch-class fold: 12 classes x 16 lanes (one DPP row per class), each lane both frames
     // fp_core.h PowerLayout: first slot | positions << 16; the fourth wave has no class: "no positions from slot 0"
-    // (its kClassLaneMin unconditional reads fetch live spectrum values, the rest the zero slot; nothing is stored)
     inv.w[3] = folds ? fold_tab[t] : 0u;
     core::lds_put_words(lds, core::kThreadSlot0 + t, inv);
-    // window recurrence (fp_core.h window_seeds), seeded per thread with cos(theta t) and cos(theta (t - 256))
+    // window recurrence (fp_core.h window_step), seeded per thread with cos(theta t) and cos(theta (t - 256))
     core::lds_put(lds, core::thread_pad_slot(t), cd{wcos[t + 256], wcos[t]});
     if (t == 0) core::lds_put(lds, core::kPowerZeroSlot, cd{0.0, 0.0});  // first read after the loop's barriers
   }
@@ -184,20 +169,20 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
       rb[k] = (reg_t)qb[tt + 256 * k];
     }
   };
-  // The pitch-class fold of a pair runs one pair late, in front of the next pair's sample conversion.  It is
-  // branch-free: the fourth wave, which owns no class, reads the zero slot and adds zeros like the others (its entry
-  // says "no positions") -- a divergent region around the loads and another around the sums made the register
-  // allocator spill the loaded values between them; only the final store is conditional.
-  auto fold = [&](uint32_t fold_entry, const PairSrc &p, int tt) {  // tt: the opaque copy of t
-    cd fv[core::kClassLaneMax];
-    core::class_lane_load(lds, fold_entry, fv);
-    cd acc = core::class_lane_add(fv);
+  // The pitch-class fold of a pair runs one pair late, interleaved with the next pair's sample conversion, in two
+  // halves (five reads, eight samples, five reads, eight samples) so that the conversion hides the reads' latency and
+  // the loaded power pairs never take more than 20 registers.  It is branch-free: the fourth wave, which owns no
+  // class, reads spectrum values and the zero slot and adds them like the others -- divergent regions around the loads
+  // and around the sums made the register allocator spill the loaded values between them.  Only the store is
+  // conditional.
+  constexpr int kFoldHalf = core::kClassLaneMax / 2;
+  auto fold_tree_store = [&](cd acc, const PairSrc &p, int tt, bool store) {  // tt: the opaque copy of t
     // fixed-order tree over the class's 16 lanes (fp_core.h class_tree_partner)
     acc = cd{acc.x + dpp_f64<0xB1>(acc.x), acc.y + dpp_f64<0xB1>(acc.y)};    // quad_perm [1,0,3,2]
     acc = cd{acc.x + dpp_f64<0x4E>(acc.x), acc.y + dpp_f64<0x4E>(acc.y)};    // quad_perm [2,3,0,1]
     acc = cd{acc.x + dpp_f64<0x141>(acc.x), acc.y + dpp_f64<0x141>(acc.y)};  // row_half_mirror
     acc = cd{acc.x + dpp_f64<0x140>(acc.x), acc.y + dpp_f64<0x140>(acc.y)};  // row_mirror
-    if ((tt & 15) == 0 && tt < kBands * core::kClassLanes) {
+    if (store && (tt & 15) == 0 && tt < kBands * core::kClassLanes) {
       double *out = chroma + p.row * kBands;  // uniform base + a 32-bit lane offset
       const uint32_t c = (uint32_t)tt >> 4;
       out[c] = acc.x;
@@ -214,11 +199,9 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     asm volatile("" : "+v"(tt));
     const cd seeds = core::lds_get(lds, core::thread_pad_slot(tt));
     const uint32_t fold_entry = core::lds_get_words(lds, core::kThreadSlot0 + tt).w[3];
-    // sample conversion, window and the first layer of stage 0, column by column (fp_core.h head_col_win)
     cd r[16];
-    double cs[4], cm[4];
-    core::window_seeds(wconst, seeds.x, seeds.y, cs, cm);
-    auto sample = [&](int k) {
+    double wc = seeds.x, wc_prev = seeds.y;
+    auto convert = [&](int k) {
       int sa, sb;
       if (CH == 1) {
         sa = ra[k];
@@ -227,47 +210,48 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
         sa = ((int)(int16_t)ra[k] + (ra[k] >> 16)) / 2;
         sb = ((int)(int16_t)rb[k] + (rb[k] >> 16)) / 2;
       }
-      return cd{(double)sa, (double)sb};
+      const double w = core::window_step(wconst, &wc, &wc_prev);
+      r[k] = cd{(double)sa * w, (double)sb * w};
     };
-    if (!cur.has_b) {  // odd frame count: the stream's last pair has no frame B (uniform, rare branch)
+    {
+      cd fv[kFoldHalf];
+      core::class_lane_load_part<0, kFoldHalf>(lds, fold_entry, fv);
 #pragma unroll
-      for (int k = 0; k < 16; k++) rb[k] = 0;
+      for (int k = 0; k < 8; k++) convert(k);
+      cd acc = fv[0];
+#pragma unroll
+      for (int i = 1; i < kFoldHalf; i++) acc = core::cadd(acc, fv[i]);
+      core::class_lane_load_part<kFoldHalf, core::kClassLaneMax>(lds, fold_entry, fv);
+#pragma unroll
+      for (int k = 8; k < 16; k++) convert(k);
+#pragma unroll
+      for (int i = 0; i < core::kClassLaneMax - kFoldHalf; i++) acc = core::cadd(acc, fv[i]);
+      fold_tree_store(acc, prev, tt, g != first);
     }
-    auto column = [&](auto n2) {
-      constexpr int N2 = decltype(n2)::value;
-      double w4[4];
-      core::window_col<N2>(wconst, cs, cm, w4);
-      core::head_col_win<N2>(r, w4, sample(N2), sample(4 + N2), sample(8 + N2), sample(12 + N2));
-    };
-    // the previous pair's fold ends before the columns start: its ten loaded power pairs and the sixteen values the
-    // columns build up would not fit the register file together (the window seeds above hide part of the reads'
-    // latency)
-    if (g != first) fold(fold_entry, prev, tt);
-    column(std::integral_constant<int, 0>{});
-    column(std::integral_constant<int, 1>{});
-    column(std::integral_constant<int, 2>{});
-    column(std::integral_constant<int, 3>{});
+    if (!cur.has_b) {  // odd frame count: the stream's last pair has no frame B (uniform branch)
+#pragma unroll
+      for (int k = 0; k < 16; k++) r[k].y = 0.0;
+    }
     // In-place decimation-in-frequency stages; which exchanges need a workgroup barrier: fp_core.h.  The stores of
     // a stage are issued tail by tail (fp_core.h dif_tail_store) so that the LDS pipeline, whose 128-bit stores cost
     // 13 cycles each, drains them under the arithmetic that follows instead of in a burst in front of a barrier.
     if (LAB & kLabSerial) {
-      core::fft16_tail<0>(r); core::fft16_tail<1>(r); core::fft16_tail<2>(r); core::fft16_tail<3>(r);
+      core::fft16(r);
       if (!(LAB & kLabNoB1)) lds_barrier();
-#pragma unroll
-      for (int j = 0; j < 16; j++) core::lds_put(lds, core::dif0_base(tt) + 272 * j, r[core::out16(j)]);
+      core::dif0_store(tt, base0, lds, r);
       if (!(LAB & kLabNoB2)) lds_barrier(); else wave_lds_fence();
-      core::dif1<0>(tt, row1, lds, r);
+      core::dif1(tt, base1, lds, r);
       wave_lds_fence();
-      core::dif2<0>(tt, row2, lds, r);
+      core::dif2(tt, lds, r);
+      core::dif2_publish(tt, lds, r);
     } else {
       if (!(LAB & kLabNoB1)) lds_barrier();  // every thread has read its share of the previous pair's powers
-      const cd *const p0 = (LAB & kLabOutTw) ? pw0 : nullptr, *const p1 = (LAB & kLabOutTw) ? pw1 : nullptr;
-      if (LAB & kLabBursts) core::dif0_tails<1>(tt, lds, r, p0); else core::dif0_tails(tt, lds, r, p0);
+      constexpr int kMode = ((LAB & kLabSpaced) ? core::kStoreSpaced : 0) | ((LAB & kLabPlainFft) ? core::kPlainFft : 0);
+      core::dif0_streamed<kMode>(tt, base0, lds, r);
       if (!(LAB & kLabNoB2)) lds_barrier(); else wave_lds_fence();
-      if (LAB & kLabBursts) core::dif1<1>(tt, row1, lds, r, p1); else core::dif1(tt, row1, lds, r, p1);
-      wave_lds_fence();                  // stage 1 -> 2 stays inside 16 consecutive lanes
-      // r[out16(j)] = Z[bin b + 16 (t & 15) + 256 j]; publishes j = 10..15
-      core::dif2(tt, (LAB & kLabOutTw) ? nullptr : row2, lds, r);
+      core::dif1_streamed<kMode>(tt, base1, lds, r);
+      wave_lds_fence();                // stage 1 -> 2 stays inside 16 consecutive lanes
+      core::dif2_streamed<kMode>(tt, lds, r);  // r[out16(j)] = Z[bin b + 16 (t & 15) + 256 j]; publishes j = 10..15
     }
     // publish -> partner reads stays inside the wave (fp_core.h group_k0)
     if (LAB & kLabExtraB) lds_barrier(); else wave_lds_fence();
@@ -290,7 +274,11 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     prev = cur;
     cur = nxt;
   }
-  fold(core::lds_get_words(lds, core::kThreadSlot0 + t).w[3], prev, t);
+  {
+    cd fv[core::kClassLaneMax];
+    core::class_lane_load(lds, core::lds_get_words(lds, core::kThreadSlot0 + t).w[3], fv);
+    fold_tree_store(core::class_lane_add(fv), prev, t, true);
+  }
 }
 
 }  // namespace stft

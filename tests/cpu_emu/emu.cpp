@@ -42,7 +42,9 @@ const Tables &tables() {
   const long double theta = 2.0L * 3.14159265358979323846264338327950288L / 4095.0L;
   t.wcos.resize(512);
   for (int i = 0; i < 512; i++) t.wcos[i] = (double)cosl(theta * (long double)(i - 256));
-  t.wconst = make_window_const(theta, kPairInputScale);
+  t.wconst.k2 = (double)(2.0L * cosl(256.0L * theta));
+  t.wconst.a = kPairInputScale * (0.54 / 32767.0);
+  t.wconst.b = kPairInputScale * (0.46 / 32767.0);
   std::vector<uint8_t> class_of_bin(kNumBins);
   for (int i = kMinBin; i < kMaxBin; i++) {
     double freq = (double)i * 11025 / 4096;
@@ -71,19 +73,15 @@ void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, do
     if (channels == 1) return src[n];
     return ((int)src[2 * n] + (int)src[2 * n + 1]) / 2;
   };
-  std::vector<double> rows(256 * 2 * kTwRow);
-  for (int t = 0; t < 256; t++) build_twiddle_rows(T.tw.data(), t, &rows[t * 2 * kTwRow], &rows[t * 2 * kTwRow + kTwRow]);
   for (int t = 0; t < 256; t++) {
-    double cs[4], cm[4], w4[4];
-    window_seeds(T.wconst, T.wcos[t + 256], T.wcos[t], cs, cm);
-    auto x = [&](int k) { return cd{(double)sample(fa, t + 256 * k), (double)sample(fb, t + 256 * k)}; };
-    cd *r = &regs[t * 16];
-    window_col<0>(T.wconst, cs, cm, w4); head_col_win<0>(r, w4, x(0), x(4), x(8), x(12));
-    window_col<1>(T.wconst, cs, cm, w4); head_col_win<1>(r, w4, x(1), x(5), x(9), x(13));
-    window_col<2>(T.wconst, cs, cm, w4); head_col_win<2>(r, w4, x(2), x(6), x(10), x(14));
-    window_col<3>(T.wconst, cs, cm, w4); head_col_win<3>(r, w4, x(3), x(7), x(11), x(15));
-    dif0_tails(t, lds.data(), r);
+    double c = T.wcos[t + 256], c_prev = T.wcos[t];
+    for (int k = 0; k < 16; k++) {
+      const int n = t + 256 * k;
+      const double w = window_step(T.wconst, &c, &c_prev);
+      regs[t * 16 + k] = cd{(double)sample(fa, n) * w, (double)sample(fb, n) * w};
+    }
   }
+  for (int t = 0; t < 256; t++) dif0_streamed(t, T.tw[t], lds.data(), &regs[t * 16]);
   // ---- workgroup barrier (stage-0 stores -> stage-1 reads).  From here to the next barrier (power image complete)
   // the kernel has only wave-level ordering: a wave may run through ALL of stage 1, stage 2, publish, partner reads
   // and power stores while another has not started stage 1.  The waves are therefore run to completion one after the
@@ -101,8 +99,8 @@ void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, do
       const int w = dir ? 3 - wi : wi;
       for (int grp = 3; grp >= 0; grp--) {
         const int t0 = 64 * w + 16 * grp;
-        for (int t = t0; t < t0 + 16; t++) dif1(t, &rows[t * 2 * kTwRow], lds.data(), &regs[t * 16]);
-        for (int t = t0; t < t0 + 16; t++) dif2(t, &rows[t * 2 * kTwRow + kTwRow], lds.data(), &regs[t * 16]);
+        for (int t = t0; t < t0 + 16; t++) dif1_streamed(t, T.tw[16 * (t & 15)], lds.data(), &regs[t * 16]);
+        for (int t = t0; t < t0 + 16; t++) dif2_streamed(t, lds.data(), &regs[t * 16]);
       }
       // wave fence; partner reads and power stores interleaved thread by thread inside the wave, both directions
       for (int i = 0; i < 64; i++) {

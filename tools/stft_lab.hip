@@ -26,7 +26,6 @@ struct Lab {
   uint32_t total_pairs = 0;
   int16_t *d_pcm = nullptr;
   stft::FpStream *d_streams = nullptr;
-  double *d_tw_rows = nullptr;
   cd *d_tw = nullptr;
   double *d_wcos = nullptr, *d_chroma = nullptr;
   core::WindowConst wconst;
@@ -63,7 +62,9 @@ static void setup(Lab &L) {
   const long double theta = 2.0L * 3.14159265358979323846264338327950288L / 4095.0L;
   std::vector<double> wcos(512);
   for (int i = 0; i < 512; i++) wcos[i] = (double)cosl(theta * (long double)(i - 256));
-  L.wconst = core::make_window_const(theta, core::kPairInputScale);
+  L.wconst.k2 = (double)(2.0L * cosl(256.0L * theta));
+  L.wconst.a = core::kPairInputScale * (0.54 / 32767.0);
+  L.wconst.b = core::kPairInputScale * (0.46 / 32767.0);
   std::vector<uint8_t> class_of_bin(core::kNumBins);
   for (int i = core::kMinBin; i < core::kMaxBin; i++) {
     double freq = (double)i * 11025 / 4096;
@@ -75,18 +76,14 @@ static void setup(Lab &L) {
   if (!core::build_power_layout(class_of_bin.data(), &layout)) { std::fprintf(stderr, "power layout does not fit\n"); std::exit(1); }
   CK(hipMalloc(&L.d_pcm, pcm.size() * 2));
   CK(hipMalloc(&L.d_streams, st.size() * sizeof(stft::FpStream)));
-  std::vector<double> rows((size_t)256 * 2 * core::kTwRow);
-  for (int th = 0; th < 256; th++) core::build_twiddle_rows(tw.data(), th, &rows[(size_t)th * 2 * core::kTwRow], &rows[(size_t)th * 2 * core::kTwRow + core::kTwRow]);
-  CK(hipMalloc(&L.d_tw_rows, rows.size() * 8));
   CK(hipMalloc(&L.d_tw, 4096 * sizeof(cd)));
-  CK(hipMemcpy(L.d_tw, tw.data(), 4096 * sizeof(cd), hipMemcpyHostToDevice));
   CK(hipMalloc(&L.d_wcos, 512 * 8));
   CK(hipMalloc(&L.d_chroma, (size_t)L.eps * (L.frames + 1) * 12 * 8));
   CK(hipMalloc(&L.d_bin_slot, sizeof(layout.bin_slot)));
   CK(hipMalloc(&L.d_fold_tab, sizeof(layout.fold)));
   CK(hipMemcpy(L.d_pcm, pcm.data(), pcm.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(L.d_streams, st.data(), st.size() * sizeof(stft::FpStream), hipMemcpyHostToDevice));
-  CK(hipMemcpy(L.d_tw_rows, rows.data(), rows.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMemcpy(L.d_tw, tw.data(), 4096 * sizeof(cd), hipMemcpyHostToDevice));
   CK(hipMemcpy(L.d_wcos, wcos.data(), 512 * 8, hipMemcpyHostToDevice));
   CK(hipMemcpy(L.d_bin_slot, layout.bin_slot, sizeof(layout.bin_slot), hipMemcpyHostToDevice));
   CK(hipMemcpy(L.d_fold_tab, layout.fold, sizeof(layout.fold), hipMemcpyHostToDevice));
@@ -115,8 +112,8 @@ static void launch_variant(Lab &L, uint32_t grid, size_t lds, uint32_t ppb) {
     attr = true;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, L.d_pcm, L.d_streams, L.eps, L.d_tw_rows, L.d_wcos, L.wconst,
-                     L.d_bin_slot, L.d_fold_tab, L.d_chroma, L.total_pairs, ppb, L.d_tw);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, L.d_pcm, L.d_streams, L.eps, L.d_tw, L.d_wcos, L.wconst,
+                     L.d_bin_slot, L.d_fold_tab, L.d_chroma, L.total_pairs, ppb);
 }
 
 static void time_once(Lab &L, Variant &v, bool record) {
@@ -160,9 +157,9 @@ int main(int argc, char **argv) {
       {"no barrier 2 (stage-0 stores -> stage-1 reads)", launch_variant<kLabNoB2>, false, 16, 0},
       {"no barrier 3 (power stores -> fold reads)", launch_variant<kLabNoB3>, false, 16, 0},
       {"no workgroup barrier at all", launch_variant<kLabNoB1 | kLabNoB2 | kLabNoB3>, false, 16, 0},
-      {"stores in bursts of four behind each tail", launch_variant<kLabBursts>, true, 16, 0},
-      {"twiddles on the producer side (round-1 arithmetic)", launch_variant<kLabOutTw>, true, 16, 0},
-      {"producer-side twiddles, stores in bursts", launch_variant<kLabOutTw | kLabBursts>, true, 16, 0},
+      {"stores spaced out under the next tail", launch_variant<kLabSpaced>, true, 16, 0},
+      {"round-1 arithmetic in the 16-point transforms", launch_variant<kLabPlainFft>, true, 16, 0},
+      {"round-1 arithmetic, stores spaced", launch_variant<kLabPlainFft | kLabSpaced>, true, 16, 0},
       {"product, 8 pairs per workgroup", launch_variant<0>, true, 8, 0},
       {"product, 32 pairs per workgroup", launch_variant<0>, true, 32, 0},
   };
