@@ -233,9 +233,10 @@ enum NeedleError needle_hip_library_use_hash_arena(NeedleHipLibrary *library, ui
                                                    size_t stride);
 size_t needle_hip_library_num_pairs(const NeedleHipLibrary *library);
 /* Runs of pairs [first_pair, first_pair+num_pairs) into caller-provided device buffers
- * (NeedleHipRun.problem = global pair index * comparator regions + region).  A sequence must fit the scan's LDS
- * staging: at most ~39 000 hashes per search window in the default kernels (2.7 h of audio at step 1, 5.3 h at the
- * default step 2); longer windows fail with NeedleError_InvalidArgument. */
+ * (NeedleHipRun.problem = global pair index * comparator regions + region).  The fast scan kernels stage a pair's
+ * destination window in LDS: up to ~39 000 hashes (2.7 h of audio at step 1, 5.3 h at the default step 2).  Pairs
+ * with a longer window are scanned from HBM by a slower kernel in the same call; nothing fails (the reference has no
+ * bound). */
 enum NeedleError needle_hip_library_search(NeedleHipLibrary *library, const struct NeedleAudioComparator *comparator,
                                            size_t first_pair, size_t num_pairs, NeedleHipRun *d_runs,
                                            uint32_t capacity, uint32_t *d_count, bool sync);

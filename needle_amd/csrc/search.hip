@@ -52,9 +52,14 @@ struct SearchProblem {
 };
 
 // One workgroup = 256 consecutive diagonals of one problem; both sequences staged in LDS.
+// STAGED = false: the sequences are read where they lie in HBM (lanes of a wave read consecutive destination hashes,
+// the source hash of a row is the same for all): the path for a pair too long for the LDS of the faster kernels
+// (a window of more than ~2.7 h of audio), which must not fail the whole library's search.  `first_problem` = index
+// of problems[0] in the launch's table (what the emitted run carries until simhash_runs_kernel swaps in the tag).
+template <bool STAGED>
 __global__ __launch_bounds__(256) void hamming_runs_kernel(const uint32_t *__restrict__ hashes,
                                                            const SearchProblem *__restrict__ problems,
-                                                           int num_problems, uint32_t threshold,
+                                                           int num_problems, uint32_t first_problem, uint32_t threshold,
                                                            NeedleHipRun *__restrict__ runs, uint32_t capacity,
                                                            uint32_t *__restrict__ count) {
   extern __shared__ uint32_t lds[];
@@ -66,10 +71,14 @@ __global__ __launch_bounds__(256) void hamming_runs_kernel(const uint32_t *__res
   }
   const SearchProblem pr = problems[lo];
   const int n = (int)pr.n, m = (int)pr.m;
-  uint32_t *s = lds, *t = lds + n;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) s[i] = hashes[pr.src_off + i];
-  for (int j = threadIdx.x; j < m; j += blockDim.x) t[j] = hashes[pr.dst_off + j];
-  __syncthreads();
+  const uint32_t *s = hashes + pr.src_off, *t = hashes + pr.dst_off;
+  if (STAGED) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = s[i];
+    for (int j = threadIdx.x; j < m; j += blockDim.x) lds[n + j] = t[j];
+    __syncthreads();
+    s = lds;
+    t = lds + n;
+  }
 
   // diagonals d = j - i with at least one cell i>=1, j>=1: d in [-(n-2), m-2]
   const int dd = (int)(blockIdx.x - pr.block_base) * kDiagsPerBlock + (int)threadIdx.x;
@@ -87,14 +96,16 @@ __global__ __launch_bounds__(256) void hamming_runs_kernel(const uint32_t *__res
     } else {
       if (run >= min_len) {  // run ended at the previous cell
         const uint32_t slot = atomicAdd(count, 1u);
-        if (slot < capacity) runs[slot] = NeedleHipRun{(uint32_t)lo, (uint32_t)(i - 1), (uint32_t)(i - 1 + d), run, 0u, 0u};
+        if (slot < capacity)
+          runs[slot] = NeedleHipRun{first_problem + (uint32_t)lo, (uint32_t)(i - 1), (uint32_t)(i - 1 + d), run, 0u, 0u};
       }
       run = 0;
     }
   }
   if (run >= min_len) {  // run reaches the table edge (i == n-1 or j == m-1, comparator.rs:197)
     const uint32_t slot = atomicAdd(count, 1u);
-    if (slot < capacity) runs[slot] = NeedleHipRun{(uint32_t)lo, (uint32_t)i_hi, (uint32_t)(i_hi + d), run, 0u, 0u};
+    if (slot < capacity)
+      runs[slot] = NeedleHipRun{first_problem + (uint32_t)lo, (uint32_t)i_hi, (uint32_t)(i_hi + d), run, 0u, 0u};
   }
 }
 
@@ -469,7 +480,9 @@ struct SearchPlan {
   std::vector<NeedleHipSeq> seqs;          // inputs ...
   std::vector<NeedleHipProblem> problems;
   int mode[3] = {0, 0, 0};                 // ... and the environment switches that steer the choice
-  std::vector<SearchProblem> meta;         // derived
+  std::vector<SearchProblem> meta;         // derived: the pairs the chosen kernel can stage, then the oversize ones
+  size_t staged = 0;                       // how many of meta go to the chosen kernel
+  uint64_t oversize_blocks = 0;            // grid of the unstaged kernel over meta[staged..]
   uint64_t blocks = 0;
   size_t lds_bytes = 0;
   bool sampled = false, fast = false;
@@ -489,7 +502,6 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
   meta.clear();
   meta.reserve(num_problems);
   uint64_t blocks = 0;
-  size_t max_lds = 0;
   for (size_t p = 0; p < num_problems; p++) {
     const NeedleHipProblem &pr = problems[p];
     if (pr.src_seq >= num_seqs || pr.dst_seq >= num_seqs)
@@ -504,52 +516,68 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     m.m = b.len;
     m.min_len = pr.min_len;
     m.tag = pr.tag;
-    m.block_base = (uint32_t)blocks;
+    m.block_base = 0;
     m.pad = 0;
-    const uint64_t diags = (uint64_t)a.len + b.len - 3;
-    blocks += (diags + kDiagsPerBlock - 1) / kDiagsPerBlock;
-    max_lds = std::max(max_lds, ((size_t)a.len + b.len) * sizeof(uint32_t));
     meta.push_back(m);
   }
-  if (blocks > 0x7FFFFFFFull) return Status::Make(NeedleError_InvalidArgument, "hamming_runs: too many problems for one launch");
+  plan->staged = 0;
+  plan->oversize_blocks = 0;
   if (!meta.empty()) {
     // The band kernel needs min_len >= its checkpoint spacing for every problem; otherwise (tiny minimum
     // durations) the general one-lane-per-diagonal kernel handles the launch.
     uint32_t smallest = 0xFFFFFFFFu;
-    size_t max_m = 0;
-    for (const SearchProblem &m : meta) {
-      smallest = std::min(smallest, m.min_len);
-      max_m = std::max<size_t>(max_m, m.m);
-    }
+    for (const SearchProblem &m : meta) smallest = std::min(smallest, m.min_len);
     const bool generic_only = mode[0] != 0;
     const bool sampled = !generic_only && smallest >= (uint32_t)(2 * kSampleW - 1 + 8) && mode[1] == 0;
     const bool fast = !generic_only && !sampled && smallest >= (uint32_t)(kBandR * kBandU);
-    size_t lds_bytes = max_lds;
+    // What a pair needs in LDS under the chosen kernel.  A pair beyond the CU's 160 KiB (a window of more than ~2.7 h
+    // of audio at step 1) goes to the end of the table and is scanned from HBM by the unstaged kernel: one such
+    // video must not fail the search of the whole library (the reference has no bound).
+    size_t lds_limit = 160 * 1024;
+    if (const char *e = getenv("NEEDLE_HIP_SEARCH_LDS_LIMIT")) lds_limit = (size_t)std::max(1, atoi(e));  // tests
+    auto lds_need = [&](const SearchProblem &m) {
+      return ((fast || sampled) ? (size_t)m.m + 2 * kBandB : (size_t)m.n + m.m) * sizeof(uint32_t);
+    };
+    std::stable_partition(meta.begin(), meta.end(), [&](const SearchProblem &m) { return lds_need(m) <= lds_limit; });
+    size_t staged = 0;
+    while (staged < meta.size() && lds_need(meta[staged]) <= lds_limit) staged++;
+    size_t lds_bytes = 0;
     int bands_per_wave = 1;
     if (fast || sampled) {
       uint64_t fb = 0, total_bands = 0;
-      size_t need = 0;
-      for (const SearchProblem &m : meta) total_bands += ((uint64_t)m.n + m.m - 3 + kBandB - 1) / kBandB;
+      for (size_t i = 0; i < staged; i++) total_bands += ((uint64_t)meta[i].n + meta[i].m - 3 + kBandB - 1) / kBandB;
       // enough workgroups to fill the chip several times over with one band per wave; beyond that, more bands
       // per wave so that each workgroup's staging of the destination sequence serves more of its pair
-      bands_per_wave = 1;
       if (sampled)
         while (bands_per_wave < 8 && total_bands / (4 * (uint64_t)bands_per_wave * 2) >= 16384) bands_per_wave *= 2;
       if (mode[2] > 0) bands_per_wave = mode[2];  // NEEDLE_HIP_BANDS_PER_WAVE: tests, tuning
-      for (SearchProblem &m : meta) {
+      for (size_t i = 0; i < staged; i++) {
+        SearchProblem &m = meta[i];
         m.block_base = (uint32_t)fb;
         const uint64_t diags = (uint64_t)m.n + m.m - 3;
         const uint64_t bands = (diags + kBandB - 1) / kBandB;
         const uint64_t per_block = 4 * (uint64_t)(sampled ? bands_per_wave : 1);
         fb += (bands + per_block - 1) / per_block;
-        need = std::max<size_t>(need, (size_t)m.m + 2 * kBandB);
+        lds_bytes = std::max(lds_bytes, lds_need(m));
       }
       blocks = fb;
-      lds_bytes = need * sizeof(uint32_t);
+    } else {
+      for (size_t i = 0; i < staged; i++) {
+        SearchProblem &m = meta[i];
+        m.block_base = (uint32_t)blocks;
+        blocks += ((uint64_t)m.n + m.m - 3 + kDiagsPerBlock - 1) / kDiagsPerBlock;
+        lds_bytes = std::max(lds_bytes, lds_need(m));
+      }
     }
-    if (lds_bytes > 160 * 1024)
-      return Status::Make(NeedleError_InvalidArgument,
-                          "hamming_runs: a sequence pair exceeds the 160 KiB LDS staging limit (~40000 hashes)");
+    uint64_t ob = 0;
+    for (size_t i = staged; i < meta.size(); i++) {  // one workgroup = 256 consecutive diagonals, as in the staged form
+      meta[i].block_base = (uint32_t)ob;
+      ob += ((uint64_t)meta[i].n + meta[i].m - 3 + kDiagsPerBlock - 1) / kDiagsPerBlock;
+    }
+    if (blocks > 0x7FFFFFFFull || ob > 0x7FFFFFFFull)
+      return Status::Make(NeedleError_InvalidArgument, "hamming_runs: too many problems for one launch");
+    plan->staged = staged;
+    plan->oversize_blocks = ob;
     plan->sampled = sampled;
     plan->fast = fast;
     plan->bands_per_wave = bands_per_wave;
@@ -612,7 +640,7 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
         !(s = ws->upload.put(&ws->problems, &ws->stage, meta, stream)).ok())
       return s;
     if (lds_bytes > 64 * 1024 && !ws->lds_attr_set) {
-      NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_kernel),
+      NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_kernel<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_band_kernel<kBandR, kBandU>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -620,21 +648,27 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       ws->lds_attr_set = true;
     }
-    {
+    const int staged = (int)plan.staged, oversize = (int)(meta.size() - plan.staged);
+    if (staged > 0) {
       KernelTimer timer("hamming_runs");
       if (sampled) {
         int sparse_max = kSparseMax;
         if (const char *e = getenv("NEEDLE_HIP_SPARSE_MAX")) sparse_max = std::max(0, atoi(e));  // tests, tuning: 0 = row by row
         hipLaunchKernelGGL((hamming_runs_sampled_kernel<kBandR, kSampleW>), dim3((uint32_t)blocks), dim3(256),
-                           lds_bytes, stream, d_hashes, ws->problems.ptr, (int)meta.size(), threshold, d_runs,
+                           lds_bytes, stream, d_hashes, ws->problems.ptr, staged, threshold, d_runs,
                            capacity, d_count, bands_per_wave, sparse_max);
       }
       else if (fast)
         hipLaunchKernelGGL((hamming_runs_band_kernel<kBandR, kBandU>), dim3((uint32_t)blocks), dim3(256), lds_bytes,
-                           stream, d_hashes, ws->problems.ptr, (int)meta.size(), threshold, d_runs, capacity, d_count);
+                           stream, d_hashes, ws->problems.ptr, staged, threshold, d_runs, capacity, d_count);
       else
-        hipLaunchKernelGGL(hamming_runs_kernel, dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
-                           ws->problems.ptr, (int)meta.size(), threshold, d_runs, capacity, d_count);
+        hipLaunchKernelGGL(hamming_runs_kernel<true>, dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
+                           ws->problems.ptr, staged, 0u, threshold, d_runs, capacity, d_count);
+    }
+    if (oversize > 0) {  // pairs too long to stage: scanned from HBM, behind the others in the table
+      KernelTimer timer("hamming_runs_unstaged");
+      hipLaunchKernelGGL(hamming_runs_kernel<false>, dim3((uint32_t)plan.oversize_blocks), dim3(256), 0, stream, d_hashes,
+                         ws->problems.ptr + staged, oversize, (uint32_t)staged, threshold, d_runs, capacity, d_count);
     }
     {
       KernelTimer timer("simhash_runs");
