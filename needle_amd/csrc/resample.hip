@@ -27,6 +27,7 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 namespace needle {
 
@@ -43,6 +44,11 @@ struct Design {
   int n = 0;                // lanes (outputs L apart) that share a phase within a tile
   std::vector<float> coef;  // [L][T]
   float *d_coef = nullptr;  // [4 shifts][L][4 G]: row a holds coef[phase][k - a] at k, zero elsewhere
+  // the same rows for resample_quad_kernel: [4 shifts][L][row_len] 16-byte groups, quad_pad zero groups in front and
+  // zeros behind, so that a row may be read from kQuadPad groups before its start to `steps` groups past it
+  float *d_coefq = nullptr;
+  void *d_quad_info = nullptr;  // [ceil(L / 4)] QuadInfo (resample_quad_kernel)
+  int row_len = 0, steps = 0, quad_pad = 0, delta = 0;
 };
 
 double bessel_i0(double x) {
@@ -297,6 +303,258 @@ __global__ __launch_bounds__(kThreads) void resample_kernel(const int16_t *__res
     if (tile_base + i < st.n_out) out[st.out_off + tile_base + i] = out_tile[i];
 }
 
+// ---- row layout, four consecutive outputs per lane ------------------------------------------------------------------
+// The kernel above reads two 16-byte LDS operands per four FMAs and runs one serial FMA chain per lane: it is bound by
+// the LDS pipeline and by the latency of that chain.  Here a lane computes FOUR CONSECUTIVE outputs 4 u + q (q = 0..3)
+// of its row.  Their windows start ~M/L samples apart (4.35 at 48 kHz), so one aligned 16-byte read of the row serves
+// all four: output q multiplies it by its own coefficient row, shifted by the whole groups d_q and the 0..3 samples a_q
+// its first tap lies past the first group of the common window (zero coefficients in front and behind leave an
+// accumulator unchanged, so the result is bit-identical).  The 16 lanes of a DPP row work on the same quad u of 16
+// different rows (outputs L apart: same four phases), so the coefficients need no LDS at all: lane i of the row loads
+// group 16 b + i of each of the four coefficient rows from the table, and step 16 b + i of every lane takes them from
+// lane i as the DPP row broadcast operand of v_fmac_f32.  Per 16 FMAs: one LDS read instead of eight, four independent
+// chains, and no per-wave copy of coefficient rows.
+constexpr int kQuadRows = 16;   // rows (outputs L apart) per tile = lanes of a DPP row
+
+#define NEEDLE_FMAC_BCAST(N)                                                                                      \
+  template <>                                                                                                    \
+  __device__ __forceinline__ void fmac_bcast<N>(float &acc, float c, float x) {                                  \
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:" #N " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(c), "v"(x)); \
+  }
+// acc += (c of lane N of this 16-lane row) * x
+template <int N>
+__device__ __forceinline__ void fmac_bcast(float &acc, float c, float x);
+NEEDLE_FMAC_BCAST(0) NEEDLE_FMAC_BCAST(1) NEEDLE_FMAC_BCAST(2) NEEDLE_FMAC_BCAST(3) NEEDLE_FMAC_BCAST(4)
+NEEDLE_FMAC_BCAST(5) NEEDLE_FMAC_BCAST(6) NEEDLE_FMAC_BCAST(7) NEEDLE_FMAC_BCAST(8) NEEDLE_FMAC_BCAST(9)
+NEEDLE_FMAC_BCAST(10) NEEDLE_FMAC_BCAST(11) NEEDLE_FMAC_BCAST(12) NEEDLE_FMAC_BCAST(13) NEEDLE_FMAC_BCAST(14)
+NEEDLE_FMAC_BCAST(15)
+#undef NEEDLE_FMAC_BCAST
+// The compiler does not see the DPP reads inside an asm statement, so it inserts no wait states between whatever last
+// wrote the coefficient registers (or EXEC) and the first of them: one s_nop 4 in front of every block of steps,
+// tied to the registers so that it cannot be moved away from them.
+__device__ __forceinline__ void dpp_wait_states(float4 (&c)[4]) {
+  asm volatile("s_nop 4"
+               : "+v"(c[0].x), "+v"(c[0].y), "+v"(c[0].z), "+v"(c[0].w), "+v"(c[1].x), "+v"(c[1].y), "+v"(c[1].z), "+v"(c[1].w),
+                 "+v"(c[2].x), "+v"(c[2].y), "+v"(c[2].z), "+v"(c[2].w), "+v"(c[3].x), "+v"(c[3].y), "+v"(c[3].z), "+v"(c[3].w));
+}
+template <int N, bool PLAIN = false>
+__device__ __forceinline__ void quad_step(const float4 (&c)[4], float4 x, float (&acc)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    if (PLAIN) {
+      acc[q] = fmaf(c[q].x, x.x, acc[q]); acc[q] = fmaf(c[q].y, x.y, acc[q]);
+      acc[q] = fmaf(c[q].z, x.z, acc[q]); acc[q] = fmaf(c[q].w, x.w, acc[q]);
+    } else {
+      fmac_bcast<N>(acc[q], c[q].x, x.x);
+      fmac_bcast<N>(acc[q], c[q].y, x.y);
+      fmac_bcast<N>(acc[q], c[q].z, x.z);
+      fmac_bcast<N>(acc[q], c[q].w, x.w);
+    }
+  }
+}
+
+// Measured on the first version of this kernel (profiles/r02_resample_lab.log): staging alone 0.19 ms, arithmetic
+// alone 0.45 ms, together 0.75 ms -- they ADD, although two workgroups share a CU, because the staging was bound by
+// its own integer arithmetic (64-bit index clamps and divisions per group) on the same SIMDs, not by HBM.  Neither
+// persistent workgroups with a start skew (0.92 ms) nor prefetching the next tile into registers (128 VGPRs, one
+// workgroup per CU: 1.26 ms) helped.  Hence: tiles that lie wholly inside their stream take a staging path with no
+// clamps and 32-bit offsets from a uniform base, and what a quad needs (first group, the four coefficient rows and
+// their shifts) comes from a table built on the host instead of four integer divisions per lane.
+// LAB (timing experiments through NEEDLE_HIP_RESAMPLE_LAB, results wrong): 1 no staging, 2 no FMA loop, 4 plain
+// v_fmac_f32 instead of the DPP form
+constexpr int kQuadGroupsInFlight = 6;  // 16-byte loads a thread keeps in flight while staging by groups
+constexpr int kQuadMaxRounds = 2;       // rounds of quads per tile (L <= 4 * 64 * 2 = 512 at 1024 threads)
+
+struct QuadInfo {     // per quad u of a row (outputs 4 u .. 4 u + 3), the same for every row and tile
+  uint32_t b0;        // first 16-byte group of the common window, from the start of the row
+  uint32_t coef[4];   // group offset into the padded coefficient table of output q's row, shift and delay applied
+};
+
+// four down-mixed samples of one aligned group as it lies in memory
+template <int CH>
+__device__ __forceinline__ float4 group_to_f32(typename std::conditional<CH == 1, int2, int4>::type v) {
+  int s0, s1, s2, s3;
+  if constexpr (CH == 1) {
+    s0 = (int16_t)v.x; s1 = v.x >> 16; s2 = (int16_t)v.y; s3 = v.y >> 16;
+  } else {  // integer down-mix (L + R) / 2, C truncation
+    s0 = ((int)(int16_t)v.x + (v.x >> 16)) / 2; s1 = ((int)(int16_t)v.y + (v.y >> 16)) / 2;
+    s2 = ((int)(int16_t)v.z + (v.z >> 16)) / 2; s3 = ((int)(int16_t)v.w + (v.w >> 16)) / 2;
+  }
+  return float4{(float)s0, (float)s1, (float)s2, (float)s3};
+}
+
+// SMALL: at most 640 threads (L <= 160), compiled for at least five waves per SIMD = two workgroups per CU (forcing 64 VGPRs for three costs spills: 0.76 ms against 0.68).
+template <int CH, bool VEC4, bool SMALL, int LAB = 0>
+__global__ __launch_bounds__(SMALL ? 640 : 1024, SMALL ? 5 : 4) void resample_quad_kernel(
+    const int16_t *__restrict__ in, const RsStream *__restrict__ streams, int num_streams,
+    const float4 *__restrict__ coefq, const QuadInfo *__restrict__ quad_info, RsGeom geo, int steps,
+    uint32_t skew_blocks, int skew_unit, int16_t *__restrict__ out) {
+  extern __shared__ float4 lds4[];  // kQuadRows rows of samples | the tile's outputs (s16)
+  // Every tile takes the same time, so the workgroups that start together (the first ones of a launch, two per CU)
+  // would stage together -- HBM saturated, the SIMDs idle -- and then compute together, HBM idle, and every later
+  // workgroup inherits that rhythm from the slot it takes over.  The first `skew_blocks` workgroups therefore start
+  // 0..3 units late (a quarter of a tile's time each, chosen by a hash of the block index): at any moment some
+  // workgroups of the device are staging and some computing.
+  if (blockIdx.x < skew_blocks && skew_unit > 0) {
+    const uint32_t late = (blockIdx.x * 2654435761u) >> 30;
+    for (uint32_t i = 0; i < late * (uint32_t)skew_unit; i++) __builtin_amdgcn_s_sleep(127);
+  }
+  float *stage = reinterpret_cast<float *>(lds4);
+  using raw_t = typename std::conditional<CH == 1, int2, int4>::type;  // four samples as they lie in memory
+  const int L = geo.L, M = geo.M;
+  int lo = 0, hi = num_streams - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (streams[mid].block_base <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const RsStream st = streams[lo];
+  const int tile_outputs = kQuadRows * L;
+  const uint64_t tile = blockIdx.x - st.block_base;
+  const uint64_t tile_base = tile * (uint64_t)tile_outputs;
+  const int half = geo.T / 2;
+  // input index of region[0]: the first tap of the tile's first output, moved down by delta to a multiple of 4
+  const long long first0 = (long long)(tile * (uint64_t)kQuadRows * (uint64_t)M) - half + 1 - geo.delta;
+  const int16_t *src = in + st.in_off;
+  const int tpr = blockDim.x / kQuadRows, row = threadIdx.x / tpr, me = threadIdx.x % tpr;
+  const int count = M + 4 * steps + 8;  // samples of a row that some lane may read
+  const int groups = (count + 3) >> 2;
+  // the tile's outputs are collected in LDS for a coalesced copy to HBM, over the START of the sample region once every
+  // lane has finished reading it (a barrier more, 4.7 KB of LDS less: three workgroups per CU at 48 kHz instead of two)
+  int16_t *out_tile = reinterpret_cast<int16_t *>(lds4);
+
+  auto sample = [&](long long idx) -> int {  // one down-mixed input sample, 0 outside the stream (branch-free load)
+    const bool ok = idx >= 0 && (uint64_t)idx < st.n_in;
+    const long long at = idx < 0 ? 0 : ((uint64_t)idx < st.n_in ? idx : (long long)st.n_in - 1);
+    int sv;
+    if (CH == 1) {
+      sv = src[at];
+    } else {
+      const int v = reinterpret_cast<const int *>(src)[at];
+      sv = ((int)(int16_t)v + (v >> 16)) / 2;  // integer down-mix, C truncation
+    }
+    return ok ? sv : 0;
+  };
+  // ---- staging: row r = its own M samples and the overlap into the next rows, as f32 ------------------------------
+  if (!(LAB & 1)) {
+    const bool by_groups = VEC4 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && st.n_in >= 4;
+    const long long tile_last = first0 + (long long)(kQuadRows - 1) * M + 4 * (long long)groups;  // one past the last sample staged
+    if (by_groups && first0 >= 0 && tile_last <= (long long)st.n_in) {
+      // the tile lies inside the stream (all but the first and last tiles of a stream): a uniform base, 32-bit
+      // offsets, no clamps
+      const raw_t *base = reinterpret_cast<const raw_t *>(src + (size_t)CH * first0);  // first0 is a multiple of 4
+      const uint32_t row_groups = (uint32_t)(row * M) >> 2;                             // M is a multiple of 4 (VEC4)
+      float4 *dst = lds4 + geo.pitch * row;
+      for (int o0 = me; o0 < groups; o0 += tpr * kQuadGroupsInFlight) {
+        raw_t v[kQuadGroupsInFlight];
+#pragma unroll
+        for (int u = 0; u < kQuadGroupsInFlight; u++) v[u] = base[row_groups + (uint32_t)min(o0 + u * tpr, groups - 1)];
+#pragma unroll
+        for (int u = 0; u < kQuadGroupsInFlight; u++)
+          if (o0 + u * tpr < groups) dst[o0 + u * tpr] = group_to_f32<CH>(v[u]);
+      }
+    } else if (by_groups) {  // a tile that sticks out of its stream: clamped loads, then the groups outside sample by sample
+      float4 *dst = lds4 + geo.pitch * row;
+      const long long from = first0 + (long long)row * M;
+      const long long last_group = ((long long)st.n_in - 4) & ~3ll;  // last aligned group wholly inside the stream
+      for (int o = me; o < groups; o += tpr) {
+        const long long idx = from + 4 * (long long)o;
+        if (idx < 0 || idx > last_group)
+          dst[o] = float4{(float)sample(idx), (float)sample(idx + 1), (float)sample(idx + 2), (float)sample(idx + 3)};
+        else
+          dst[o] = group_to_f32<CH>(*reinterpret_cast<const raw_t *>(src + (size_t)CH * idx));
+      }
+    } else {  // unaligned stream or M not a multiple of 4: sample by sample, eight loads in flight
+      float *dst = stage + 4 * geo.pitch * row;
+      const long long from = first0 + (long long)row * M;
+      constexpr int kU = 8;
+      int o = me;
+      for (; o + (kU - 1) * tpr < count; o += tpr * kU) {
+        int v[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) v[u] = sample(from + o + u * tpr);
+#pragma unroll
+        for (int u = 0; u < kU; u++) dst[o + u * tpr] = (float)v[u];
+      }
+      for (; o < count; o += tpr) dst[o] = (float)sample(from + o);
+    }
+  }
+  __syncthreads();
+
+  // ---- quads: DPP row dr of the workgroup takes quad u = round * rows + dr; lane j of the row takes row j ----------
+  const int quads = (L + 3) >> 2, dpp_rows = blockDim.x >> 4;
+  const int j = threadIdx.x & 15, dr = threadIdx.x >> 4;
+  const int nblk = (LAB & 2) ? 0 : (steps + 15) >> 4;
+  const bool last_half = (steps & 15) != 0;  // steps is a multiple of 8: the last block may have 8 steps only
+  int16_t res[kQuadMaxRounds][4] = {};
+  for (int u0 = 0; u0 < quads; u0 += dpp_rows) {
+    const int u = u0 + dr;
+    const bool live = u < quads;           // uniform per DPP row, not per wave: dead rows compute and store nothing
+    const QuadInfo qi = quad_info[live ? u : quads - 1];
+    const float4 *cptr[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) cptr[q] = coefq + qi.coef[q] + j;
+    const float4 *xs = lds4 + j * geo.pitch + qi.b0;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 c[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) c[q] = cptr[q][0];
+    for (int b = 0; b < nblk; b++) {
+      float4 cn[4];
+      const int nb = b + 1 < nblk ? 16 * (b + 1) : 16 * b;  // (the last block re-reads its own groups: no branch)
+#pragma unroll
+      for (int q = 0; q < 4; q++) cn[q] = cptr[q][nb];
+      const float4 *x = xs + 16 * b;
+      dpp_wait_states(c);
+      quad_step<0, (LAB & 4) != 0>(c, x[0], acc);
+      quad_step<1, (LAB & 4) != 0>(c, x[1], acc);
+      quad_step<2, (LAB & 4) != 0>(c, x[2], acc);
+      quad_step<3, (LAB & 4) != 0>(c, x[3], acc);
+      quad_step<4, (LAB & 4) != 0>(c, x[4], acc);
+      quad_step<5, (LAB & 4) != 0>(c, x[5], acc);
+      quad_step<6, (LAB & 4) != 0>(c, x[6], acc);
+      quad_step<7, (LAB & 4) != 0>(c, x[7], acc);
+      if (!(last_half && b + 1 == nblk)) {
+        quad_step<8, (LAB & 4) != 0>(c, x[8], acc);
+        quad_step<9, (LAB & 4) != 0>(c, x[9], acc);
+        quad_step<10, (LAB & 4) != 0>(c, x[10], acc);
+        quad_step<11, (LAB & 4) != 0>(c, x[11], acc);
+        quad_step<12, (LAB & 4) != 0>(c, x[12], acc);
+        quad_step<13, (LAB & 4) != 0>(c, x[13], acc);
+        quad_step<14, (LAB & 4) != 0>(c, x[14], acc);
+        quad_step<15, (LAB & 4) != 0>(c, x[15], acc);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) c[q] = cn[q];
+    }
+    // results of this round, kept in registers until every lane is done with the sample region (rounds <= kMaxRounds)
+    const int rd = u0 / dpp_rows;
+#pragma unroll
+    for (int k = 0; k < kQuadMaxRounds; k++)
+      if (k == rd) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          float r = rintf(acc[q]);
+          res[k][q] = (int16_t)fminf(fmaxf(r, -32768.0f), 32767.0f);
+        }
+      }
+  }
+  __syncthreads();  // the sample region is dead: its start becomes the output tile
+#pragma unroll
+  for (int k = 0; k < kQuadMaxRounds; k++) {
+    const int u = k * dpp_rows + dr;
+    if (u < quads) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int o = 4 * u + q;
+        if (o < L && tile_base + (uint64_t)o + (uint64_t)L * j < st.n_out) out_tile[o + L * j] = res[k][q];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < tile_outputs; i += blockDim.x)
+    if (tile_base + i < st.n_out) out[st.out_off + tile_base + i] = out_tile[i];
+}
+
 }  // namespace
 
 size_t resample_out_len(size_t n_in, int rate) {
@@ -347,9 +605,49 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
             shifted[((size_t)a * d->L + p) * 4 * d->G + k + a] = d->coef[(size_t)p * d->T + k];
       NEEDLE_HIP_TRY(hipMalloc((void **)&d->d_coef, shifted.size() * sizeof(float)));
       NEEDLE_HIP_TRY(hipMemcpy(d->d_coef, shifted.data(), shifted.size() * sizeof(float), hipMemcpyHostToDevice));
+      // resample_quad_kernel: the first taps of a lane's four outputs lie up to span = ceil(3 M / L) samples apart, 3
+      // more for the alignment of the first and 3 for a row's shift
+      const int span = (3 * d->M + d->L - 1) / d->L;
+      d->steps = (((d->T + span + 6 + 3) / 4) + 7) & ~7;
+      d->quad_pad = (span + 3) / 4 + 1;
+      d->row_len = d->quad_pad + std::max(d->G, d->steps) + 16;
+      std::vector<float> padded((size_t)4 * d->L * 4 * d->row_len, 0.f);
+      for (int a = 0; a < 4; a++)
+        for (int p = 0; p < d->L; p++)
+          for (int k = 0; k < d->T; k++)
+            padded[((size_t)a * d->L + p) * 4 * d->row_len + 4 * d->quad_pad + k + a] = d->coef[(size_t)p * d->T + k];
+      NEEDLE_HIP_TRY(hipMalloc((void **)&d->d_coefq, padded.size() * sizeof(float)));
+      NEEDLE_HIP_TRY(hipMemcpy(d->d_coefq, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
+      // per quad: where its common window starts and which (shifted, delayed) coefficient row each output reads
+      d->delta = d->M % 4 == 0 ? ((1 - d->T / 2) % 4 + 4) % 4 : 0;
+      const int quads = (d->L + 3) / 4;
+      std::vector<QuadInfo> info((size_t)quads);
+      for (int u = 0; u < quads; u++) {
+        int b0 = 0;
+        for (int q = 0; q < 4; q++) {
+          const int o = std::min(4 * u + q, d->L - 1);
+          const long long pm = (long long)o * d->M;
+          const int cp = (int)(pm / d->L), phase = (int)(pm - (long long)cp * d->L);
+          const int rel = cp + d->delta;
+          if (q == 0) b0 = rel >> 2;
+          const int off = rel - 4 * b0, dq = off >> 2, a = off & 3;
+          info[u].coef[q] = (uint32_t)(((size_t)a * d->L + phase) * d->row_len + (size_t)(d->quad_pad - dq));
+        }
+        info[u].b0 = (uint32_t)b0;
+      }
+      NEEDLE_HIP_TRY(hipMalloc(&d->d_quad_info, info.size() * sizeof(QuadInfo)));
+      NEEDLE_HIP_TRY(hipMemcpy(d->d_quad_info, info.data(), info.size() * sizeof(QuadInfo), hipMemcpyHostToDevice));
     }
   }
-  const uint64_t tile_outputs = (uint64_t)d->n * d->L;
+  // Decimation steps of 64 samples or more use the row layout; there the kernel with four consecutive outputs per
+  // lane applies (NEEDLE_HIP_RESAMPLE_V1 forces the first kernel: tests and A/B timing).
+  const int quad_pitch = ((d->M + 4 * d->steps + 8 + 3) / 4) | 1;
+  const size_t quad_lds = (size_t)kQuadRows * quad_pitch * 16;  // (the output tile reuses the start of the region)
+  const int quad_threads = std::min(1024, ((16 * ((d->L + 3) / 4) + 63) / 64) * 64);
+  const bool quad = d->M >= kRowModeMinM && d->L >= 4 && quad_lds <= 160 * 1024 &&
+                    (size_t)kQuadRows * d->L * 2 <= quad_lds &&
+                    (d->L + 3) / 4 <= kQuadMaxRounds * (quad_threads / 16) && getenv("NEEDLE_HIP_RESAMPLE_V1") == nullptr;
+  const uint64_t tile_outputs = quad ? (uint64_t)kQuadRows * d->L : (uint64_t)d->n * d->L;
   std::vector<RsStream> meta;
   uint64_t blocks = 0;
   for (const ResampleSpan &sp : spans) {
@@ -379,6 +677,69 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
     w.second->mark(stream);
     RsGeom geo;
     geo.L = d->L; geo.M = d->M; geo.T = d->T; geo.G = d->G;
+    if (quad) {
+      geo.n_log2 = 4;
+      geo.pitch = quad_pitch;
+      geo.region_slots = kQuadRows * quad_pitch;
+      const bool vec4 = d->M % 4 == 0;
+      geo.delta = d->delta;
+      const void *variants[13] = {reinterpret_cast<const void *>(resample_quad_kernel<1, false, false>),
+                                  reinterpret_cast<const void *>(resample_quad_kernel<1, true, false>),
+                                  reinterpret_cast<const void *>(resample_quad_kernel<2, false, false>),
+                                  reinterpret_cast<const void *>(resample_quad_kernel<2, true, false>),
+                                  reinterpret_cast<const void *>(resample_quad_kernel<1, false, true>),
+                                  reinterpret_cast<const void *>(resample_quad_kernel<1, true, true>),
+                                  reinterpret_cast<const void *>(resample_quad_kernel<2, false, true>),
+                                  reinterpret_cast<const void *>(resample_quad_kernel<2, true, true>),
+                                  reinterpret_cast<const void *>(resample_quad_kernel<2, true, true, 1>),
+                                  reinterpret_cast<const void *>(resample_quad_kernel<2, true, true, 2>),
+                                  reinterpret_cast<const void *>(resample_quad_kernel<2, true, true, 3>),
+                                  reinterpret_cast<const void *>(resample_quad_kernel<2, true, true, 4>),
+                                  reinterpret_cast<const void *>(resample_quad_kernel<2, true, true, 5>)};
+      static std::map<int, size_t> quad_attr;  // largest dynamic LDS size announced per device
+      if (quad_attr[dev] < quad_lds) {
+        for (const void *fn : variants)
+          NEEDLE_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)quad_lds));
+        quad_attr[dev] = quad_lds;
+      }
+      // one DPP row (16 lanes) per quad of a row's outputs, whole waves, at most 1024 threads
+      const int threads = quad_threads;
+      // start skew (see the kernel): the workgroups resident at first, in units of s_sleep 127 = 8 128 cycles
+      int cus = 256;
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      const uint32_t skew_blocks = (uint32_t)std::max(cus, 1) * (quad_lds <= 80 * 1024 ? 2u : 1u);
+      int skew_unit = blocks > 2 * (uint64_t)skew_blocks ? 1 : 0;
+      if (const char *e = getenv("NEEDLE_HIP_RESAMPLE_SKEW")) skew_unit = std::max(0, atoi(e));  // tuning
+      KernelTimer timer("resample");
+      const float4 *coefq = reinterpret_cast<const float4 *>(d->d_coefq);
+      auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(threads), quad_lds, stream, d_in, w.first->ptr,
+                           (int)meta.size(), coefq, static_cast<const QuadInfo *>(d->d_quad_info), geo, d->steps, skew_blocks,
+                           skew_unit, d_out);
+      };
+      const int lab = getenv("NEEDLE_HIP_RESAMPLE_LAB") ? atoi(getenv("NEEDLE_HIP_RESAMPLE_LAB")) : 0;
+      const bool small = threads <= 640;
+      if (lab && channels == 2 && vec4 && small) {  // timing experiments (tools/rslab.sh): wrong results on purpose
+        if (lab == 1) launch(resample_quad_kernel<2, true, true, 1>);
+        else if (lab == 2) launch(resample_quad_kernel<2, true, true, 2>);
+        else if (lab == 3) launch(resample_quad_kernel<2, true, true, 3>);
+        else if (lab == 4) launch(resample_quad_kernel<2, true, true, 4>);
+        else launch(resample_quad_kernel<2, true, true, 5>);
+      } else if (channels == 1) {
+        if (vec4 && small) launch(resample_quad_kernel<1, true, true>);
+        else if (vec4) launch(resample_quad_kernel<1, true, false>);
+        else if (small) launch(resample_quad_kernel<1, false, true>);
+        else launch(resample_quad_kernel<1, false, false>);
+      } else {
+        if (vec4 && small) launch(resample_quad_kernel<2, true, true>);
+        else if (vec4) launch(resample_quad_kernel<2, true, false>);
+        else if (small) launch(resample_quad_kernel<2, false, true>);
+        else launch(resample_quad_kernel<2, false, false>);
+      }
+      NEEDLE_HIP_TRY(hipGetLastError());
+      if (sync) NEEDLE_HIP_TRY(hipStreamSynchronize(library_stream()));
+      return Status::Ok();
+    }
     geo.n_log2 = 0;
     while ((1 << geo.n_log2) < d->n) geo.n_log2++;
     const bool row_mode = d->M >= kRowModeMinM && d->n <= kRowModeMaxN;
