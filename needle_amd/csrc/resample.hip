@@ -626,9 +626,10 @@ __global__ __launch_bounds__(THREADS) void resample_dec_kernel(const int16_t *__
   float acc[Q];
 #pragma unroll
   for (int q = 0; q < Q; q++) acc[q] = 0.f;
+  typedef float v4f __attribute__((ext_vector_type(4), aligned(16)));  // one 128-bit LDS read per slot
 #pragma unroll
   for (int s = 0; s < kSteps; s++) {
-    const float4 x = xs[s];
+    const v4f x = *reinterpret_cast<const v4f *>(xs + s);
     const float xv[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
     for (int q = 0; q < Q; q++) {
