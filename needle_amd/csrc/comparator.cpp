@@ -5,9 +5,12 @@
 #include <cmath>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <tuple>
 
@@ -34,6 +37,68 @@ unsigned host_workers(uint64_t work) {  // NEEDLE_HOST_THREADS=1 forces the sequ
   return (work < (1u << 22) || hw <= 1) ? 1u : std::min(hw, 64u);
 }
 
+// Host threads that outlive a call.  A search-only call over a few hundred files is a handful of parallel phases of
+// ~1 ms each (file reads, arena, heap entries, best matches): creating and joining 15 threads per phase cost as much
+// as the phases themselves.  The pool grows to the largest worker count asked for and is never destroyed (its threads
+// sleep on a condition variable; the process may exit underneath them).  One job at a time; a phase that is itself
+// running on a pool thread (nested use) falls back to running inline.
+class HostPool {
+ public:
+  static HostPool &instance() {
+    static HostPool *pool = new HostPool();
+    return *pool;
+  }
+  // runs body() on `workers` threads (the caller included) and returns when all of them have finished
+  void run(unsigned workers, const std::function<void()> &body) {
+    if (workers <= 1 || inside_) {
+      body();
+      return;
+    }
+    std::unique_lock<std::mutex> job_lock(job_mu_);  // one job at a time
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      while (threads_.size() + 1 < workers) threads_.emplace_back(&HostPool::worker, this, threads_.size());
+      body_ = &body;
+      wanted_ = workers - 1;  // pool threads 0 .. wanted_-1 take part
+      running_ = wanted_;
+      generation_++;
+    }
+    wake_.notify_all();
+    body();
+    std::unique_lock<std::mutex> lock(mu_);
+    done_.wait(lock, [&] { return running_ == 0; });
+    body_ = nullptr;
+  }
+
+ private:
+  void worker(size_t index) {
+    inside_ = true;
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void()> *body = nullptr;
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        wake_.wait(lock, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (index < wanted_) body = body_;
+      }
+      if (body) {
+        (*body)();
+        std::lock_guard<std::mutex> lock(mu_);
+        if (--running_ == 0) done_.notify_all();
+      }
+    }
+  }
+  std::mutex job_mu_, mu_;
+  std::condition_variable wake_, done_;
+  std::vector<std::thread> threads_;
+  const std::function<void()> *body_ = nullptr;
+  size_t wanted_ = 0, running_ = 0;
+  uint64_t generation_ = 0;
+  static thread_local bool inside_;
+};
+thread_local bool HostPool::inside_ = false;
+
 // f(begin, end) over [0, n) in chunks of `grain`, on `workers` threads (this one included)
 template <class F>
 void parallel_chunks(size_t n, size_t grain, unsigned workers, F f) {
@@ -42,13 +107,10 @@ void parallel_chunks(size_t n, size_t grain, unsigned workers, F f) {
     return;
   }
   std::atomic<size_t> next{0};
-  auto body = [&]() {
+  const std::function<void()> body = [&]() {
     for (size_t b = next.fetch_add(grain); b < n; b = next.fetch_add(grain)) f(b, std::min(n, b + grain));
   };
-  std::vector<std::thread> pool;
-  for (unsigned w = 1; w < workers; w++) pool.emplace_back(body);
-  body();
-  for (std::thread &t : pool) t.join();
+  HostPool::instance().run((unsigned)std::min<size_t>(workers, (n + grain - 1) / grain), body);
 }
 
 // distinct_matches (:434-454) as a count: links[a] = #{b : popcount(h[a] ^ h[b]) < bound}, a itself included.
@@ -397,34 +459,65 @@ Status Comparator::run_with_frame_hashes(const std::vector<const FrameHashesData
   const size_t n = fh.size();
   const size_t regions = include_endings_ ? 2 : 1;
   EpilogueTrace trace;
-  // hash arena: [video][region] sequences back to back
-  std::vector<uint32_t> arena;
+  // hash arena: [video][region] sequences back to back; filled, and the minimum run lengths derived, on host threads
   std::vector<NeedleHipSeq> seqs(n * regions);
   std::vector<uint32_t> min_len(n * regions, 0);
-  for (size_t v = 0; v < n; v++) {
+  uint64_t total = 0;
+  for (size_t v = 0; v < n; v++)
     for (size_t r = 0; r < regions; r++) {
       const std::vector<HashTs> &seq = r == 0 ? fh[v]->opening : fh[v]->ending;
-      seqs[v * regions + r] = NeedleHipSeq{(uint32_t)arena.size(), (uint32_t)seq.size()};
-      for (const HashTs &h : seq) arena.push_back(h.hash);
-      min_len[v * regions + r] = min_run_length(seq, r == 0 ? min_opening_duration_ : min_ending_duration_);
+      if (total + seq.size() > UINT32_MAX)  // offsets into the arena are 32-bit on the device (NeedleHipSeq.offset)
+        return Status::Make(NeedleError_InvalidArgument, "library too large for one search call: more than 2^32 hashes or sequence pairs");
+      seqs[v * regions + r] = NeedleHipSeq{(uint32_t)total, (uint32_t)seq.size()};
+      total += seq.size();
     }
-  }
+  std::vector<uint32_t> arena(total);
+  const unsigned workers = host_workers(total * 16);
+  parallel_chunks(n, 8, workers, [&](size_t v0, size_t v1) {
+    for (size_t v = v0; v < v1; v++)
+      for (size_t r = 0; r < regions; r++) {
+        const std::vector<HashTs> &seq = r == 0 ? fh[v]->opening : fh[v]->ending;
+        uint32_t *dst = arena.data() + seqs[v * regions + r].offset;
+        for (size_t k = 0; k < seq.size(); k++) dst[k] = seq[k].hash;
+        min_len[v * regions + r] = min_run_length(seq, r == 0 ? min_opening_duration_ : min_ending_duration_);
+      }
+  });
   const size_t np = pair_count(n);
-  // offsets into the arena and problem tags are 32-bit on the device (NeedleHipSeq.offset, NeedleHipProblem.tag)
-  if (arena.size() > UINT32_MAX || np * regions > UINT32_MAX)
+  if (np * regions > UINT32_MAX)  // problem tags are 32-bit on the device (NeedleHipProblem.tag)
     return Status::Make(NeedleError_InvalidArgument, "library too large for one search call: more than 2^32 hashes or sequence pairs");
+  if (include_endings_)
+    for (size_t v = 0; v < n && n > 1; v++)
+      if (fh[v]->ending.empty())  // :271-273; the caller unwrap()s (every video is in some pair)
+        return Status::Make(NeedleError_Unknown, "no ending hash data present");
+  // (i, j) in the reference's i-major order (:537-545).  A pair one of whose sequences can hold no run long enough is
+  // left out; when there is none such (the usual case) slot p * regions + r of the table is known up front and the
+  // table is filled on host threads.
   std::vector<NeedleHipProblem> problems;
-  problems.reserve(np * regions);
-  for (size_t p = 0, i = 0, j = 1; p < np; p++) {  // (i, j) in the reference's i-major order (:537-545)
-    if (include_endings_ && (fh[i]->ending.empty() || fh[j]->ending.empty()))  // :271-273; the caller unwrap()s
-      return Status::Make(NeedleError_Unknown, "no ending hash data present");
-    for (size_t r = 0; r < regions; r++) {
-      const uint32_t a = min_len[i * regions + r], b = min_len[j * regions + r];
-      if (a == 0 || b == 0) continue;  // no run of this pair can satisfy the duration test
-      problems.push_back(NeedleHipProblem{(uint32_t)(i * regions + r), (uint32_t)(j * regions + r), std::max(a, b),
-                                          (uint32_t)(p * regions + r)});
+  const bool dense = std::find(min_len.begin(), min_len.end(), 0u) == min_len.end();
+  if (dense) {
+    problems.resize(np * regions);
+    parallel_chunks(np, 8192, host_workers((uint64_t)np * 256), [&](size_t p0, size_t p1) {
+      size_t i, j;
+      pair_at(n, p0, &i, &j);
+      for (size_t p = p0; p < p1; p++) {
+        for (size_t r = 0; r < regions; r++)
+          problems[p * regions + r] = NeedleHipProblem{(uint32_t)(i * regions + r), (uint32_t)(j * regions + r),
+                                                       std::max(min_len[i * regions + r], min_len[j * regions + r]),
+                                                       (uint32_t)(p * regions + r)};
+        if (++j == n) j = ++i + 1;
+      }
+    });
+  } else {
+    problems.reserve(np * regions);
+    for (size_t p = 0, i = 0, j = 1; p < np; p++) {
+      for (size_t r = 0; r < regions; r++) {
+        const uint32_t a = min_len[i * regions + r], b = min_len[j * regions + r];
+        if (a == 0 || b == 0) continue;  // no run of this pair can satisfy the duration test
+        problems.push_back(NeedleHipProblem{(uint32_t)(i * regions + r), (uint32_t)(j * regions + r), std::max(a, b),
+                                            (uint32_t)(p * regions + r)});
+      }
+      if (++j == n) j = ++i + 1;
     }
-    if (++j == n) j = ++i + 1;
   }
   trace.lap("arena + pair table", problems.size());
   std::vector<NeedleHipRun> runs;
