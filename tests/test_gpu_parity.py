@@ -580,8 +580,10 @@ def test_resampler_bit_exact_and_analyzer_accepts_decode_rates(tmp_path):
     # 44.1k: contiguous LDS layout, one phase; 48k/32k/16k/8k: row layout; 22.05k and 12345: lanes with different tap
     # alignment (coefficients straight from global memory); 96k: longest filter; 11025: identity + down-mix
     # 192k / 176.4k: filters too long for the per-wave coefficient scratch (global-memory coefficient path, fewer rows)
-    for rate, ch in [(44100, 2), (48000, 2), (48000, 1), (22050, 1), (32000, 2), (8000, 1), (11025, 2), (96000, 2),
-                     (16000, 1), (12345, 1), (192000, 2), (176400, 1)]:
+    # round 2: 44.1k / 22.05k take the integer-decimation kernel (scalar coefficients), the row-layout rates the kernel with
+    # four outputs per lane and DPP-broadcast coefficients, 88.2k / 12345 / 192k / 176.4k / 11025 the first kernel
+    for rate, ch in [(44100, 2), (44100, 1), (48000, 2), (48000, 1), (22050, 1), (22050, 2), (32000, 2), (8000, 1),
+                     (11025, 2), (96000, 2), (16000, 1), (12345, 1), (88200, 2), (192000, 2), (176400, 1)]:
         pcms = []
         for n in (0, 1, 777, rate * 3 + 17):
             t = np.arange(n) / rate
