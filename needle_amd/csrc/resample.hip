@@ -388,7 +388,7 @@ __device__ __forceinline__ float4 group_to_f32(typename std::conditional<CH == 1
 template <int CH, bool VEC4, bool SMALL, int LAB = 0>
 __global__ __launch_bounds__(SMALL ? 640 : 1024, SMALL ? 5 : 4) void resample_quad_kernel(
     const int16_t *__restrict__ in, const RsStream *__restrict__ streams, int num_streams,
-    const float4 *__restrict__ coefq, const QuadInfo *__restrict__ quad_info, RsGeom geo, int steps,
+    const float4 *__restrict__ coefq, const QuadInfo *__restrict__ quad_info, RsGeom geo, int steps, int splits,
     uint32_t skew_blocks, int skew_unit, int16_t *__restrict__ out) {
   extern __shared__ float4 lds4[];  // kQuadRows rows of samples | the tile's outputs (s16)
   // Every tile takes the same time, so the workgroups that start together (the first ones of a launch, two per CU)
@@ -410,15 +410,24 @@ __global__ __launch_bounds__(SMALL ? 640 : 1024, SMALL ? 5 : 4) void resample_qu
   }
   const RsStream st = streams[lo];
   const int tile_outputs = kQuadRows * L;
-  const uint64_t tile = blockIdx.x - st.block_base;
+  // A tile (16 rows x L outputs) is cut into `splits` workgroups along its rows: quads [q0, q1) of every row.  A
+  // workgroup then stages a fraction of each row (plus the window overlap) -- smaller workgroups, more of them per CU,
+  // so that some stage while others compute.
+  const int quads = (L + 3) >> 2, quads_per_split = (quads + splits - 1) / splits;
+  const uint32_t in_stream = blockIdx.x - st.block_base;
+  const uint64_t tile = in_stream / (uint32_t)splits;
+  const int q0 = (int)(in_stream % (uint32_t)splits) * quads_per_split, q1 = min(quads, q0 + quads_per_split);
+  if (q0 >= q1) return;
   const uint64_t tile_base = tile * (uint64_t)tile_outputs;
   const int half = geo.T / 2;
-  // input index of region[0]: the first tap of the tile's first output, moved down by delta to a multiple of 4
-  const long long first0 = (long long)(tile * (uint64_t)kQuadRows * (uint64_t)M) - half + 1 - geo.delta;
+  const int g0 = (int)quad_info[q0].b0;  // first group of a row this workgroup reads
+  // input index of region[0]: the first tap of the tile's first output, moved down by delta to a multiple of 4, plus
+  // the groups of a row in front of this workgroup's share
+  const long long first0 = (long long)(tile * (uint64_t)kQuadRows * (uint64_t)M) - half + 1 - geo.delta + 4ll * g0;
   const int16_t *src = in + st.in_off;
   const int tpr = blockDim.x / kQuadRows, row = threadIdx.x / tpr, me = threadIdx.x % tpr;
-  const int count = M + 4 * steps + 8;  // samples of a row that some lane may read
-  const int groups = (count + 3) >> 2;
+  const int groups = (int)quad_info[q1 - 1].b0 - g0 + steps + 2;  // groups of a row that some lane may read
+  const int count = 4 * groups;
   // the tile's outputs are collected in LDS for a coalesced copy to HBM, over the START of the sample region once every
   // lane has finished reading it (a barrier more, 4.7 KB of LDS less: three workgroups per CU at 48 kHz instead of two)
   int16_t *out_tile = reinterpret_cast<int16_t *>(lds4);
@@ -482,19 +491,19 @@ __global__ __launch_bounds__(SMALL ? 640 : 1024, SMALL ? 5 : 4) void resample_qu
   __syncthreads();
 
   // ---- quads: DPP row dr of the workgroup takes quad u = round * rows + dr; lane j of the row takes row j ----------
-  const int quads = (L + 3) >> 2, dpp_rows = blockDim.x >> 4;
+  const int dpp_rows = blockDim.x >> 4;
   const int j = threadIdx.x & 15, dr = threadIdx.x >> 4;
   const int nblk = (LAB & 2) ? 0 : (steps + 15) >> 4;
   const bool last_half = (steps & 15) != 0;  // steps is a multiple of 8: the last block may have 8 steps only
   int16_t res[kQuadMaxRounds][4] = {};
-  for (int u0 = 0; u0 < quads; u0 += dpp_rows) {
+  for (int u0 = q0; u0 < q1; u0 += dpp_rows) {
     const int u = u0 + dr;
-    const bool live = u < quads;           // uniform per DPP row, not per wave: dead rows compute and store nothing
-    const QuadInfo qi = quad_info[live ? u : quads - 1];
+    const bool live = u < q1;              // uniform per DPP row, not per wave: dead rows compute and store nothing
+    const QuadInfo qi = quad_info[live ? u : q1 - 1];
     const float4 *cptr[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) cptr[q] = coefq + qi.coef[q] + j;
-    const float4 *xs = lds4 + j * geo.pitch + qi.b0;
+    const float4 *xs = lds4 + j * geo.pitch + ((int)qi.b0 - g0);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     float4 c[4];
 #pragma unroll
@@ -528,7 +537,7 @@ __global__ __launch_bounds__(SMALL ? 640 : 1024, SMALL ? 5 : 4) void resample_qu
       for (int q = 0; q < 4; q++) c[q] = cn[q];
     }
     // results of this round, kept in registers until every lane is done with the sample region (rounds <= kMaxRounds)
-    const int rd = u0 / dpp_rows;
+    const int rd = (u0 - q0) / dpp_rows;
 #pragma unroll
     for (int k = 0; k < kQuadMaxRounds; k++)
       if (k == rd) {
@@ -539,21 +548,25 @@ __global__ __launch_bounds__(SMALL ? 640 : 1024, SMALL ? 5 : 4) void resample_qu
         }
       }
   }
-  __syncthreads();  // the sample region is dead: its start becomes the output tile
+  __syncthreads();  // the sample region is dead: its start becomes the output tile, [row][output - 4 q0]
+  const int o0 = 4 * q0, seg = min(L, 4 * q1) - o0;  // this workgroup's outputs of a row
 #pragma unroll
   for (int k = 0; k < kQuadMaxRounds; k++) {
-    const int u = k * dpp_rows + dr;
-    if (u < quads) {
+    const int u = q0 + k * dpp_rows + dr;
+    if (u < q1) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int o = 4 * u + q;
-        if (o < L && tile_base + (uint64_t)o + (uint64_t)L * j < st.n_out) out_tile[o + L * j] = res[k][q];
+        if (o < L) out_tile[j * seg + (o - o0)] = res[k][q];
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < tile_outputs; i += blockDim.x)
-    if (tile_base + i < st.n_out) out[st.out_off + tile_base + i] = out_tile[i];
+  for (int i = threadIdx.x; i < kQuadRows * seg; i += blockDim.x) {
+    const int r = i / seg, o = o0 + i - r * seg;
+    const uint64_t m = tile_base + (uint64_t)o + (uint64_t)L * r;
+    if (m < st.n_out) out[st.out_off + m] = out_tile[i];
+  }
 }
 
 // ---- integer decimation (L = 1: 44.1 kHz -> 11.025 kHz and its relatives) -----------------------------------------------
@@ -739,12 +752,22 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
   }
   // Decimation steps of 64 samples or more use the row layout; there the kernel with four consecutive outputs per
   // lane applies (NEEDLE_HIP_RESAMPLE_V1 forces the first kernel: tests and A/B timing).
-  const int quad_pitch = ((d->M + 4 * d->steps + 8 + 3) / 4) | 1;
+  // a tile's rows are cut into `quad_splits` workgroups (see the kernel); the rows of a workgroup: the groups between
+  // the first reads of its first and last quad, the window, two groups of slack
+  // (measured at 48 kHz, 37 quads: 1 / 2 / 3 / 4 / 6 workgroups per tile 0.77 / 0.72 / 0.64 / 0.72 / 0.81 ms: about
+  // 16 quads = 256 threads per workgroup)
+  const int quads_all = (d->L + 3) / 4;
+  int quad_splits = (quads_all + 15) / 16;
+  if (const char *e = getenv("NEEDLE_HIP_RESAMPLE_SPLITS")) quad_splits = std::max(1, atoi(e));  // tuning
+  quad_splits = std::min(quad_splits, quads_all);
+  const int quads_per_split = (quads_all + quad_splits - 1) / quad_splits;
+  const int row_groups = ((quads_per_split - 1) * 4 * d->M + d->L - 1) / d->L / 4 + 2 + d->steps + 2;
+  const int quad_pitch = row_groups | 1;
   const size_t quad_lds = (size_t)kQuadRows * quad_pitch * 16;  // (the output tile reuses the start of the region)
-  const int quad_threads = std::min(1024, ((16 * ((d->L + 3) / 4) + 63) / 64) * 64);
+  const int quad_threads = std::min(1024, ((16 * quads_per_split + 63) / 64) * 64);
   const bool quad = d->M >= kRowModeMinM && d->L >= 4 && quad_lds <= 160 * 1024 &&
-                    (size_t)kQuadRows * d->L * 2 <= quad_lds &&
-                    (d->L + 3) / 4 <= kQuadMaxRounds * (quad_threads / 16) && getenv("NEEDLE_HIP_RESAMPLE_V1") == nullptr;
+                    (size_t)kQuadRows * 4 * quads_per_split * 2 <= quad_lds &&
+                    quads_per_split <= kQuadMaxRounds * (quad_threads / 16) && getenv("NEEDLE_HIP_RESAMPLE_V1") == nullptr;
   // integer decimation by 4 or 2 (44.1 / 22.05 kHz): the kernel with scalar coefficients
   constexpr int kDecThreads = 256;
   const int dec_q = d->L == 1 && d->T == 32 * d->M ? (d->M == 4 ? 5 : d->M == 2 ? 6 : 0) : 0;
@@ -760,7 +783,7 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
     m.n_out = resample_out_len(sp.n_in, rate);
     m.block_base = (uint32_t)blocks;
     m.pad = 0;
-    blocks += (m.n_out + tile_outputs - 1) / tile_outputs;
+    blocks += (m.n_out + tile_outputs - 1) / tile_outputs * (quad && !dec ? (uint64_t)quad_splits : 1);
     if (m.n_out) meta.push_back(m);
   }
   if (blocks > 0x7FFFFFFFull) return Status::Make(NeedleError_InvalidArgument, "resample: batch too large for one launch");
@@ -831,8 +854,8 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
       const float4 *coefq = reinterpret_cast<const float4 *>(d->d_coefq);
       auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(threads), quad_lds, stream, d_in, w.first->ptr,
-                           (int)meta.size(), coefq, static_cast<const QuadInfo *>(d->d_quad_info), geo, d->steps, skew_blocks,
-                           skew_unit, d_out);
+                           (int)meta.size(), coefq, static_cast<const QuadInfo *>(d->d_quad_info), geo, d->steps, quad_splits,
+                           skew_blocks, skew_unit, d_out);
       };
       const int lab = getenv("NEEDLE_HIP_RESAMPLE_LAB") ? atoi(getenv("NEEDLE_HIP_RESAMPLE_LAB")) : 0;
       const bool small = threads <= 640;
