@@ -13,6 +13,7 @@
 #include <mutex>
 #include <thread>
 #include <tuple>
+#include <unistd.h>
 
 #include "needle_core.h"
 
@@ -57,6 +58,11 @@ class HostPool {
     std::unique_lock<std::mutex> job_lock(job_mu_);  // one job at a time
     {
       std::lock_guard<std::mutex> lock(mu_);
+      if (owner_ != getpid()) {  // after a fork the pool's threads exist in the parent only: start over
+        new std::vector<std::thread>(std::move(threads_));  // (never destroyed: the thread objects are not joinable here)
+        threads_.clear();
+        owner_ = getpid();
+      }
       while (threads_.size() + 1 < workers) threads_.emplace_back(&HostPool::worker, this, threads_.size());
       body_ = &body;
       wanted_ = workers - 1;  // pool threads 0 .. wanted_-1 take part
@@ -95,6 +101,7 @@ class HostPool {
   const std::function<void()> *body_ = nullptr;
   size_t wanted_ = 0, running_ = 0;
   uint64_t generation_ = 0;
+  pid_t owner_ = getpid();
   static thread_local bool inside_;
 };
 thread_local bool HostPool::inside_ = false;

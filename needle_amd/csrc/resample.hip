@@ -361,8 +361,9 @@ __device__ __forceinline__ void quad_step(const float4 (&c)[4], float4 x, float 
 // workgroup per CU: 1.26 ms) helped.  Hence: tiles that lie wholly inside their stream take a staging path with no
 // clamps and 32-bit offsets from a uniform base, and what a quad needs (first group, the four coefficient rows and
 // their shifts) comes from a table built on the host instead of four integer divisions per lane.
-// LAB (timing experiments through NEEDLE_HIP_RESAMPLE_LAB, results wrong): 1 no staging, 2 no FMA loop, 4 plain
-// v_fmac_f32 instead of the DPP form
+// LAB (timing experiments, results wrong; instantiated only in a library built with -DNEEDLE_HIP_LAB_BUILD, which
+// tools/rslab.sh builds beside the product, and selected there through NEEDLE_HIP_RESAMPLE_LAB): 1 no staging, 2 no FMA
+// loop, 4 plain v_fmac_f32 instead of the DPP form
 constexpr int kQuadGroupsInFlight = 6;  // 16-byte loads a thread keeps in flight while staging by groups
 constexpr int kQuadMaxRounds = 2;       // rounds of quads per tile (L <= 4 * 64 * 2 = 512 at 1024 threads)
 
@@ -823,7 +824,7 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
       geo.region_slots = kQuadRows * quad_pitch;
       const bool vec4 = d->M % 4 == 0;
       geo.delta = d->delta;
-      const void *variants[13] = {reinterpret_cast<const void *>(resample_quad_kernel<1, false, false>),
+      const void *variants[] = {reinterpret_cast<const void *>(resample_quad_kernel<1, false, false>),
                                   reinterpret_cast<const void *>(resample_quad_kernel<1, true, false>),
                                   reinterpret_cast<const void *>(resample_quad_kernel<2, false, false>),
                                   reinterpret_cast<const void *>(resample_quad_kernel<2, true, false>),
@@ -831,11 +832,14 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
                                   reinterpret_cast<const void *>(resample_quad_kernel<1, true, true>),
                                   reinterpret_cast<const void *>(resample_quad_kernel<2, false, true>),
                                   reinterpret_cast<const void *>(resample_quad_kernel<2, true, true>),
+#ifdef NEEDLE_HIP_LAB_BUILD
                                   reinterpret_cast<const void *>(resample_quad_kernel<2, true, true, 1>),
                                   reinterpret_cast<const void *>(resample_quad_kernel<2, true, true, 2>),
                                   reinterpret_cast<const void *>(resample_quad_kernel<2, true, true, 3>),
                                   reinterpret_cast<const void *>(resample_quad_kernel<2, true, true, 4>),
-                                  reinterpret_cast<const void *>(resample_quad_kernel<2, true, true, 5>)};
+                                  reinterpret_cast<const void *>(resample_quad_kernel<2, true, true, 5>),
+#endif
+      };
       static std::map<int, size_t> quad_attr;  // largest dynamic LDS size announced per device
       if (quad_attr[dev] < quad_lds) {
         for (const void *fn : variants)
@@ -857,14 +861,20 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
                            (int)meta.size(), coefq, static_cast<const QuadInfo *>(d->d_quad_info), geo, d->steps, quad_splits,
                            skew_blocks, skew_unit, d_out);
       };
-      const int lab = getenv("NEEDLE_HIP_RESAMPLE_LAB") ? atoi(getenv("NEEDLE_HIP_RESAMPLE_LAB")) : 0;
       const bool small = threads <= 640;
+#ifdef NEEDLE_HIP_LAB_BUILD
+      const int lab = getenv("NEEDLE_HIP_RESAMPLE_LAB") ? atoi(getenv("NEEDLE_HIP_RESAMPLE_LAB")) : 0;
+#else
+      const int lab = 0;  // the product has no wrong-result variants
+#endif
       if (lab && channels == 2 && vec4 && small) {  // timing experiments (tools/rslab.sh): wrong results on purpose
+#ifdef NEEDLE_HIP_LAB_BUILD
         if (lab == 1) launch(resample_quad_kernel<2, true, true, 1>);
         else if (lab == 2) launch(resample_quad_kernel<2, true, true, 2>);
         else if (lab == 3) launch(resample_quad_kernel<2, true, true, 3>);
         else if (lab == 4) launch(resample_quad_kernel<2, true, true, 4>);
         else launch(resample_quad_kernel<2, true, true, 5>);
+#endif
       } else if (channels == 1) {
         if (vec4 && small) launch(resample_quad_kernel<1, true, true>);
         else if (vec4) launch(resample_quad_kernel<1, true, false>);
