@@ -156,6 +156,53 @@ void emu_stft_chroma_pair(const int16_t *fa, const int16_t *fb, int channels, do
   }
 }
 
+// The STFT kernel's power layout (fp_core.h build_power_layout): every bin 10..1307 has a slot of its own among the dead
+// slots (columns 0..7) of a row owned by the wave that owns the bin; the 192 fold lanes together read every bin's slot
+// exactly once and nothing else but the zero slot; the two packed forms round-trip.  Returns 0, or a negative code.
+int emu_power_layout_check() {
+  const Tables &T = tables();
+  std::vector<int> owner(kLds2Slots, -1);
+  for (int k = kMinBin; k < kMaxBin; k++) {
+    const int slot = T.layout.bin_slot[k - kMinBin];
+    if (slot < 0 || slot >= kFftSlots) return -1;
+    const int row = slot / 17, col = slot % 17;
+    if (col > 7) return -2;                                  // columns 8, 9 are spare, 10..15 the partner values, 16 the pad
+    if (wave_of_k0(row >> 4) != wave_of_k0(k & 15)) return -3;  // another wave's row
+    if (owner[slot] != -1) return -4;                        // two bins in one slot
+    owner[slot] = k;
+  }
+  std::vector<int> reads(kLds2Slots, 0);
+  for (int c = 0; c < 12; c++)
+    for (int l = 0; l < kClassLanes; l++) {
+      const uint32_t e = T.layout.fold[16 * c + l];
+      const int base = (int)(e & 0xffffu), count = (int)(e >> 16);
+      if (count < kClassLaneMin || count > kClassLaneMax) return -5;
+      for (int i = 0; i < count; i++) reads[base + 17 * i]++;
+    }
+  for (int s2 = 0; s2 < kLds2Slots; s2++)
+    if (reads[s2] != (owner[s2] != -1 ? 1 : 0)) return -6;    // a bin not folded, folded twice, or a foreign slot read
+  // every thread's six bins: inside the range iff the thread's wave owns them; threads of all four waves together own
+  // each bin exactly once
+  std::vector<int> seen(kNumBins, 0);
+  for (int t = 0; t < kThreads; t++)
+    for (int j = 0; j < kBinsPerThread; j++) {
+      const int kf = dif_bin_of(t, j);
+      if (kf >= kMinBin && kf < kMaxBin) {
+        if (wave_of_k0(kf & 15) != (t >> 6)) return -7;
+        seen[kf - kMinBin]++;
+      }
+    }
+  for (int i = 0; i < kNumBins; i++)
+    if (seen[i] != 1) return -8;
+  // the sixteen lane groups are a permutation of the low digits, partners in the same wave
+  int digits = 0;
+  for (int g = 0; g < 16; g++) {
+    digits |= 1 << group_k0(g);
+    if (wave_of_k0(group_k0(g)) != (g >> 2) || wave_of_k0((16 - group_k0(g)) & 15) != (g >> 2)) return -9;
+  }
+  return digits == 0xffff ? 0 : -10;
+}
+
 // classify_kernel, one item: 16 feature rows in, raw u32 out
 uint32_t emu_classify(const double *window16x12) { return classify_window(window16x12, &tables().thr); }
 

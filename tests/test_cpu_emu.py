@@ -48,6 +48,13 @@ def test_stft_pair_schedule_matches_oracle_chroma(emu):
     assert np.max(np.abs(a - chroma[0]) / chroma[0]) < 1e-12
 
 
+def test_power_layout_of_the_stft_kernel_is_consistent(emu):
+    """Structure of the round-2 schedule that no numerical test would localise: wave-local power slots, fold lanes that
+    read every bin exactly once, the lane-group permutation that keeps a bin's partner in its wave."""
+    emu.emu_power_layout_check.restype = C.c_int
+    assert emu.emu_power_layout_check() == 0
+
+
 def test_classifier_unrolled_regions_match_oracle_items(emu):
     e = synth.make_episode(1, 40.0, 10.0)
     items, _, feats, margin = O.fingerprint(e.pcm[: 20 * 11025], debug=True)
