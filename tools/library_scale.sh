@@ -5,5 +5,10 @@ E=${1:-1000}
 cd "$(dirname "$0")/.."
 free -g | sed -n 2p
 start=$(date +%s)
+# the synthesis of the episodes is silent for minutes: a heartbeat keeps a supervised run (gpurun) from looking hung
+( while sleep 60; do echo "[library_scale] $(( $(date +%s) - start )) s: still running" >&2; done ) &
+HEARTBEAT=$!
 timeout ${2:-1500} python bench.py --episodes "$E" --minutes 45 --steps ${3:-2} --warmup 1 --no-cpu-baseline
-echo "exit $? after $(( $(date +%s) - start )) s"
+rc=$?
+kill $HEARTBEAT 2>/dev/null
+echo "exit $rc after $(( $(date +%s) - start )) s"
