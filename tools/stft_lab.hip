@@ -40,11 +40,14 @@ static void setup(Lab &L) {
   L.total_pairs = (uint32_t)(L.eps * pairs_per_ep);
   std::vector<int16_t> pcm(L.samples_per_ep * L.eps + 8192);
   uint32_t x = 12345;
-  for (size_t i = 0; i < pcm.size(); i++) {  // a few tones + noise: not silence, not white
+  const size_t generated = std::min(pcm.size(), L.samples_per_ep * 28 + 8192);  // beyond 28 streams: copies of them
+  for (size_t i = 0; i < generated; i++) {  // a few tones + noise: not silence, not white
     x = x * 1664525u + 1013904223u;
     const double ph = (double)i / 11025.0;
     pcm[i] = (int16_t)(6000.0 * std::sin(6.2831853 * 220.0 * ph) + 3000.0 * std::sin(6.2831853 * 1333.0 * ph) + (double)((int)(x >> 20) - 2048));
   }
+  for (size_t i = generated; i < pcm.size(); i += L.samples_per_ep * 28)
+    std::memcpy(&pcm[i], &pcm[0], std::min(L.samples_per_ep * 28, pcm.size() - i) * sizeof(int16_t));
   std::vector<stft::FpStream> st(L.eps);
   for (int e = 0; e < L.eps; e++) {
     stft::FpStream m{};
@@ -143,6 +146,7 @@ static void check_variant(Lab &L, Variant &v) {
 
 int main(int argc, char **argv) {
   Lab L;
+  if (argc > 2) L.eps = std::atoi(argv[2]);  // more streams: PCM far beyond the caches (library scale)
   setup(L);
   using namespace needle::stft;
   const int reps = argc > 1 ? std::atoi(argv[1]) : 40;
