@@ -109,8 +109,6 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   if (first >= last) return;
   const cd base0 = tw[t], base1 = tw[16 * (t & 15)];  // W_4096^t, W_4096^{16 n0}: loop-invariant twiddle bases
 
-  // ---- loop invariants of this thread, packed so they cost few registers --------------------------------------
-  // where the powers of its six bins (register j of stage 2) go in the class-sorted LDS image
   // ---- loop invariants of this thread live in LDS (two private 16-byte slots, fp_core.h) and are read back once per
   // pair: kept in registers they are spilled to scratch, whose reloads stall the top of every pair -----------------
   const bool folds = t < kBands * core::kClassLanes;
