@@ -385,6 +385,71 @@ __device__ __forceinline__ float4 group_to_f32(typename std::conditional<CH == 1
   return float4{(float)s0, (float)s1, (float)s2, (float)s3};
 }
 
+// Staging of a tile's sixteen rows for the kernels with four outputs per lane: row r = `groups` aligned groups of four
+// down-mixed samples from input index first0 + r M on, as f32, at lds4 + pitch r; zeros outside the stream.  blockDim.x /
+// 16 threads per row.
+template <int CH, bool VEC4>
+__device__ __forceinline__ void stage_quad_rows(float4 *lds4, const int16_t *src, uint64_t n_in, long long first0, int M,
+                                                int pitch, int groups) {
+  using raw_t = typename std::conditional<CH == 1, int2, int4>::type;  // four samples as they lie in memory
+  float *stage = reinterpret_cast<float *>(lds4);
+  const int tpr = blockDim.x / kQuadRows, row = threadIdx.x / tpr, me = threadIdx.x % tpr;
+  const int count = 4 * groups;
+  auto sample = [&](long long idx) -> int {  // one down-mixed input sample, 0 outside the stream (branch-free load)
+    const bool ok = idx >= 0 && (uint64_t)idx < n_in;
+    const long long at = idx < 0 ? 0 : ((uint64_t)idx < n_in ? idx : (long long)n_in - 1);
+    int sv;
+    if (CH == 1) {
+      sv = src[at];
+    } else {
+      const int v = reinterpret_cast<const int *>(src)[at];
+      sv = ((int)(int16_t)v + (v >> 16)) / 2;  // integer down-mix, C truncation
+    }
+    return ok ? sv : 0;
+  };
+  const bool by_groups = VEC4 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && n_in >= 4;
+  const long long tile_last = first0 + (long long)(kQuadRows - 1) * M + 4 * (long long)groups;  // one past the last sample staged
+  if (by_groups && first0 >= 0 && tile_last <= (long long)n_in) {
+    // the tile lies inside the stream (all but the first and last tiles of a stream): a uniform base, 32-bit
+    // offsets, no clamps
+    const raw_t *base = reinterpret_cast<const raw_t *>(src + (size_t)CH * first0);  // first0 is a multiple of 4
+    const uint32_t row_groups = (uint32_t)(row * M) >> 2;                             // M is a multiple of 4 (VEC4)
+    float4 *dst = lds4 + pitch * row;
+    for (int o0 = me; o0 < groups; o0 += tpr * kQuadGroupsInFlight) {
+      raw_t v[kQuadGroupsInFlight];
+#pragma unroll
+      for (int u = 0; u < kQuadGroupsInFlight; u++) v[u] = base[row_groups + (uint32_t)min(o0 + u * tpr, groups - 1)];
+#pragma unroll
+      for (int u = 0; u < kQuadGroupsInFlight; u++)
+        if (o0 + u * tpr < groups) dst[o0 + u * tpr] = group_to_f32<CH>(v[u]);
+    }
+  } else if (by_groups) {  // a tile that sticks out of its stream: clamped loads, then the groups outside sample by sample
+    float4 *dst = lds4 + pitch * row;
+    const long long from = first0 + (long long)row * M;
+    const long long last_group = ((long long)n_in - 4) & ~3ll;  // last aligned group wholly inside the stream
+    for (int o = me; o < groups; o += tpr) {
+      const long long idx = from + 4 * (long long)o;
+      if (idx < 0 || idx > last_group)
+        dst[o] = float4{(float)sample(idx), (float)sample(idx + 1), (float)sample(idx + 2), (float)sample(idx + 3)};
+      else
+        dst[o] = group_to_f32<CH>(*reinterpret_cast<const raw_t *>(src + (size_t)CH * idx));
+    }
+  } else {  // unaligned stream or M not a multiple of 4: sample by sample, eight loads in flight
+    float *dst = stage + 4 * pitch * row;
+    const long long from = first0 + (long long)row * M;
+    constexpr int kU = 8;
+    int o = me;
+    for (; o + (kU - 1) * tpr < count; o += tpr * kU) {
+      int v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; u++) v[u] = sample(from + o + u * tpr);
+#pragma unroll
+      for (int u = 0; u < kU; u++) dst[o + u * tpr] = (float)v[u];
+    }
+    for (; o < count; o += tpr) dst[o] = (float)sample(from + o);
+  }
+}
+
 // SMALL: at most 640 threads (L <= 160), compiled for at least five waves per SIMD = two workgroups per CU (forcing 64 VGPRs for three costs spills: 0.76 ms against 0.68).
 template <int CH, bool VEC4, bool SMALL, int LAB = 0>
 __global__ __launch_bounds__(SMALL ? 640 : 1024, SMALL ? 5 : 4) void resample_quad_kernel(
@@ -401,8 +466,6 @@ __global__ __launch_bounds__(SMALL ? 640 : 1024, SMALL ? 5 : 4) void resample_qu
     const uint32_t late = (blockIdx.x * 2654435761u) >> 30;
     for (uint32_t i = 0; i < late * (uint32_t)skew_unit; i++) __builtin_amdgcn_s_sleep(127);
   }
-  float *stage = reinterpret_cast<float *>(lds4);
-  using raw_t = typename std::conditional<CH == 1, int2, int4>::type;  // four samples as they lie in memory
   const int L = geo.L, M = geo.M;
   int lo = 0, hi = num_streams - 1;
   while (lo < hi) {
@@ -426,69 +489,12 @@ __global__ __launch_bounds__(SMALL ? 640 : 1024, SMALL ? 5 : 4) void resample_qu
   // the groups of a row in front of this workgroup's share
   const long long first0 = (long long)(tile * (uint64_t)kQuadRows * (uint64_t)M) - half + 1 - geo.delta + 4ll * g0;
   const int16_t *src = in + st.in_off;
-  const int tpr = blockDim.x / kQuadRows, row = threadIdx.x / tpr, me = threadIdx.x % tpr;
   const int groups = (int)quad_info[q1 - 1].b0 - g0 + steps + 2;  // groups of a row that some lane may read
-  const int count = 4 * groups;
   // the tile's outputs are collected in LDS for a coalesced copy to HBM, over the START of the sample region once every
   // lane has finished reading it (a barrier more, 4.7 KB of LDS less: three workgroups per CU at 48 kHz instead of two)
   int16_t *out_tile = reinterpret_cast<int16_t *>(lds4);
 
-  auto sample = [&](long long idx) -> int {  // one down-mixed input sample, 0 outside the stream (branch-free load)
-    const bool ok = idx >= 0 && (uint64_t)idx < st.n_in;
-    const long long at = idx < 0 ? 0 : ((uint64_t)idx < st.n_in ? idx : (long long)st.n_in - 1);
-    int sv;
-    if (CH == 1) {
-      sv = src[at];
-    } else {
-      const int v = reinterpret_cast<const int *>(src)[at];
-      sv = ((int)(int16_t)v + (v >> 16)) / 2;  // integer down-mix, C truncation
-    }
-    return ok ? sv : 0;
-  };
-  // ---- staging: row r = its own M samples and the overlap into the next rows, as f32 ------------------------------
-  if (!(LAB & 1)) {
-    const bool by_groups = VEC4 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && st.n_in >= 4;
-    const long long tile_last = first0 + (long long)(kQuadRows - 1) * M + 4 * (long long)groups;  // one past the last sample staged
-    if (by_groups && first0 >= 0 && tile_last <= (long long)st.n_in) {
-      // the tile lies inside the stream (all but the first and last tiles of a stream): a uniform base, 32-bit
-      // offsets, no clamps
-      const raw_t *base = reinterpret_cast<const raw_t *>(src + (size_t)CH * first0);  // first0 is a multiple of 4
-      const uint32_t row_groups = (uint32_t)(row * M) >> 2;                             // M is a multiple of 4 (VEC4)
-      float4 *dst = lds4 + geo.pitch * row;
-      for (int o0 = me; o0 < groups; o0 += tpr * kQuadGroupsInFlight) {
-        raw_t v[kQuadGroupsInFlight];
-#pragma unroll
-        for (int u = 0; u < kQuadGroupsInFlight; u++) v[u] = base[row_groups + (uint32_t)min(o0 + u * tpr, groups - 1)];
-#pragma unroll
-        for (int u = 0; u < kQuadGroupsInFlight; u++)
-          if (o0 + u * tpr < groups) dst[o0 + u * tpr] = group_to_f32<CH>(v[u]);
-      }
-    } else if (by_groups) {  // a tile that sticks out of its stream: clamped loads, then the groups outside sample by sample
-      float4 *dst = lds4 + geo.pitch * row;
-      const long long from = first0 + (long long)row * M;
-      const long long last_group = ((long long)st.n_in - 4) & ~3ll;  // last aligned group wholly inside the stream
-      for (int o = me; o < groups; o += tpr) {
-        const long long idx = from + 4 * (long long)o;
-        if (idx < 0 || idx > last_group)
-          dst[o] = float4{(float)sample(idx), (float)sample(idx + 1), (float)sample(idx + 2), (float)sample(idx + 3)};
-        else
-          dst[o] = group_to_f32<CH>(*reinterpret_cast<const raw_t *>(src + (size_t)CH * idx));
-      }
-    } else {  // unaligned stream or M not a multiple of 4: sample by sample, eight loads in flight
-      float *dst = stage + 4 * geo.pitch * row;
-      const long long from = first0 + (long long)row * M;
-      constexpr int kU = 8;
-      int o = me;
-      for (; o + (kU - 1) * tpr < count; o += tpr * kU) {
-        int v[kU];
-#pragma unroll
-        for (int u = 0; u < kU; u++) v[u] = sample(from + o + u * tpr);
-#pragma unroll
-        for (int u = 0; u < kU; u++) dst[o + u * tpr] = (float)v[u];
-      }
-      for (; o < count; o += tpr) dst[o] = (float)sample(from + o);
-    }
-  }
+  if (!(LAB & 1)) stage_quad_rows<CH, VEC4>(lds4, src, st.n_in, first0, M, geo.pitch, groups);
   __syncthreads();
 
   // ---- quads: DPP row dr of the workgroup takes quad u = round * rows + dr; lane j of the row takes row j ----------

@@ -11,12 +11,18 @@
 template <int OP>
 __global__ __launch_bounds__(256) void rate_kernel(double *out, int iters, double x, double y) {
   double a[16];
+  int ib[16];
   asm volatile("" : "+v"(x), "+v"(y));
 #pragma unroll
   for (int i = 0; i < 16; i++) a[i] = x * (threadIdx.x + i) + 1.0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) ib[i] = threadIdx.x * i;
   for (int it = 0; it < iters; it++) {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
+      if (OP == 7) { ib[i] += it; a[i] = a[i] + (double)ib[i]; }                    // v_add_u32 + v_cvt_f64_i32 + v_add_f64
+      if (OP == 8) { ib[i] += it; a[i] = a[i] + x; }                                // v_add_u32 + v_add_f64
+      if (OP == 9) { ib[i] = __builtin_amdgcn_sbfe(ib[i] + it, 0, 16); a[i] = a[i] + x; }  // v_add_u32 + v_bfe_i32 + v_add_f64
       if (OP == 0) a[i] = a[i] + x;
       if (OP == 1) a[i] = a[i] * y;
       if (OP == 2) a[i] = __builtin_fma(a[i], y, x);
@@ -28,7 +34,7 @@ __global__ __launch_bounds__(256) void rate_kernel(double *out, int iters, doubl
   }
   double s = 0;
 #pragma unroll
-  for (int i = 0; i < 16; i++) s += a[i];
+  for (int i = 0; i < 16; i++) s += a[i] + ((OP >= 7) ? (double)ib[i] : 0.0);
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
@@ -104,6 +110,9 @@ int main() {
   run<6>("v_fma_f64 (three VGPR-pair operands)", 16, d_out);
   run<3>("half v_fma_f64, half v_add_f64", 16, d_out);
   run<4>("half v_mul_f64, half v_add_f64", 16, d_out);
+  run<8>("v_add_u32 + v_add_f64 (per PAIR)", 16, d_out);
+  run<7>("v_add_u32 + v_cvt_f64_i32 + v_add_f64 (per TRIPLE)", 16, d_out);
+  run<9>("v_add_u32 + v_bfe_i32 + v_add_f64 (per TRIPLE)", 16, d_out);
   run_chain<1, 1>(d_out);
   run_chain<2, 1>(d_out);
   run_chain<4, 1>(d_out);
