@@ -110,9 +110,9 @@ int main() {
   run<6>("v_fma_f64 (three VGPR-pair operands)", 16, d_out);
   run<3>("half v_fma_f64, half v_add_f64", 16, d_out);
   run<4>("half v_mul_f64, half v_add_f64", 16, d_out);
-  run<8>("v_add_u32 + v_add_f64 (per PAIR)", 16, d_out);
-  run<7>("v_add_u32 + v_cvt_f64_i32 + v_add_f64 (per TRIPLE)", 16, d_out);
-  run<9>("v_add_u32 + v_bfe_i32 + v_add_f64 (per TRIPLE)", 16, d_out);
+  run<8>("v_add_u32 + v_add_f64 (cycles per PAIR)", 16, d_out);
+  run<7>("v_add_u32 + v_cvt_f64_i32 + v_add_f64 (cycles per TRIPLE)", 16, d_out);
+  run<9>("v_add_u32 + v_bfe_i32 + v_add_f64 (cycles per TRIPLE)", 16, d_out);
   run_chain<1, 1>(d_out);
   run_chain<2, 1>(d_out);
   run_chain<4, 1>(d_out);
