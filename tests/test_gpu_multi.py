@@ -140,11 +140,13 @@ def _check_ranks(got, lib, want, ref, world, backend):
             assert g["hashes"][v] == [h for h, _ in ref[v].opening]     # rows fingerprinted by other ranks included
 
 
-@pytest.mark.parametrize("world,shard_epilogue,slab_runs", [(2, "0", None), (2, "1", None), (3, "1", 4), (2, "0", 4)])
+@pytest.mark.parametrize("world,shard_epilogue,slab_runs", [(2, "0", None), (2, "1", None), (3, "1", 4), (2, "0", 4),
+                                                            (5, "1", None)])
 def test_ranks_over_host_transport_on_one_gpu(lib7, tmp_path, world, shard_epilogue, slab_runs):
     """The complete N-rank path of the library -- own-block analyze, all-gather of rows, own pair range, all-gather of
     run slabs, (sharded) epilogue, all-gather of results, two jobs in flight -- between real processes that share
-    device 0, over the host-staged transport.  (3, 7): blocks of 3, 3, 1."""
+    device 0, over the host-staged transport.  (3, 7): blocks of 3, 3, 1; (5, 7): blocks of 2, 2, 2, 1, 0 -- a rank with no
+    video of its own, as rank 7 of an 8-rank job over 28 episodes."""
     ref, want = _oracle(lib7)
     env = {"NEEDLE_HIP_COMM": "host", "NEEDLE_HIP_SHARD_EPILOGUE": shard_epilogue}
     if slab_runs:
