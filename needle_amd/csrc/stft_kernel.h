@@ -189,6 +189,11 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   };
   PairSrc cur = locate(first), prev = cur;
   issue_loads(cur);
+  // The samples are carried around the loop as sign-extended 32-bit values.  If every value that enters the loop's phi
+  // is "sext(load)", the optimiser moves the extension behind the phi, and each sample then costs a global_load_ushort
+  // plus a v_bfe_i32 at its use; an opaque first set keeps the extension with the in-loop loads (global_load_sshort).
+#pragma unroll
+  for (int k = 0; k < 16; k++) asm volatile("" : "+v"(ra[k]), "+v"(rb[k]));
 
   for (uint32_t g = first; g < last; g++) {
     // all per-thread address arithmetic is redone per pair from this opaque copy of the thread index: kept
