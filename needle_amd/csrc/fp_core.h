@@ -41,13 +41,11 @@ constexpr int kBinsPerThread = 6;  // registers j = 0..5 of a thread hold every 
 // stride-17 access patterns of the stages are then bank-conflict free for 16-byte elements.
 constexpr int kFft2N = 4096;
 constexpr int kFftSlots = kFft2N + kFft2N / 16;  // padded complex slots of the transform's image
-// Behind the image: one 16-byte slot per thread for loop invariants that would otherwise occupy (spilled) registers,
-// the constant zero and the trash slot of the power image.  A thread's OTHER private slot is its pad inside the image
-// (slot 17 t + 16, touched by no stage).
-constexpr int kThreadSlot0 = kFftSlots;                 // + t: packed power slots (3 words), fold entry (1 word)
-constexpr int kPowerZeroSlot = kThreadSlot0 + 256;      // holds (0, 0): read in place of positions beyond a lane's count
+// Behind the image: the constant zero and the trash slot of the power image.  A thread's private slot for the loop
+// invariants that do not fit its registers is its pad inside the image (slot 17 t + 16, touched by no stage).
+constexpr int kPowerZeroSlot = kFftSlots;               // holds (0, 0): read in place of positions beyond a lane's count
 constexpr int kPowerTrashSlot = kPowerZeroSlot + 1;     // takes the powers of the bins outside 10..1307, never read
-constexpr int kLds2Slots = kPowerTrashSlot + 1;         // 73 760 bytes: two workgroups per CU
+constexpr int kLds2Slots = kPowerTrashSlot + 1;         // 69 664 bytes: two workgroups per CU
 NEEDLE_HD int thread_pad_slot(int t) { return 17 * t + 16; }  // window recurrence seeds
 
 NEEDLE_HD int pidx(int i) { return i + (i >> 4); }
@@ -275,7 +273,7 @@ NEEDLE_HD int dif1_base(int t) { return 272 * thread_k0(t) + (t & 15); }
 NEEDLE_HD int dif2_base(int t) { return 17 * (16 * thread_k0(t) + (t & 15)); }
 // N - (K + 256 j) = (256 - K) + 256 (15 - j) for K != 0: low byte K' = 256 - K, register 15 - j of the thread that
 // owns K'.  K = 0: bins 256 j, partners 256 (16 - j) = slot 16 - j; j = 0 (bin 0, discarded) then reads a pad
-// slot (16: some thread's private words, harmless).
+// slot (16: thread 0's window seeds, harmless).
 NEEDLE_HD int dif_partner_base(int t) {
   const int K = thread_k0(t) + 16 * (t & 15);
   const int Kp = (256 - K) & 255;

@@ -109,29 +109,29 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   if (first >= last) return;
   const cd base0 = tw[t], base1 = tw[16 * (t & 15)];  // W_4096^t, W_4096^{16 n0}: loop-invariant twiddle bases
 
-  // ---- loop invariants of this thread live in LDS (two private 16-byte slots, fp_core.h) and are read back once per
-  // pair: kept in registers they are spilled to scratch, whose reloads stall the top of every pair -----------------
+  // ---- loop invariants of this thread.  Where the powers of its six bins go and its share of the fold stay in
+  // registers (four words; the compiler derives the ten LDS addresses from them once: 227 VGPRs, no scratch -- check
+  // both after any change to this kernel, the budget is 256).  The window seeds do not fit as well (the compiler then
+  // also keeps all sixteen window values of the thread and spills inside the loop): they live in the thread's private
+  // pad slot of the LDS image and are read back once per pair. ------------------------------------------------------
   const bool folds = t < kBands * core::kClassLanes;
-  {
-    core::Words4 inv;
+  core::Words4 inv;
 #pragma unroll
-    for (int j = 0; j < core::kBinsPerThread; j += 2) {  // where the powers of its six bins go in the power image
-      uint32_t idx[2];
+  for (int j = 0; j < core::kBinsPerThread; j += 2) {  // where the powers of its six bins go in the power image
+    uint32_t idx[2];
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int kf = core::dif_bin_of(t, j + h);
-        idx[h] = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : (uint32_t)core::kPowerTrashSlot;
-      }
-      inv.w[j >> 1] = core::pack_slots(idx[0], idx[1]);
+    for (int h = 0; h < 2; h++) {
+      const int kf = core::dif_bin_of(t, j + h);
+      idx[h] = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : (uint32_t)core::kPowerTrashSlot;
     }
-    // its share of the pitch-class fold: 12 classes x 16 lanes (one DPP row per class), each lane both frames
-    // fp_core.h PowerLayout: first slot | positions << 16; the fourth wave has no class: "no positions from slot 0"
-    inv.w[3] = folds ? fold_tab[t] : 0u;
-    core::lds_put_words(lds, core::kThreadSlot0 + t, inv);
-    // window recurrence (fp_core.h window_step), seeded per thread with cos(theta t) and cos(theta (t - 256))
-    core::lds_put(lds, core::thread_pad_slot(t), cd{wcos[t + 256], wcos[t]});
-    if (t == 0) core::lds_put(lds, core::kPowerZeroSlot, cd{0.0, 0.0});  // first read after the loop's barriers
+    inv.w[j >> 1] = core::pack_slots(idx[0], idx[1]);
   }
+  // its share of the pitch-class fold: 12 classes x 16 lanes (one DPP row per class), each lane both frames
+  // fp_core.h PowerLayout: first slot | positions << 16; the fourth wave has no class: "no positions from slot 0"
+  const uint32_t fold_entry = folds ? fold_tab[t] : 0u;
+  // window recurrence (fp_core.h window_step), seeded per thread with cos(theta t) and cos(theta (t - 256))
+  core::lds_put(lds, core::thread_pad_slot(t), cd{wcos[t + 256], wcos[t]});
+  if (t == 0) core::lds_put(lds, core::kPowerZeroSlot, cd{0.0, 0.0});  // first read after the loop's barriers
 
   // ---- the stream (region of the batch) the current pair belongs to; consecutive pairs rarely change it ------
   int si = find_stream<&FpStream::pair_base>(streams, num_streams, first);
@@ -201,7 +201,6 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     int tt = t;
     asm volatile("" : "+v"(tt));
     const cd seeds = core::lds_get(lds, core::thread_pad_slot(tt));
-    const uint32_t fold_entry = core::lds_get_words(lds, core::kThreadSlot0 + tt).w[3];
     cd r[16];
     double wc = seeds.x, wc_prev = seeds.y;
     auto convert = [&](int k) {
@@ -262,7 +261,6 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     // partners Z[N - k] of the six bins: one base + constants, all six reads in flight together
     cd yp[core::kBinsPerThread];
     core::dif_partner_load(tt, lds, yp);
-    const core::Words4 inv = core::lds_get_words(lds, core::kThreadSlot0 + tt);  // packed power slots
     double pwa[core::kBinsPerThread], pwb[core::kBinsPerThread];
 #pragma unroll
     for (int j = 0; j < core::kBinsPerThread; j++) core::dif_power_of(r[core::out16(j)], yp[j], &pwa[j], &pwb[j]);
@@ -279,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   }
   {
     cd fv[core::kClassLaneMax];
-    core::class_lane_load(lds, core::lds_get_words(lds, core::kThreadSlot0 + t).w[3], fv);
+    core::class_lane_load(lds, fold_entry, fv);
     fold_tree_store(core::class_lane_add(fv), prev, t, true);
   }
 }
