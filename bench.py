@@ -88,6 +88,91 @@ def cpu_model() -> str:
     return "unknown"
 
 
+class DeviceTelemetry:
+    """Engine clock, temperature and power of the bench's device, read from its sysfs node while the timed region
+    runs (a thread, one read per ~2 ms; nothing is added to the GPU's queue).  The driver times a region of a few tens
+    of milliseconds right after a short warm-up, so the clock the kernels actually ran at belongs in the line: a
+    device that is still ramping up, or one that is power-capped under sustained f64 load, runs the same code slower."""
+
+    def __init__(self, capi):
+        import glob
+        import threading
+        self.node, self.samples, self._stop, self._thread = None, [], threading.Event(), None
+        self.source = "unavailable"
+        try:
+            node = os.path.join("/sys/bus/pci/devices", capi.device_pci_bus_id().lower())
+            if self._sclk(os.path.join(node, "pp_dpm_sclk")) is not None:
+                self.node, self.source = node, "sysfs pp_dpm_sclk, sampled inside the timed region"
+                hw = glob.glob(os.path.join(node, "hwmon", "hwmon*"))
+                self.hwmon = hw[0] if hw else None
+        except Exception:                                        # noqa: BLE001 -- diagnostics must never fail a run
+            self.node = None
+        self._threading = threading
+
+    @staticmethod
+    def _sclk(path):
+        try:
+            for line in open(path):
+                if "*" in line:
+                    return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError):
+            pass
+        return None
+
+    def _read_int(self, name):
+        try:
+            return int(open(os.path.join(self.hwmon, name)).read())
+        except (OSError, ValueError, TypeError):
+            return None
+
+    def start(self):
+        if not self.node:
+            return
+        self.samples, path = [], os.path.join(self.node, "pp_dpm_sclk")
+        self._stop.clear()
+
+        def run():
+            while not self._stop.is_set():
+                v = self._sclk(path)
+                if v is not None:
+                    self.samples.append(v)
+                time.sleep(0.002)
+        self._thread = self._threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        out = {"sclk_mhz": None, "sclk_mhz_min": None, "sclk_mhz_max": None, "temperature_c": None, "power_w": None,
+               "samples": 0, "source": self.source}
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+            self._thread = None
+        if self.node and self.samples:
+            s = self.samples
+            out.update(sclk_mhz=round(sum(s) / len(s), 1), sclk_mhz_min=min(s), sclk_mhz_max=max(s), samples=len(s))
+            t = max((v for v in (self._read_int(f"temp{i}_input") for i in (1, 2, 3)) if v is not None), default=None)
+            p = self._read_int("power1_average") or self._read_int("power1_input")
+            out["temperature_c"] = None if t is None else round(t / 1000.0, 1)
+            out["power_w"] = None if p is None else round(p / 1e6, 1)
+            return out
+        try:                                                     # no readable sysfs node: one sample right after the region
+            r = subprocess.run(["rocm-smi", "--showclocks", "--showtemp", "--showpower", "--json"], capture_output=True,
+                               text=True, timeout=20)
+            card = next(iter(json.loads(r.stdout).values()))
+            for k, v in card.items():
+                lk = k.lower()
+                if "sclk clock speed" in lk:
+                    out["sclk_mhz"] = float(str(v).strip("()").lower().replace("mhz", ""))
+                elif "temperature" in lk and "junction" in lk:
+                    out["temperature_c"] = float(v)
+                elif "power" in lk and "socket" in lk:
+                    out["power_w"] = float(v)
+            out["source"] = "rocm-smi, ONE sample taken right after the timed region (the clock may already have dropped)"
+        except Exception:                                        # noqa: BLE001
+            pass
+        return out
+
+
 def cpu_baseline(eps, results_gpu, hashes_gpu):
     """The oracle on the host cores (rank 0, N = 1 only): same episodes, same pairs, reference cost
     structure.  Bounded: the whole 28-episode job when the core count makes it ~<= 30 s, else a prefix of
@@ -231,7 +316,16 @@ def search_only(capi, synth, episodes, minutes, reps=5):
                     "H2D of hashes, scan, simhash, D2H of runs, host epilogue; wall clock per call"}
 
 
-# ---- launcher: `python bench.py --gpus N` without a launcher's environment --------------------------------------
+# ---- launching N ranks -----------------------------------------------------------------------------------------------
+# Every rank of an N > 1 run is TWO processes: a supervisor that never touches a GPU and the worker it starts.  A
+# collective that never completes (the first multi-rank RCCL bring-up happens on the driver's clock) cannot be
+# cancelled from inside the process that is stuck in it, so the supervisors do it from outside: rank 0's supervisor
+# gives the workers `--launch-timeout` seconds to finish; if they do not, or one dies, it tells every supervisor
+# (through a file rendezvous of their own) to kill its worker and start it once more over the host-staged transport
+# (NEEDLE_HIP_COMM=host: shared memory, nothing from the interconnect).  The result line is written by worker 0 into
+# the supervisors' directory and printed by supervisor 0 only when an attempt has succeeded, so exactly one JSON line
+# comes out whatever happened on the way.  Under torchrun (the driver's form) each launched process is a supervisor;
+# `python bench.py --gpus N` without a launcher's environment starts the N supervisors itself.
 def _free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -240,45 +334,99 @@ def _free_port() -> int:
     return port
 
 
+def _kill(proc) -> None:
+    if proc is not None and proc.poll() is None:
+        proc.kill()                                              # by PID: this process started it
+    if proc is not None:
+        proc.wait()
+
+
+def supervise_rank(rank: int, world: int, timeout_s: float) -> int:
+    from needle_amd import rendezvous                            # file exchange only: nothing here touches a GPU
+    sup = rendezvous.FileRendezvous(rank, world, timeout_s=max(120.0, timeout_s), role="sup")
+    backend0 = os.environ.get("NEEDLE_HIP_COMM", "rccl")
+    proc = None
+    try:
+        for attempt in range(2):
+            env = dict(os.environ, NEEDLE_BENCH_WORKER="1", NEEDLE_BENCH_SUP_DIR=sup.dir, NEEDLE_BENCH_ATTEMPT=str(attempt),
+                       NEEDLE_RDZV_NONCE=f"{os.path.basename(sup.dir)}-a{attempt}")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if attempt:
+                env["NEEDLE_HIP_COMM"] = "host"
+            proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                    stdout=sys.stderr)           # the JSON line travels through the directory
+            t_start = time.monotonic()
+            decision = None
+            reported = False
+            while decision is None:
+                code = proc.poll()
+                if code is not None and not reported:
+                    sup.set(f"exit.{attempt}.{rank}", str(code).encode())
+                    reported = True
+                if rank == 0:
+                    codes = [sup.try_get(f"exit.{attempt}.{r}") for r in range(world)]
+                    finished = [sup.try_get(f"finished.{attempt}.{r}") is not None for r in range(world)]
+                    if all(finished):
+                        decision = b"done"
+                    elif any(c is not None and c != b"0" for c in codes):
+                        decision = b"retry:a rank failed"
+                    elif time.monotonic() - t_start > timeout_s:
+                        stuck = [r for r in range(world) if not finished[r]]
+                        decision = f"retry:ranks {stuck} did not finish within {timeout_s:g} s".encode()
+                    if decision is not None:
+                        sup.set(f"decision.{attempt}", decision)
+                else:
+                    decision = sup.try_get(f"decision.{attempt}")
+                    if decision is None and time.monotonic() - t_start > timeout_s + 60.0:
+                        print(f"[bench] supervisor {rank}: no decision from supervisor 0; giving up", file=sys.stderr)
+                        return 1
+                if decision is None:
+                    time.sleep(0.02)
+            if decision == b"done":
+                try:
+                    proc.wait(timeout=20.0)                      # communicator teardown; nothing depends on it
+                except subprocess.TimeoutExpired:
+                    pass
+                _kill(proc)
+                if rank == 0:
+                    sys.stdout.write(sup.get(f"result.{attempt}", timeout_s=5.0).decode())
+                    sys.stdout.flush()
+                sup.barrier("bye")
+                return 0
+            _kill(proc)
+            why = decision.decode().split(":", 1)[-1]
+            last = attempt == 1 or backend0 == "host"
+            if rank == 0:
+                print(f"[bench] attempt {attempt} over {'host' if attempt else backend0}: {why}; "
+                      f"{'giving up' if last else 'every rank restarts over the host-staged transport (NEEDLE_HIP_COMM=host)'}",
+                      file=sys.stderr, flush=True)
+            if last:
+                return 1
+            sup.barrier(f"killed.{attempt}")                     # nobody of attempt 0 is alive when attempt 1 starts
+        return 1
+    finally:
+        _kill(proc)
+        if rank == 0:
+            time.sleep(0.2)
+            sup.remove()
+
+
 def spawn_ranks(n: int, timeout_s: float) -> int:
-    """Starts the N rank processes (this process never touches a GPU), rank 0 on our stdout.  A launch that does not
-    finish in time (a collective that never completes) is killed by PID and repeated once over the host-staged
-    transport, which needs nothing from the interconnect."""
-    for attempt in range(2):
-        env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if attempt:
-            env["NEEDLE_HIP_COMM"] = "host"
-        procs = []
-        for rank in range(n):
-            renv = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=renv,
-                                          stdout=None if rank == 0 else sys.stderr))
-        deadline = time.monotonic() + timeout_s
-        codes = [None] * n
-        while any(c is None for c in codes) and time.monotonic() < deadline:
-            for i, p in enumerate(procs):
-                if codes[i] is None:
-                    codes[i] = p.poll()
-            if any(c not in (None, 0) for c in codes):
-                break
+    """`python bench.py --gpus N` without a launcher's environment: starts the N per-rank supervisors (this process
+    never touches a GPU) and waits for them; they carry the timeout and the retry."""
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                              env=dict(env, RANK=str(rank), LOCAL_RANK=str(rank)),
+                              stdout=None if rank == 0 else sys.stderr) for rank in range(n)]
+    deadline = time.monotonic() + 2.0 * timeout_s + 180.0
+    try:
+        while any(p.poll() is None for p in procs) and time.monotonic() < deadline:
             time.sleep(0.05)
-        failed = any(c not in (None, 0) for c in codes)
-        hung = any(c is None for c in codes)
-        if hung or failed:
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()
-            for p in procs:
-                p.wait()
-        if not hung and not failed:
-            return 0
-        print(f"[bench] launch attempt {attempt}: {'timed out' if hung and not failed else 'a rank failed'}"
-              f"{'; retrying over the host-staged transport' if attempt == 0 and env.get('NEEDLE_HIP_COMM') != 'host' else ''}",
-              file=sys.stderr)
-        if os.environ.get("NEEDLE_HIP_COMM") == "host":
-            break
-    return 1
+    finally:
+        for p in procs:
+            _kill(p)
+    return 0 if all(p.returncode == 0 for p in procs) else 1
 
 
 def main() -> None:
@@ -293,7 +441,10 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / search_only / roofline_search")
     ap.add_argument("--search-only-episodes", type=int, default=280)
     ap.add_argument("--force-comm", action="store_true", help="create a 1-rank communicator even at N=1")
-    ap.add_argument("--launch-timeout", type=float, default=1500.0)
+    ap.add_argument("--launch-timeout", type=float, default=120.0,
+                    help="N > 1: seconds the ranks of one attempt get before they are killed and restarted over the "
+                         "host-staged transport (an 8-rank run takes ~15 s)")
+    ap.add_argument("--selftest-worker", choices=["ok", "hang", "fail"], help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -302,6 +453,20 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and os.environ.get("NEEDLE_BENCH_WORKER") != "1":
+        raise SystemExit(supervise_rank(rank, world, args.launch_timeout))
+    sup_dir, attempt = os.environ.get("NEEDLE_BENCH_SUP_DIR"), os.environ.get("NEEDLE_BENCH_ATTEMPT", "0")
+    if args.selftest_worker:                                     # tests/test_bench_launcher_cpu.py: the protocol, no GPU
+        if args.selftest_worker != "ok" and os.environ.get("NEEDLE_HIP_COMM") != "host":
+            if args.selftest_worker == "fail" and rank == world - 1:
+                raise SystemExit(3)
+            time.sleep(3600)                                     # "a collective that never completes"
+        if rank == 0:
+            with open(os.path.join(sup_dir, f"result.{attempt}"), "w") as f:
+                f.write(json.dumps({"selftest": args.selftest_worker, "n_gpus": world,
+                                    "comm": os.environ.get("NEEDLE_HIP_COMM", "rccl"), "attempt": int(attempt)}) + "\n")
+        open(os.path.join(sup_dir, f"finished.{attempt}.{rank}"), "w").close()
+        return
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np
@@ -311,7 +476,11 @@ def main() -> None:
         raise SystemExit("bench.py needs a HIP device: the needle path has no CPU fallback")
     rdzv = None
     if world > 1 or args.force_comm:
-        rdzv = rendezvous.init_comm(capi, rank, world, local_rank % capi.device_count())
+        # workers of one attempt share the nonce their supervisors exported (their parents differ)
+        rdzv = rendezvous.init_comm(capi, rank, world, local_rank % capi.device_count(),
+                                    key=os.environ.get("NEEDLE_RDZV_NONCE") if sup_dir else None)
+        print(f"[bench] rank {rank}/{world}: communicator up over {capi.comm_backend()} "
+              f"(device {local_rank % capi.device_count()})", file=sys.stderr, flush=True)
     else:
         capi.set_device(0)
 
@@ -383,11 +552,15 @@ def main() -> None:
     timed[0], acc[0] = [dominant], kernel_ms
     capi.set_kernel_timing(dominant)
     barrier()
+    telemetry = DeviceTelemetry(capi) if rank == 0 else None
+    if telemetry:
+        telemetry.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
+    device_state = telemetry.stop() if telemetry else None
     extra_steps = min(args.steps, 10)
     timed[0], acc[0] = list(kernel_names), extra_ms
     capi.set_kernel_timing("all")
@@ -411,11 +584,15 @@ def main() -> None:
         else:
             abytes = algorithmic_bytes(dominant, windows[f0:f0 + c0], kept[f0:f0 + c0], 0, 0)
         achieved = abytes / (avg[dominant] * 1e-3) / 1e9 if avg[dominant] > 0 else 0.0
-        traffic = None
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes/launch from rocprofv3 PMC passes (N = 1 launch shape)
         if os.path.exists(tpath) and world == 1:
             try:
-                traffic = json.load(open(tpath)).get(dominant)
+                tj = json.load(open(tpath))
+                traffic = tj.get(dominant)
+                if traffic is not None:
+                    traffic_source = (f"{tj.get('source', 'profiles/traffic.json')}: rocprofv3 --pmc pass of an earlier run of "
+                                      "this command, NOT measured in this run (counters cannot be read from inside it)")
             except Exception:
                 traffic = None
         compute = None
@@ -441,6 +618,7 @@ def main() -> None:
                        "comm": capi.comm_backend()},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": int(abytes),
                          "avg_launch_ms": round(avg[dominant], 5), "compute": compute},
             "kernel_ms_per_step": {k: round(v, 5) for k, v in avg.items()},
@@ -449,6 +627,7 @@ def main() -> None:
             "host_ms_per_step": {"enqueue": round(host_ms["enqueue"] / args.steps, 4),
                                  "wait_and_epilogue": round(host_ms["wait_and_epilogue"] / max(finished[0], 1), 4)},
             "runs_per_step": state["runs"],
+            "device_state": device_state,
             "detected": sum(1 for r in state["results"] if r is not None and r.opening is not None),
         }
         if not args.no_extras:
@@ -478,9 +657,17 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             hashes = [lib.frame_hashes(v).opening_data()[0] for v in range(n)]
             out["cpu_baseline"] = cpu_baseline(eps, state["results"], hashes)
-        print(json.dumps(out), flush=True)
+        if sup_dir:                                              # supervisor 0 prints it once the attempt has succeeded
+            tmp = os.path.join(sup_dir, f".result.{attempt}.tmp")
+            with open(tmp, "w") as f:
+                f.write(json.dumps(out) + "\n")
+            os.replace(tmp, os.path.join(sup_dir, f"result.{attempt}"))
+        else:
+            print(json.dumps(out), flush=True)
     if rdzv is not None:
         capi.comm_barrier()
+        if sup_dir:                                              # every collective of this rank has completed
+            open(os.path.join(sup_dir, f"finished.{attempt}.{rank}"), "w").close()
         capi.comm_finalize()
         rdzv.close()
 

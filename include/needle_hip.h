@@ -27,6 +27,9 @@ extern "C" {
 enum NeedleError needle_hip_device_count(int *count);
 enum NeedleError needle_hip_set_device(int ordinal);
 enum NeedleError needle_hip_synchronize(void);
+/* PCI address of the current device, "0000:c1:00.0" form (NUL-terminated): lets a host program find the device's
+ * sysfs node (clocks, temperature) without HIP headers.  Diagnostics only. */
+enum NeedleError needle_hip_device_pci_bus_id(char out[32]);
 /* The HIP stream (a hipStream_t) every kernel and copy of this library is enqueued on, for the current device:
  * lets a caller order its own device work (collectives, framework kernels) against the library's by stream
  * order or events instead of host synchronisation.  NULL without a device. */

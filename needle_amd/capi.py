@@ -70,6 +70,7 @@ NEEDLE_H_SYMBOLS = [
     "needle_audio_comparator_run"]
 NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_device_count", "needle_hip_set_device", "needle_hip_synchronize", "needle_hip_stream",
+    "needle_hip_device_pci_bus_id",
     "needle_hip_last_error_message",
     "needle_hip_version", "needle_hip_malloc", "needle_hip_free", "needle_hip_memcpy_h2d", "needle_hip_memcpy_d2h",
     "needle_hip_host_free", "needle_hip_last_kernel_ms", "needle_hip_set_kernel_timing", "needle_hip_fingerprint_sample_rate",
@@ -224,6 +225,13 @@ def device_count() -> int:
 
 def set_device(ordinal: int) -> None:
     check(lib().needle_hip_set_device(ordinal))
+
+
+def device_pci_bus_id() -> str:
+    buf = C.create_string_buffer(32)
+    lib().needle_hip_device_pci_bus_id.argtypes = [C.c_char_p]
+    check(lib().needle_hip_device_pci_bus_id(buf))
+    return buf.value.decode()
 
 
 def synchronize() -> None:

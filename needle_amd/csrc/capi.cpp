@@ -325,6 +325,21 @@ enum NeedleError needle_hip_set_device(int ordinal) {
   });
 }
 
+enum NeedleError needle_hip_device_pci_bus_id(char out[32]) {
+  if (!out) return NeedleError_NullArgument;
+  return guarded([&]() -> NeedleError {
+    Status s = ensure_device();
+    if (!s.ok()) return report(s);
+    int dev = 0;
+    out[0] = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(out, 32, dev) != hipSuccess) {
+      (void)hipGetLastError();
+      return report(Status::Make(NeedleError_Unknown, "the HIP runtime did not name the device's PCI address"));
+    }
+    return NeedleError_Ok;
+  });
+}
+
 enum NeedleError needle_hip_synchronize(void) {
   return guarded([&]() -> NeedleError {
     Status s = ensure_device();

@@ -247,7 +247,14 @@ Status comm_init(const uint8_t id[128], int rank, int world) {
     return s;
   }
   g_comm = c;
-  if (world > 1) {
+  // ONE RCCL communicator by default.  RCCL serialises the collectives of one communicator in the order they were
+  // enqueued even when they sit on different streams, and every rank enqueues them in the same program order (hash
+  // rows of job k, run slabs of job k, hash rows of job k + 1, ...), so nothing can deadlock; the price is that job
+  // k + 1's row gather starts behind job k's (small) slab gather.  Two communicators on one device run their kernels
+  // concurrently, which NCCL documents as deadlock-prone unless the device can co-schedule both on every rank:
+  // NEEDLE_HIP_COMM_DUAL=1 opts into that (a second communicator for the download stream) for measurements.
+  const char *dual = getenv("NEEDLE_HIP_COMM_DUAL");
+  if (world > 1 && dual && atoi(dual) != 0) {
     // the side communicator's id travels over the first one: every rank contributes 128 bytes, rank 0's count
     std::vector<uint8_t> mine(128, 0), all((size_t)world * 128, 0);
     if (rank == 0) {

@@ -33,8 +33,8 @@ Status comm_create_id(uint8_t id[128]);                      // rank 0; backend 
 Status comm_init(const uint8_t id[128], int rank, int world);  // collective over all ranks; binds the current device
 void comm_finalize();
 
-// Which of the two RCCL communicators a collective runs on: kData is used on the library stream (hash rows),
-// kSide on the download stream (run lists, results), so that the two streams never serialise on one communicator.
+// Which channel a collective belongs to: kData is used on the library stream (hash rows), kSide on the download
+// stream (run lists, results).  Both map to ONE RCCL communicator unless NEEDLE_HIP_COMM_DUAL=1 (comm.cpp comm_init).
 enum CommChannel { kData = 0, kSide = 1 };
 
 // All-gather of `bytes` per rank in stream order: rank r's block lands at d_recv + r * bytes on every rank.

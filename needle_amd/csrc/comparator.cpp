@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -70,10 +71,23 @@ class HostPool {
       generation_++;
     }
     wake_.notify_all();
-    body();
+    // An exception (bad_alloc inside a phase) must not unwind past this frame while pool threads still run *body_: it
+    // and its by-reference captures live on the caller's stack.  The caller's own exception, or the first one a pool
+    // thread caught, is rethrown once every participant has finished.
+    std::exception_ptr mine;
+    try {
+      body();
+    } catch (...) {
+      mine = std::current_exception();
+    }
     std::unique_lock<std::mutex> lock(mu_);
     done_.wait(lock, [&] { return running_ == 0; });
     body_ = nullptr;
+    std::exception_ptr theirs = error_;
+    error_ = nullptr;
+    lock.unlock();
+    if (mine) std::rethrow_exception(mine);
+    if (theirs) std::rethrow_exception(theirs);
   }
 
  private:
@@ -89,8 +103,14 @@ class HostPool {
         if (index < wanted_) body = body_;
       }
       if (body) {
-        (*body)();
+        std::exception_ptr err;
+        try {
+          (*body)();
+        } catch (...) {
+          err = std::current_exception();
+        }
         std::lock_guard<std::mutex> lock(mu_);
+        if (err && !error_) error_ = err;
         if (--running_ == 0) done_.notify_all();
       }
     }
@@ -99,6 +119,7 @@ class HostPool {
   std::condition_variable wake_, done_;
   std::vector<std::thread> threads_;
   const std::function<void()> *body_ = nullptr;
+  std::exception_ptr error_;  // first exception thrown by a pool thread in the current job
   size_t wanted_ = 0, running_ = 0;
   uint64_t generation_ = 0;
   pid_t owner_ = getpid();

@@ -425,6 +425,12 @@ Status fingerprint_in_batches(const std::vector<size_t> &num_values, int channel
   uint64_t group_values = (32ull << 20) / sizeof(int16_t);
   if (const char *e = getenv("NEEDLE_HIP_LAUNCH_GROUP_BYTES")) group_values = (uint64_t)std::max(2ll, atoll(e)) / sizeof(int16_t);
   hipStream_t stream = library_stream(), up = upload_stream();
+  // Every exit of this function -- the error returns included -- waits for the copies already enqueued: they read the
+  // caller's (pinned) buffers and the slab ring asynchronously, and the contract is that those are free on return.
+  struct DrainUploads {
+    hipStream_t s;
+    ~DrainUploads() { (void)hipStreamSynchronize(s); }
+  } drain_uploads{up};
   OverlapEvents *ev = overlap_events();
   HostEntryWorkspace *ws = host_entry_workspace();  // grow-only arenas, guarded by gpu_mutex()
   DeviceBuffer<int16_t> &d_pcm = ws->d_pcm, &d_mono = ws->d_mono;
@@ -515,7 +521,7 @@ Status fingerprint_in_batches(const std::vector<size_t> &num_values, int channel
   }
   // every copy out of host memory has executed when this returns (the callers' buffers and the slab ring are free)
   NEEDLE_HIP_TRY(hipStreamSynchronize(up));
-  return Status::Ok();
+  return Status::Ok();  // (drain_uploads then finds the stream idle)
 }
 
 }  // namespace

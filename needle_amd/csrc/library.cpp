@@ -268,8 +268,11 @@ enum NeedleError needle_hip_library_set_pcm(NeedleHipLibrary *lib, const int16_t
     Status s = plan_windows(lib, pcm, num_values, channels, true, &src, &len, &dst, nullptr, &total);
     if (!s.ok()) return report(s);
     if (!(s = lib->d_pcm.reserve(std::max<uint64_t>(total, 1))).ok()) return report(s);
-    if (!(s = gpu_upload_pcm(src, len, dst, lib->d_pcm.ptr)).ok()) return report(s);
-    if (hipStreamSynchronize(library_stream()) != hipSuccess) return report(Status::Make(NeedleError_Unknown, "PCM upload failed"));
+    s = gpu_upload_pcm(src, len, dst, lib->d_pcm.ptr);
+    // also on the error path: copies already enqueued read the caller's buffers asynchronously
+    const bool drained = hipStreamSynchronize(library_stream()) == hipSuccess;
+    if (!s.ok()) return report(s);
+    if (!drained) return report(Status::Make(NeedleError_Unknown, "PCM upload failed"));
     lib->have_pcm = true;
     lib->pcm_resident = true;
     return NeedleError_Ok;

@@ -1,4 +1,4 @@
-"""Sharding plan and exchange steps of a multi-GPU analyze+search job (one process per GPU).
+"""TEST HELPER (not product code): sharding plan and exchange steps of a multi-GPU analyze+search job (one process per GPU).
 
 The reference parallelises with rayon over videos (analyzer.rs:440-444) and over pairs
 (comparator.rs:553-563); both are independent units, so across G GPUs:

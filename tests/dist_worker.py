@@ -1,5 +1,5 @@
 """Worker for tests/test_dist_cpu.py: one rank of a world_size-N gloo job that pushes the sharding plan of
-needle_amd/dist.py through real collectives on CPU tensors.  Compute is a CPU stand-in (planted hash rows;
+tests/dist_plan.py through real collectives on CPU tensors.  Compute is a CPU stand-in (planted hash rows;
 runs from the kernel-emulation fixture) — the point is the exchange logic, not the arithmetic."""
 import ctypes as C
 import json
@@ -12,7 +12,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from needle_amd import dist as ndist  # noqa: E402
+from tests import dist_plan as ndist  # noqa: E402
 
 
 class EmuRun(C.Structure):

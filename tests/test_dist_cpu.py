@@ -8,7 +8,7 @@ import sys
 
 import pytest
 
-from needle_amd import dist as ndist
+from tests import dist_plan as ndist
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 

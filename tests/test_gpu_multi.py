@@ -200,6 +200,58 @@ def test_bench_gpus_flag_spawns_the_ranks_itself(tmp_path):
     assert line["steps"] == 3 and line["value"] > 0
 
 
+def _bench(args, env_extra, launcher=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(env_extra)
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0]), out.stderr
+
+
+@pytest.mark.parametrize("episodes,idle_rank", [(28, None), (25, 5)])
+def test_bench_six_ranks_share_one_gpu_over_the_host_transport(episodes, idle_rank):
+    """BASELINE.json configs[3]'s code path with as many ranks as one box may run on its GPU (6): bench.py starts a
+    supervisor + worker per rank, every worker drives device 0, collectives go over the host-staged transport.  28
+    episodes in blocks of 5 leave rank 5 with 3; 25 episodes leave it with none (ceil(25 / 6) = 5): a rank that
+    fingerprints nothing still scans its pair range and takes part in every gather."""
+    line, err = _bench(["--gpus", "6", "--episodes", str(episodes), "--minutes", "2", "--intro-seconds", "30", "--steps", "3",
+                        "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--launch-timeout", "300"],
+                       {"NEEDLE_HIP_COMM": "host"})
+    assert line["n_gpus"] == 6 and line["config"]["comm"] == "host" and line["detected"] == episodes
+    assert line["config"]["pairs"] == episodes * (episodes - 1) // 2 and line["value"] > 0
+    assert err.count("communicator up over host") == 6
+    if idle_rank is not None:
+        first, count = capi.comm_shard(episodes, 6, idle_rank)
+        assert count == 0
+
+
+def test_bench_under_torchrun_the_drivers_form():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`: each launched process becomes a
+    supervisor (never touching the GPU) with a worker child; RANK / LOCAL_RANK / WORLD_SIZE come from the launcher.
+    Two ranks on the one device, so the transport is the host-staged one."""
+    pytest.importorskip("torch")
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", "29517"]
+    line, err = _bench(["--gpus", "2", "--episodes", "6", "--minutes", "2", "--intro-seconds", "30", "--steps", "3",
+                        "--warmup", "1", "--no-extras", "--no-cpu-baseline"], {"NEEDLE_HIP_COMM": "host"}, launcher)
+    assert line["n_gpus"] == 2 and line["detected"] == 6 and line["config"]["comm"] == "host"
+
+
+def test_rccl_refusing_two_ranks_per_device_falls_back_in_process():
+    """Default transport (RCCL) with two ranks on ONE device: ncclCommInitRank fails (or is refused) on this box, every
+    rank votes through the rendezvous and all switch to the host transport inside the same processes; the line says
+    which transport carried the job."""
+    line, err = _bench(["--gpus", "2", "--episodes", "5", "--minutes", "2", "--intro-seconds", "30", "--steps", "2",
+                        "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--launch-timeout", "90"], {})
+    assert line["n_gpus"] == 2 and line["detected"] == 5
+    if capi.device_count() < 2:
+        assert line["config"]["comm"] == "host"
+        assert "host-staged transport" in err
+
+
 def test_analyzer_keeps_progress_in_front_of_a_bad_file(tmp_path):
     """analyzer.rs:414-417,447-451: the reference's sequential map has analysed AND persisted every video in front of
     the one that fails.  Here: two good files, one that is not RIFF/WAVE, one more good file -> the call fails with the

@@ -765,11 +765,11 @@ def test_fingerprint_signal_zoo_bit_exact():
 
 @pytest.mark.parametrize("n,world", [(7, 2), (4, 3)])       # (4, 3): blocks of 2, 2 and 0 episodes -- a rank that owns none
 def test_two_simulated_ranks_on_one_device_equal_single_library(n, world):
-    """The multi-GPU plan of needle_amd/dist.py with two Library objects standing in for two ranks on one device:
+    """The multi-GPU plan of tests/dist_plan.py with two Library objects standing in for two ranks on one device:
     each holds the PCM of its own episode block only, fingerprints it into a caller-owned arena, the arenas exchange
     row blocks (what the all-gather does), each scans its own range of the pair list, the run lists are
     concatenated and rank 0 finalises.  Result = the single-library result = the oracle's."""
-    from needle_amd import dist as ndist
+    from tests import dist_plan as ndist
     eps = synth.make_library(n, 90.0, 20.0)
     lens = [len(e.pcm) for e in eps]
     cmp = capi.Comparator([f"ep{k}.wav" for k in range(n)], min_opening_duration=10)
