@@ -87,6 +87,16 @@ enum NeedleError needle_hip_fingerprint_device(const int16_t *d_pcm, const uint6
                                                int channels, uint32_t step, uint32_t *d_items,
                                                const uint64_t *item_offsets, bool sync);
 
+/* Arithmetic of the fingerprinter.  The u32 items are DEFINED on a double-precision pipeline (chromaprint on an f64
+ * FFT; oracle/ora_chromaprint.c).  By default the STFT runs a single-precision first pass and every item is either
+ * certified -- all 48 threshold comparisons clear a data-dependent error radius, so the f64 pipeline provably takes the
+ * same decisions -- or recomputed: the frames it covers go through the f64 kernel again and the item is classified
+ * from those.  The emitted items are therefore the f64 pipeline's, bit for bit.  Environment: NEEDLE_HIP_STFT=f64 runs
+ * the f64 kernel over everything; NEEDLE_HIP_CERT_K scales the radius (default 64; 0 accepts every first-pass item,
+ * for tests).  counts = {items fingerprinted, items recomputed in f64, chunks of 4 frame pairs, chunks recomputed}
+ * on the current device since the last reset; waits for the library stream. */
+enum NeedleError needle_hip_fingerprint_cert_stats(uint64_t counts[4], bool reset);
+
 /* Test hook: intermediate stages of one stream, copied to the host.  chroma [frames][12] (energy per
  * pitch class per FFT frame), features [frames-4][12] (FIR-filtered, L2-normalised). NULLs allowed. */
 enum NeedleError needle_hip_fingerprint_debug(const int16_t *pcm, size_t num_values, int channels,

@@ -70,7 +70,7 @@ NEEDLE_H_SYMBOLS = [
     "needle_audio_comparator_run"]
 NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_device_count", "needle_hip_set_device", "needle_hip_synchronize", "needle_hip_stream",
-    "needle_hip_device_pci_bus_id",
+    "needle_hip_device_pci_bus_id", "needle_hip_fingerprint_cert_stats",
     "needle_hip_last_error_message",
     "needle_hip_version", "needle_hip_malloc", "needle_hip_free", "needle_hip_memcpy_h2d", "needle_hip_memcpy_d2h",
     "needle_hip_host_free", "needle_hip_last_kernel_ms", "needle_hip_set_kernel_timing", "needle_hip_fingerprint_sample_rate",
@@ -246,6 +246,14 @@ def stream_ptr() -> int:
     if not p:
         raise RuntimeError("no HIP device: the library has no stream")
     return int(p)
+
+
+def cert_stats(reset: bool = False) -> dict:
+    """Counts of the certified f32 first pass (needle_hip_fingerprint_cert_stats)."""
+    v = (C.c_uint64 * 4)()
+    lib().needle_hip_fingerprint_cert_stats.argtypes = [C.POINTER(C.c_uint64), C.c_bool]
+    check(lib().needle_hip_fingerprint_cert_stats(v, reset))
+    return {"items": int(v[0]), "items_recomputed": int(v[1]), "chunks": int(v[2]), "chunks_recomputed": int(v[3])}
 
 
 def int_valu_ceiling() -> float:

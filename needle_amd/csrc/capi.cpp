@@ -416,6 +416,14 @@ enum NeedleError needle_hip_host_alloc_free(void *host_ptr) {
   return NeedleError_Ok;
 }
 
+enum NeedleError needle_hip_fingerprint_cert_stats(uint64_t counts[4], bool reset) {
+  if (!counts) return NeedleError_NullArgument;
+  return guarded([&]() -> NeedleError {
+    Status s = gpu_fingerprint_cert_stats(counts, reset);
+    return s.ok() ? NeedleError_Ok : report(s);
+  });
+}
+
 enum NeedleError needle_hip_int_valu_ceiling(double *cells_per_second) {
   if (!cells_per_second) return NeedleError_NullArgument;
   return guarded([&]() -> NeedleError {

@@ -10,8 +10,10 @@
 //
 // HBM traffic that matters is the PCM read (2 B/sample, each sample touched by 3 overlapping frames:
 // re-reads are served by L2) and 96 B/frame of chroma; everything else stays on chip.
+#include "fingerprint32.h"
 #include "fp_core.h"
 #include "hipctx.h"
+#include "stft32_kernel.h"
 #include "stft_kernel.h"
 
 #include <algorithm>
@@ -41,6 +43,9 @@ struct FpTables {
   core::WindowConst wconst;         // fp_core.h window_step
   uint32_t *fold_tab = nullptr;     // [12 * 16] fold thread -> first slot | positions << 16 (fp_core.h PowerLayout)
   core::ClassifierThresholds *thr = nullptr;
+  // f32 first pass (stft32_kernel.h): correctly rounded twiddles and window
+  core::cf *tw32 = nullptr;         // [4096]
+  float *win32 = nullptr;           // [4096] (0.54 - 0.46 cos(theta n)) / 32767 / 2
 };
 
 std::mutex g_tab_mu;
@@ -105,6 +110,17 @@ Status get_tables(FpTables *out) {
   NEEDLE_HIP_TRY(hipMemcpy(t.tw, tw.data(), tw.size() * sizeof(cd), hipMemcpyHostToDevice));
   NEEDLE_HIP_TRY(hipMemcpy(t.wcos, wcos.data(), wcos.size() * sizeof(double), hipMemcpyHostToDevice));
   NEEDLE_HIP_TRY(hipMemcpy(t.thr, &thr, sizeof(thr), hipMemcpyHostToDevice));
+  std::vector<core::cf> tw32(4096);
+  std::vector<float> win32(4096);
+  for (int k = 0; k < 4096; k++) {
+    const long double a = -2.0L * 3.14159265358979323846264338327950288L * k / 4096.0L;
+    tw32[k] = core::cf{(float)cosl(a), (float)sinl(a)};
+    win32[k] = (float)((long double)core::kPairInputScale * (0.54L - 0.46L * cosl(theta * (long double)k)) / 32767.0L);
+  }
+  NEEDLE_HIP_TRY(hipMalloc((void **)&t.tw32, tw32.size() * sizeof(core::cf)));
+  NEEDLE_HIP_TRY(hipMalloc((void **)&t.win32, win32.size() * sizeof(float)));
+  NEEDLE_HIP_TRY(hipMemcpy(t.tw32, tw32.data(), tw32.size() * sizeof(core::cf), hipMemcpyHostToDevice));
+  NEEDLE_HIP_TRY(hipMemcpy(t.win32, win32.data(), win32.size() * sizeof(float), hipMemcpyHostToDevice));
   g_tables[dev] = t;
   *out = t;
   return Status::Ok();
@@ -183,6 +199,162 @@ __global__ __launch_bounds__(256) void features_classify_kernel(const double *__
     items[st.item_off + k0 + lane] = core::classify_window<kFeatPitch>(mine + lane * step * kFeatPitch, thr);
 }
 
+// ---- certified first pass -----------------------------------------------------------------------------------------
+// The chroma of stft_chroma32_kernel carries the f32 transform's error.  Measured with the kernel's own arithmetic
+// stepped on the CPU (tools/f32_gate.py, profiles/r03_f32_gate.log): with v = (1 + a) / (1 + b) the input of a
+// classifier,
+//     |log v32 - log v64|  <=  1.8 * S,     S = max over the item's 16 feature rows of  u sqrt(E_row / n_row),
+// u = 2^-24, n_row the row's L2 norm (what the features are divided by) and E_row its frames' total energy
+// sum |X_k|^2 over ALL bins through the same 5-tap FIR -- on 28 x 24 min of synthetic episodes and on a zoo of signals
+// that spans S from 1e-7 (tonal, in band) to 3e-4 (a strong tone outside chromaprint's band over a weak one inside).
+// An item is ACCEPTED only if all 16 x 3 comparisons "v < exp(t)" clear their threshold by more than r = K S in
+// log v (K = 64: 35 x the worst ratio observed) and none of its rows is within the same relative distance of the
+// 0.01 norm cut; every other item (0.1 % of them on audio) is listed, the chunks of frame pairs its 20 frames span
+// are listed once, stft_chroma_kernel<LISTED> overwrites those chroma rows in f64 and fixup_items_kernel recomputes
+// the item from them with the arithmetic of features_classify_kernel.  So every emitted u32 is either certified to
+// equal the f64 pipeline's or IS the f64 pipeline's.
+struct CertItem {
+  uint32_t row;   // chroma row of the item's first frame (global in the batch)
+  uint32_t pad;
+  uint64_t out;   // where its u32 goes in d_items
+};
+struct CertWork {      // zeroed before every batch (header + bitmap)
+  uint32_t item_count, chunk_count, pad[2];
+};
+struct CertStats {     // cumulative, read by needle_hip_fingerprint_cert_stats
+  unsigned long long items_recomputed, chunks_recomputed;
+};
+constexpr float kCertU = 5.9604644775390625e-08f;  // 2^-24
+constexpr float kEnergyScale = 16384.0f;            // N * 4: the kernel's samples carry a factor 1/2 (fp_core.h)
+
+// feature_row + the row's error scale sigma = u sqrt(E_row / n_row); +inf if the row sits within k sigma (relative) of
+// the 0.01 cut, 0 if it is safely under it (features exactly zero in both pipelines) or silent.
+__device__ __forceinline__ float feature_row_cert(const double *__restrict__ in, const float *__restrict__ en, float k,
+                                                  double *out) {
+  const double coef[5] = {0.25, 0.75, 1.0, 0.75, 0.25};
+  double v[kBands];
+  double squares = 0.0;
+#pragma unroll
+  for (int c = 0; c < kBands; c++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) acc += in[j * kBands + c] * coef[j];
+    v[c] = acc;
+    squares += acc * acc;
+  }
+  const double norm = squares > 0.0 ? sqrt(squares) : 0.0;
+  float e_row = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 5; j++)
+    e_row += (float)coef[j] * ((en[j * stft::kEnergyParts] + en[j * stft::kEnergyParts + 1]) +
+                               (en[j * stft::kEnergyParts + 2] + en[j * stft::kEnergyParts + 3]));
+  float sigma = 0.0f;
+  if (e_row > 0.0f) {
+    const float n32 = fmaxf((float)norm, 1e-30f);
+    sigma = kCertU * sqrtf(kEnergyScale * e_row / n32);
+    if (fabsf(n32 - 0.01f) <= k * sigma * n32 + 1e-9f) sigma = __builtin_inff();
+  }
+  if (norm < 0.01) {
+#pragma unroll
+    for (int c = 0; c < kBands; c++) out[c] = 0.0;
+    return sigma == __builtin_inff() ? sigma : 0.0f;
+  }
+#pragma unroll
+  for (int c = 0; c < kBands; c++) out[c] = v[c] / norm;
+  return sigma;
+}
+
+// classify_window + "is any of the 48 comparisons within rr (relative) of its threshold"
+template <int PITCH>
+__device__ __forceinline__ uint32_t classify_window_cert(const double *w, const core::ClassifierThresholds *thr, double rr,
+                                                         bool *uncertain) {
+  double a[16], b[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) a[i] = b[i] = 0.0;
+  core::WindowStep<0, 0, PITCH>::run(w, a, b);
+  uint32_t bits = 0;
+  bool unc = false;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const double ratio = (1.0 + a[i]) / (1.0 + b[i]);
+    const double t0 = thr->e[i][0], t1 = thr->e[i][1], t2 = thr->e[i][2];
+    const unsigned q = ratio < t1 ? (ratio < t0 ? 0u : 1u) : (ratio < t2 ? 2u : 3u);
+    // |log ratio - t| <= r  <=  |ratio - e^t| <= e^t (r + r^2)   (rr = r + r^2, r < 1)
+    unc = unc || fabs(ratio - t0) <= t0 * rr || fabs(ratio - t1) <= t1 * rr || fabs(ratio - t2) <= t2 * rr;
+    bits = (bits << 2) | (q ^ (q >> 1));
+  }
+  *uncertain = unc;
+  return bits;
+}
+
+__global__ __launch_bounds__(256) void features_classify_cert_kernel(
+    const double *__restrict__ chroma, const float *__restrict__ energy, const FpStream *__restrict__ streams, int num_streams,
+    const core::ClassifierThresholds *__restrict__ thr, uint32_t step, uint32_t items_per_tile, uint32_t *__restrict__ items,
+    uint32_t total_tiles, float cert_k, uint32_t chunk_pairs, CertWork *__restrict__ work, uint32_t *__restrict__ chunk_bitmap,
+    uint32_t *__restrict__ chunk_list, CertItem *__restrict__ item_list) {
+  __shared__ double tiles[4][kTileRowsMax * kFeatPitch];
+  __shared__ float sigmas[4][kTileRowsMax];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t g = blockIdx.x * 4 + wave;
+  if (g >= total_tiles) return;  // wave-uniform; the waves of a workgroup never wait for each other
+  const int si = find_stream<&FpStream::tile_base>(streams, num_streams, g);
+  const FpStream st = streams[si];
+  const uint32_t k0 = (g - st.tile_base) * items_per_tile;
+  const uint32_t count = min(items_per_tile, st.kept - k0);
+  const uint32_t x0 = k0 * step;
+  const uint32_t rows = (count - 1) * step + 16;
+  double *mine = tiles[wave];
+  float *sig = sigmas[wave];
+  const double *in = chroma + ((uint64_t)st.frame_base + x0) * kBands;
+  const float *en = energy + ((uint64_t)st.frame_base + x0) * stft::kEnergyParts;
+  for (uint32_t r = lane; r < rows; r += 64)
+    sig[r] = feature_row_cert(in + (uint64_t)r * kBands, en + (uint64_t)r * stft::kEnergyParts, cert_k, mine + r * kFeatPitch);
+  wave_lds_fence();
+  if (lane < count) {
+    float s_max = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) s_max = fmaxf(s_max, sig[lane * step + r]);
+    bool unc = false;
+    const double r = (double)cert_k * (double)s_max;   // +inf when a row is at the norm cut
+    const uint32_t bits = classify_window_cert<kFeatPitch>(mine + lane * step * kFeatPitch, thr, r + r * r, &unc);
+    unc = unc || !(r < 0.25);                           // out of the calibrated regime: recompute
+    const uint64_t out = st.item_off + k0 + lane;
+    items[out] = bits;
+    if (unc) {
+      const uint32_t x = x0 + lane * step;              // raw item = first frame of the 20 it covers
+      item_list[atomicAdd(&work->item_count, 1u)] = CertItem{st.frame_base + x, 0u, out};
+      const uint32_t p0 = st.pair_base + x / 2, p1 = st.pair_base + min(x + 19u, st.frames - 1u) / 2;
+      for (uint32_t c = p0 / chunk_pairs; c <= p1 / chunk_pairs; c++) {
+        const uint32_t bit = 1u << (c & 31u);
+        if (!(atomicOr(&chunk_bitmap[c >> 5], bit) & bit)) chunk_list[atomicAdd(&work->chunk_count, 1u)] = c;
+      }
+    }
+  }
+}
+
+// one wave per listed item: its 16 feature rows from the (now f64) chroma rows, then the 16 classifiers -- the
+// arithmetic of features_classify_kernel, function for function
+__global__ __launch_bounds__(256) void fixup_items_kernel(const double *__restrict__ chroma,
+                                                          const core::ClassifierThresholds *__restrict__ thr,
+                                                          const CertWork *__restrict__ work, const CertItem *__restrict__ item_list,
+                                                          uint32_t *__restrict__ items, CertStats *__restrict__ stats) {
+  __shared__ double tiles[4][16 * kFeatPitch];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t n = work->item_count;
+  double *mine = tiles[wave];
+  for (uint32_t i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+    const CertItem it = item_list[i];
+    if (lane < 16) feature_row(chroma + ((uint64_t)it.row + lane) * kBands, mine + lane * kFeatPitch);
+    wave_lds_fence();
+    if (lane == 0) items[it.out] = core::classify_window<kFeatPitch>(mine, thr);
+    wave_lds_fence();  // the next item of this wave overwrites the tile
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    atomicAdd(&stats->items_recomputed, (unsigned long long)n);
+    atomicAdd(&stats->chunks_recomputed, (unsigned long long)work->chunk_count);
+  }
+}
+
 // ---- kernel 3: 16 classifiers over a 16x12 window, one thread per kept item ----------------------------------
 __global__ __launch_bounds__(256) void classify_kernel(const double *__restrict__ feat,
                                                        const FpStream *__restrict__ streams, int num_streams,
@@ -220,6 +392,12 @@ struct FpWorkspace {
     return *descriptors[k];
   }
   bool lds_attr_set = false;  // the STFT kernel's 68 KiB of dynamic LDS needs an explicit opt-in
+  // certified first pass: frame energies, control block (CertWork + chunk bitmap), the two lists, cumulative counts
+  DeviceBuffer<float> energy;
+  DeviceBuffer<uint32_t> cert_ctl, chunk_list;
+  DeviceBuffer<CertItem> item_list;
+  CertStats *stats = nullptr;                     // device
+  uint64_t items_total = 0, chunks_total = 0;     // host: what the device counts are fractions of
 };
 std::mutex g_ws_mu;
 std::map<int, FpWorkspace *> g_ws;
@@ -293,38 +471,102 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       if (!(s = desc.upload.put(&desc.streams, &desc.stage, meta, stream)).ok()) return s;
       const int n = (int)meta.size();
       if (!ws->lds_attr_set) {
-        const void *variants[2] = {reinterpret_cast<const void *>(stft_chroma_kernel<1>),
-                                   reinterpret_cast<const void *>(stft_chroma_kernel<2>)};
+        const void *variants[4] = {reinterpret_cast<const void *>(stft_chroma_kernel<1, 0, false>),
+                                   reinterpret_cast<const void *>(stft_chroma_kernel<2, 0, false>),
+                                   reinterpret_cast<const void *>(stft_chroma_kernel<1, 0, true>),
+                                   reinterpret_cast<const void *>(stft_chroma_kernel<2, 0, true>)};
         for (const void *fn : variants)
           NEEDLE_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)(core::kLds2Slots * sizeof(cd))));
         ws->lds_attr_set = true;
       }
+      int cus = 256;
+      {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        cus = std::max(cus, 1);
+      }
+      // Pairs per workgroup.  The device holds `slots` workgroups at a time.  A launch of more than
+      // about two rounds of workgroups balances itself (workgroups retire at different times and the dispatcher
+      // backfills: measured, a "whole rounds" choice of the size changed 7- and 14-episode launches by < 2 %), so
+      // long launches keep kPairsPerBlock.  A SHORT launch -- one rank's share of a sharded job, a single file --
+      // is cut so that every slot gets one workgroup: 4 episodes x 24 min = 11 626 pairs run as 506 workgroups of
+      // 23 pairs (0.153 ms) instead of 727 of 16 (0.162 ms); one episode as 485 workgroups of 6 instead of 182 of 16.
+      auto pairs_per_block = [&](uint64_t slots) {
+        uint32_t ppb = kPairsPerBlock;
+        if ((pairs + kPairsPerBlock - 1) / kPairsPerBlock < 2 * slots)
+          ppb = (uint32_t)std::min<uint64_t>(40, std::max<uint64_t>(4, (pairs + slots - 1) / slots));
+        if (const char *e = getenv("NEEDLE_STFT_PAIRS")) ppb = (uint32_t)std::max(1, atoi(e));
+        return ppb;
+      };
+      // The certified f32 first pass is the default; NEEDLE_HIP_STFT=f64 runs the f64 kernel over everything (the
+      // arithmetic the contract is defined on; also taken when a caller asks for the intermediate stages).
+      const char *mode_env = getenv("NEEDLE_HIP_STFT");
+      const bool certified = !(mode_env && std::strcmp(mode_env, "f64") == 0) && d_chroma_dbg == nullptr && d_feat_dbg == nullptr &&
+                             getenv("NEEDLE_HIP_SEPARATE_CLASSIFY") == nullptr && tiles > 0;
+      if (certified) {
+        float cert_k = 64.0f;  // 35 x the worst |log v32 - log v64| / S observed (profiles/r03_f32_gate.log)
+        if (const char *e = getenv("NEEDLE_HIP_CERT_K")) cert_k = std::max(0.0f, (float)atof(e));  // tests: 0 = accept everything
+        constexpr uint32_t kChunkPairs = 4;
+        const uint64_t nchunks = (pairs + kChunkPairs - 1) / kChunkPairs;
+        const size_t ctl_words = sizeof(CertWork) / 4 + (size_t)((nchunks + 31) / 32);
+        if (!(s = ws->energy.reserve(frames * stft::kEnergyParts)).ok() || !(s = ws->cert_ctl.reserve(ctl_words)).ok() ||
+            !(s = ws->chunk_list.reserve(nchunks)).ok() || !(s = ws->item_list.reserve(std::max<uint64_t>(kept, 1))).ok())
+          return s;
+        if (!ws->stats) {
+          NEEDLE_HIP_TRY(hipMalloc((void **)&ws->stats, sizeof(CertStats)));
+          NEEDLE_HIP_TRY(hipMemsetAsync(ws->stats, 0, sizeof(CertStats), stream));
+        }
+        NEEDLE_HIP_TRY(hipMemsetAsync(ws->cert_ctl.ptr, 0, ctl_words * 4, stream));
+        CertWork *work = reinterpret_cast<CertWork *>(ws->cert_ctl.ptr);
+        uint32_t *bitmap = ws->cert_ctl.ptr + sizeof(CertWork) / 4;
+        {
+          KernelTimer timer("stft_chroma32");
+          const uint32_t ppb = pairs_per_block((uint64_t)kStft32WavesPerSimd * (uint64_t)cus);
+          const uint32_t grid = (uint32_t)(((pairs + ppb - 1) / ppb + 7) / 8 * 8);  // multiple of 8: see the XCD mapping
+          if (!(s = launch_stft_chroma32(channels, grid, stream, d_pcm, desc.streams.ptr, n, tab.tw32, tab.win32, tab.bin_slot,
+                                         tab.fold_tab, ws->chroma.ptr, ws->energy.ptr, (uint32_t)pairs, ppb)).ok())
+            return s;
+        }
+        {
+          KernelTimer timer("features_cert");
+          hipLaunchKernelGGL(features_classify_cert_kernel, dim3((uint32_t)((tiles + 3) / 4)), dim3(256), 0, stream,
+                             ws->chroma.ptr, ws->energy.ptr, desc.streams.ptr, n, tab.thr, step, items_per_tile, d_items,
+                             (uint32_t)tiles, cert_k, kChunkPairs, work, bitmap, ws->chunk_list.ptr, ws->item_list.ptr);
+        }
+        {
+          KernelTimer timer("stft_fallback");
+          const uint32_t grid = (uint32_t)std::min<uint64_t>(2ull * (uint64_t)cus, nchunks);
+          const stft::ChunkList list{ws->chunk_list.ptr, &work->chunk_count};
+          auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm, desc.streams.ptr, n,
+                               tab.tw, tab.wcos, tab.wconst, tab.bin_slot, tab.fold_tab, ws->chroma.ptr, (uint32_t)pairs,
+                               kChunkPairs, list);
+          };
+          if (channels == 1) launch(stft_chroma_kernel<1, 0, true>); else launch(stft_chroma_kernel<2, 0, true>);
+        }
+        {
+          KernelTimer timer("fixup_items");
+          hipLaunchKernelGGL(fixup_items_kernel, dim3(64), dim3(256), 0, stream, ws->chroma.ptr, tab.thr, work,
+                             ws->item_list.ptr, d_items, ws->stats);
+        }
+        ws->items_total += kept;
+        ws->chunks_total += nchunks;
+        NEEDLE_HIP_TRY(hipGetLastError());
+        begin = end;
+        continue;
+      }
       {
         KernelTimer timer("stft_chroma");
-        // Pairs per workgroup.  The device holds `slots` workgroups at a time (2 per CU).  A launch of more than
-        // about two rounds of workgroups balances itself (workgroups retire at different times and the dispatcher
-        // backfills: measured, a "whole rounds" choice of the size changed 7- and 14-episode launches by < 2 %), so
-        // long launches keep kPairsPerBlock.  A SHORT launch -- one rank's share of a sharded job, a single file --
-        // is cut so that every slot gets one workgroup: 4 episodes x 24 min = 11 626 pairs run as 506 workgroups of
-        // 23 pairs (0.153 ms) instead of 727 of 16 (0.162 ms); one episode as 485 workgroups of 6 instead of 182 of 16.
-        uint32_t ppb = kPairsPerBlock;
-        {
-          int cus = 256, dev = 0;
-          (void)hipGetDevice(&dev);
-          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-          const uint64_t slots = 2ull * (uint64_t)std::max(cus, 1);
-          if ((pairs + kPairsPerBlock - 1) / kPairsPerBlock < 2 * slots)
-            ppb = (uint32_t)std::min<uint64_t>(40, std::max<uint64_t>(4, (pairs + slots - 1) / slots));
-        }
-        if (const char *e = getenv("NEEDLE_STFT_PAIRS")) ppb = (uint32_t)std::max(1, atoi(e));
+        const uint32_t ppb = pairs_per_block(2ull * (uint64_t)cus);
         const uint32_t grid = (uint32_t)(((pairs + ppb - 1) / ppb + 7) / 8 * 8);  // multiple of 8: see the XCD mapping
         auto launch = [&](auto kernel) {
           hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm,
                              desc.streams.ptr, n, tab.tw, tab.wcos, tab.wconst, tab.bin_slot, tab.fold_tab, ws->chroma.ptr,
-                             (uint32_t)pairs, ppb);
+                             (uint32_t)pairs, ppb, stft::ChunkList{nullptr, nullptr});
         };
-        if (channels == 1) launch(stft_chroma_kernel<1>); else launch(stft_chroma_kernel<2>);
+        if (channels == 1) launch(stft_chroma_kernel<1, 0, false>); else launch(stft_chroma_kernel<2, 0, false>);
       }
       const bool separate = d_feat_dbg != nullptr || getenv("NEEDLE_HIP_SEPARATE_CLASSIFY") != nullptr;
       if (separate) {  // a caller wants the features themselves (tests): kernels 2 and 3 one after the other
@@ -356,6 +598,28 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
     begin = end;
   }
   if (sync) NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+  return Status::Ok();
+}
+
+// {items fingerprinted, items recomputed in f64, chunks of frame pairs, chunks recomputed} since the last reset, on the
+// current device; waits for the library stream.
+Status gpu_fingerprint_cert_stats(uint64_t out[4], bool reset) {
+  std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
+  Status s = ensure_device();
+  if (!s.ok()) return s;
+  FpWorkspace *ws = workspace();
+  CertStats host{0, 0};
+  hipStream_t stream = library_stream();
+  if (ws->stats) {
+    NEEDLE_HIP_TRY(hipMemcpyAsync(&host, ws->stats, sizeof(host), hipMemcpyDeviceToHost, stream));
+    if (reset) NEEDLE_HIP_TRY(hipMemsetAsync(ws->stats, 0, sizeof(CertStats), stream));
+    NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  out[0] = ws->items_total;
+  out[1] = host.items_recomputed;
+  out[2] = ws->chunks_total;
+  out[3] = host.chunks_recomputed;
+  if (reset) ws->items_total = ws->chunks_total = 0;
   return Status::Ok();
 }
 

@@ -1,0 +1,27 @@
+// The f32 first pass of the STFT in a translation unit of its own: it is compiled with -fno-slp-vectorize.  Left to
+// itself the SLP vectoriser turns this kernel's complex arithmetic into v_pk_*_f32 (no faster per flop on gfx950 than
+// two plain instructions) at the price of 135 register moves per frame pair and, because packed operands need aligned
+// register pairs, 74 spilled VGPRs at three waves per SIMD; without it the kernel takes 163 VGPRs and no scratch.
+#include "fingerprint32.h"
+
+#include "hipctx.h"
+#include "stft32_kernel.h"
+
+namespace needle {
+
+Status launch_stft_chroma32(int channels, uint32_t grid, hipStream_t stream, const int16_t *d_pcm,
+                            const stft::FpStream *streams, int num_streams, const core::cf *tw32, const float *win32,
+                            const uint16_t *bin_slot, const uint32_t *fold_tab, double *chroma, float *energy,
+                            uint32_t total_pairs, uint32_t pairs_per_block) {
+  const size_t lds_bytes = core::kLds2Slots * sizeof(core::cf);  // 34 832 B: under the 64 KiB that needs no opt-in
+  if (channels == 1)
+    hipLaunchKernelGGL((stft::stft_chroma32_kernel<1, kStft32WavesPerSimd>), dim3(grid), dim3(256), lds_bytes, stream, d_pcm,
+                       streams, num_streams, tw32, win32, bin_slot, fold_tab, chroma, energy, total_pairs, pairs_per_block);
+  else
+    hipLaunchKernelGGL((stft::stft_chroma32_kernel<2, kStft32WavesPerSimd>), dim3(grid), dim3(256), lds_bytes, stream, d_pcm,
+                       streams, num_streams, tw32, win32, bin_slot, fold_tab, chroma, energy, total_pairs, pairs_per_block);
+  NEEDLE_HIP_TRY(hipGetLastError());
+  return Status::Ok();
+}
+
+}  // namespace needle

@@ -18,18 +18,27 @@
 namespace needle {
 namespace core {
 
-struct cd {  // 8-byte aligned on purpose: LDS traffic as paired 64-bit accesses measured faster than b128 here
-  double x, y;
+// One complex value.  The transform below is written once over the complex type C: cd (f64, the arithmetic the u32
+// contract is defined on) and cf (f32, the certified first pass: stft32_kernel.h).
+template <typename T>
+struct cx {
+  typedef T real;
+  T x, y;
 };
+typedef cx<double> cd;
+typedef cx<float> cf;
 
-NEEDLE_HD cd cadd(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
-NEEDLE_HD cd csub(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
-NEEDLE_HD cd cmul(cd a, cd b) { return cd{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+NEEDLE_HD double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
+NEEDLE_HD float fmad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <class C> NEEDLE_HD C cadd(C a, C b) { return C{a.x + b.x, a.y + b.y}; }
+template <class C> NEEDLE_HD C csub(C a, C b) { return C{a.x - b.x, a.y - b.y}; }
+template <class C> NEEDLE_HD C cmul(C a, C b) { return C{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 // complex multiply with explicit fused multiply-adds (2 mul + 2 fma): same on host (fma()) and device
-NEEDLE_HD cd cmulf(cd a, cd b) {
-  return cd{__builtin_fma(a.x, b.x, -(a.y * b.y)), __builtin_fma(a.x, b.y, a.y * b.x)};
+template <class C> NEEDLE_HD C cmulf(C a, C b) {
+  return C{fmad(a.x, b.x, -(a.y * b.y)), fmad(a.x, b.y, a.y * b.x)};
 }
-NEEDLE_HD cd mul_neg_i(cd a) { return cd{a.y, -a.x}; }
+template <class C> NEEDLE_HD C mul_neg_i(C a) { return C{a.y, -a.x}; }
 
 constexpr int kThreads = 256;    // threads per frame pair
 constexpr int kMinBin = 10;      // max(1, round(4096*28/11025))
@@ -50,8 +59,8 @@ NEEDLE_HD int thread_pad_slot(int t) { return 17 * t + 16; }  // window recurren
 
 NEEDLE_HD int pidx(int i) { return i + (i >> 4); }
 
-NEEDLE_HD void bfly4(cd &a0, cd &a1, cd &a2, cd &a3) {
-  cd e0 = cadd(a0, a2), e1 = csub(a0, a2), e2 = cadd(a1, a3), e3 = mul_neg_i(csub(a1, a3));
+template <class C> NEEDLE_HD void bfly4(C &a0, C &a1, C &a2, C &a3) {
+  C e0 = cadd(a0, a2), e1 = csub(a0, a2), e2 = cadd(a1, a3), e3 = mul_neg_i(csub(a1, a3));
   a0 = cadd(e0, e2);
   a1 = cadd(e1, e3);
   a2 = csub(e0, e2);
@@ -62,17 +71,16 @@ NEEDLE_HD void bfly4(cd &a0, cd &a1, cd &a2, cd &a3) {
 // register holding X[j].
 NEEDLE_HD int out16(int j) { return 4 * (j & 3) + (j >> 2); }
 
-NEEDLE_HD double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
-
 // Last layer of the 16-point transform for one k1: bfly4 over (b0, w1 b1, w2 b2, w3 b3) with the constant
 // twiddles folded into fused multiply-adds.  The caller passes E0 = b0 + w2 b2, E1 = b0 - w2 b2 and, for the odd
 // pair, v = u1 + rho u3, v' = u1 - rho u3 where w1 b1 = g u1 and w3 b3 = g rho u3: then E2 = g v, E3 = -i g v'
 // are never formed, the four outputs are E0 +- g v and E1 +- g (-i v') (8 FMAs in place of 8 adds).
-NEEDLE_HD void bfly4_tail(cd E0, cd E1, cd v, cd vp, double g, cd &o0, cd &o1, cd &o2, cd &o3) {
-  o0 = cd{fmad(g, v.x, E0.x), fmad(g, v.y, E0.y)};
-  o2 = cd{fmad(-g, v.x, E0.x), fmad(-g, v.y, E0.y)};
-  o1 = cd{fmad(g, vp.y, E1.x), fmad(-g, vp.x, E1.y)};
-  o3 = cd{fmad(-g, vp.y, E1.x), fmad(g, vp.x, E1.y)};
+template <class C>
+NEEDLE_HD void bfly4_tail(C E0, C E1, C v, C vp, typename C::real g, C &o0, C &o1, C &o2, C &o3) {
+  o0 = C{fmad(g, v.x, E0.x), fmad(g, v.y, E0.y)};
+  o2 = C{fmad(-g, v.x, E0.x), fmad(-g, v.y, E0.y)};
+  o1 = C{fmad(g, vp.y, E1.x), fmad(-g, vp.x, E1.y)};
+  o3 = C{fmad(-g, vp.y, E1.x), fmad(g, vp.x, E1.y)};
 }
 
 // The transform in two parts, so that a caller can start storing the outputs of one k1 while the next is computed:
@@ -81,7 +89,7 @@ NEEDLE_HD void bfly4_tail(cd E0, cd E1, cd v, cd vp, double g, cd &o0, cd &o1, c
 // W_16^1 = (c, -s), W_16^2 = (h, -h), W_16^3 = (s, -c), W_16^6 = (-h, -h), W_16^9 = (-c, s); t8 = s / c = tan(pi/8),
 // ct8 = c / s.  A twiddle w = g (1, tau) costs two FMAs for u = (1, tau) x and its scale g rides on the FMAs of the
 // following additions: 144 instructions per transform instead of 168.
-NEEDLE_HD void fft16_head(cd *a) {
+template <class C> NEEDLE_HD void fft16_head(C *a) {
 #pragma unroll
   for (int n2 = 0; n2 < 4; n2++) bfly4(a[n2], a[4 + n2], a[8 + n2], a[12 + n2]);
 }
@@ -92,26 +100,27 @@ NEEDLE_HD void fft16_head(cd *a) {
 struct NoHook {
   NEEDLE_HD void operator()(int) const {}
 };
-template <int K1, typename HOOK = NoHook, bool PLAIN = false>
-NEEDLE_HD void fft16_tail(cd *a, HOOK hook = HOOK()) {
-  const double c = 0.92387953251128673848, s = 0.38268343236508977173, h = 0.70710678118654752440;
-  const double t8 = 0.41421356237309504880, ct8 = 2.41421356237309504880;
-  cd E0, E1, v, vp;
-  double g = 1.0;
+template <int K1, typename HOOK = NoHook, bool PLAIN = false, class C = cd>
+NEEDLE_HD void fft16_tail(C *a, HOOK hook = HOOK()) {
+  typedef typename C::real T;
+  const T c = (T)0.92387953251128673848, s = (T)0.38268343236508977173, h = (T)0.70710678118654752440;
+  const T t8 = (T)0.41421356237309504880, ct8 = (T)2.41421356237309504880;
+  C E0, E1, v, vp;
+  T g = (T)1.0;
   if (K1 == 0 || PLAIN) {  // no twiddles left: v = b1 + b3, v' = b1 - b3, plain additions below
-    cd b0 = a[4 * K1], b1 = a[4 * K1 + 1], b2 = a[4 * K1 + 2], b3 = a[4 * K1 + 3];
+    C b0 = a[4 * K1], b1 = a[4 * K1 + 1], b2 = a[4 * K1 + 2], b3 = a[4 * K1 + 3];
     if (PLAIN && K1 == 1) {
-      b1 = cd{b1.x * c + b1.y * s, b1.y * c - b1.x * s};       // W1 = (c, -s)
-      b2 = cd{(b2.x + b2.y) * h, (b2.y - b2.x) * h};           // W2 = (h, -h)
-      b3 = cd{b3.x * s + b3.y * c, b3.y * s - b3.x * c};       // W3 = (s, -c)
+      b1 = C{b1.x * c + b1.y * s, b1.y * c - b1.x * s};       // W1 = (c, -s)
+      b2 = C{(b2.x + b2.y) * h, (b2.y - b2.x) * h};           // W2 = (h, -h)
+      b3 = C{b3.x * s + b3.y * c, b3.y * s - b3.x * c};       // W3 = (s, -c)
     } else if (PLAIN && K1 == 2) {
-      b1 = cd{(b1.x + b1.y) * h, (b1.y - b1.x) * h};           // W2
-      b2 = cd{b2.y, -b2.x};                                    // W4 = -i
-      b3 = cd{(b3.y - b3.x) * h, -(b3.x + b3.y) * h};          // W6 = (-h, -h)
+      b1 = C{(b1.x + b1.y) * h, (b1.y - b1.x) * h};           // W2
+      b2 = C{b2.y, -b2.x};                                    // W4 = -i
+      b3 = C{(b3.y - b3.x) * h, -(b3.x + b3.y) * h};          // W6 = (-h, -h)
     } else if (PLAIN && K1 == 3) {
-      b1 = cd{b1.x * s + b1.y * c, b1.y * s - b1.x * c};       // W3
-      b2 = cd{(b2.y - b2.x) * h, -(b2.x + b2.y) * h};          // W6
-      b3 = cd{-(b3.x * c) - b3.y * s, b3.x * s - b3.y * c};    // W9 = (-c, s)
+      b1 = C{b1.x * s + b1.y * c, b1.y * s - b1.x * c};       // W3
+      b2 = C{(b2.y - b2.x) * h, -(b2.x + b2.y) * h};          // W6
+      b3 = C{-(b3.x * c) - b3.y * s, b3.x * s - b3.y * c};    // W9 = (-c, s)
     }
     E0 = cadd(b0, b2);
     E1 = csub(b0, b2);
@@ -122,62 +131,62 @@ NEEDLE_HD void fft16_tail(cd *a, HOOK hook = HOOK()) {
     a[4 * K1] = cadd(E0, v);
     a[4 * K1 + 2] = csub(E0, v);
     hook(2);
-    a[4 * K1 + 1] = cd{E1.x + vp.y, E1.y - vp.x};
-    a[4 * K1 + 3] = cd{E1.x - vp.y, E1.y + vp.x};
+    a[4 * K1 + 1] = C{E1.x + vp.y, E1.y - vp.x};
+    a[4 * K1 + 3] = C{E1.x - vp.y, E1.y + vp.x};
     hook(3);
     return;
   } else if (K1 == 1) {  // w = (1, W1, W2, W3)
-    const cd b0 = a[4], b1 = a[5], b2 = a[6], b3 = a[7];
-    const cd u2 = cd{b2.x + b2.y, b2.y - b2.x};  // W2 b2 = h u2
-    E0 = cd{fmad(h, u2.x, b0.x), fmad(h, u2.y, b0.y)};
-    E1 = cd{fmad(-h, u2.x, b0.x), fmad(-h, u2.y, b0.y)};
+    const C b0 = a[4], b1 = a[5], b2 = a[6], b3 = a[7];
+    const C u2 = C{b2.x + b2.y, b2.y - b2.x};  // W2 b2 = h u2
+    E0 = C{fmad(h, u2.x, b0.x), fmad(h, u2.y, b0.y)};
+    E1 = C{fmad(-h, u2.x, b0.x), fmad(-h, u2.y, b0.y)};
     hook(0);
-    const cd u1 = cd{fmad(t8, b1.y, b1.x), fmad(-t8, b1.x, b1.y)};    // W1 b1 = c u1
-    const cd u3 = cd{fmad(ct8, b3.y, b3.x), fmad(-ct8, b3.x, b3.y)};  // W3 b3 = s u3 = c t8 u3
-    v = cd{fmad(t8, u3.x, u1.x), fmad(t8, u3.y, u1.y)};
-    vp = cd{fmad(-t8, u3.x, u1.x), fmad(-t8, u3.y, u1.y)};
+    const C u1 = C{fmad(t8, b1.y, b1.x), fmad(-t8, b1.x, b1.y)};    // W1 b1 = c u1
+    const C u3 = C{fmad(ct8, b3.y, b3.x), fmad(-ct8, b3.x, b3.y)};  // W3 b3 = s u3 = c t8 u3
+    v = C{fmad(t8, u3.x, u1.x), fmad(t8, u3.y, u1.y)};
+    vp = C{fmad(-t8, u3.x, u1.x), fmad(-t8, u3.y, u1.y)};
     g = c;
   } else if (K1 == 2) {  // w = (1, W2, W4, W6)
-    const cd b0 = a[8], b1 = a[9], b2 = a[10], b3 = a[11];
-    E0 = cd{b0.x + b2.y, b0.y - b2.x};  // W4 = -i
-    E1 = cd{b0.x - b2.y, b0.y + b2.x};
+    const C b0 = a[8], b1 = a[9], b2 = a[10], b3 = a[11];
+    E0 = C{b0.x + b2.y, b0.y - b2.x};  // W4 = -i
+    E1 = C{b0.x - b2.y, b0.y + b2.x};
     hook(0);
-    const cd u1 = cd{b1.x + b1.y, b1.y - b1.x};  // W2 b1 = h u1
-    const cd n3 = cd{b3.x - b3.y, b3.x + b3.y};  // W6 b3 = -h n3
-    v = cd{u1.x - n3.x, u1.y - n3.y};
-    vp = cd{u1.x + n3.x, u1.y + n3.y};
+    const C u1 = C{b1.x + b1.y, b1.y - b1.x};  // W2 b1 = h u1
+    const C n3 = C{b3.x - b3.y, b3.x + b3.y};  // W6 b3 = -h n3
+    v = C{u1.x - n3.x, u1.y - n3.y};
+    vp = C{u1.x + n3.x, u1.y + n3.y};
     g = h;
   } else {  // K1 == 3: w = (1, W3, W6, W9)
-    const cd b0 = a[12], b1 = a[13], b2 = a[14], b3 = a[15];
-    const cd n2 = cd{b2.x - b2.y, b2.x + b2.y};  // W6 b2 = -h n2
-    E0 = cd{fmad(-h, n2.x, b0.x), fmad(-h, n2.y, b0.y)};
-    E1 = cd{fmad(h, n2.x, b0.x), fmad(h, n2.y, b0.y)};
+    const C b0 = a[12], b1 = a[13], b2 = a[14], b3 = a[15];
+    const C n2 = C{b2.x - b2.y, b2.x + b2.y};  // W6 b2 = -h n2
+    E0 = C{fmad(-h, n2.x, b0.x), fmad(-h, n2.y, b0.y)};
+    E1 = C{fmad(h, n2.x, b0.x), fmad(h, n2.y, b0.y)};
     hook(0);
-    const cd u1 = cd{fmad(ct8, b1.y, b1.x), fmad(-ct8, b1.x, b1.y)};  // W3 b1 = s u1
-    const cd u3 = cd{fmad(t8, b3.y, b3.x), fmad(-t8, b3.x, b3.y)};    // W9 b3 = -c u3 = -s ct8 u3
-    v = cd{fmad(-ct8, u3.x, u1.x), fmad(-ct8, u3.y, u1.y)};
-    vp = cd{fmad(ct8, u3.x, u1.x), fmad(ct8, u3.y, u1.y)};
+    const C u1 = C{fmad(ct8, b1.y, b1.x), fmad(-ct8, b1.x, b1.y)};  // W3 b1 = s u1
+    const C u3 = C{fmad(t8, b3.y, b3.x), fmad(-t8, b3.x, b3.y)};    // W9 b3 = -c u3 = -s ct8 u3
+    v = C{fmad(-ct8, u3.x, u1.x), fmad(-ct8, u3.y, u1.y)};
+    vp = C{fmad(ct8, u3.x, u1.x), fmad(ct8, u3.y, u1.y)};
     g = s;
   }
   hook(1);
   // E2 = g v and E3 = -i g v' are never formed: the outputs are E0 +- g v and E1 +- g (-i v')
-  a[4 * K1] = cd{fmad(g, v.x, E0.x), fmad(g, v.y, E0.y)};
-  a[4 * K1 + 2] = cd{fmad(-g, v.x, E0.x), fmad(-g, v.y, E0.y)};
+  a[4 * K1] = C{fmad(g, v.x, E0.x), fmad(g, v.y, E0.y)};
+  a[4 * K1 + 2] = C{fmad(-g, v.x, E0.x), fmad(-g, v.y, E0.y)};
   hook(2);
-  a[4 * K1 + 1] = cd{fmad(g, vp.y, E1.x), fmad(-g, vp.x, E1.y)};
-  a[4 * K1 + 3] = cd{fmad(-g, vp.y, E1.x), fmad(g, vp.x, E1.y)};
+  a[4 * K1 + 1] = C{fmad(g, vp.y, E1.x), fmad(-g, vp.x, E1.y)};
+  a[4 * K1 + 3] = C{fmad(-g, vp.y, E1.x), fmad(g, vp.x, E1.y)};
   hook(3);
 }
-NEEDLE_HD void fft16(cd *a) {
+template <class C> NEEDLE_HD void fft16(C *a) {
   fft16_head(a);
-  fft16_tail<0>(a);
-  fft16_tail<1>(a);
-  fft16_tail<2>(a);
-  fft16_tail<3>(a);
+  fft16_tail<0, NoHook, false, C>(a);
+  fft16_tail<1, NoHook, false, C>(a);
+  fft16_tail<2, NoHook, false, C>(a);
+  fft16_tail<3, NoHook, false, C>(a);
 }
 
-// One complex slot as a single 128-bit LDS access (slots are 16-byte aligned).  128-bit accesses take a 16-bit
-// immediate byte offset, so every slot of the form base + constant costs no address arithmetic.
+// One complex slot as a single LDS access (slots are naturally aligned): 128 bits for cd, 64 bits for cf.  Both take a
+// 16-bit immediate byte offset, so every slot of the form base + constant costs no address arithmetic.
 NEEDLE_HD cd lds_get(const cd *lds, int slot) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef double v2d __attribute__((ext_vector_type(2), aligned(16)));
@@ -191,6 +200,23 @@ NEEDLE_HD void lds_put(cd *lds, int slot, cd v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef double v2d __attribute__((ext_vector_type(2), aligned(16)));
   *reinterpret_cast<v2d *>(lds + slot) = v2d{v.x, v.y};
+#else
+  lds[slot] = v;
+#endif
+}
+NEEDLE_HD cf lds_get(const cf *lds, int slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float v2f __attribute__((ext_vector_type(2), aligned(8)));
+  const v2f v = *reinterpret_cast<const v2f *>(lds + slot);
+  return cf{v.x, v.y};
+#else
+  return lds[slot];
+#endif
+}
+NEEDLE_HD void lds_put(cf *lds, int slot, cf v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float v2f __attribute__((ext_vector_type(2), aligned(8)));
+  *reinterpret_cast<v2f *>(lds + slot) = v2f{v.x, v.y};
 #else
   lds[slot] = v;
 #endif
@@ -228,6 +254,15 @@ NEEDLE_HD void lds_put_bytes(cd *lds, uint32_t byte_off, cd v) {
   *reinterpret_cast<v2d *>(reinterpret_cast<char *>(lds) + byte_off) = v2d{v.x, v.y};
 #else
   lds[byte_off / sizeof(cd)] = v;
+#endif
+}
+// cf: the packed word still carries slot * 16 (one table for both widths); a cf slot is 8 bytes
+NEEDLE_HD void lds_put_bytes(cf *lds, uint32_t byte_off16, cf v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float v2f __attribute__((ext_vector_type(2), aligned(8)));
+  *reinterpret_cast<v2f *>(reinterpret_cast<char *>(lds) + (byte_off16 >> 1)) = v2f{v.x, v.y};
+#else
+  lds[byte_off16 / 16] = v;
 #endif
 }
 
@@ -282,29 +317,29 @@ NEEDLE_HD int dif_partner_base(int t) {
 
 // stage 0: r holds the inputs x[t + 256 k]; leaves the stage's outputs in the same slots.  Split in two so the
 // kernel can keep the register-only half ahead of the barrier that frees the LDS image of the previous pair.
-NEEDLE_HD void dif0_store(int t, cd base0, cd *lds, const cd *r) {
+template <class C> NEEDLE_HD void dif0_store(int t, C base0, C *lds, const C *r) {
   const int o = dif0_base(t);
   lds_put(lds, o, r[out16(0)]);
-  cd w = base0;
+  C w = base0;
 #pragma unroll
   for (int j = 1; j < 16; j++) {
     lds_put(lds, o + 272 * j, cmulf(r[out16(j)], w));
     if (j < 15) w = cmulf(w, base0);
   }
 }
-NEEDLE_HD void dif0(int t, cd base0, cd *lds, cd *r) {
+template <class C> NEEDLE_HD void dif0(int t, C base0, C *lds, C *r) {
   fft16(r);
   dif0_store(t, base0, lds, r);
 }
 
 // stage 1, in place; base1 = W_4096^{16 (t & 15)}
-NEEDLE_HD void dif1(int t, cd base1, cd *lds, cd *r) {
+template <class C> NEEDLE_HD void dif1(int t, C base1, C *lds, C *r) {
   const int o = dif1_base(t);
 #pragma unroll
   for (int k = 0; k < 16; k++) r[k] = lds_get(lds, o + 17 * k);
   fft16(r);
   lds_put(lds, o, r[out16(0)]);
-  cd w = base1;
+  C w = base1;
 #pragma unroll
   for (int j = 1; j < 16; j++) {
     lds_put(lds, o + 17 * j, cmulf(r[out16(j)], w));
@@ -317,67 +352,77 @@ NEEDLE_HD void dif1(int t, cd base1, cd *lds, cd *r) {
 // its twiddle multiply) go out one at a time at four points of tail k1 + 1, the last tail's own four behind it;
 // otherwise each tail's four follow it directly.  MODE bit 1 (kPlainFft): round-1 arithmetic in the tails.
 enum : int { kStoreSpaced = 1, kPlainFft = 2 };
-NEEDLE_HD void twiddle_powers(cd base, cd *pw) {
+template <class C> NEEDLE_HD void twiddle_powers(C base, C *pw) {
   pw[1] = base;
 #pragma unroll
   for (int j = 2; j < 16; j++) pw[j] = cmulf(pw[j - 1], base);
 }
-template <int K1>
+template <int K1, class C = cd>
 struct StoreHook {
   int o, pitch;
-  cd *lds;
-  const cd *r;
-  const cd *pw;
+  C *lds;
+  const C *r;
+  const C *pw;
   NEEDLE_HD void operator()(int k2) const {
     const int j = K1 + 4 * k2;
     lds_put(lds, o + pitch * j, j == 0 ? r[4 * K1 + k2] : cmulf(r[4 * K1 + k2], pw[j]));
   }
 };
-template <int MODE>
-NEEDLE_HD void dif_tails_store(int o, int pitch, const cd *pw, cd *lds, cd *r) {
+template <int MODE, class C>
+NEEDLE_HD void dif_tails_store(int o, int pitch, const C *pw, C *lds, C *r) {
   constexpr bool P = (MODE & kPlainFft) != 0;
   if (MODE & kStoreSpaced) {
     fft16_tail<0, NoHook, P>(r);
-    fft16_tail<1, StoreHook<0>, P>(r, StoreHook<0>{o, pitch, lds, r, pw});
-    fft16_tail<2, StoreHook<1>, P>(r, StoreHook<1>{o, pitch, lds, r, pw});
-    fft16_tail<3, StoreHook<2>, P>(r, StoreHook<2>{o, pitch, lds, r, pw});
+    fft16_tail<1, StoreHook<0, C>, P>(r, StoreHook<0, C>{o, pitch, lds, r, pw});
+    fft16_tail<2, StoreHook<1, C>, P>(r, StoreHook<1, C>{o, pitch, lds, r, pw});
+    fft16_tail<3, StoreHook<2, C>, P>(r, StoreHook<2, C>{o, pitch, lds, r, pw});
 #pragma unroll
-    for (int k2 = 0; k2 < 4; k2++) StoreHook<3>{o, pitch, lds, r, pw}(k2);
+    for (int k2 = 0; k2 < 4; k2++) StoreHook<3, C>{o, pitch, lds, r, pw}(k2);
   } else {
     fft16_tail<0, NoHook, P>(r);
 #pragma unroll
-    for (int k2 = 0; k2 < 4; k2++) StoreHook<0>{o, pitch, lds, r, pw}(k2);
+    for (int k2 = 0; k2 < 4; k2++) StoreHook<0, C>{o, pitch, lds, r, pw}(k2);
     fft16_tail<1, NoHook, P>(r);
 #pragma unroll
-    for (int k2 = 0; k2 < 4; k2++) StoreHook<1>{o, pitch, lds, r, pw}(k2);
+    for (int k2 = 0; k2 < 4; k2++) StoreHook<1, C>{o, pitch, lds, r, pw}(k2);
     fft16_tail<2, NoHook, P>(r);
 #pragma unroll
-    for (int k2 = 0; k2 < 4; k2++) StoreHook<2>{o, pitch, lds, r, pw}(k2);
+    for (int k2 = 0; k2 < 4; k2++) StoreHook<2, C>{o, pitch, lds, r, pw}(k2);
     fft16_tail<3, NoHook, P>(r);
 #pragma unroll
-    for (int k2 = 0; k2 < 4; k2++) StoreHook<3>{o, pitch, lds, r, pw}(k2);
+    for (int k2 = 0; k2 < 4; k2++) StoreHook<3, C>{o, pitch, lds, r, pw}(k2);
   }
 }
-template <int MODE = 0>
-NEEDLE_HD void dif0_streamed(int t, cd base0, cd *lds, cd *r) {
-  cd pw[16];
-  twiddle_powers(base0, pw);
+// (the _pw forms take the fifteen powers pw[1..15] of the stage's twiddle base ready-made: the f32 pass computes them
+// in double once per thread, so that every twiddle is correctly rounded instead of a chain of f32 products)
+template <int MODE = 0, class C>
+NEEDLE_HD void dif0_streamed_pw(int t, const C *pw, C *lds, C *r) {
   fft16_head(r);
   dif_tails_store<MODE>(dif0_base(t), 272, pw, lds, r);
 }
-template <int MODE = 0>
-NEEDLE_HD void dif1_streamed(int t, cd base1, cd *lds, cd *r) {
-  cd pw[16];
-  twiddle_powers(base1, pw);
+template <int MODE = 0, class C>
+NEEDLE_HD void dif1_streamed_pw(int t, const C *pw, C *lds, C *r) {
   const int o = dif1_base(t);
 #pragma unroll
   for (int k = 0; k < 16; k++) r[k] = lds_get(lds, o + 17 * k);
   fft16_head(r);
   dif_tails_store<MODE>(o, 17, pw, lds, r);
 }
+template <int MODE = 0, class C>
+NEEDLE_HD void dif0_streamed(int t, C base0, C *lds, C *r) {
+  C pw[16];
+  twiddle_powers(base0, pw);
+  dif0_streamed_pw<MODE>(t, pw, lds, r);
+}
+template <int MODE = 0, class C>
+NEEDLE_HD void dif1_streamed(int t, C base1, C *lds, C *r) {
+  C pw[16];
+  twiddle_powers(base1, pw);
+  dif1_streamed_pw<MODE>(t, pw, lds, r);
+}
 
 // stage 2: afterwards r[out16(j)] = Z[dif_bin_of(t, j)]
-NEEDLE_HD void dif2(int t, const cd *lds, cd *r) {
+template <class C> NEEDLE_HD void dif2(int t, const C *lds, C *r) {
   const int o = dif2_base(t);
 #pragma unroll
   for (int k = 0; k < 16; k++) r[k] = lds_get(lds, o + k);
@@ -385,7 +430,7 @@ NEEDLE_HD void dif2(int t, const cd *lds, cd *r) {
 }
 
 // publish the registers other threads read as partners (bins >= 2789 live in j = 10..15), in place
-NEEDLE_HD void dif2_publish(int t, cd *lds, const cd *r) {
+template <class C> NEEDLE_HD void dif2_publish(int t, C *lds, const C *r) {
   const int o = dif2_base(t);
 #pragma unroll
   for (int j = 10; j < 16; j++) lds_put(lds, o + j, r[out16(j)]);
@@ -393,8 +438,8 @@ NEEDLE_HD void dif2_publish(int t, cd *lds, const cd *r) {
 
 // stage 2 with the publish stores streamed out the same way (j = 12, 13 are outputs of tails 0 and 1, j = 10, 14 of
 // tail 2, j = 11, 15 of tail 3)
-template <int MODE = 0>
-NEEDLE_HD void dif2_streamed(int t, cd *lds, cd *r) {
+template <int MODE = 0, class C>
+NEEDLE_HD void dif2_streamed(int t, C *lds, C *r) {
   constexpr bool P = (MODE & kPlainFft) != 0;
   const int o = dif2_base(t);
 #pragma unroll
@@ -404,14 +449,14 @@ NEEDLE_HD void dif2_streamed(int t, cd *lds, cd *r) {
   fft16_tail<1, NoHook, P>(r);
   if (MODE & kStoreSpaced) {
     struct Hook2 {
-      int o; cd *lds; const cd *r;
+      int o; C *lds; const C *r;
       NEEDLE_HD void operator()(int i) const {
         if (i == 1) lds_put(lds, o + 12, r[3]);
         if (i == 3) lds_put(lds, o + 13, r[7]);
       }
     };
     struct Hook3 {
-      int o; cd *lds; const cd *r;
+      int o; C *lds; const C *r;
       NEEDLE_HD void operator()(int i) const {
         if (i == 1) lds_put(lds, o + 10, r[10]);
         if (i == 3) lds_put(lds, o + 14, r[11]);
@@ -434,7 +479,7 @@ NEEDLE_HD void dif2_streamed(int t, cd *lds, cd *r) {
 }
 
 // the partners Z[N - k] of this thread's bins in registers j = 0..kBinsPerThread-1, all reads issued together
-NEEDLE_HD void dif_partner_load(int t, const cd *lds, cd *y) {
+template <class C> NEEDLE_HD void dif_partner_load(int t, const C *lds, C *y) {
   const int o = dif_partner_base(t);
 #pragma unroll
   for (int j = 0; j < kBinsPerThread; j++) y[j] = lds_get(lds, o + 15 - j);
@@ -465,19 +510,22 @@ NEEDLE_HD double window_step(const WindowConst &wc, double *c, double *c_prev) {
 constexpr double kPairInputScale = 0.5;
 
 // powers of one bin for the two frames from Z[k] and its partner Z[N - k]
-NEEDLE_HD void dif_power_of(cd z, cd y, double *pa, double *pb) {
-  const double ar = z.x + y.x, ai = z.y - y.y;  // X_A
-  const double br = z.y + y.y, bi = y.x - z.x;  // X_B
+template <class C>
+NEEDLE_HD void dif_power_of(C z, C y, typename C::real *pa, typename C::real *pb) {
+  const typename C::real ar = z.x + y.x, ai = z.y - y.y;  // X_A
+  const typename C::real br = z.y + y.y, bi = y.x - z.x;  // X_B
   *pa = fmad(ar, ar, ai * ai);
   *pb = fmad(br, br, bi * bi);
 }
 // powers of this thread's bin in register j (any bin 0 < k < 4096; bin 0 reads a slot that holds something else,
 // for callers that discard it)
-NEEDLE_HD void dif_bin_power_any(int t, int j, const cd *lds, const cd *r, double *pa, double *pb) {
+template <class C>
+NEEDLE_HD void dif_bin_power_any(int t, int j, const C *lds, const C *r, typename C::real *pa, typename C::real *pb) {
   dif_power_of(r[out16(j)], lds_get(lds, dif_partner_base(t) + 15 - j), pa, pb);
 }
 // the same, j = 0..5; false if the bin is outside 10..1307
-NEEDLE_HD bool dif_bin_power(int t, int j, const cd *lds, const cd *r, int *kf_out, double *pa, double *pb) {
+template <class C>
+NEEDLE_HD bool dif_bin_power(int t, int j, const C *lds, const C *r, int *kf_out, typename C::real *pa, typename C::real *pb) {
   const int kf = dif_bin_of(t, j);
   *kf_out = kf;
   if (kf < kMinBin || kf >= kMaxBin) return false;
@@ -550,21 +598,28 @@ inline bool build_power_layout(const uint8_t *class_of_bin, PowerLayout *out) {
   return true;
 }
 
+// f32 first pass only: every thread also leaves the sum of squares of its 16 (windowed) samples of the two frames in
+// the spare column 8 of its own stage-2 row, and the fourth wave -- which owns no pitch class -- folds the 256 partials
+// like a class: lane l takes rows 4 l .. 4 l + 3, the DPP tree sums each of its four rows of 16 lanes, so a frame's
+// energy arrives as four partial sums.
+NEEDLE_HD int energy_slot(int t) { return 17 * (16 * thread_k0(t) + (t & 15)) + 8; }
+NEEDLE_HD uint32_t energy_fold_entry(int l) { return (uint32_t)(17 * 4 * l + 8) | (4u << 16); }  // l = 0..63
+
 // One fold lane's share of its class: `count` positions from slot `base`, 17 slots apart, both frames at once (x =
 // frame A, y = frame B); reads beyond the count fetch the zero slot.  Split into the loads and the sums so the kernel
 // can put other work between them.
-template <int FROM, int TO>
-NEEDLE_HD void class_lane_load_part(const cd *lds, uint32_t fold_entry, cd *v) {  // v[i - FROM], i = FROM..TO-1
+template <int FROM, int TO, class C>
+NEEDLE_HD void class_lane_load_part(const C *lds, uint32_t fold_entry, C *v) {  // v[i - FROM], i = FROM..TO-1
   const int base = (int)(fold_entry & 0xffffu), count = (int)(fold_entry >> 16);
 #pragma unroll
   for (int i = FROM; i < TO; i++)
     v[i - FROM] = lds_get(lds, (i < kClassLaneMin || i < count) ? base + 17 * i : kPowerZeroSlot);
 }
-NEEDLE_HD void class_lane_load(const cd *lds, uint32_t fold_entry, cd *v) {
+template <class C> NEEDLE_HD void class_lane_load(const C *lds, uint32_t fold_entry, C *v) {
   class_lane_load_part<0, kClassLaneMax>(lds, fold_entry, v);
 }
-NEEDLE_HD cd class_lane_add(const cd *v) {
-  cd acc = v[0];
+template <class C> NEEDLE_HD C class_lane_add(const C *v) {
+  C acc = v[0];
 #pragma unroll
   for (int i = 1; i < kClassLaneMax; i++) acc = cadd(acc, v[i]);
   return acc;

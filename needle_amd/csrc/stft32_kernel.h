@@ -1,0 +1,198 @@
+// stft_chroma32_kernel: the f32 FIRST PASS of the analyze half.
+//
+// The u32 contract is defined on the f64 pipeline (oracle/ora_chromaprint.c), and stft_chroma_kernel (stft_kernel.h)
+// is within ~1.3x of the floor of its f64 decomposition.  This kernel runs the SAME schedule -- two real frames per
+// 4096-point complex transform, radix 16 x 3 in place in one padded LDS image, wave-local power image, DPP fold -- in
+// f32: half the LDS bytes, half the registers (three to four workgroups per CU instead of two) and the f32 issue
+// rate.  Its chroma is NOT the contract's; it is a first pass whose every consumer is certified:
+// features_classify_cert_kernel (fingerprint.hip) accepts an item only if all 48 threshold comparisons clear a
+// data-dependent radius, and every other item is recomputed from f64 chroma (stft_chroma_kernel over the listed
+// chunks of frame pairs + fixup_items_kernel).  What the radius needs from here is the frame's total energy
+// E = sum |x|^2 next to its 12 pitch-class sums: with a strong component outside chromaprint's band (a 5 kHz tone, a
+// DC offset) the f32 transform's noise floor is set by E, not by the in-band energy the features are normalised by.
+//
+// Differences from the f64 kernel besides the width: the window and the twiddle powers are correctly rounded table
+// values (an f32 recurrence / running product would add more error than the transform itself); every thread leaves
+// the sum of squares of its 16 samples of each frame in the spare column 8 of its stage-2 row and the fourth wave --
+// which owns no pitch class -- folds the 256 partials like a class (fp_core.h energy_slot / energy_fold_entry).
+#pragma once
+
+#include "stft_kernel.h"
+
+namespace needle {
+namespace stft {
+
+using core::cf;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
+constexpr int kEnergyParts = 4;  // partial sums per frame (one per DPP row of the fourth wave)
+
+template <int CH, int WAVES_PER_SIMD = 3>
+__global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
+    const int16_t *__restrict__ pcm, const FpStream *__restrict__ streams, int num_streams, const cf *__restrict__ tw32,
+    const float *__restrict__ win32, const uint16_t *__restrict__ bin_slot, const uint32_t *__restrict__ fold_tab,
+    double *__restrict__ chroma, float *__restrict__ energy, uint32_t total_pairs, uint32_t pairs_per_block) {
+  extern __shared__ cf lds32[];  // core::kLds2Slots complex slots of 8 bytes
+  cf *const lds = lds32;
+  using raw_t = typename std::conditional<CH == 1, int16_t, int>::type;
+  const int t = threadIdx.x;
+  const uint32_t per_xcd = gridDim.x >> 3;  // one contiguous eighth of the timeline per XCD (stft_kernel.h)
+  const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t first = logical * pairs_per_block;
+  const uint32_t last = min(total_pairs, first + pairs_per_block);
+  if (first >= last) return;
+
+  // ---- loop invariants: the fifteen twiddle powers of both stages (table values, correctly rounded), the thread's
+  // sixteen window values, where the powers of its six bins go, its share of the fold
+  cf pw0[16], pw1[16];
+  float win[16];
+#pragma unroll
+  for (int j = 1; j < 16; j++) {
+    pw0[j] = tw32[(t * j) & 4095];
+    pw1[j] = tw32[(16 * (t & 15) * j) & 4095];
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) win[k] = win32[t + 256 * k];
+  core::Words4 inv;
+#pragma unroll
+  for (int j = 0; j < core::kBinsPerThread; j += 2) {
+    uint32_t idx[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int kf = core::dif_bin_of(t, j + h);
+      idx[h] = (kf >= core::kMinBin && kf < core::kMaxBin) ? bin_slot[kf - core::kMinBin] : (uint32_t)core::kPowerTrashSlot;
+    }
+    inv.w[j >> 1] = core::pack_slots(idx[0], idx[1]);
+  }
+  const uint32_t fold_entry = t < kBands * core::kClassLanes ? fold_tab[t] : core::energy_fold_entry(t - kBands * core::kClassLanes);
+  if (t == 0) core::lds_put(lds, core::kPowerZeroSlot, cf{0.0f, 0.0f});  // first read after the loop's barriers
+
+  int si = find_stream<&FpStream::pair_base>(streams, num_streams, first);
+  FpStream st = streams[si];
+  uint32_t st_end = st.pair_base + (st.frames + 1) / 2;
+  auto locate = [&](uint32_t g) {  // g must not decrease between calls
+    while (g >= st_end) {
+      st = streams[++si];
+      st_end = st.pair_base + (st.frames + 1) / 2;
+    }
+    const uint32_t fa = 2 * (g - st.pair_base);
+    PairSrc p;
+    p.has_b = fa + 1 < st.frames;
+    p.a = pcm + st.pcm_off + (uint64_t)fa * kHop * CH;
+    p.b = p.has_b ? p.a + kHop * CH : p.a;
+    p.row = (uint64_t)st.frame_base + fa;
+    return p;
+  };
+  using reg_t = int;
+  reg_t ra[16], rb[16];
+  auto issue_loads = [&](const PairSrc &p) {
+    const raw_t *qa = reinterpret_cast<const raw_t *>(p.a), *qb = reinterpret_cast<const raw_t *>(p.b);
+    int tt = t;
+    asm volatile("" : "+v"(tt));  // an opaque INDEX keeps these global (not flat) loads inside the loop (stft_kernel.h)
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      ra[k] = (reg_t)qa[tt + 256 * k];
+      rb[k] = (reg_t)qb[tt + 256 * k];
+    }
+  };
+  constexpr int kFoldHalf = core::kClassLaneMax / 2;
+  auto fold_tree_store = [&](cf acc, const PairSrc &p, int tt, bool store) {
+    // fixed-order tree over the 16 lanes of the row (fp_core.h class_tree_partner)
+    acc = cf{acc.x + dpp_f32<0xB1>(acc.x), acc.y + dpp_f32<0xB1>(acc.y)};    // quad_perm [1,0,3,2]
+    acc = cf{acc.x + dpp_f32<0x4E>(acc.x), acc.y + dpp_f32<0x4E>(acc.y)};    // quad_perm [2,3,0,1]
+    acc = cf{acc.x + dpp_f32<0x141>(acc.x), acc.y + dpp_f32<0x141>(acc.y)};  // row_half_mirror
+    acc = cf{acc.x + dpp_f32<0x140>(acc.x), acc.y + dpp_f32<0x140>(acc.y)};  // row_mirror
+    if (store && (tt & 15) == 0) {
+      const uint32_t c = (uint32_t)tt >> 4;
+      if (c < (uint32_t)kBands) {
+        double *out = chroma + p.row * kBands;
+        out[c] = (double)acc.x;
+        if (p.has_b) out[kBands + c] = (double)acc.y;
+      } else {  // the fourth wave: rows 12..15 hold the four partial sums of the frames' energy
+        float *out = energy + p.row * kEnergyParts;
+        out[c - kBands] = acc.x;
+        if (p.has_b) out[kEnergyParts + c - kBands] = acc.y;
+      }
+    }
+  };
+  PairSrc cur = locate(first), prev = cur;
+  issue_loads(cur);
+#pragma unroll
+  for (int k = 0; k < 16; k++) asm volatile("" : "+v"(ra[k]), "+v"(rb[k]));  // keep the sign extension with the loads
+
+  for (uint32_t g = first; g < last; g++) {
+    int tt = t;
+    asm volatile("" : "+v"(tt));
+    cf r[16];
+    float ea = 0.0f, eb = 0.0f;
+    auto convert = [&](int k) {
+      int sa, sb;
+      if (CH == 1) {
+        sa = ra[k];
+        sb = rb[k];
+      } else {  // AudioProcessor::LoadStereo: (L + R) / 2, C truncation
+        sa = ((int)(int16_t)ra[k] + (ra[k] >> 16)) / 2;
+        sb = ((int)(int16_t)rb[k] + (rb[k] >> 16)) / 2;
+      }
+      const float w = win[k];
+      const cf x{(float)sa * w, (float)sb * w};
+      r[k] = x;
+      ea = core::fmad(x.x, x.x, ea);
+      eb = core::fmad(x.y, x.y, eb);
+    };
+    {
+      cf fv[kFoldHalf];
+      core::class_lane_load_part<0, kFoldHalf>(lds, fold_entry, fv);
+#pragma unroll
+      for (int k = 0; k < 8; k++) convert(k);
+      cf acc = fv[0];
+#pragma unroll
+      for (int i = 1; i < kFoldHalf; i++) acc = core::cadd(acc, fv[i]);
+      core::class_lane_load_part<kFoldHalf, core::kClassLaneMax>(lds, fold_entry, fv);
+#pragma unroll
+      for (int k = 8; k < 16; k++) convert(k);
+#pragma unroll
+      for (int i = 0; i < core::kClassLaneMax - kFoldHalf; i++) acc = core::cadd(acc, fv[i]);
+      fold_tree_store(acc, prev, tt, g != first);
+    }
+    if (!cur.has_b) {  // odd frame count: the stream's last pair has no frame B (uniform branch)
+#pragma unroll
+      for (int k = 0; k < 16; k++) r[k].y = 0.0f;
+      eb = 0.0f;
+    }
+    lds_barrier();  // every thread has read its share of the previous pair's powers and energy partials
+    core::dif0_streamed_pw<0>(tt, pw0, lds, r);
+    lds_barrier();  // stage 0 -> 1 crosses waves
+    core::dif1_streamed_pw<0>(tt, pw1, lds, r);
+    wave_lds_fence();  // stage 1 -> 2 stays inside 16 consecutive lanes
+    core::dif2_streamed<0>(tt, lds, r);
+    wave_lds_fence();  // publish -> partner reads stays inside the wave (fp_core.h group_k0)
+
+    cf yp[core::kBinsPerThread];
+    core::dif_partner_load(tt, lds, yp);
+    float pwa[core::kBinsPerThread], pwb[core::kBinsPerThread];
+#pragma unroll
+    for (int j = 0; j < core::kBinsPerThread; j++) core::dif_power_of(r[core::out16(j)], yp[j], &pwa[j], &pwb[j]);
+#pragma unroll
+    for (int j = 0; j < core::kBinsPerThread; j++)
+      core::lds_put_bytes(lds, (j & 1) ? core::slot_bytes<1>(inv.w[j >> 1]) : core::slot_bytes<0>(inv.w[j >> 1]), cf{pwa[j], pwb[j]});
+    core::lds_put(lds, core::energy_slot(tt), cf{ea, eb});  // spare column 8 of this thread's own stage-2 row
+    const PairSrc nxt = locate(min(g + 1, last - 1));  // last pair: harmless re-read
+    issue_loads(nxt);
+    lds_barrier();  // the power image is complete
+    prev = cur;
+    cur = nxt;
+  }
+  {
+    cf fv[core::kClassLaneMax];
+    core::class_lane_load(lds, fold_entry, fv);
+    fold_tree_store(core::class_lane_add(fv), prev, t, true);
+  }
+}
+
+}  // namespace stft
+}  // namespace needle

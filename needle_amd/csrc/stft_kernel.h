@@ -84,7 +84,18 @@ struct PairSrc {
 //  64  round-1 arithmetic in the 16-point transforms (168 instead of 144 instructions each)
 enum : int { kLabNoB1 = 1, kLabNoB2 = 2, kLabExtraB = 4, kLabNoB3 = 8, kLabSerial = 16, kLabSpaced = 32, kLabPlainFft = 64 };
 
-template <int CH, int LAB = 0>
+// LISTED: the workgroups walk a device-resident LIST of chunks (chunk c = pairs [c * pairs_per_block, + pairs_per_block)
+// of the batch) instead of the whole batch: the f64 recomputation of the frames whose f32 first pass could not be
+// certified (fingerprint.hip).  The list and its length are written by an earlier kernel of the same stream; the grid
+// is fixed and a workgroup takes entries blockIdx.x, + gridDim.x, ... until the list is exhausted (every wave reads
+// the same length, so every wave leaves).  A pair's result does not depend on which workgroup computes it, or in which
+// company: the chroma rows written here are bit-identical to those of the plain launch.
+struct ChunkList {
+  const uint32_t *chunks;
+  const uint32_t *count;
+};
+
+template <int CH, int LAB = 0, bool LISTED = false>
 __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__restrict__ pcm,
                                                              const FpStream *__restrict__ streams, int num_streams,
                                                              const cd *__restrict__ tw,
@@ -92,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
                                                              const uint16_t *__restrict__ bin_slot,
                                                              const uint32_t *__restrict__ fold_tab,
                                                              double *__restrict__ chroma, uint32_t total_pairs,
-                                                             uint32_t pairs_per_block) {
+                                                             uint32_t pairs_per_block, ChunkList list = ChunkList{nullptr, nullptr}) {
   extern __shared__ cd lds[];  // core::kLds2Slots complex slots
   using raw_t = typename std::conditional<CH == 1, int16_t, int>::type;  // one sample, or one packed L|R pair
   const int t = threadIdx.x;
@@ -102,11 +113,18 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   // overlap is re-read from that XCD's L2 (the grid is a multiple of 8).  Measured: fabric fetches per launch
   // 482 MB either way for 445 MB of PCM -- the boundary overlap of a plain mapping is only 28 MB and was mostly
   // caught by the memory-side cache already -- and no change in kernel time; kept because it is never worse.
-  const uint32_t per_xcd = gridDim.x >> 3;
-  const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  const uint32_t first = logical * pairs_per_block;
-  const uint32_t last = min(total_pairs, first + pairs_per_block);
-  if (first >= last) return;
+  uint32_t first, last;
+  uint32_t list_at = blockIdx.x, list_len = 0;
+  if (LISTED) {
+    list_len = *list.count;
+    if (list_at >= list_len) return;
+  } else {
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    first = logical * pairs_per_block;
+    last = min(total_pairs, first + pairs_per_block);
+    if (first >= last) return;
+  }
   const cd base0 = tw[t], base1 = tw[16 * (t & 15)];  // W_4096^t, W_4096^{16 n0}: loop-invariant twiddle bases
 
   // ---- loop invariants of this thread.  Where the powers of its six bins go and its share of the fold stay in
@@ -133,6 +151,11 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
   core::lds_put(lds, core::thread_pad_slot(t), cd{wcos[t + 256], wcos[t]});
   if (t == 0) core::lds_put(lds, core::kPowerZeroSlot, cd{0.0, 0.0});  // first read after the loop's barriers
 
+  do {  // LISTED: once per listed chunk of this workgroup; otherwise once
+  if (LISTED) {
+    first = list.chunks[list_at] * pairs_per_block;
+    last = min(total_pairs, first + pairs_per_block);
+  }
   // ---- the stream (region of the batch) the current pair belongs to; consecutive pairs rarely change it ------
   int si = find_stream<&FpStream::pair_base>(streams, num_streams, first);
   FpStream st = streams[si];
@@ -280,6 +303,10 @@ __global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__re
     core::class_lane_load(lds, fold_entry, fv);
     fold_tree_store(core::class_lane_add(fv), prev, t, true);
   }
+  // (LISTED: the next chunk's first stores into the image sit behind barrier 1 of its first pair, which every
+  // thread reaches only after these reads)
+  list_at += gridDim.x;
+  } while (LISTED && list_at < list_len);
 }
 
 }  // namespace stft

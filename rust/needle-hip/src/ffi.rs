@@ -104,6 +104,8 @@ extern "C" {
     pub fn needle_hip_synchronize() -> NeedleError;
     /// PCI address of the current device ("0000:c1:00.0", NUL-terminated) into a 32-byte buffer.
     pub fn needle_hip_device_pci_bus_id(out: *mut c_char) -> NeedleError;
+    /// {items, items recomputed in f64, chunks, chunks recomputed} of the certified f32 first pass.
+    pub fn needle_hip_fingerprint_cert_stats(counts: *mut u64, reset: bool) -> NeedleError;
     /// The library's `hipStream_t` on the current device (NULL without one).
     pub fn needle_hip_stream() -> *mut c_void;
     pub fn needle_hip_analyzer_run_pcm(

@@ -34,8 +34,10 @@ def built():
     emu_src = os.path.join(ROOT, "tests", "cpu_emu", "emu.cpp")
     emu_so = os.path.join(ROOT, "tests", "cpu_emu", "libemu.so")
     if _newer([emu_src, os.path.join(csrc, "fp_core.h")], emu_so):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", emu_so, emu_src],
-                       check=True)
+        # -mfma: the explicit fma()/fmaf() calls of fp_core.h become instructions (a software fmaf is ~50x slower);
+        # -ffp-contract=off: nothing else is fused -- the same arithmetic as the device code
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-o", emu_so,
+                        emu_src], check=True)
     return True
 
 

@@ -1,0 +1,207 @@
+"""GPU tests (-m gpu) of the certified f32 first pass of the fingerprinter (needle_amd/csrc/stft32_kernel.h,
+features_classify_cert_kernel / fixup_items_kernel in fingerprint.hip).
+
+The contract: every emitted u32 equals the f64 pipeline's (the oracle's), although most items never see an f64 FFT.
+What is tested: equality with the oracle on audio, on a zoo of hostile signals and on inputs CONSTRUCTED to put a
+classifier input within ~1e-8 of one of its thresholds -- far inside the f32 pass's own error -- on both sides of it;
+that those constructed items are indeed sent to the f64 recomputation; that with the radius switched off
+(NEEDLE_HIP_CERT_K=0: accept every first-pass item) the same inputs DO come out wrong, i.e. the test would notice a
+radius that is too small; and that the observed first-pass error stays an order of magnitude under the radius."""
+import os
+
+import numpy as np
+import pytest
+
+from needle_amd import capi, synth
+from oracle import oracle as O
+from tests import np_chromaprint as N
+
+pytestmark = pytest.mark.gpu
+THR = np.array([c[4:7] for c in N.CLASSIFIERS])
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert capi.device_count() > 0, "GPU tests need a HIP device (the product has no CPU fallback)"
+
+
+def _mode(monkeypatch, stft=None, k=None):
+    for name, v in (("NEEDLE_HIP_STFT", stft), ("NEEDLE_HIP_CERT_K", k)):
+        if v is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, str(v))
+
+
+def test_certified_equals_f64_kernel_equals_oracle_and_recomputes_a_little(monkeypatch):
+    eps = synth.make_library(6, 240.0, 40.0)
+    pcms = [e.pcm[: len(e.pcm) // 2] for e in eps]
+    want = [O.fingerprint(p) for p in pcms]
+    _mode(monkeypatch, stft="f64")
+    capi.cert_stats(reset=True)
+    f64 = capi.fingerprint(pcms, step=1)
+    assert capi.cert_stats()["items"] == 0                      # the f64 kernel ran over everything
+    _mode(monkeypatch)
+    cert = capi.fingerprint(pcms, step=1)
+    st = capi.cert_stats(reset=True)
+    for a, b, w in zip(cert, f64, want):
+        assert a.tolist() == b.tolist() == w.tolist()
+    assert st["items"] == sum(len(w) for w in want)
+    assert 0 < st["items_recomputed"] < 0.02 * st["items"], st   # audio: ~0.2 % at step 1
+    assert 0 < st["chunks_recomputed"] < 0.15 * st["chunks"], st
+
+
+def test_stereo_and_ragged_batches_through_the_first_pass(monkeypatch):
+    _mode(monkeypatch)
+    rng = np.random.default_rng(3)
+    eps = [synth.make_episode(k, 31.0 + 3.7 * k, 9.0) for k in range(5)]
+    stereo = [np.repeat(e.pcm, 2) for e in eps]                  # L = R
+    for p in stereo:                                             # ... and a little channel difference
+        p[1::2] = np.clip(p[1::2].astype(np.int32) + rng.integers(-3, 4, len(p) // 2), -32768, 32767)
+    got = capi.fingerprint(stereo, step=2, channels=2)
+    for g, p in zip(got, stereo):
+        total = p[0::2].astype(np.int32) + p[1::2].astype(np.int32)
+        mono = np.where(total < 0, -((-total) // 2), total // 2)  # (L + R) / 2 with C truncation
+        assert g.tolist() == O.fingerprint(mono.astype(np.int16))[::2].tolist()
+    short = [np.zeros(100, dtype=np.int16), eps[0].pcm[:4096], eps[1].pcm[:4096 + 1365 * 19], eps[2].pcm[:4096 + 1365 * 20 - 1]]
+    got = capi.fingerprint(short, step=1)
+    assert [len(g) for g in got] == [0, 0, 1, 1]
+    for g, p in zip(got, short):
+        assert g.tolist() == O.fingerprint(p).tolist()
+
+
+def _log_values(pcm):
+    chroma, _ = N.chroma_of(pcm, np.float64)
+    return N.classifier_values(chroma)[0]                        # [items, 16]
+
+
+def _near_threshold_pairs(count, seed):
+    """PCM snippets (one raw item each: 20 frames) whose f64 classifier input sits just below / just above one of
+    its thresholds.  Two different snippets A, B differ in the 2-bit code of some classifier; on the segment
+    round(A + alpha (B - A)) the input crosses a threshold, and bisection over alpha finds two NEIGHBOURING
+    quantised signals on either side of it -- the closest the s16 grid allows; pairs with margins under 5e-8 in log v
+    are kept (the f32 pass's own error is ~1e-8 typically, 2e-7 at worst)."""
+    rng = np.random.default_rng(seed)
+    n = 4096 + 19 * 1365
+    out = []
+    k = 0
+    while len(out) < count and k < 12 * count:
+        k += 1
+        a = synth.make_episode(100 + k, 12.0, 0.0).pcm[5000: 5000 + n].astype(np.float64)
+        b = synth.make_episode(400 + k, 12.0, 0.0).pcm[7000: 7000 + n].astype(np.float64)
+        pcm = lambda al: np.rint(a + al * (b - a)).astype(np.int16)                      # noqa: E731
+        va, vb = _log_values(pcm(0.0))[0], _log_values(pcm(1.0))[0]
+        qa, qb = (va[:, None] >= THR).sum(axis=1), (vb[:, None] >= THR).sum(axis=1)
+        cands = np.nonzero(qa != qb)[0]
+        if len(cands) == 0:
+            continue
+        c = int(rng.choice(cands))
+        t = THR[c][min(qa[c], qb[c])]                            # a threshold between the two codes
+        lo, hi = 0.0, 1.0
+        side = lambda al: _log_values(pcm(al))[0][c] >= t         # noqa: E731
+        s_lo = side(lo)
+        if side(hi) == s_lo:
+            continue
+        for _ in range(60):
+            mid = 0.5 * (lo + hi)
+            if np.array_equal(pcm(mid), pcm(lo)) or np.array_equal(pcm(mid), pcm(hi)):
+                break
+            if side(mid) == s_lo:
+                lo = mid
+            else:
+                hi = mid
+        m_lo = abs(_log_values(pcm(lo))[0][c] - t)
+        m_hi = abs(_log_values(pcm(hi))[0][c] - t)
+        if max(m_lo, m_hi) < 5e-8:
+            out.append((pcm(lo), pcm(hi), c, m_lo, m_hi))
+    return out
+
+
+@pytest.fixture(scope="module")
+def adversarial():
+    pairs = _near_threshold_pairs(40, seed=17)      # (the emulated f32 arithmetic gets ~1 in 10 of these wrong)
+    assert len(pairs) >= 30
+    return pairs
+
+
+def test_items_constructed_at_a_threshold_are_recomputed_and_exact(adversarial, monkeypatch):
+    _mode(monkeypatch)
+    pcms = [p for lo, hi, *_ in adversarial for p in (lo, hi)]
+    want = [O.fingerprint(p) for p in pcms]
+    assert all(len(w) == 1 for w in want)
+    # the two sides of a pair differ in the oracle exactly in the targeted classifier's code
+    for i, (lo, hi, c, m_lo, m_hi) in enumerate(adversarial):
+        x = int(want[2 * i][0]) ^ int(want[2 * i + 1][0])
+        assert x != 0 and (x & ~(3 << (2 * (15 - c)))) == 0, (i, c, hex(x), m_lo, m_hi)
+    capi.cert_stats(reset=True)
+    got = capi.fingerprint(pcms, step=1)
+    st = capi.cert_stats(reset=True)
+    assert [g.tolist() for g in got] == [w.tolist() for w in want]
+    assert st["items"] == len(pcms) and st["items_recomputed"] == len(pcms), st   # every one of them was uncertain
+
+
+def test_without_the_radius_the_same_items_come_out_wrong(adversarial, monkeypatch):
+    """NEEDLE_HIP_CERT_K=0 accepts every first-pass item: the f32 transform's error (~1e-7 in log v) then decides the
+    comparisons constructed to within ~1e-8, and some land on the wrong side.  This is the test that would fail if the
+    certification were vacuous."""
+    pcms = [p for lo, hi, *_ in adversarial for p in (lo, hi)]
+    want = [O.fingerprint(p).tolist() for p in pcms]
+    _mode(monkeypatch, k=0)
+    capi.cert_stats(reset=True)
+    got = [g.tolist() for g in capi.fingerprint(pcms, step=1)]
+    st = capi.cert_stats(reset=True)
+    assert st["items_recomputed"] == 0
+    wrong = sum(g != w for g, w in zip(got, want))
+    assert wrong >= 1, "the f32 first pass reproduced every near-threshold decision: the adversarial set is too tame"
+    _mode(monkeypatch)
+    assert [g.tolist() for g in capi.fingerprint(pcms, step=1)] == want
+
+
+def test_hostile_signals_certified_or_recomputed(monkeypatch):
+    """Signals whose f32 error is dominated by energy OUTSIDE chromaprint's band (what the radius' E term is for), rows
+    at the 0.01 norm cut, silence, full scale."""
+    _mode(monkeypatch)
+    rng = np.random.default_rng(23)
+    n = 14 * 11025
+    t = np.arange(n) / 11025.0
+    z = {
+        "weak-inband+strong-5k": 30 * np.sin(2 * np.pi * 440 * t) + 30000 * np.sin(2 * np.pi * 5000.0 * t),
+        "weakest-inband+strong-5k": 3 * np.sin(2 * np.pi * 440 * t) + 30000 * np.sin(2 * np.pi * 5000.0 * t),
+        "weak-inband+strong-dc": 300 * np.sin(2 * np.pi * 440 * t) + 30000,
+        "noise3+strong-5k": rng.standard_normal(n) * 3 + 30000 * np.sin(2 * np.pi * 5100 * t),
+        "weak-inband+strong-12hz": 100 * np.sin(2 * np.pi * 440 * t) + 30000 * np.sin(2 * np.pi * 12 * t),
+        "chirp-fullscale": 30000 * np.sin(2 * np.pi * (20 * t + 0.5 * 390 * t * t)),
+        "square-fullscale": np.where(np.sin(2 * np.pi * 220 * t) >= 0, 32767.0, -32768.0),
+        "quiet-tone": 20 * np.sin(2 * np.pi * 440 * t),
+        "tone+lsb-noise": 12000 * np.sin(2 * np.pi * 523.25 * t) + rng.standard_normal(n) * 0.7,
+        "silence": np.zeros(n),
+        "silence-then-tone": np.where(t > 6.0, 9000 * np.sin(2 * np.pi * 330 * t), 0.0),
+    }
+    for amp in (0.6, 0.8, 1.0, 1.3, 2.0):                       # noise whose feature norm straddles the 0.01 cut
+        z[f"noise{amp}"] = rng.standard_normal(n) * amp
+    pcms = [np.clip(np.rint(v), -32768, 32767).astype(np.int16) for v in z.values()]
+    capi.cert_stats(reset=True)
+    got = capi.fingerprint(pcms, step=1)
+    st = capi.cert_stats(reset=True)
+    for name, g, p in zip(z, got, pcms):
+        assert g.tolist() == O.fingerprint(p).tolist(), name
+    assert st["items_recomputed"] > 0                            # the out-of-band cases cannot all be certified
+
+
+def test_first_pass_error_stays_an_order_of_magnitude_inside_the_radius(monkeypatch):
+    """The calibration of tools/f32_gate.py re-measured on the device: with the radius switched off, the number of
+    items that differ from the oracle on 40 minutes of audio must be tiny (the gate saw 1 in 81 116), and every one
+    of them must be an item the radius would have sent to the f64 path."""
+    eps = synth.make_library(4, 1200.0, 60.0)
+    pcms = [e.pcm[: len(e.pcm) // 2] for e in eps]
+    want = [O.fingerprint(p) for p in pcms]
+    _mode(monkeypatch, k=0)
+    raw = capi.fingerprint(pcms, step=1)
+    differ = sum(int((g != w).sum()) for g, w in zip(raw, want))
+    total = sum(len(w) for w in want)
+    assert differ <= max(3, total // 5000), (differ, total)
+    _mode(monkeypatch, k=8)                                      # an eighth of the product's radius is already enough here
+    tight = capi.fingerprint(pcms, step=1)
+    assert all(g.tolist() == w.tolist() for g, w in zip(tight, want))
+    _mode(monkeypatch)
+    assert all(g.tolist() == w.tolist() for g, w in zip(capi.fingerprint(pcms, step=1), want))

@@ -10,7 +10,13 @@ L2 norm, 16 area-ratio classifiers) in f64 from either chroma.  Reported:
   * the calibration of a data-dependent bound  |d chroma_c| <= k1 u chroma_c + k2 u sqrt(chroma_c E) + k3 u^2 E
     with E = sum |X|^2 of the frame (all bins), u = 2^-24.
 
-usage: python tools/f32_gate.py [episodes=28] [minutes=24] [out.json]
+The f32 STFT is the kernel's own arithmetic (radix 16 x 3 in place, correctly rounded window and twiddle tables,
+explicit FMAs), stepped on the CPU by tests/cpu_emu (`emu`, default), or scipy's pocketfft in f32 (`scipy`).
+Second table: the DATA-DEPENDENT radius the product uses, r = K * S with S = max over the item's 16 feature rows of
+u * sqrt(E_row / norm_row) (E_row, norm_row: the FIR'd frame energy and chroma norm) -- the observed error divided by S
+is what K has to cover.
+
+usage: python tools/f32_gate.py [episodes=28] [minutes=24] [out.json] [emu|scipy]
 """
 from __future__ import annotations
 
@@ -19,84 +25,36 @@ import os
 import sys
 
 import numpy as np
-import scipy.fft as sfft
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from needle_amd import synth  # noqa: E402
-from tests.np_chromaprint import CLASSIFIERS, note_table  # noqa: E402
+from tests.np_chromaprint import CLASSIFIERS, chroma_of, classifier_values  # noqa: E402
 
 U = 2.0 ** -24
-W64 = (1.0 / 32767.0) * (0.54 - 0.46 * np.cos(np.arange(4096) * 2.0 * np.pi / 4095))
-W32 = W64.astype(np.float32)
-K, NOTE = note_table()
-ORDER = np.argsort(NOTE, kind="stable")
-STARTS = np.searchsorted(NOTE[ORDER], np.arange(12))
 
 
-def frames_of(pcm, dtype):
-    n = len(pcm)
-    nf = 0 if n < 4096 else (n - 4096) // 1365 + 1
-    idx = np.arange(nf)[:, None] * 1365 + np.arange(4096)[None, :]
-    return pcm.astype(dtype)[idx]
+_EMU = None
 
 
-def chroma_of(pcm, dtype):
-    """chroma [frames, 12] and E = sum over ALL bins of |X|^2 (two-sided), arithmetic in `dtype`."""
-    out, energy = [], []
-    w = W64 if dtype == np.float64 else W32
-    n = len(pcm)
-    nf = 0 if n < 4096 else (n - 4096) // 1365 + 1
-    for f0 in range(0, nf, 1024):
-        f1 = min(nf, f0 + 1024)
-        idx = np.arange(f0, f1)[:, None] * 1365 + np.arange(4096)[None, :]
-        x = pcm[idx].astype(dtype) * w
-        spec = sfft.rfft(x, axis=1)
-        assert spec.dtype == (np.complex128 if dtype == np.float64 else np.complex64)
-        power = spec.real * spec.real + spec.imag * spec.imag
-        out.append(np.add.reduceat(power[:, K[ORDER]], STARTS, axis=1))
-        energy.append((x * x).sum(axis=1).astype(np.float64) * 4096.0)
-    return np.concatenate(out).astype(np.float64), np.concatenate(energy)
-
-
-def classifier_values(chroma):
-    """log v for every raw item and classifier: [items, 16]; also the feature norms [rows]."""
-    coef = np.array([0.25, 0.75, 1.0, 0.75, 0.25])
-    rows = len(chroma) - 4
-    fir = sum(coef[j] * chroma[j:j + rows] for j in range(5))
-    norm = np.sqrt((fir ** 2).sum(axis=1))
-    feat = np.where(norm[:, None] < 0.01, 0.0, fir / np.where(norm[:, None] == 0, 1, norm[:, None]))
-    items = rows - 15
-    integ = np.zeros((rows + 1, 13), dtype=np.longdouble)
-    integ[1:, 1:] = feat.astype(np.longdouble).cumsum(axis=0).cumsum(axis=1)
-    x = np.arange(items)
-
-    def area(r1, c1, r2, c2):
-        return (integ[x + r2, c2] - integ[x + r1, c2] - integ[x + r2, c1] + integ[x + r1, c1]).astype(np.float64)
-    vals = np.empty((items, 16))
-    for c, (t, y, h, wd, *_thr) in enumerate(CLASSIFIERS):
-        if t == 0:
-            a, b = area(0, y, wd, y + h), 0.0
-        elif t == 1:
-            a, b = area(0, y + h // 2, wd, y + h), area(0, y, wd, y + h // 2)
-        elif t == 2:
-            a, b = area(wd // 2, y, wd, y + h), area(0, y, wd // 2, y + h)
-        elif t == 3:
-            a = area(0, y + h // 2, wd // 2, y + h) + area(wd // 2, y, wd, y + h // 2)
-            b = area(0, y, wd // 2, y + h // 2) + area(wd // 2, y + h // 2, wd, y + h)
-        elif t == 4:
-            h3 = h // 3
-            a = area(0, y + h3, wd, y + 2 * h3)
-            b = area(0, y, wd, y + h3) + area(0, y + 2 * h3, wd, y + h)
-        else:
-            w3 = wd // 3
-            a = area(w3, y, 2 * w3, y + h)
-            b = area(0, y, w3, y + h) + area(2 * w3, y, wd, y + h)
-        vals[:, c] = np.log((1.0 + a) / (1.0 + b))
-    return vals, norm
+def chroma_emu32(pcm):
+    """f32 pass exactly as stft_chroma32_kernel computes it (tests/cpu_emu/emu.cpp): chroma, E = N sum x^2."""
+    global _EMU
+    import ctypes as C
+    if _EMU is None:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        _EMU = C.CDLL(os.path.join(root, "tests", "cpu_emu", "libemu.so"))
+        _EMU.emu_stft_chroma_stream.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+    nf = 0 if len(pcm) < 4096 else (len(pcm) - 4096) // 1365 + 1
+    ch, en = np.zeros((nf, 12)), np.zeros((nf, 4), dtype=np.float32)
+    _EMU.emu_stft_chroma_stream(pcm.ctypes.data, len(pcm), 1, ch.ctypes.data, en.ctypes.data)
+    return ch, en.astype(np.float64).sum(axis=1) * 16384.0     # the kernel's samples carry a factor 1/2
 
 
 THR = np.array([c[4:7] for c in CLASSIFIERS])            # [16, 3]
 RADII = [1e-7, 3e-7, 1e-6, 3e-6, 1e-5, 3e-5, 1e-4, 3e-4, 1e-3]
+KS = [4, 8, 16, 32, 64, 128, 256]
+MODE = "emu"
 
 
 def quantise(vals):
@@ -106,11 +64,14 @@ def quantise(vals):
 
 def analyse(pcm, step=2, chunk_frames=16):
     c64, e64 = chroma_of(pcm, np.float64)
-    c32, _ = chroma_of(pcm, np.float32)
+    c32, e32 = chroma_emu32(pcm) if MODE == "emu" else (chroma_of(pcm, np.float32)[0], e64)
     v64, n64 = classifier_values(c64)
-    v32, n32 = classifier_values(c32)
+    v32, n32, scale = classifier_values(c32, e32)
     err = np.abs(v32 - v64)
     kept = np.arange(0, len(v64), step)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = np.where(scale > 0, err.max(axis=1) / np.maximum(scale, 1e-300), 0.0)
+    err_unscaled = float(err.max(axis=1)[scale == 0].max()) if (scale == 0).any() else 0.0
     flips = int((quantise(v32[kept]) != quantise(v64[kept])).any(axis=1).sum())
     margin32 = np.abs(v32[:, :, None] - THR[None]).min(axis=(1, 2))          # per raw item, f32 pass
     nframes = len(c64)
@@ -124,6 +85,15 @@ def analyse(pcm, step=2, chunk_frames=16):
         chunks = np.zeros(nchunks, dtype=bool)
         chunks[np.nonzero(touched)[0] // chunk_frames] = True
         table[r] = (len(bad), len(kept), int(touched.sum()), nframes, int(chunks.sum()), nchunks)
+    ktable = {}
+    for kk in KS:
+        bad = kept[margin32[kept] <= kk * scale[kept]]
+        touched = np.zeros(nframes, dtype=bool)
+        for i in bad:
+            touched[i:i + 20] = True
+        c8 = np.zeros((nframes + 7) // 8, dtype=bool)            # the product's fallback chunks: 4 frame pairs
+        c8[np.nonzero(touched)[0] // 8] = True
+        ktable[kk] = (len(bad), len(kept), int(touched.sum()), nframes, int(c8.sum()), len(c8))
     # calibration of the chroma error model
     dc = np.abs(c32 - c64)
     e = e64[:, None]
@@ -131,7 +101,9 @@ def analyse(pcm, step=2, chunk_frames=16):
         k2 = np.where(c64 > 0, dc / (U * np.sqrt(c64 * e)), 0.0)
         k1 = np.where(c64 > 0, dc / (U * c64), 0.0)
     norm_cut = int((np.abs(n64 - 0.01) < 1e-6).sum())
-    return dict(err_max=float(err.max()), err_p999=float(np.quantile(err, 0.999)), err_mean=float(err.mean()),
+    return dict(ratio_max=float(ratio.max()), scale_min=float(scale[scale > 0].min()) if (scale > 0).any() else 0.0,
+                scale_max=float(scale.max()), err_where_scale_is_zero=err_unscaled, ktable=ktable,
+                err_max=float(err.max()), err_p999=float(np.quantile(err, 0.999)), err_mean=float(err.mean()),
                 flips=flips, table=table, k2_max=float(k2.max()), k2_p999=float(np.quantile(k2, 0.999)),
                 k1_max=float(k1.max()), norm_near_cut=norm_cut,
                 rel_chroma_err_max=float((dc.max(axis=1) / np.maximum(c64.max(axis=1), 1e-300)).max()))
@@ -153,16 +125,28 @@ def zoo():
     z["two-tones"] = 3000 * np.sin(2 * np.pi * 261.63 * t) + 3000 * np.sin(2 * np.pi * 2093.0 * t)
     z["weak-inband+strong-5k"] = 30 * np.sin(2 * np.pi * 440 * t) + 30000 * np.sin(2 * np.pi * 5000.0 * t)
     z["square-fullscale"] = np.where(np.sin(2 * np.pi * 220 * t) >= 0, 32767.0, -32768.0)
+    z["weakest-inband+strong-5k"] = 3 * np.sin(2 * np.pi * 440 * t) + 30000 * np.sin(2 * np.pi * 5000.0 * t)
+    z["weak-inband+strong-dc"] = 300 * np.sin(2 * np.pi * 440 * t) + 30000
+    z["noise3+strong-5k"] = np.clip(np.rint(rng.standard_normal(n) * 3 + 30000 * np.sin(2 * np.pi * 5100 * t)), -32768, 32767)
+    z["weak-inband+strong-12hz"] = 100 * np.sin(2 * np.pi * 440 * t) + 30000 * np.sin(2 * np.pi * 12 * t)
+    z["chirp-fullscale"] = 30000 * np.sin(2 * np.pi * (20 * t + 0.5 * 390 * t * t))
+    z["quiet-tone"] = 20 * np.sin(2 * np.pi * 440 * t)
+    z["tone+lsb-noise"] = np.clip(np.rint(12000 * np.sin(2 * np.pi * 523.25 * t) + rng.standard_normal(n) * 0.7), -32768, 32767)
     return {k: np.asarray(v).astype(np.int16) for k, v in z.items()}
 
 
 def main():
+    global MODE
+    if len(sys.argv) > 4:
+        MODE = sys.argv[4]
     n_eps = int(sys.argv[1]) if len(sys.argv) > 1 else 28
     minutes = float(sys.argv[2]) if len(sys.argv) > 2 else 24.0
     out = sys.argv[3] if len(sys.argv) > 3 else None
     report = {"corpus": f"{n_eps} x {minutes} min synthetic episodes (opening halves), step 2, chunks of 16 frames",
               "episodes": [], "zoo": {}}
     agg = {r: [0, 0, 0, 0, 0, 0] for r in RADII}
+    kagg = {k: [0, 0, 0, 0, 0, 0] for k in KS}
+    worst_ratio = zoo_ratio = 0.0
     worst = 0.0
     flips = 0
     for k in range(n_eps):
@@ -173,17 +157,26 @@ def main():
         for r in RADII:
             for i, v in enumerate(res["table"][r]):
                 agg[r][i] += v
+        for kk in KS:
+            for i, v in enumerate(res["ktable"][kk]):
+                kagg[kk][i] += v
+        worst_ratio = max(worst_ratio, res["ratio_max"])
         res["table"] = {str(r): v for r, v in res["table"].items()}
+        res["ktable"] = {str(r): v for r, v in res["ktable"].items()}
         report["episodes"].append(res)
         print(f"ep {k}: err max {res['err_max']:.3e} p99.9 {res['err_p999']:.3e} mean {res['err_mean']:.3e} "
-              f"flips {res['flips']} k2 max {res['k2_max']:.2f} k1 max {res['k1_max']:.2f}", flush=True)
+              f"flips {res['flips']} err/S max {res['ratio_max']:.3f} S [{res['scale_min']:.2e}, {res['scale_max']:.2e}]",
+              flush=True)
     for name, pcm in zoo().items():
         res = analyse(pcm, step=1)
         res["table"] = {str(r): v for r, v in res["table"].items()}
+        zoo_ratio = max(zoo_ratio, res["ratio_max"])
+        k32 = res["ktable"][32]
+        res["ktable"] = {str(r): v for r, v in res["ktable"].items()}
         report["zoo"][name] = res
-        print(f"zoo {name}: err max {res['err_max']:.3e} flips {res['flips']} k2 max {res['k2_max']:.2f} "
-              f"k1 max {res['k1_max']:.2f} relchroma {res['rel_chroma_err_max']:.2e} "
-              f"uncertain@1e-5 {res['table']['1e-05'][0]}/{res['table']['1e-05'][1]}", flush=True)
+        print(f"zoo {name}: err max {res['err_max']:.3e} flips {res['flips']} err/S max {res['ratio_max']:.3f} "
+              f"S [{res['scale_min']:.2e}, {res['scale_max']:.2e}] err where S = 0: {res['err_where_scale_is_zero']:.1e} "
+              f"uncertain at K = 32: {k32[0]}/{k32[1]}", flush=True)
     print(f"\ncorpus: worst |log v32 - log v64| = {worst:.3e}; items whose hash would flip without a fallback: {flips}")
     print("radius   items uncertain      frames touched     chunks(16 frames) touched   headroom over worst")
     summary = {}
@@ -193,7 +186,19 @@ def main():
                                headroom=r / worst if worst else None)
         print(f"{r:7.0e}  {a[0]:8d}/{a[1]} = {a[0] / a[1]:.4%}   {a[2] / a[3]:.4%}   {a[4] / a[5]:.4%}"
               f"   {r / worst if worst else float('inf'):.1f}x")
+    print(f"\ndata-dependent radius r = K * S: worst err / S on the corpus {worst_ratio:.3f}, on the signal zoo {zoo_ratio:.3f}")
+    print("   K   items uncertain      frames touched     chunks (4 pairs) touched   headroom over worst err/S (corpus, zoo)")
+    ksummary = {}
+    top = max(worst_ratio, zoo_ratio)
+    for kk in KS:
+        a = kagg[kk]
+        ksummary[str(kk)] = dict(items_frac=a[0] / a[1], frames_frac=a[2] / a[3], chunks_frac=a[4] / a[5],
+                                 headroom=kk / top if top else None)
+        print(f"{kk:4d}  {a[0]:8d}/{a[1]} = {a[0] / a[1]:.4%}   {a[2] / a[3]:.4%}   {a[4] / a[5]:.4%}   {kk / top:.1f}x")
     report["summary"] = summary
+    report["summary_data_dependent"] = ksummary
+    report["worst_err_over_scale"] = {"corpus": worst_ratio, "zoo": zoo_ratio}
+    report["f32_arithmetic"] = MODE
     report["worst_err"] = worst
     if out:
         with open(out, "w") as f:

@@ -116,7 +116,7 @@ static void launch_variant(Lab &L, uint32_t grid, size_t lds, uint32_t ppb) {
     attr_lds = lds;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, L.d_pcm, L.d_streams, L.eps, L.d_tw, L.d_wcos, L.wconst,
-                     L.d_bin_slot, L.d_fold_tab, L.d_chroma, L.total_pairs, ppb);
+                     L.d_bin_slot, L.d_fold_tab, L.d_chroma, L.total_pairs, ppb, stft::ChunkList{nullptr, nullptr});
 }
 
 static void time_once(Lab &L, Variant &v, bool record) {
