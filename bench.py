@@ -641,7 +641,7 @@ def main() -> None:
                 "items": round(cs["items_recomputed"] / max(cs["items"], 1), 6),
                 "frame_pair_chunks": round(cs["chunks_recomputed"] / max(cs["chunks"], 1), 6),
                 "what": "share of the kept items the f32 first pass could not certify (recomputed from f64 chroma) and of "
-                        "the 4-pair chunks of frame pairs the f64 kernel therefore ran over again; every emitted u32 is the "
+                        "the 2-pair chunks of frame pairs the f64 kernel therefore ran over again; every emitted u32 is the "
                         "f64 pipeline's either way", "counts": cs},
             "device_state": device_state,
             "detected": sum(1 for r in state["results"] if r is not None and r.opening is not None),

@@ -93,7 +93,7 @@ enum NeedleError needle_hip_fingerprint_device(const int16_t *d_pcm, const uint6
  * same decisions -- or recomputed: the frames it covers go through the f64 kernel again and the item is classified
  * from those.  The emitted items are therefore the f64 pipeline's, bit for bit.  Environment: NEEDLE_HIP_STFT=f64 runs
  * the f64 kernel over everything; NEEDLE_HIP_CERT_K scales the radius (default 64; 0 accepts every first-pass item,
- * for tests).  counts = {items fingerprinted, items recomputed in f64, chunks of 4 frame pairs, chunks recomputed}
+ * for tests).  counts = {items fingerprinted, items recomputed in f64, chunks of 2 frame pairs, chunks recomputed}
  * on the current device since the last reset; waits for the library stream. */
 enum NeedleError needle_hip_fingerprint_cert_stats(uint64_t counts[4], bool reset);
 

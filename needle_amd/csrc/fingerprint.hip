@@ -508,7 +508,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       if (certified) {
         float cert_k = 64.0f;  // 35 x the worst |log v32 - log v64| / S observed (profiles/r03_f32_gate.log)
         if (const char *e = getenv("NEEDLE_HIP_CERT_K")) cert_k = std::max(0.0f, (float)atof(e));  // tests: 0 = accept everything
-        constexpr uint32_t kChunkPairs = 4;
+        constexpr uint32_t kChunkPairs = 2;  // 634 four-pair chunks per 28 x 24 min job are two rounds of the 512 workgroup slots; two-pair chunks fit one
         const uint64_t nchunks = (pairs + kChunkPairs - 1) / kChunkPairs;
         const size_t ctl_words = sizeof(CertWork) / 4 + (size_t)((nchunks + 31) / 32);
         if (!(s = ws->energy.reserve(frames * stft::kEnergyParts)).ok() || !(s = ws->cert_ctl.reserve(ctl_words)).ok() ||

@@ -31,7 +31,16 @@ __device__ __forceinline__ float dpp_f32(float x) {
 
 constexpr int kEnergyParts = 4;  // partial sums per frame (one per DPP row of the fourth wave)
 
-template <int CH, int WAVES_PER_SIMD = 3>
+// LAB bits (tools/stft32_lab.hip only; 0 = product; results are wrong or incomplete with any of them set)
+enum : int {
+  kLab32NoEnergy = 1,   // no energy partials (what the radius' E term costs)
+  kLab32WinLoad = 2,    // window values re-read from the table for every pair instead of 16 loop-invariant registers
+  kLab32NoB1 = 4, kLab32NoB2 = 8, kLab32NoB3 = 16,  // a workgroup barrier replaced by a wave fence
+  kLab32NoFold = 32,    // no fold reads / tree / chroma store
+  kLab32NoPower = 64,   // no partner reads, powers, power stores
+};
+
+template <int CH, int WAVES_PER_SIMD = 3, int LAB = 0>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
     const int16_t *__restrict__ pcm, const FpStream *__restrict__ streams, int num_streams, const cf *__restrict__ tw32,
     const float *__restrict__ win32, const uint16_t *__restrict__ bin_slot, const uint32_t *__restrict__ fold_tab,
@@ -55,8 +64,10 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
     pw0[j] = tw32[(t * j) & 4095];
     pw1[j] = tw32[(16 * (t & 15) * j) & 4095];
   }
+  if (!(LAB & kLab32WinLoad)) {
 #pragma unroll
-  for (int k = 0; k < 16; k++) win[k] = win32[t + 256 * k];
+    for (int k = 0; k < 16; k++) win[k] = win32[t + 256 * k];
+  }
   core::Words4 inv;
 #pragma unroll
   for (int j = 0; j < core::kBinsPerThread; j += 2) {
@@ -138,13 +149,18 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
         sa = ((int)(int16_t)ra[k] + (ra[k] >> 16)) / 2;
         sb = ((int)(int16_t)rb[k] + (rb[k] >> 16)) / 2;
       }
-      const float w = win[k];
+      const float w = (LAB & kLab32WinLoad) ? win32[tt + 256 * k] : win[k];
       const cf x{(float)sa * w, (float)sb * w};
       r[k] = x;
-      ea = core::fmad(x.x, x.x, ea);
-      eb = core::fmad(x.y, x.y, eb);
+      if (!(LAB & kLab32NoEnergy)) {
+        ea = core::fmad(x.x, x.x, ea);
+        eb = core::fmad(x.y, x.y, eb);
+      }
     };
-    {
+    if (LAB & kLab32NoFold) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) convert(k);
+    } else {
       cf fv[kFoldHalf];
       core::class_lane_load_part<0, kFoldHalf>(lds, fold_entry, fv);
 #pragma unroll
@@ -164,26 +180,30 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
       for (int k = 0; k < 16; k++) r[k].y = 0.0f;
       eb = 0.0f;
     }
-    lds_barrier();  // every thread has read its share of the previous pair's powers and energy partials
+    if (!(LAB & kLab32NoB1)) lds_barrier(); else wave_lds_fence();  // every thread has read its share of the previous pair's powers and energy partials
     core::dif0_streamed_pw<0>(tt, pw0, lds, r);
-    lds_barrier();  // stage 0 -> 1 crosses waves
+    if (!(LAB & kLab32NoB2)) lds_barrier(); else wave_lds_fence();  // stage 0 -> 1 crosses waves
     core::dif1_streamed_pw<0>(tt, pw1, lds, r);
     wave_lds_fence();  // stage 1 -> 2 stays inside 16 consecutive lanes
     core::dif2_streamed<0>(tt, lds, r);
     wave_lds_fence();  // publish -> partner reads stays inside the wave (fp_core.h group_k0)
 
-    cf yp[core::kBinsPerThread];
-    core::dif_partner_load(tt, lds, yp);
-    float pwa[core::kBinsPerThread], pwb[core::kBinsPerThread];
+    if (!(LAB & kLab32NoPower)) {
+      cf yp[core::kBinsPerThread];
+      core::dif_partner_load(tt, lds, yp);
+      float pwa[core::kBinsPerThread], pwb[core::kBinsPerThread];
 #pragma unroll
-    for (int j = 0; j < core::kBinsPerThread; j++) core::dif_power_of(r[core::out16(j)], yp[j], &pwa[j], &pwb[j]);
+      for (int j = 0; j < core::kBinsPerThread; j++) core::dif_power_of(r[core::out16(j)], yp[j], &pwa[j], &pwb[j]);
 #pragma unroll
-    for (int j = 0; j < core::kBinsPerThread; j++)
-      core::lds_put_bytes(lds, (j & 1) ? core::slot_bytes<1>(inv.w[j >> 1]) : core::slot_bytes<0>(inv.w[j >> 1]), cf{pwa[j], pwb[j]});
-    core::lds_put(lds, core::energy_slot(tt), cf{ea, eb});  // spare column 8 of this thread's own stage-2 row
+      for (int j = 0; j < core::kBinsPerThread; j++)
+        core::lds_put_bytes(lds, (j & 1) ? core::slot_bytes<1>(inv.w[j >> 1]) : core::slot_bytes<0>(inv.w[j >> 1]), cf{pwa[j], pwb[j]});
+    } else {
+      asm volatile("" ::"v"(r[0].x), "v"(r[5].y), "v"(r[10].x), "v"(r[15].y));
+    }
+    if (!(LAB & kLab32NoEnergy)) core::lds_put(lds, core::energy_slot(tt), cf{ea, eb});  // spare column 8 of this thread's own stage-2 row
     const PairSrc nxt = locate(min(g + 1, last - 1));  // last pair: harmless re-read
     issue_loads(nxt);
-    lds_barrier();  // the power image is complete
+    if (!(LAB & kLab32NoB3)) lds_barrier(); else wave_lds_fence();  // the power image is complete
     prev = cur;
     cur = nxt;
   }
