@@ -266,6 +266,29 @@ def end_to_end(capi, eps, cmp, n_pairs, reps=6):
     return out
 
 
+def search_roofline(ceiling_cells, issued_evals, covered_cells, scan_ms):
+    """The scan kernel against the integer-VALU roof.  ceiling_cells: needle_hip_int_valu_ceiling(), cells/s of a
+    4-instruction cell (xor, popcount, compare, select) on registers, measured in this run.  issued_evals: cell
+    evaluations the scan ISSUES per launch (3 instructions each; needle_hip_scan_issued_evaluations, counted in an
+    untimed launch of the same work).  frac = issued lane-instructions/s over the ceiling's lane-instructions/s: <= 1
+    by construction.  What the aligned-window scan saves by NOT evaluating cells is `pruning_factor`, kept apart."""
+    if not issued_evals or scan_ms <= 0:
+        return {"error": "no count from the counting launch"}
+    sec = scan_ms * 1e-3
+    achieved, peak = 3.0 * issued_evals / sec, 4.0 * ceiling_cells
+    return {"bound": "int valu", "kernel": "hamming_runs", "unit": "lane-instructions/s",
+            "achieved": round(achieved, 1), "peak": round(peak, 1), "frac": round(achieved / peak, 4),
+            "issued_cell_evaluations_per_launch": int(issued_evals), "avg_launch_ms": round(scan_ms, 5),
+            "ceiling_cells_per_s": round(ceiling_cells, 1),
+            "covered_table_cells_per_launch": covered_cells,
+            "covered_table_cells_per_s": round(covered_cells / sec, 1),
+            "pruning_factor": round(covered_cells / issued_evals, 2),
+            "note": "achieved = 3 (xor, popcount, compare) x the cell evaluations the scan issues, padding and repeated lanes "
+                    "included, / kernel time; peak = 4 x the measured rate of the 4-instruction cell on registers.  "
+                    "pruning_factor = cells of the reference's table covered per evaluation issued: algorithmic skipping, "
+                    "not machine utilisation"}
+
+
 def search_only(capi, synth, episodes, minutes, reps=5):
     """BASELINE.json configs[2]: `episodes` x 24-min episodes as real .needle.dat files (written once by this
     analyzer from synthetic audio), then needle_audio_comparator_run(analyze=false) timed from disk: file reads,
@@ -298,6 +321,14 @@ def search_only(capi, synth, episodes, minutes, reps=5):
             scan.append(capi.last_kernel_ms("hamming_runs"))
             simh.append(capi.last_kernel_ms("simhash_runs"))
     capi.set_kernel_timing(None)
+    os.environ["NEEDLE_HIP_SCAN_COUNT"] = "1"                   # one more call through the counting scan (untimed)
+    try:
+        cmp.run(analyze=False, display=False)
+        capi.scan_issued_evaluations(reset=True)
+        cmp.run(analyze=False, display=False)
+        issued = capi.scan_issued_evaluations(reset=True)
+    finally:
+        del os.environ["NEEDLE_HIP_SCAN_COUNT"]
     for p in paths:
         try:
             os.unlink(os.path.splitext(p)[0] + ".needle.dat")
@@ -313,7 +344,7 @@ def search_only(capi, synth, episodes, minutes, reps=5):
     return {"episodes": episodes, "pairs": pairs, "hashes_per_episode": int(n_h),
             "wall_ms": round(1e3 * wall, 3), "pairs_per_s": round(pairs / wall, 1),
             "scan_kernel_ms": round(sum(scan) / len(scan), 4), "simhash_kernel_ms": round(sum(simh) / len(simh), 4),
-            "table_cells": float(pairs) * n_h * n_h, "prepare_s": round(prep_s, 2),
+            "table_cells": float(pairs) * n_h * n_h, "prepare_s": round(prep_s, 2), "issued_evals": issued,
             "what": "needle_audio_comparator_run(analyze=false) over .needle.dat files in the page cache: read + parse, "
                     "H2D of hashes, scan, simhash, D2H of runs, host epilogue; wall clock per call"}
 
@@ -574,6 +605,19 @@ def main() -> None:
         step(False)
     barrier()
     capi.set_kernel_timing(None)
+    # what the scan ISSUES, for roofline_search: one more (untimed) job through the counting instantiation of the kernel
+    issued_evals = None
+    if not args.no_extras:
+        os.environ["NEEDLE_HIP_SCAN_COUNT"] = "1"
+        try:
+            step(False)
+            barrier()
+            capi.scan_issued_evaluations(reset=True)
+            step(False)
+            barrier()
+            issued_evals = capi.scan_issued_evaluations(reset=True)
+        finally:
+            del os.environ["NEEDLE_HIP_SCAN_COUNT"]
     if world > 1:
         elapsed = float(capi.comm_all_gather(np.array([elapsed], dtype=np.float64)).max())
 
@@ -648,27 +692,22 @@ def main() -> None:
         }
         if not args.no_extras:
             try:
-                ceiling = capi.int_valu_ceiling()
-                cells = float(pcount) * kept[0] * kept[0]
-                scan_ms = avg["hamming_runs"]
-                out["roofline_search"] = {
-                    "bound": "int valu", "kernel": "hamming_runs", "unit": "table cells/s",
-                    "achieved": round(cells / (scan_ms * 1e-3), 1) if scan_ms > 0 else None, "peak": round(ceiling, 1),
-                    "frac": round(cells / (scan_ms * 1e-3) / ceiling, 4) if scan_ms > 0 else None,
-                    "cells_per_launch": cells, "avg_launch_ms": round(scan_ms, 5),
-                    "note": "peak = needle_hip_int_valu_ceiling(), measured in this run: every cell of the reference's "
-                            "table evaluated with xor/popcount/compare/select on registers.  achieved = cells of the "
-                            "table COVERED per second; the aligned-window scan proves most cells irrelevant without "
-                            "evaluating them (a run of >= min_len must cover an aligned 8-row window), so frac > 1 "
-                            "means algorithmic skipping, not a faster ALU"}
+                out["roofline_search"] = search_roofline(capi.int_valu_ceiling(), issued_evals, float(pcount) * kept[0] * kept[0],
+                                                         avg["hamming_runs"])
+                if dominant in ("hamming_runs", "simhash_runs"):   # the scan dominates (library scale): it is not HBM-bound
+                    rs = out["roofline_search"]
+                    out["roofline"].update(bound="int valu", achieved=rs["achieved"], peak=rs["peak"], unit=rs["unit"], frac=rs["frac"],
+                                           hbm={"achieved_gbs": round(achieved, 2), "peak_gbs": HBM_PEAK_GBS,
+                                                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                                                "note": "integer-VALU-bound by construction (~1450 ops per byte): the HBM fraction says nothing"})
             except capi.NeedleError as e:
                 out["roofline_search"] = {"error": str(e)}
         if world == 1 and not args.no_extras:
             out["end_to_end"] = end_to_end(capi, eps, cmp, n_pairs)
             so = search_only(capi, synth, args.search_only_episodes, 24.0)
             if "roofline_search" in out and "peak" in out["roofline_search"]:
-                so["cells_per_s"] = round(so["table_cells"] / (so["scan_kernel_ms"] * 1e-3), 1)
-                so["frac_of_int_valu_ceiling"] = round(so["cells_per_s"] / out["roofline_search"]["peak"], 4)
+                so["roofline"] = search_roofline(out["roofline_search"]["ceiling_cells_per_s"], so.pop("issued_evals"),
+                                                 so["table_cells"], so["scan_kernel_ms"])
             out["search_only"] = so
         if world == 1 and not args.no_cpu_baseline:
             hashes = [lib.frame_hashes(v).opening_data()[0] for v in range(n)]

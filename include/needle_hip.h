@@ -60,6 +60,13 @@ void needle_hip_set_kernel_timing(const char *kernels);
  * per-cell instruction sequence (xor, popcount, compare, select) with operands in registers -- the integer-VALU
  * ceiling a brute-force evaluation of every cell of comparator.rs:176-187 cannot exceed.  Takes ~10 ms. */
 enum NeedleError needle_hip_int_valu_ceiling(double *cells_per_second);
+/* The other half of that roofline.  The fast scan does not evaluate every cell of the table: a run of >= min_len must
+ * cover an aligned 8-row window, so only those rows are looked at, and most windows are abandoned after three of them.
+ * With NEEDLE_HIP_SCAN_COUNT=1 in the environment every scan launch runs a COUNTING instantiation of the same kernel
+ * (slower; never time it) that adds up the cell evaluations it ISSUES -- xor / popcount / compare over a wave's 64
+ * lanes, inside the table or not.  This returns the sum since the last reset (waits for the library stream):
+ * issued evaluations per second of the UNCOUNTED kernel against needle_hip_int_valu_ceiling() is a fraction <= 1. */
+enum NeedleError needle_hip_scan_issued_evaluations(uint64_t *lane_evaluations, bool reset);
 
 /* ---- fingerprint: the chromaprint Context replacement -------------------------------------------
  * Replaces chromaprint::Context::{start,feed,finish,get_fingerprint_raw,get_delay,get_item_duration,
@@ -225,6 +232,11 @@ size_t needle_hip_library_rows_per_video(const NeedleHipLibrary *library);
  * videos this rank does not own.  Crops to the opening window and uploads. */
 enum NeedleError needle_hip_library_set_pcm(NeedleHipLibrary *library, const int16_t *const *pcm,
                                             const size_t *num_values, int channels);
+/* The same for PCM that is already in HBM (decoded or generated on the device): d_pcm[i] are DEVICE pointers, NULL for
+ * videos this rank does not own.  The search windows are copied device to device into the library's arena; the caller's
+ * buffers are free on return. */
+enum NeedleError needle_hip_library_set_pcm_device(NeedleHipLibrary *library, const int16_t *const *d_pcm,
+                                                   const size_t *num_values, int channels);
 /* The streaming form ("analyze streamed from host-pinned PCM", BASELINE.json configs[4]): the search windows of the
  * videos with a non-NULL pointer are copied to the device in order on an upload stream and fingerprinted group by
  * group (~32 MiB of PCM each) on the library stream as they land, straight into their arena rows; nothing of the PCM

@@ -70,7 +70,7 @@ NEEDLE_H_SYMBOLS = [
     "needle_audio_comparator_run"]
 NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_device_count", "needle_hip_set_device", "needle_hip_synchronize", "needle_hip_stream",
-    "needle_hip_device_pci_bus_id", "needle_hip_fingerprint_cert_stats",
+    "needle_hip_device_pci_bus_id", "needle_hip_fingerprint_cert_stats", "needle_hip_scan_issued_evaluations",
     "needle_hip_last_error_message",
     "needle_hip_version", "needle_hip_malloc", "needle_hip_free", "needle_hip_memcpy_h2d", "needle_hip_memcpy_d2h",
     "needle_hip_host_free", "needle_hip_last_kernel_ms", "needle_hip_set_kernel_timing", "needle_hip_fingerprint_sample_rate",
@@ -83,7 +83,7 @@ NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_frame_hashes_read", "needle_hip_frame_hashes_write", "needle_hip_header_md5",
     "needle_hip_analyzer_run_pcm", "needle_hip_comparator_run_with_frame_hashes", "needle_hip_library_new",
     "needle_hip_library_free", "needle_hip_library_include_endings", "needle_hip_library_rows_per_video",
-    "needle_hip_library_set_pcm", "needle_hip_library_analyze",
+    "needle_hip_library_set_pcm", "needle_hip_library_set_pcm_device", "needle_hip_library_analyze",
     "needle_hip_library_hash_arena", "needle_hip_library_use_hash_arena", "needle_hip_library_num_pairs", "needle_hip_library_search",
     "needle_hip_library_fetch_runs_begin", "needle_hip_library_fetch_runs_end",
     "needle_hip_library_finalize", "needle_hip_library_frame_hashes",
@@ -254,6 +254,14 @@ def cert_stats(reset: bool = False) -> dict:
     lib().needle_hip_fingerprint_cert_stats.argtypes = [C.POINTER(C.c_uint64), C.c_bool]
     check(lib().needle_hip_fingerprint_cert_stats(v, reset))
     return {"items": int(v[0]), "items_recomputed": int(v[1]), "chunks": int(v[2]), "chunks_recomputed": int(v[3])}
+
+
+def scan_issued_evaluations(reset: bool = False) -> int:
+    """Cell evaluations issued by the counting scan launches (NEEDLE_HIP_SCAN_COUNT=1) since the last reset."""
+    v = C.c_uint64(0)
+    lib().needle_hip_scan_issued_evaluations.argtypes = [C.POINTER(C.c_uint64), C.c_bool]
+    check(lib().needle_hip_scan_issued_evaluations(C.byref(v), reset))
+    return int(v.value)
 
 
 def int_valu_ceiling() -> float:
@@ -651,6 +659,13 @@ class Library:
         ptrs = (C.c_void_p * self.n)(*[None if a is None else a.ctypes.data for a in arrs])
         lens = (C.c_size_t * self.n)(*list(num_values))
         check(lib().needle_hip_library_set_pcm(self._h, ptrs, lens, channels))
+
+    def set_pcm_device(self, d_ptrs: Sequence[Optional[int]], num_values: Sequence[int], channels: int = 1) -> None:
+        """PCM already in HBM: device pointers (None for videos of other ranks), copied device to device."""
+        ptrs = (C.c_void_p * self.n)(*[None if p is None else int(p) for p in d_ptrs])
+        lens = (C.c_size_t * self.n)(*list(num_values))
+        lib().needle_hip_library_set_pcm_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]
+        check(lib().needle_hip_library_set_pcm_device(self._h, ptrs, lens, channels))
 
     def stream_pcm(self, pcm: Sequence[Optional[np.ndarray]], num_values: Sequence[int], channels: int = 1) -> None:
         """Upload + fingerprint overlapped, PCM not kept (needle_hip_library_stream_pcm)."""

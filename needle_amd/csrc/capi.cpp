@@ -424,6 +424,14 @@ enum NeedleError needle_hip_fingerprint_cert_stats(uint64_t counts[4], bool rese
   });
 }
 
+enum NeedleError needle_hip_scan_issued_evaluations(uint64_t *lane_evaluations, bool reset) {
+  if (!lane_evaluations) return NeedleError_NullArgument;
+  return guarded([&]() -> NeedleError {
+    Status s = gpu_scan_issued_evaluations(lane_evaluations, reset);
+    return s.ok() ? NeedleError_Ok : report(s);
+  });
+}
+
 enum NeedleError needle_hip_int_valu_ceiling(double *cells_per_second) {
   if (!cells_per_second) return NeedleError_NullArgument;
   return guarded([&]() -> NeedleError {

@@ -279,6 +279,29 @@ enum NeedleError needle_hip_library_set_pcm(NeedleHipLibrary *lib, const int16_t
   });
 }
 
+enum NeedleError needle_hip_library_set_pcm_device(NeedleHipLibrary *lib, const int16_t *const *d_pcm,
+                                                   const size_t *num_values, int channels) {
+  if (!lib || !d_pcm || !num_values) return NeedleError_NullArgument;
+  if (channels != 1 && channels != 2) return NeedleError_InvalidArgument;
+  return guarded([&]() -> NeedleError {
+    std::vector<const int16_t *> src;
+    std::vector<size_t> len;
+    std::vector<uint64_t> dst;
+    uint64_t total = 0;
+    Status s = plan_windows(lib, d_pcm, num_values, channels, true, &src, &len, &dst, nullptr, &total);
+    if (!s.ok()) return report(s);
+    if (!(s = lib->d_pcm.reserve(std::max<uint64_t>(total, 1))).ok()) return report(s);
+    hipStream_t stream = library_stream();
+    for (size_t i = 0; i < src.size(); i++)  // the search windows only, device to device, in stream order
+      if (hipMemcpyAsync(lib->d_pcm.ptr + dst[i], src[i], len[i] * sizeof(int16_t), hipMemcpyDeviceToDevice, stream) != hipSuccess)
+        return report(Status::Make(NeedleError_Unknown, "device-to-device PCM copy failed"));
+    if (hipStreamSynchronize(stream) != hipSuccess) return report(Status::Make(NeedleError_Unknown, "PCM copy failed"));
+    lib->have_pcm = true;
+    lib->pcm_resident = true;
+    return NeedleError_Ok;
+  });
+}
+
 enum NeedleError needle_hip_library_stream_pcm(NeedleHipLibrary *lib, const int16_t *const *pcm, const size_t *num_values,
                                                int channels) {
   if (!lib || !pcm || !num_values) return NeedleError_NullArgument;

@@ -241,14 +241,21 @@ __global__ __launch_bounds__(256) void hamming_runs_band_kernel(const uint32_t *
 // Per evaluated cell: v_xor, v_bcnt, v_cmp (+ one scalar AND of lane masks); at the default 20 s minimum
 // (min_len 82, W 8, P 75) that is 3 VALU on at most 10.7 % of the cells -- typically 4 % (the first three rows of
 // each window, plus the few diagonals that survive them, finished one at a time) -- instead of 4 VALU on all of them.
-template <int R, int W>
+// COUNT (diagnostic instantiation, NEEDLE_HIP_SCAN_COUNT=1; never the timed one): every wave also counts the
+// xor / popcount / compare groups it ISSUES (one group = the three instructions over its 64 lanes, whether a lane's
+// cell lies inside the table, on the padding or repeats another lane's) and adds the total to *eval_groups when it
+// leaves -- the numerator of an honest roofline: issued cell evaluations per second against the measured
+// integer-VALU ceiling, <= 1 by construction, unlike the cells of the reference's table the scan merely COVERS.
+template <int R, int W, bool COUNT = false>
 __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_t *__restrict__ hashes,
                                                                    const SearchProblem *__restrict__ problems,
                                                                    int num_problems, uint32_t threshold,
                                                                    NeedleHipRun *__restrict__ runs,
                                                                    uint32_t capacity, uint32_t *__restrict__ count,
-                                                                   int bands_per_wave, int sparse_max) {
+                                                                   int bands_per_wave, int sparse_max,
+                                                                   unsigned long long *__restrict__ eval_groups) {
   constexpr int B = 64 * R;
+  unsigned long long groups = 0;  // COUNT only
   extern __shared__ uint32_t lds[];
   int lo = 0, hi = num_problems - 1;
   while (lo < hi) {
@@ -329,6 +336,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
 #pragma unroll
       for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv[s] ^ E[s + r]) <= threshold);
     }
+    if (COUNT) groups += kSampleHead * R;
     // exact resolution of one diagonal whose W window cells all match, by the whole wave (d is wave-uniform)
     auto resolve = [&](const int d) {
       const int ilo = d < 0 ? 1 - d : 1;
@@ -341,6 +349,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
       while (e <= fwd_limit) {
         const int row = e + lane;
         const bool bad = row <= fwd_limit && (uint32_t)__popc(lsrc[row] ^ ldst[B + row + d]) > threshold;
+        if (COUNT) groups += 1;
         const unsigned long long mm = __ballot(bad);
         if (mm) {
           e += __ffsll((long long)mm) - 1;
@@ -360,6 +369,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
       while (q >= ilo) {
         const int row = q - lane;
         const bool bad = row >= ilo && (uint32_t)__popc(lsrc[row] ^ ldst[B + row + d]) > threshold;
+        if (COUNT) groups += 1;
         const unsigned long long mm = __ballot(bad);
         if (mm) {
           a = q - (__ffsll((long long)mm) - 1) + 1;
@@ -407,6 +417,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
           const int d = D0 + src_lane * R + r;  // wave-uniform
           const int row = w0 + tail_off;
           const bool bad = (uint32_t)__popc(sv_tail ^ ldst[B + row + d]) > threshold;
+          if (COUNT) groups += 1;
           if (__ballot(bad) == 0) resolve(d);
         }
       }
@@ -418,6 +429,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
 #pragma unroll
       for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv[s] ^ E[s + r]) <= threshold);
     }
+    if (COUNT) groups += (W - kSampleHead) * R;
     // ---- candidates: resolved one at a time by the whole wave ----
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -430,6 +442,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
     }
   }
   }  // bands of this wave
+  if (COUNT && lane == 0) atomicAdd(eval_groups, groups);
 }
 
 // ---- simhash of every emitted run (comparator.rs:149-153,226-229) -----------------------------------------------
@@ -597,6 +610,7 @@ struct SearchWorkspace {
   DescriptorUpload<SearchProblem> upload;
   SearchPlan plan;            // of the last launch
   bool lds_attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in, per device
+  unsigned long long *eval_groups = nullptr;  // device; NEEDLE_HIP_SCAN_COUNT=1 launches add to it
 };
 std::mutex g_ws_mu;
 std::map<int, SearchWorkspace *> g_ws;
@@ -644,7 +658,9 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_band_kernel<kBandR, kBandU>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_sampled_kernel<kBandR, kSampleW>),
+      NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_sampled_kernel<kBandR, kSampleW, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_sampled_kernel<kBandR, kSampleW, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       ws->lds_attr_set = true;
     }
@@ -654,9 +670,19 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
       if (sampled) {
         int sparse_max = kSparseMax;
         if (const char *e = getenv("NEEDLE_HIP_SPARSE_MAX")) sparse_max = std::max(0, atoi(e));  // tests, tuning: 0 = row by row
-        hipLaunchKernelGGL((hamming_runs_sampled_kernel<kBandR, kSampleW>), dim3((uint32_t)blocks), dim3(256),
-                           lds_bytes, stream, d_hashes, ws->problems.ptr, staged, threshold, d_runs,
-                           capacity, d_count, bands_per_wave, sparse_max);
+        if (getenv("NEEDLE_HIP_SCAN_COUNT")) {  // diagnostic: the same scan, counting what it issues
+          if (!ws->eval_groups) {
+            NEEDLE_HIP_TRY(hipMalloc((void **)&ws->eval_groups, sizeof(unsigned long long)));
+            NEEDLE_HIP_TRY(hipMemsetAsync(ws->eval_groups, 0, sizeof(unsigned long long), stream));
+          }
+          hipLaunchKernelGGL((hamming_runs_sampled_kernel<kBandR, kSampleW, true>), dim3((uint32_t)blocks), dim3(256),
+                             lds_bytes, stream, d_hashes, ws->problems.ptr, staged, threshold, d_runs, capacity, d_count,
+                             bands_per_wave, sparse_max, ws->eval_groups);
+        } else {
+          hipLaunchKernelGGL((hamming_runs_sampled_kernel<kBandR, kSampleW, false>), dim3((uint32_t)blocks), dim3(256),
+                             lds_bytes, stream, d_hashes, ws->problems.ptr, staged, threshold, d_runs, capacity, d_count,
+                             bands_per_wave, sparse_max, (unsigned long long *)nullptr);
+        }
       }
       else if (fast)
         hipLaunchKernelGGL((hamming_runs_band_kernel<kBandR, kBandU>), dim3((uint32_t)blocks), dim3(256), lds_bytes,
@@ -678,6 +704,24 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
     NEEDLE_HIP_TRY(hipGetLastError());
   }
   if (sync) NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+  return Status::Ok();
+}
+
+// Cell evaluations ISSUED by the sampled scan's counting launches (NEEDLE_HIP_SCAN_COUNT=1) since the last reset:
+// groups of xor / popcount / compare over a wave's 64 lanes, times 64.
+Status gpu_scan_issued_evaluations(uint64_t *lane_evaluations, bool reset) {
+  std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
+  Status s = ensure_device();
+  if (!s.ok()) return s;
+  SearchWorkspace *ws = workspace();
+  unsigned long long groups = 0;
+  hipStream_t stream = library_stream();
+  if (ws->eval_groups) {
+    NEEDLE_HIP_TRY(hipMemcpyAsync(&groups, ws->eval_groups, sizeof(groups), hipMemcpyDeviceToHost, stream));
+    if (reset) NEEDLE_HIP_TRY(hipMemsetAsync(ws->eval_groups, 0, sizeof(unsigned long long), stream));
+    NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  *lane_evaluations = (uint64_t)groups * 64u;
   return Status::Ok();
 }
 

@@ -103,3 +103,60 @@ def write_wav(path: str, pcm: np.ndarray, channels: int = 1, rate: int = RATE) -
                 + (16).to_bytes(2, "little"))
         f.write(b"data" + nbytes.to_bytes(4, "little"))
         f.write(data.tobytes())
+
+
+# ---- libraries generated in HBM (csrc/synth_hip.hip): tests and measurements at library scale -------------------------
+_HIP_LIB = None
+
+
+def _hip_lib():
+    global _HIP_LIB
+    if _HIP_LIB is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libneedle_synth_hip.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = ctypes.CDLL(path)
+        lib.needle_synth_hip_library.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                                 ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64,
+                                                 ctypes.c_uint64, ctypes.c_void_p]
+        lib.needle_synth_hip_library.restype = ctypes.c_int
+        _HIP_LIB = lib
+    return _HIP_LIB
+
+
+class DeviceLibrary:
+    """`n` episodes of `samples` mono s16 values each, generated on the device: a unique tonal body per episode and
+    one shared intro of `intro_s` seconds at the offsets episode_layout() gives (the whole stream is meant to be the
+    opening search window: use with opening_search_percentage = 1.0).  Not the host generator's samples -- its own
+    (csrc/synth_hip.hip); a checker reads the PCM it wants back with episode()."""
+
+    def __init__(self, n: int, samples: int, intro_s: float, first_episode: int = 0, seed_base: int = EPISODE_SEED):
+        from . import capi
+        self.n, self.samples = n, samples
+        self.stride = (samples + 7) & ~7                       # every episode 16-byte aligned
+        self.intro_len = int(intro_s * RATE)
+        # the window generated is the first half of an episode twice as long: same offsets as make_episode(k, 2 * ...)
+        self.intro_off = np.array([episode_layout(first_episode + k, 2 * samples, intro_s, 0.0)[0] for k in range(n)],
+                                  dtype=np.uint32)
+        assert int(self.intro_off.max()) + self.intro_len <= samples
+        self._buf = capi.DeviceBuffer(self.stride * 2 * n)
+        off = capi.DeviceBuffer(4 * n)
+        capi.check(capi.lib().needle_hip_memcpy_h2d(off.ptr, self.intro_off.ctypes.data, self.intro_off.nbytes))
+        rc = _hip_lib().needle_synth_hip_library(self._buf.ptr, self.stride, n, first_episode, samples, off.ptr,
+                                                 self.intro_len, seed_base, INTRO_SEED, capi.stream_ptr())
+        if rc != 0:
+            raise RuntimeError(f"needle_synth_hip_library: HIP error {rc}")
+        capi.synchronize()
+
+    def pointers(self):
+        return [self._buf.ptr + 2 * self.stride * k for k in range(self.n)]
+
+    def episode(self, k: int) -> np.ndarray:
+        """Episode k's PCM, copied to the host."""
+        from . import capi
+        out = np.zeros(self.samples, dtype=np.int16)
+        capi.check(capi.lib().needle_hip_memcpy_d2h(out.ctypes.data, self._buf.ptr + 2 * self.stride * k, out.nbytes))
+        return out
+
+    def free(self) -> None:
+        self._buf = None

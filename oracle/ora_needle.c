@@ -507,6 +507,84 @@ ora_entry *ora_longest_common_hash_match(const ora_comparator *c, const ora_hash
   return heap.data;
 }
 
+/* The same function WITHOUT the table, for checks at sizes where 2 x 8 bytes x n x m per pair is out of reach (a
+ * 2000-episode library): every diagonal d = j - i is walked once with a running match length -- t[i][j] of :176-187 --
+ * a run's last cell (the cells :196-200 stop at: t != 0 and, unless on the last row / column, t[i+1][j+1] == 0) is
+ * put through the validity test of :212-223 on the spot, and the survivors are pushed in the order the reverse walk
+ * of :191-192 meets them (i descending, then j descending).  Same entries, same BinaryHeap array as the literal
+ * form (tests/test_oracle.py compares the two entry by entry). */
+typedef struct {
+  size_t i, j, len;
+} run_end_t;
+
+static int run_end_walk_order(const void *pa, const void *pb) {
+  const run_end_t *a = (const run_end_t *)pa, *b = (const run_end_t *)pb;
+  if (a->i != b->i) return a->i > b->i ? -1 : 1;
+  if (a->j != b->j) return a->j > b->j ? -1 : 1;
+  return 0;
+}
+
+ora_entry *ora_longest_common_hash_match_tablefree(const ora_comparator *c, const ora_hash_ts *src, size_t n,
+                                                   const ora_hash_ts *dst, size_t m, ora_ns src_hash_duration,
+                                                   ora_ns dst_hash_duration, bool is_opening, size_t *n_out) {
+  *n_out = 0;
+  if (n == 0 || m == 0) return NULL; /* :165-167 */
+  const bool is_ending = !is_opening;
+  const ora_ns min_dur = is_opening ? c->min_opening_duration : c->min_ending_duration;
+  run_end_t *ends = NULL;
+  size_t n_ends = 0, cap = 0;
+  if (n >= 2 && m >= 2) {
+    const long d_first = -((long)n - 2), d_last = (long)m - 2;
+    for (long d = d_first; d <= d_last; d++) { /* cells with both indices >= 1 (:179-180) */
+      const long lo = d < 0 ? 1 - d : 1, hi = ((long)n - 1) < ((long)m - 1 - d) ? ((long)n - 1) : ((long)m - 1 - d);
+      size_t run = 0;
+      for (long a = lo; a <= hi + 1; a++) {
+        if (a <= hi && (uint32_t)__builtin_popcount(src[a].hash ^ dst[a + d].hash) <= c->hash_match_threshold) {
+          run++;
+          continue;
+        }
+        if (run) { /* the run's last cell is (a - 1, a - 1 + d), t = run */
+          const size_t i = (size_t)(a - 1), j = (size_t)(a - 1 + d);
+          if (dur_sub(src[i].ts, src[i - run].ts) >= min_dur && dur_sub(dst[j].ts, dst[j - run].ts) >= min_dur) {
+            if (n_ends == cap) {
+              cap = cap ? 2 * cap : 16;
+              ends = (run_end_t *)realloc(ends, cap * sizeof(run_end_t));
+            }
+            ends[n_ends++] = (run_end_t){i, j, run};
+          }
+        }
+        run = 0;
+      }
+    }
+  }
+  qsort(ends, n_ends, sizeof(run_end_t), run_end_walk_order);
+  heap_t heap = {0, 0, 0};
+  for (size_t k = 0; k < n_ends; k++) {
+    const size_t i = ends[k].i, j = ends[k].j, len = ends[k].len;
+    ora_entry e;
+    memset(&e, 0, sizeof(e));
+    e.score = len;
+    e.src_start = src[i - len].ts;
+    e.src_end = src[i].ts;
+    e.dst_start = dst[j - len].ts;
+    e.dst_end = dst[j].ts;
+    e.src_match_hash = compute_hash_for_match(src, n, i - len, i);
+    e.dst_match_hash = compute_hash_for_match(dst, m, j - len, j);
+    e.is_src_opening = is_opening;
+    e.is_src_ending = is_ending;
+    e.is_dst_opening = is_opening;
+    e.is_dst_ending = is_ending;
+    e.src_hash_duration = src_hash_duration;
+    e.dst_hash_duration = dst_hash_duration;
+    e.src_end_idx = (uint32_t)i;
+    e.dst_end_idx = (uint32_t)j;
+    heap_push(&heap, &e);
+  }
+  free(ends);
+  *n_out = heap.len;
+  return heap.data;
+}
+
 /* OpeningAndEndingInfo, comparator.rs:47-62 */
 typedef struct {
   ora_entry *src_openings, *dst_openings, *src_endings, *dst_endings;
@@ -519,21 +597,22 @@ static void push_entry(ora_entry **v, size_t *n, const ora_entry *e) {
   (*v)[(*n)++] = *e;
 }
 
+typedef ora_entry *(*lcs_fn)(const ora_comparator *, const ora_hash_ts *, size_t, const ora_hash_ts *, size_t, ora_ns, ora_ns,
+                             bool, size_t *);
+
 /* comparator.rs:252-308; returns 1 on FrameHashDataNoEnding */
-static int find_opening_and_ending(const ora_comparator *c, const ora_frame_hashes *s,
-                                   const ora_frame_hashes *d, info_t *info) {
+static int find_opening_and_ending_with(lcs_fn lcs, const ora_comparator *c, const ora_frame_hashes *s,
+                                        const ora_frame_hashes *d, info_t *info) {
   memset(info, 0, sizeof(*info));
   size_t n1 = 0, n2 = 0;
-  ora_entry *e1 = ora_longest_common_hash_match(c, s->opening, s->n_opening, d->opening, d->n_opening,
-                                                s->hash_duration, d->hash_duration, true, &n1);
+  ora_entry *e1 = lcs(c, s->opening, s->n_opening, d->opening, d->n_opening, s->hash_duration, d->hash_duration, true, &n1);
   ora_entry *e2 = NULL;
   if (c->include_endings) {
     if (s->n_ending == 0 || d->n_ending == 0) {
       free(e1);
       return 1;
     }
-    e2 = ora_longest_common_hash_match(c, s->ending, s->n_ending, d->ending, d->n_ending,
-                                       s->hash_duration, d->hash_duration, false, &n2);
+    e2 = lcs(c, s->ending, s->n_ending, d->ending, d->n_ending, s->hash_duration, d->hash_duration, false, &n2);
   }
   for (size_t k = 0; k < n1 + n2; k++) {
     const ora_entry *e = k < n1 ? &e1[k] : &e2[k - n1];
@@ -550,6 +629,11 @@ static int find_opening_and_ending(const ora_comparator *c, const ora_frame_hash
   free(e2);
   info->empty = !(info->n_src_openings || info->n_dst_openings || info->n_src_endings || info->n_dst_endings);
   return 0;
+}
+
+static int find_opening_and_ending(const ora_comparator *c, const ora_frame_hashes *s, const ora_frame_hashes *d,
+                                   info_t *info) {
+  return find_opening_and_ending_with(ora_longest_common_hash_match, c, s, d, info);
 }
 
 static void info_free(info_t *i) {
@@ -721,6 +805,49 @@ int ora_run_with_frame_hashes(const ora_comparator *c, const ora_frame_hashes *f
   free(infos);
   free(pi);
   free(pj);
+  return rc;
+}
+
+/* comparator.rs:524-629 for SELECTED videos of a library too large for the full call: every pair that involves a
+ * selected video goes through find_opening_and_ending (table-free form of the pair function), is entered in that
+ * video's info_map in the global pair order (:534-545,583-588: as source if the video is the pair's first member),
+ * and find_best_match gives its result.  out[k] belongs to videos[k].  Same return codes. */
+int ora_run_selected_videos(const ora_comparator *c, const ora_frame_hashes *fh, size_t nv, const size_t *videos,
+                            size_t n_sel, ora_search_result *out) {
+  int rc = 0;
+  for (size_t k = 0; k < n_sel && rc == 0; k++) {
+    const size_t v = videos[k];
+    /* the pairs of v in global order: (u, v) for u < v [v is the destination], then (v, u) for u > v [source] */
+    info_t *infos = (info_t *)calloc(nv ? nv : 1, sizeof(info_t));
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+    for (long u = 0; u < (long)nv; u++) {
+      if ((size_t)u == v) {
+        infos[u].empty = 1;
+        continue;
+      }
+      const ora_frame_hashes *s = (size_t)u < v ? &fh[u] : &fh[v], *d = (size_t)u < v ? &fh[v] : &fh[u];
+      int r = find_opening_and_ending_with(ora_longest_common_hash_match_tablefree, c, s, d, &infos[u]);
+      if (r) {
+#pragma omp critical
+        rc = r;
+      }
+    }
+    if (rc == 0) {
+      match_t *matches = (match_t *)malloc((nv ? nv : 1) * sizeof(match_t));
+      size_t nm = 0;
+      for (size_t u = 0; u < nv; u++) {
+        if (u == v || infos[u].empty) continue;
+        matches[nm].info = &infos[u];
+        matches[nm].is_source = u > v; /* pair (v, u): v is the source */
+        nm++;
+      }
+      rc = find_best_match(c, matches, nm, &out[k]);
+      free(matches);
+    }
+    for (size_t u = 0; u < nv; u++)
+      if (u != v) info_free(&infos[u]);
+    free(infos);
+  }
   return rc;
 }
 

@@ -84,6 +84,12 @@ ora_entry *ora_longest_common_hash_match(const ora_comparator *c, const ora_hash
                                          const ora_hash_ts *dst, size_t m, ora_ns src_hash_duration,
                                          ora_ns dst_hash_duration, bool is_opening, size_t *n_out);
 
+/* The same entries without the table (every diagonal walked once, validity tested at each run's end, pushes in the
+ * reverse walk's order): for checks at library scale.  Compared entry by entry with the literal form in tests/. */
+ora_entry *ora_longest_common_hash_match_tablefree(const ora_comparator *c, const ora_hash_ts *src, size_t n,
+                                                   const ora_hash_ts *dst, size_t m, ora_ns src_hash_duration,
+                                                   ora_ns dst_hash_duration, bool is_opening, size_t *n_out);
+
 typedef struct {
   bool has_result;  /* false <=> find_best_match returned None: video is skipped, comparator.rs:608-617 */
   bool has_opening, has_ending;
@@ -94,6 +100,12 @@ typedef struct {
  * Returns 0 ok; 1 = FrameHashDataNoEnding (comparator.rs:271-273); 2 = Duration underflow (Rust panic). */
 int ora_run_with_frame_hashes(const ora_comparator *c, const ora_frame_hashes *fh, size_t n_videos,
                               ora_search_result *out);
+
+/* comparator.rs:524-629 for the videos[0..n_sel) of a library of n_videos, through the table-free pair function:
+ * what ora_run_with_frame_hashes returns for those videos, at a cost of n_sel x n_videos pair scans instead of
+ * n_videos^2 / 2 tables.  out[k] is the result of videos[k]. */
+int ora_run_selected_videos(const ora_comparator *c, const ora_frame_hashes *fh, size_t n_videos, const size_t *videos,
+                            size_t n_sel, ora_search_result *out);
 
 /* thread count used by ora_run_with_frame_hashes / ora_analyze_batch (the rayon pool stand-in) */
 /* An OPTIMISED CPU variant of the pair scan, for an honest second CPU baseline: no table, every

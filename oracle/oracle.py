@@ -116,6 +116,11 @@ def lib():
     L.ora_run_with_frame_hashes.argtypes = [C.POINTER(CComparator), C.POINTER(CFrameHashes), C.c_size_t,
                                             C.POINTER(CSearchResult)]
     L.ora_run_with_frame_hashes.restype = C.c_int
+    L.ora_longest_common_hash_match_tablefree.argtypes = L.ora_longest_common_hash_match.argtypes
+    L.ora_longest_common_hash_match_tablefree.restype = C.POINTER(CEntry)
+    L.ora_run_selected_videos.argtypes = [C.POINTER(CComparator), C.POINTER(CFrameHashes), C.c_size_t,
+                                          C.POINTER(C.c_size_t), C.c_size_t, C.POINTER(CSearchResult)]
+    L.ora_run_selected_videos.restype = C.c_int
     L.ora_set_threads.argtypes = [C.c_int]
     L.ora_get_threads.restype = C.c_int
     L.ora_analyze_batch.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_size_t,
@@ -323,14 +328,16 @@ def frame_hashes_read(path: str):
     return 0, fh
 
 
-def longest_common_hash_match(cmp: Comparator, src, dst, src_hd: int, dst_hd: int, is_opening: bool = True):
-    """Entries in BinaryHeap backing-array order, as dicts."""
+def longest_common_hash_match(cmp: Comparator, src, dst, src_hd: int, dst_hd: int, is_opening: bool = True,
+                              tablefree: bool = False):
+    """Entries in BinaryHeap backing-array order, as dicts.  tablefree: the diagonal-walk form of the same function
+    (ora_longest_common_hash_match_tablefree), used for checks at library scale."""
     cc = cmp.to_c()
     s = (HashTs * max(len(src), 1))(*[HashTs(h, t) for h, t in src])
     d = (HashTs * max(len(dst), 1))(*[HashTs(h, t) for h, t in dst])
     n = C.c_size_t(0)
-    p = lib().ora_longest_common_hash_match(C.byref(cc), s, len(src), d, len(dst), src_hd, dst_hd, is_opening,
-                                            C.byref(n))
+    fn = lib().ora_longest_common_hash_match_tablefree if tablefree else lib().ora_longest_common_hash_match
+    p = fn(C.byref(cc), s, len(src), d, len(dst), src_hd, dst_hd, is_opening, C.byref(n))
     out = []
     for i in range(n.value):
         e = p[i]
@@ -361,6 +368,39 @@ def run_with_frame_hashes(cmp: Comparator, fhs: Sequence[FrameHashes], threads: 
             out.append(SearchResult((r.opening_start, r.opening_end) if r.has_opening else None,
                                     (r.ending_start, r.ending_end) if r.has_ending else None))
     return out
+
+
+HASH_TS_DTYPE = np.dtype([("hash", "<u4"), ("pad", "<u4"), ("ts", "<u8")])   # struct HashTs as the C compiler lays it out
+
+
+def run_selected_videos(cmp: Comparator, hashes: Sequence[np.ndarray], timestamps: Sequence[np.ndarray],
+                        hash_duration_ns: int, videos: Sequence[int], threads: int = 1):
+    """comparator.rs:524-629 for `videos` of a library given as numpy arrays (opening window only): what
+    run_with_frame_hashes returns for those videos, through the table-free pair function
+    (ora_run_selected_videos) -- the form that stays feasible at 2000 episodes."""
+    assert C.sizeof(HashTs) == HASH_TS_DTYPE.itemsize
+    keep, arr = [], (CFrameHashes * max(len(hashes), 1))()
+    empty = (HashTs * 1)()
+    for v, (h, t) in enumerate(zip(hashes, timestamps)):
+        buf = np.zeros(len(h), dtype=HASH_TS_DTYPE)
+        buf["hash"], buf["ts"] = h, t
+        keep.append(buf)
+        arr[v].opening = C.cast(buf.ctypes.data, C.POINTER(HashTs))
+        arr[v].n_opening = len(h)
+        arr[v].ending = C.cast(empty, C.POINTER(HashTs))
+        arr[v].n_ending = 0
+        arr[v].hash_duration = hash_duration_ns
+    cc = cmp.to_c()
+    sel = (C.c_size_t * max(len(videos), 1))(*[int(v) for v in videos])
+    res = (CSearchResult * max(len(videos), 1))()
+    lib().ora_set_threads(threads)
+    rc = lib().ora_run_selected_videos(C.byref(cc), arr, len(hashes), sel, len(videos), res)
+    lib().ora_set_threads(1)
+    if rc:
+        raise RuntimeError(f"ora_run_selected_videos failed: {rc}")
+    return [None if not r.has_result else
+            SearchResult((r.opening_start, r.opening_end) if r.has_opening else None,
+                         (r.ending_start, r.ending_end) if r.has_ending else None) for r in res[:len(videos)]]
 
 
 def diagonal_runs_all_pairs(seqs: Sequence[np.ndarray], threshold: int, min_len: int, threads: int = 1,

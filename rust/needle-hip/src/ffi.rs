@@ -106,6 +106,8 @@ extern "C" {
     pub fn needle_hip_device_pci_bus_id(out: *mut c_char) -> NeedleError;
     /// {items, items recomputed in f64, chunks, chunks recomputed} of the certified f32 first pass.
     pub fn needle_hip_fingerprint_cert_stats(counts: *mut u64, reset: bool) -> NeedleError;
+    /// Cell evaluations issued by the counting instantiation of the scan (NEEDLE_HIP_SCAN_COUNT=1).
+    pub fn needle_hip_scan_issued_evaluations(lane_evaluations: *mut u64, reset: bool) -> NeedleError;
     /// The library's `hipStream_t` on the current device (NULL without one).
     pub fn needle_hip_stream() -> *mut c_void;
     pub fn needle_hip_analyzer_run_pcm(
@@ -170,6 +172,13 @@ extern "C" {
     pub fn needle_hip_library_set_pcm(
         library: *mut NeedleHipLibrary,
         pcm: *const *const i16,
+        num_values: *const usize,
+        channels: c_int,
+    ) -> NeedleError;
+    /// `d_pcm[i]` are DEVICE pointers (PCM decoded or generated on the GPU), NULL for videos of other ranks.
+    pub fn needle_hip_library_set_pcm_device(
+        library: *mut NeedleHipLibrary,
+        d_pcm: *const *const i16,
         num_values: *const usize,
         channels: c_int,
     ) -> NeedleError;

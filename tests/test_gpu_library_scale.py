@@ -93,3 +93,88 @@ def test_library_scale_hashes_runs_and_results_match_oracle(monkeypatch):
     want_m = O.run_with_frame_hashes(O.Comparator(), ofh, threads=threads)
     assert [None if r is None else (r.opening, r.ending) for r in res_m] == \
            [None if r is None else (r.opening, r.ending) for r in want_m]
+
+
+CONFIG4_EPISODES = int(os.environ.get("NEEDLE_TEST_CONFIG4_EPISODES", "2000"))
+
+
+def test_config4_full_size_on_one_gpu():
+    """BASELINE.json configs[4] at its FULL size on one MI355X: 2000 episodes x 45 min, 1 999 000 pairs, 59.5 GB of
+    opening-window PCM -- generated in HBM (13 minutes of host synthesis otherwise), so the PCM is resident and the job
+    is analyze + search + epilogue.  The oracle cannot run this job; it checks, with the GPU's own hashes as input where
+    the stage under test starts from hashes:
+      (1) the u32 hashes of sampled episodes against its f64 pipeline on the PCM read back from the device;
+      (2) the run list of all 2016 pairs among 64 sampled episodes against its table-free scan;
+      (3) the final results of 24 sampled videos -- each depends on its 1999 pairs -- against comparator.rs:524-629
+          through the table-free pair function (oracle/ora_needle.h ora_run_selected_videos);
+    and the planted ground truth: every episode's opening is detected on the shared intro."""
+    assert capi.device_count() > 0
+    n, threads = CONFIG4_EPISODES, _cpus()
+    samples = int(round(MINUTES * 60.0 / 2 * 11025))            # 14 883 750: the opening half of 45 minutes
+    gen = synth.DeviceLibrary(n, samples, 90.0)
+    rng = np.random.default_rng(4)
+    sample_eps = sorted(set([0, 1, n // 3, n // 2, n - 2, n - 1]))
+    sample_pcm = {v: gen.episode(v) for v in sample_eps}
+    lib = capi.Library(n, opening_search_percentage=1.0)
+    lib.set_pcm_device(gen.pointers(), [samples] * n)
+    gen.free()
+    cmp = capi.Comparator([f"episode-{k:04d}.wav" for k in range(n)])
+    lib.job_begin(cmp, 0)
+    results, found = lib.job_end(cmp, 0)                         # first job: run slabs grow, scan repeated
+    lib.job_begin(cmp, 1)
+    results2, found2 = lib.job_end(cmp, 1)
+    assert found == found2 and found >= n * (n - 1) // 2
+    got_all = [None if r is None else (r.opening, r.ending) for r in results]
+    assert got_all == [None if r is None else (r.opening, r.ending) for r in results2]
+    assert sum(1 for r in results if r is not None and r.opening is not None) == n      # detected: 2000
+    # planted truth: the opening found covers most of the 90 s intro at the episode's offset (the reference's clock
+    # runs 0.65 % slow and a hash covers 2.7 s: DESIGN.md §2 -- +-2.5 s is that, not a tolerance of this build)
+    for v in range(0, n, max(1, n // 50)):
+        start, end = results[v].opening
+        off = gen.intro_off[v] / 11025.0
+        clock = 0.123 / (1365 / 11025.0)
+        assert abs(start / 1e9 - off * clock) < 4.0 and abs(end / 1e9 - (off + 90.0) * clock) < 4.0, (v, start, end, off)
+
+    # every video's kept hashes in one copy of the arena
+    d_arena, stride = lib.hash_arena()
+    kept = 5441
+    arena = np.zeros(n * stride, dtype=np.uint32)
+    capi.check(capi.lib().needle_hip_memcpy_d2h(arena.ctypes.data, d_arena, arena.nbytes))
+    gpu_hashes = [arena[v * stride: v * stride + kept] for v in range(n)]
+    hd = O.duration_from_secs_f32(0.3)
+    fh0 = lib.frame_hashes(0)
+    assert len(fh0.opening_data()[0]) == kept and fh0.opening_data()[0].tolist() == gpu_hashes[0].tolist()
+    ts = fh0.opening_data()[1].astype(np.uint64)                 # the same for every video: equal lengths
+
+    # (1) hashes
+    ref = O.analyze_batch([sample_pcm[v] for v in sample_eps], 1, hd, threads=threads)
+    for v, fh in zip(sample_eps, ref):
+        assert gpu_hashes[v].tolist() == [h for h, _ in fh.opening], f"episode {v}"
+        assert ts.tolist() == [t for _, t in fh.opening]
+
+    # (2) runs of the pairs among 64 sampled episodes
+    cap = max(2 * found, 1 << 16)
+    d_runs, d_count = capi.DeviceBuffer(cap * capi.RUN_DTYPE.itemsize), capi.DeviceBuffer(4)
+    lib.search(cmp, 0, lib.num_pairs(), d_runs.ptr, cap, d_count.ptr, sync=True)
+    k = int(d_count.to_host(np.uint32, 1)[0])
+    assert k == found
+    runs = d_runs.to_host(capi.RUN_DTYPE, k)
+    sub = np.sort(rng.choice(n, size=min(64, n), replace=False))
+    pos = -np.ones(n, dtype=np.int64)
+    pos[sub] = np.arange(len(sub))
+    # global pair index -> (i, j): row i of the upper triangle starts at i n - i (i + 1) / 2
+    starts = np.array([i * n - i * (i + 1) // 2 for i in range(n)], dtype=np.int64)
+    pi = np.searchsorted(starts, runs["problem"].astype(np.int64), side="right") - 1
+    pj = runs["problem"].astype(np.int64) - starts[pi] + pi + 1
+    inside = (pos[pi] >= 0) & (pos[pj] >= 0)
+    m = len(sub)
+    local = pos[pi[inside]] * m - pos[pi[inside]] * (pos[pi[inside]] + 1) // 2 + (pos[pj[inside]] - pos[pi[inside]] - 1)
+    got = np.stack([local, runs["src_end"][inside], runs["dst_end"][inside], runs["len"][inside]], axis=1).astype(np.uint32)
+    total, want = O.diagonal_runs_all_pairs([gpu_hashes[v] for v in sub], 10, 82, threads=threads, capacity=4 * len(got) + 1024)
+    assert total == len(got) and total >= m * (m - 1) // 2
+    assert np.array_equal(got[np.lexsort((got[:, 2], got[:, 1], got[:, 0]))], want[np.lexsort((want[:, 2], want[:, 1], want[:, 0]))])
+
+    # (3) final results of sampled videos: each is a function of all its n - 1 pairs
+    sel = sorted(set([0, n - 1] + rng.choice(n, size=min(22, n), replace=False).tolist()))
+    want_sel = O.run_selected_videos(O.Comparator(), gpu_hashes, [ts] * n, hd, sel, threads=threads)
+    assert [None if r is None else (r.opening, r.ending) for r in want_sel] == [got_all[v] for v in sel]

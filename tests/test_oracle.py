@@ -14,6 +14,7 @@ import struct
 import numpy as np
 import pytest
 
+from needle_amd import synth
 from oracle import oracle as O
 
 from . import np_chromaprint as NP
@@ -435,3 +436,49 @@ def test_oracle_stages_reproduce_chromaprints_unit_test_vectors():
     frame[163] = frame[9] = frame[1308] = 1.0
     feats = O.chroma_features(28, 3520, 4096, 11025, frame)
     assert feats[11] == 1.0 and sum(feats) == 1.0
+
+
+# ---- the table-free restatement used for checks at library scale ---------------------------------------------------
+def test_tablefree_pair_function_equals_the_literal_one():
+    """ora_longest_common_hash_match_tablefree walks diagonals instead of filling comparator.rs:175's table; it must
+    return the same entries in the same BinaryHeap array order -- on planted runs, chance runs at a low minimum
+    duration (many entries: ties in score, walk order matters), runs that end on the table's last row / column, and
+    with the index-0 row and column excluded (:179-180)."""
+    rng = np.random.default_rng(5)
+    hd = O.duration_from_secs_f32(0.3)
+
+    def seq(hashes):
+        return O.step_and_timestamp(np.repeat(np.asarray(hashes, dtype=np.uint32), 2)[: 2 * len(hashes) - 1], hd)
+
+    base = rng.integers(0, 2 ** 32, 400, dtype=np.uint64).astype(np.uint32)
+    shared = rng.integers(0, 2 ** 32, 120, dtype=np.uint64).astype(np.uint32)
+    a, b = base.copy(), rng.integers(0, 2 ** 32, 380, dtype=np.uint64).astype(np.uint32)
+    a[30:150] = shared
+    b[200:320] = shared ^ (1 << rng.integers(0, 32, 120)).astype(np.uint32)          # one bit off: still a match
+    a[-40:] = b[-40:]                                                               # a run that ends at both table edges
+    b[0:50] = a[0:50]                                                               # a run through index 0
+    cases = [(O.Comparator(), a, b), (O.Comparator(min_opening_duration=2 * NS), a, b),
+             (O.Comparator(min_opening_duration=0), a[:90], b[:70]),
+             (O.Comparator(hash_match_threshold=14, min_opening_duration=1 * NS), a, b),
+             (O.Comparator(min_opening_duration=5 * NS), a, a)]
+    for cmp, x, y in cases:
+        want = O.longest_common_hash_match(cmp, seq(x), seq(y), hd, hd)
+        got = O.longest_common_hash_match(cmp, seq(x), seq(y), hd, hd, tablefree=True)
+        assert got == want and len(want) > 0
+    want = O.longest_common_hash_match(O.Comparator(min_ending_duration=3 * NS), seq(a), seq(b), hd, hd, is_opening=False)
+    assert O.longest_common_hash_match(O.Comparator(min_ending_duration=3 * NS), seq(a), seq(b), hd, hd, False, True) == want
+
+
+def test_selected_videos_equal_the_full_call():
+    eps = synth.make_library(6, 90.0, 20.0)
+    hd = O.duration_from_secs_f32(0.3)
+    fhs = O.analyze_batch([e.pcm[: len(e.pcm) // 2] for e in eps], 1, hd)
+    cmp = O.Comparator(min_opening_duration=10 * NS)
+    full = O.run_with_frame_hashes(cmp, fhs)
+    hashes = [np.array([h for h, _ in f.opening], dtype=np.uint32) for f in fhs]
+    ts = [np.array([t for _, t in f.opening], dtype=np.uint64) for f in fhs]
+    sel = [4, 0, 5, 2]
+    got = O.run_selected_videos(cmp, hashes, ts, hd, sel, threads=3)
+    assert [None if r is None else (r.opening, r.ending) for r in got] == \
+           [None if full[v] is None else (full[v].opening, full[v].ending) for v in sel]
+    assert all(r is not None and r.opening is not None for r in got)

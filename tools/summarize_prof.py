@@ -9,7 +9,8 @@ import os
 import sys
 from collections import defaultdict
 
-KERNELS = {"stft_chroma": "stft_chroma_kernel", "fir_norm": "fir_norm_kernel", "features_classify": "features_classify_kernel",
+KERNELS = {"stft_chroma32": "stft_chroma32_kernel", "features_cert": "features_classify_cert_kernel", "fixup_items": "fixup_items_kernel",
+           "stft_chroma": "stft_chroma_kernel", "fir_norm": "fir_norm_kernel", "features_classify": "features_classify_kernel",
            "classify": "classify_kernel",
            "hamming_runs_sampled": "hamming_runs_sampled_kernel", "hamming_runs_band": "hamming_runs_band_kernel", "hamming_runs": "hamming_runs_kernel",
            "simhash_runs": "simhash_runs_kernel"}
@@ -18,6 +19,8 @@ KERNELS = {"stft_chroma": "stft_chroma_kernel", "fir_norm": "fir_norm_kernel", "
 def short(name):
     for k, v in KERNELS.items():
         if v in name:
+            if k == "stft_chroma" and (", true>" in name or "Lb1E" in name):
+                return "stft_fallback"                            # the LISTED instantiation: f64 recomputation of listed chunks
             return k
     return None
 
@@ -40,7 +43,7 @@ def main():
     for k, v in dur.items():
         print(f"| {k} | {len(v)} | {sum(v)/len(v):.1f} | {min(v):.1f} | {max(v):.1f} |")
     pmc = defaultdict(lambda: defaultdict(list))
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         for r in rows(os.path.join(out, sub, "**", "*counter_collection.csv")):
             k = short(r.get("Kernel_Name", ""))
             if k:
@@ -61,11 +64,11 @@ def main():
             line.append(f"HBM bytes/launch (2*FETCH+WRITE) = {fb + wb:.4g} (fetch {fb:.4g}, write {wb:.4g})")
         print("- " + ", ".join(line))
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"))
-    for name in ("stats.log",):
+    for name in ("stats.log", "plain.json"):
         p = os.path.join(out, name)
         if os.path.exists(p):
             for ln in open(p):
-                if ln.startswith("{\"metric\""):
+                if ln.startswith("{\"metric\"") or ln.startswith("{\"episodes\""):
                     print("\n## bench line under the profiler\n\n```\n" + ln.strip() + "\n```")
 
 
