@@ -519,12 +519,14 @@ def main() -> None:
 
     n = args.episodes
     total_samples = int(round(args.minutes * 60.0 * RATE))
-    first, count = capi.comm_shard(n, world, rank)
-    # every rank needs every length (metadata); only its own block's PCM
+    lib = capi.Library(n)
+    # every rank needs every length (metadata), but only the PCM its share of the fingerprinting depends on: the hashes
+    # of all episodes are cut into `world` equal blocks (3.5 episodes' worth each for 28 on 8), and rank_videos names
+    # the episodes a rank's block meets
+    first, count = lib.rank_videos([total_samples] * n, world, rank)
     mine = {k: synth.make_episode(k, args.minutes * 60.0, args.intro_seconds) for k in range(first, first + count)}
     if world == 1:
         eps = [mine[k] for k in range(n)]
-    lib = capi.Library(n)
     lib.set_pcm([mine[k].pcm if k in mine else None for k in range(n)], [total_samples] * n)
     cmp = capi.Comparator([f"episode-{k:04d}.wav" for k in range(n)])
     cmp.handle()
@@ -628,11 +630,10 @@ def main() -> None:
         avg[dominant] = kernel_ms[dominant] / args.steps         # live, inside the timed region
         # per-launch work of THIS rank's launch of the dominant kernel
         _, pcount = capi.comm_shard(n_pairs, world, 0)
-        f0, c0 = capi.comm_shard(n, world, 0)
         if dominant in ("hamming_runs", "simhash_runs"):
             abytes = algorithmic_bytes("hamming_runs", windows, kept, pcount, state["runs"] // world)
-        else:
-            abytes = algorithmic_bytes(dominant, windows[f0:f0 + c0], kept[f0:f0 + c0], 0, 0)
+        else:                                                    # a rank fingerprints 1 / world of the hashes
+            abytes = algorithmic_bytes(dominant, windows, kept, 0, 0) / world
         cs = capi.cert_stats()
         certified = cs["items"] > 0
         achieved = abytes / (avg[dominant] * 1e-3) / 1e9 if avg[dominant] > 0 else 0.0
@@ -649,7 +650,7 @@ def main() -> None:
                 traffic = None
         compute = None
         if dominant in ("stft_chroma", "stft_chroma32") and avg[dominant] > 0:   # what actually bounds it: VALU issue + LDS exchange
-            fl = stft_flops(windows[f0:f0 + c0])
+            fl = stft_flops(windows) / world
             tf = fl / (avg[dominant] * 1e-3) / 1e12
             peak = F64_VALU_PEAK_TFLOPS if dominant == "stft_chroma" else F32_VALU_PEAK_TFLOPS
             compute = {"bound": "f64 valu" if dominant == "stft_chroma" else "f32 valu", "achieved": round(tf, 2), "peak": peak,
@@ -667,7 +668,7 @@ def main() -> None:
                                    f"(BASELINE.json configs[1]; configs[3] sharding when n_gpus > 1)",
                        "episodes": n, "pairs": n_pairs, "hashes_per_episode": kept[0],
                        "parallelism": "1 gpu" if world == 1 else
-                       f"{world} ranks, one process per GPU: episode blocks + pair ranges, 2 all-gathers per job "
+                       f"{world} ranks, one process per GPU: equal blocks of hashes + pair ranges, 2 all-gathers per job "
                        f"inside libneedle_capi.so ({capi.comm_backend()})",
                        "comm": capi.comm_backend()},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,

@@ -286,15 +286,15 @@ enum NeedleError needle_hip_library_frame_hashes(NeedleHipLibrary *library, size
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI --------------------------------------------------
  * The reference parallelises inside one process with rayon when `threading` is set: over videos in
  * Analyzer::run (analyzer.rs:437-445) and over pairs in Comparator::run_with_frame_hashes
- * (comparator.rs:549-564).  Across the GPUs of a node the same two fan-outs are: videos in contiguous blocks
- * per rank, pairs in contiguous ranges of the lexicographic pair list per rank, and two all-gathers between
+ * (comparator.rs:549-564).  Across the GPUs of a node the same two fan-outs are: the hashes of all videos in equal
+ * contiguous blocks per rank, pairs in contiguous ranges of the lexicographic pair list per rank, and two all-gathers between
  * them (hash rows after analyze, run lists after search) -- all inside this library, on its own streams, with
  * librccl loaded on demand (no link-time dependency; no torch).  A process is one rank and drives one device:
  *
  *   rank 0: needle_hip_comm_create_id(id); hand the 128 bytes to the other ranks by any means (file, socket, MPI)
  *   all   : needle_hip_set_device(local_rank); needle_hip_comm_init(id, rank, world_size);
- *           library_new / set_pcm (PCM pointers for the videos of needle_hip_comm_shard(n, ...) only, NULL for
- *           the rest) / job_begin / job_end ...; needle_hip_comm_finalize()
+ *           library_new / set_pcm (PCM pointers for the videos of needle_hip_library_rank_videos(...) only, NULL
+ *           for the rest) / job_begin / job_end ...; needle_hip_comm_finalize()
  *
  * Results are identical for every world size: the run set is a union over disjoint pair ranges and the epilogue
  * orders it.  NEEDLE_HIP_COMM=host selects a host-staged transport over POSIX shared memory instead of RCCL (ranks of
@@ -312,6 +312,15 @@ enum NeedleError needle_hip_comm_barrier(void);
 enum NeedleError needle_hip_comm_all_gather_host(const void *send, void *recv, size_t bytes_per_rank);
 /* The sharding plan: `units` (videos, pairs) in world_size contiguous blocks of ceil(units / world_size). */
 void needle_hip_comm_shard(size_t units, int world_size, int rank, size_t *first, size_t *count);
+
+/* Which videos' PCM a rank has to hold.  The fingerprinting is sharded by HASHES, not by videos: the arena
+ * u32[rows][stride] is cut, as one flat array, into world_size equal blocks and a rank computes the hashes of its block
+ * from the stretch of PCM they depend on -- 28 episodes on 8 ranks are 3.5 episodes' worth of frames each, no rank
+ * idles (whole videos would give 7 x 4 + 0).  For the stream lengths `num_values` (all videos; what set_pcm will be
+ * given) this names the videos [first_video, first_video + video_count) whose rows rank `rank`'s block meets: pass
+ * their PCM to set_pcm, NULL for the others.  A pure function of the library's parameters and the lengths. */
+enum NeedleError needle_hip_library_rank_videos(const NeedleHipLibrary *library, const size_t *num_values, int channels,
+                                                int world_size, int rank, size_t *first_video, size_t *video_count);
 
 /* One analyze+search job of the library across the communicator (or on one GPU without one), in two halves so
  * that two jobs can be in flight (slot 0 / 1): _begin enqueues this rank's fingerprinting, the all-gather of hash

@@ -83,7 +83,8 @@ NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_frame_hashes_read", "needle_hip_frame_hashes_write", "needle_hip_header_md5",
     "needle_hip_analyzer_run_pcm", "needle_hip_comparator_run_with_frame_hashes", "needle_hip_library_new",
     "needle_hip_library_free", "needle_hip_library_include_endings", "needle_hip_library_rows_per_video",
-    "needle_hip_library_set_pcm", "needle_hip_library_set_pcm_device", "needle_hip_library_analyze",
+    "needle_hip_library_set_pcm", "needle_hip_library_set_pcm_device", "needle_hip_library_rank_videos",
+    "needle_hip_library_analyze",
     "needle_hip_library_hash_arena", "needle_hip_library_use_hash_arena", "needle_hip_library_num_pairs", "needle_hip_library_search",
     "needle_hip_library_fetch_runs_begin", "needle_hip_library_fetch_runs_end",
     "needle_hip_library_finalize", "needle_hip_library_frame_hashes",
@@ -659,6 +660,15 @@ class Library:
         ptrs = (C.c_void_p * self.n)(*[None if a is None else a.ctypes.data for a in arrs])
         lens = (C.c_size_t * self.n)(*list(num_values))
         check(lib().needle_hip_library_set_pcm(self._h, ptrs, lens, channels))
+
+    def rank_videos(self, num_values: Sequence[int], world: int, rank: int, channels: int = 1) -> Tuple[int, int]:
+        """(first, count) of the videos whose PCM `rank` of `world` must hold (needle_hip_library_rank_videos)."""
+        lens = (C.c_size_t * self.n)(*list(num_values))
+        first, count = C.c_size_t(0), C.c_size_t(0)
+        lib().needle_hip_library_rank_videos.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int,
+                                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        check(lib().needle_hip_library_rank_videos(self._h, lens, channels, world, rank, C.byref(first), C.byref(count)))
+        return first.value, count.value
 
     def set_pcm_device(self, d_ptrs: Sequence[Optional[int]], num_values: Sequence[int], channels: int = 1) -> None:
         """PCM already in HBM: device pointers (None for videos of other ranks), copied device to device."""

@@ -91,7 +91,7 @@ struct NeedleHipLibrary {
   static constexpr size_t kSlabHeader = 32;
   uint32_t slab_runs = 0;      // per-rank run capacity of the next job (grows on overflow)
   uint32_t last_max_count = 0;  // largest per-rank run count of the last finished job: sizes the one-trip download
-  size_t arena_rows = 0;       // rows the arena was allocated with (world * block * regions)
+  size_t arena_rows = 0;       // rows the arena was allocated with
   ~NeedleHipLibrary() {
     for (Fetch &f : fetch) {
       if (f.host) (void)hipHostFree(f.host);
@@ -107,9 +107,16 @@ struct NeedleHipLibrary {
 
   size_t regions() const { return endings ? 2 : 1; }
   size_t rows() const { return n * regions(); }
-  // with a communicator the arena holds world blocks of ceil(n / world) videos, so that a plain all-gather of
-  // equal-sized row blocks fills it (the rows past n * regions are padding nobody reads)
-  size_t padded_rows() const { return shard_block(n, comm_world()) * (size_t)comm_world() * regions(); }
+  // Sharding of the fingerprinting across ranks (analyzer.rs:437-445 across GPUs).  The unit is not the video but the
+  // HASH: the arena u32[rows][stride] is cut, as one flat array, into world equal blocks -- stride is a multiple of 64
+  // chosen so that rows * stride divides by 64 * world -- and a rank fingerprints exactly the hashes of its block:
+  // for every row the block meets, the columns it meets, computed from the SUB-WINDOW of that row's PCM those hashes
+  // depend on (hash k of a row is a function of frames k * step .. k * step + 19 only; blocks start on multiples of 64
+  // hashes, so a sub-window starts on an even frame and the two-frames-per-transform pairing is the whole window's).
+  // 28 episodes on 8 ranks are then 3.5 rows each instead of 7 x 4 + 0; one in-place all-gather of equal blocks
+  // fills the arena as before.
+  size_t flat_block(int world) const { return rows() * stride / (size_t)std::max(world, 1); }
+  bool flat_shardable(int world) const { return world <= 1 || (stride % 64 == 0 && (rows() * (stride / 64)) % (size_t)world == 0); }
   void ensure_shells() {  // per-video timestamps for the epilogue: the runs carry their simhashes, hashes stay in HBM
     if (shells.size() == n) return;
     shells.assign(n, {});
@@ -219,9 +226,11 @@ Status plan_windows(NeedleHipLibrary *lib, const int16_t *const *pcm, const size
       }
     }
   }
-  size_t stride = ((size_t)max_kept + 63) & ~(size_t)63;  // rows start 256-byte aligned
-  if (stride == 0) stride = 64;
-  const size_t arena_rows = std::max(lib->rows(), lib->padded_rows());
+  // rows start 256-byte aligned; with a communicator, rows * stride also divides into world blocks of whole 64-hash tiles
+  size_t tiles_per_row = std::max<size_t>(1, ((size_t)max_kept + 63) / 64);
+  while (comm_world() > 1 && (lib->rows() * tiles_per_row) % (size_t)comm_world()) tiles_per_row++;
+  size_t stride = 64 * tiles_per_row;
+  const size_t arena_rows = lib->rows();
   // NeedleHipSeq.offset and NeedleHipProblem.tag are 32-bit on the device
   if ((uint64_t)arena_rows * stride > UINT32_MAX || (uint64_t)pair_count(lib->n) * R > UINT32_MAX)
     return Status::Make(NeedleError_InvalidArgument, "library too large for one job: more than 2^32 arena hashes or sequence pairs");
@@ -529,6 +538,43 @@ enum NeedleError needle_hip_library_frame_hashes(NeedleHipLibrary *lib, size_t i
 // ---- the whole job, across the communicator ------------------------------------------------------------------------
 namespace {
 
+// The rows and columns of the arena that rank `rank`'s flat block meets: f(row, first column, end column), columns
+// clipped to the row's kept hashes (the rest of a row is padding).
+template <typename F>
+void for_rows_of_block(const NeedleHipLibrary *lib, int world, int rank, F &&f) {
+  const size_t B = lib->flat_block(world), begin = (size_t)rank * B, end = begin + B;
+  if (!lib->stride) return;
+  for (size_t row = begin / lib->stride; row < lib->rows() && row * lib->stride < end; row++) {
+    const size_t r0 = row * lib->stride;
+    const size_t c0 = begin > r0 ? begin - r0 : 0, c1 = std::min<size_t>(std::min(end - r0, lib->stride), lib->win[row].kept);
+    if (c0 < c1) f(row, c0, c1);
+  }
+}
+
+// Fingerprints this rank's block: per row the sub-window of PCM its columns depend on, hashes straight to their places.
+NeedleError analyze_flat_block(NeedleHipLibrary *lib, int world, int rank) {
+  if (world <= 1) return needle_hip_library_analyze(lib, 0, lib->n, false);
+  std::vector<StreamSpan> spans;
+  Status bad;
+  for_rows_of_block(lib, world, rank, [&](size_t row, size_t c0, size_t c1) {
+    const Window &w = lib->win[row];
+    if (w.pcm_off == ~0ull) {
+      bad = Status::Make(NeedleError_InvalidArgument, "video " + std::to_string(row / lib->regions()) +
+                                                          " has no PCM on this rank (needle_hip_library_rank_videos names the videos a rank needs)");
+      return;
+    }
+    // hashes c0 .. c1-1 = raw items c0 step .. (c1 - 1) step = frames c0 step .. (c1 - 1) step + 19
+    const uint64_t x0 = (uint64_t)c0 * lib->step, frames = (uint64_t)(c1 - 1 - c0) * lib->step + 20;
+    const uint64_t samples = (frames - 1) * (uint64_t)kHop + (uint64_t)kFrameSize;
+    spans.push_back(StreamSpan{w.pcm_off + x0 * (uint64_t)kHop * (uint64_t)lib->channels, samples * (uint64_t)lib->channels,
+                               (uint64_t)row * lib->stride + c0});
+  });
+  if (!bad.ok()) return report(bad);
+  if (spans.empty()) return NeedleError_Ok;
+  Status s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->arena, false);
+  return s.ok() ? NeedleError_Ok : report(s);
+}
+
 uint32_t round_up4(uint64_t v) { return (uint32_t)std::min<uint64_t>((v + 3) & ~(uint64_t)3, 0xfffffffcu); }
 
 Status job_buffers(NeedleHipLibrary *lib, NeedleHipLibrary::Job &j, int world) {
@@ -638,6 +684,49 @@ void needle_hip_comm_shard(size_t units, int world_size, int rank, size_t *first
   if (count) *count = c;
 }
 
+enum NeedleError needle_hip_library_rank_videos(const NeedleHipLibrary *lib, const size_t *num_values, int channels, int world_size,
+                                                int rank, size_t *first_video, size_t *video_count) {
+  if (!lib || !num_values || !first_video || !video_count) return NeedleError_NullArgument;
+  if ((channels != 1 && channels != 2) || world_size < 1 || rank < 0 || rank >= world_size) return NeedleError_InvalidArgument;
+  return guarded([&]() -> NeedleError {
+    // the geometry plan_windows will arrive at for these lengths, without touching the library
+    NeedleHipLibrary plan;
+    plan.n = lib->n;
+    plan.endings = lib->endings;
+    plan.step = lib->step;
+    const size_t R = plan.regions();
+    plan.win.assign(plan.rows(), Window{});
+    uint32_t max_kept = 0;
+    for (size_t v = 0; v < plan.n; v++) {
+      size_t open_samples = 0, end_first = 0;
+      ns_t seek = 0;
+      const size_t samples = num_values[v] / (size_t)channels;
+      Status s = Analyzer::windows(samples, kSampleRate, lib->opening_pct, lib->ending_pct, &open_samples, &end_first, &seek);
+      if (!s.ok()) return report(s);
+      for (size_t r = 0; r < R; r++) {
+        plan.win[v * R + r].kept = (uint32_t)num_kept(r == 0 ? open_samples : samples - end_first, lib->step);
+        max_kept = std::max(max_kept, plan.win[v * R + r].kept);
+      }
+    }
+    size_t tiles_per_row = std::max<size_t>(1, ((size_t)max_kept + 63) / 64);
+    while (world_size > 1 && (plan.rows() * tiles_per_row) % (size_t)world_size) tiles_per_row++;
+    plan.stride = 64 * tiles_per_row;
+    size_t lo = plan.n, hi = 0;
+    if (world_size == 1) {
+      lo = 0;
+      hi = plan.n;
+    } else {
+      for_rows_of_block(&plan, world_size, rank, [&](size_t row, size_t, size_t) {
+        lo = std::min(lo, row / R);
+        hi = std::max(hi, row / R + 1);
+      });
+    }
+    *first_video = lo < hi ? lo : 0;
+    *video_count = lo < hi ? hi - lo : 0;
+    return NeedleError_Ok;
+  });
+}
+
 enum NeedleError needle_hip_library_job_begin(NeedleHipLibrary *lib, const struct NeedleAudioComparator *comparator, int slot) {
   if (!lib || !comparator) return NeedleError_NullArgument;
   if (slot < 0 || slot > 1 || !lib->have_pcm) return NeedleError_InvalidArgument;
@@ -645,18 +734,18 @@ enum NeedleError needle_hip_library_job_begin(NeedleHipLibrary *lib, const struc
     NeedleHipLibrary::Job &j = lib->job[slot];
     if (j.pending) return report(Status::Make(NeedleError_InvalidArgument, "job slot still pending"));
     const int world = comm_world(), rank = comm_rank();
-    if (lib->arena_rows < lib->padded_rows())
+    if (!lib->flat_shardable(world))
       return report(Status::Make(NeedleError_InvalidArgument,
-                                 "the hash arena predates the communicator: call needle_hip_library_set_pcm after needle_hip_comm_init"));
-    // 1. fingerprint this rank's block of videos into its arena rows (analyzer.rs:437-445 across GPUs)
-    size_t first = 0, count = 0;
-    shard_range(lib->n, world, rank, &first, &count);
-    // (after needle_hip_library_stream_pcm the rows are already there: the PCM was fingerprinted as it was uploaded)
-    NeedleError e = count && lib->pcm_resident ? needle_hip_library_analyze(lib, first, count, false) : NeedleError_Ok;
+                                 "the hash arena does not divide into this communicator's blocks: call needle_hip_library_set_pcm "
+                                 "after needle_hip_comm_init (or adopt an arena of rows x stride with rows * stride / 64 a multiple of the world size)"));
+    // 1. fingerprint this rank's block of HASHES (NeedleHipLibrary::flat_block) into the arena (analyzer.rs:437-445
+    // across GPUs).  (After needle_hip_library_stream_pcm the rows are already there: the PCM was fingerprinted as it
+    // was uploaded.)
+    NeedleError e = lib->pcm_resident ? analyze_flat_block(lib, world, rank) : NeedleError_Ok;
     if (e != NeedleError_Ok) return e;
-    // 2. every rank gets every hash row: one in-place all-gather of equal row blocks, in stream order
+    // 2. every rank gets every hash: one in-place all-gather of the equal blocks, in stream order
     if (comm_get()) {
-      const size_t block_bytes = shard_block(lib->n, world) * lib->regions() * lib->stride * sizeof(uint32_t);
+      const size_t block_bytes = lib->flat_block(world) * sizeof(uint32_t);
       Status s = comm_all_gather(kData, reinterpret_cast<const uint8_t *>(lib->arena) + (size_t)rank * block_bytes, lib->arena,
                                  block_bytes, library_stream());
       if (!s.ok()) return report(s);

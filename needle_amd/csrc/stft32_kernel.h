@@ -38,6 +38,8 @@ enum : int {
   kLab32NoB1 = 4, kLab32NoB2 = 8, kLab32NoB3 = 16,  // a workgroup barrier replaced by a wave fence
   kLab32NoFold = 32,    // no fold reads / tree / chroma store
   kLab32NoPower = 64,   // no partner reads, powers, power stores
+  kLab32Clock = 128,    // thread 0 stamps s_memtime / s_memrealtime around the pair loop into `energy` (as 4 x u64 per
+                        // workgroup): the clock the kernel really ran at = d memtime / d memrealtime x 100 MHz
 };
 
 template <int CH, int WAVES_PER_SIMD = 3, int LAB = 0>
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
         double *out = chroma + p.row * kBands;
         out[c] = (double)acc.x;
         if (p.has_b) out[kBands + c] = (double)acc.y;
-      } else {  // the fourth wave: rows 12..15 hold the four partial sums of the frames' energy
+      } else if (!(LAB & kLab32Clock)) {  // the fourth wave: rows 12..15 hold the four partial sums of the frames' energy
         float *out = energy + p.row * kEnergyParts;
         out[c - kBands] = acc.x;
         if (p.has_b) out[kEnergyParts + c - kBands] = acc.y;
@@ -134,6 +136,11 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
   issue_loads(cur);
 #pragma unroll
   for (int k = 0; k < 16; k++) asm volatile("" : "+v"(ra[k]), "+v"(rb[k]));  // keep the sign extension with the loads
+  uint64_t stamp_core = 0, stamp_real = 0;
+  if (LAB & kLab32Clock) {
+    stamp_core = __builtin_amdgcn_s_memtime();
+    stamp_real = __builtin_amdgcn_s_memrealtime();
+  }
 
   for (uint32_t g = first; g < last; g++) {
     int tt = t;
@@ -206,6 +213,14 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
     if (!(LAB & kLab32NoB3)) lds_barrier(); else wave_lds_fence();  // the power image is complete
     prev = cur;
     cur = nxt;
+  }
+  if (LAB & kLab32Clock) {  // the stamps replace the energy output of this diagnostic build
+    if (t == 0) {
+      uint64_t *o = reinterpret_cast<uint64_t *>(energy) + 2 * (size_t)logical;
+      o[0] = __builtin_amdgcn_s_memtime() - stamp_core;
+      o[1] = __builtin_amdgcn_s_memrealtime() - stamp_real;
+    }
+    return;
   }
   {
     cf fv[core::kClassLaneMax];

@@ -175,6 +175,16 @@ extern "C" {
         num_values: *const usize,
         channels: c_int,
     ) -> NeedleError;
+    /// Videos `[first_video, first_video + video_count)` whose PCM rank `rank` of `world_size` must hold.
+    pub fn needle_hip_library_rank_videos(
+        library: *const NeedleHipLibrary,
+        num_values: *const usize,
+        channels: c_int,
+        world_size: c_int,
+        rank: c_int,
+        first_video: *mut usize,
+        video_count: *mut usize,
+    ) -> NeedleError;
     /// `d_pcm[i]` are DEVICE pointers (PCM decoded or generated on the GPU), NULL for videos of other ranks.
     pub fn needle_hip_library_set_pcm_device(
         library: *mut NeedleHipLibrary,

@@ -28,16 +28,17 @@ def gpu_main(out, n, seconds):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     rdzv = rendezvous.init_comm(capi, rank, world, int(os.environ.get("LOCAL_RANK", "0")),
                                 key=os.environ["NEEDLE_TEST_RDZV_KEY"])
-    first, count = capi.comm_shard(n, world, rank)
     total = int(round(seconds * synth.RATE))
-    mine = {k: synth.make_episode(k, seconds, 20.0) for k in range(first, first + count)}
     lib = capi.Library(n)
     if os.environ.get("NEEDLE_TEST_ENDINGS"):
         lib.include_endings()
+    first, count = lib.rank_videos([total] * n, world, rank)      # the episodes this rank's block of hashes depends on
+    mine = {k: synth.make_episode(k, seconds, 20.0) for k in range(first, first + count)}
     lib.set_pcm([mine[k].pcm if k in mine else None for k in range(n)], [total] * n)
     cmp = capi.Comparator([f"ep{k}.wav" for k in range(n)], min_opening_duration=10,
                           include_endings=bool(os.environ.get("NEEDLE_TEST_ENDINGS")))
     jobs = []
+    capi.set_kernel_timing("stft_chroma32,stft_chroma")
     lib.job_begin(cmp, 0)
     lib.job_begin(cmp, 1)
     jobs.append(lib.job_end(cmp, 0))
@@ -45,8 +46,11 @@ def gpu_main(out, n, seconds):
     jobs.append(lib.job_end(cmp, 1))
     jobs.append(lib.job_end(cmp, 0))
     hashes = [lib.frame_hashes(v).opening_data()[0].tolist() for v in range(n)]
+    stft_ms = max(capi.last_kernel_ms("stft_chroma32"), capi.last_kernel_ms("stft_chroma"))
+    capi.set_kernel_timing(None)
     with open(f"{out}.{rank}", "w") as f:
         json.dump({"rank": rank, "backend": capi.comm_backend(), "world": capi.comm_world_size(),
+                   "videos_held": [first, count], "stft_ms": stft_ms,
                    "jobs": [{"results": _res(r), "runs": k} for r, k in jobs], "hashes": hashes}, f)
     capi.comm_barrier()
     capi.comm_finalize()

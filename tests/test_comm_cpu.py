@@ -98,3 +98,23 @@ def test_gloo_world_run_exchange_and_sharded_epilogue(tmp_path, world, n):
         assert g["sharded"] == g["full"] == g["oracle"]
         assert all(r is not None and r[0] is not None for r in g["sharded"])
     assert all(g["sharded"] == got[0]["sharded"] for g in got)
+
+
+def test_rank_videos_cuts_the_hashes_not_the_videos():
+    """needle_hip_library_rank_videos: 28 episodes x 24 min on 8 ranks are 3.5 episodes' worth of hashes each -- every
+    rank holds 4 or 5 (partly needed) episodes and none idles; the shares tile the library in order."""
+    total = 24 * 60 * 11025
+    lib = capi.Library(28)
+    assert lib.rank_videos([total] * 28, 1, 0) == (0, 28)
+    shares = [lib.rank_videos([total] * 28, 8, r) for r in range(8)]
+    assert all(4 <= c <= 5 for _, c in shares), shares
+    assert shares[0][0] == 0 and shares[-1][0] + shares[-1][1] == 28
+    for (f0, c0), (f1, _) in zip(shares, shares[1:]):
+        assert f0 + c0 - 1 <= f1 <= f0 + c0                       # neighbours share at most the episode on their border
+    # ragged lengths and endings: still a tiling, still nobody idle
+    lens = [int((10 + 3 * (k % 5)) * 60 * 11025) for k in range(9)]
+    lib2 = capi.Library(9).include_endings()
+    shares = [lib2.rank_videos(lens, 4, r) for r in range(4)]
+    assert shares[0][0] == 0 and shares[-1][0] + shares[-1][1] == 9 and all(c >= 1 for _, c in shares)
+    with pytest.raises(capi.NeedleError):
+        lib.rank_videos([total] * 28, 8, 8)

@@ -159,6 +159,22 @@ int main(int argc, char **argv) {
   for (Variant &v : vs) check_variant(L, v);
   for (int r = 0; r < reps; r++)
     for (Variant &v : vs) time_once(L, v, true);
+  {  // the clock the product schedule really runs at: stamps of every workgroup, taken after the timing loop (chip warm)
+    Variant clk{"clock stamps", launch_variant<3, kLab32Clock>, false, 16};
+    CK(hipMemset(L.d_energy, 0, (size_t)L.eps * (L.frames + 1) * 4 * 4));
+    for (int i = 0; i < 20; i++) time_once(L, vs[0], false);
+    time_once(L, clk, true);
+    const size_t wgs = (L.total_pairs + 15) / 16;
+    std::vector<uint64_t> st(2 * wgs);
+    CK(hipMemcpy(st.data(), L.d_energy, st.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> mhz;
+    for (size_t w = 0; w < wgs; w++)
+      if (st[2 * w + 1]) mhz.push_back(100.0 * (double)st[2 * w] / (double)st[2 * w + 1]);
+    std::sort(mhz.begin(), mhz.end());
+    if (!mhz.empty())
+      std::printf("in-kernel clock (s_memtime / s_memrealtime x 100 MHz over the pair loop, %zu workgroups): min %.0f  median %.0f  max %.0f MHz; "
+                  "that launch took %.4f ms\n", mhz.size(), mhz.front(), mhz[mhz.size() / 2], mhz.back(), clk.ms[0]);
+  }
   for (Variant &v : vs) {
     std::sort(v.ms.begin(), v.ms.end());
     std::printf("%-52s ppb=%2u  min %.4f  q25 %.4f  med %.4f ms", v.name, v.ppb, v.ms.front(), v.ms[v.ms.size() / 4], v.ms[v.ms.size() / 2]);
