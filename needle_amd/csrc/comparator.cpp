@@ -141,7 +141,8 @@ void parallel_chunks(size_t n, size_t grain, unsigned workers, F f) {
   HostPool::instance().run((unsigned)std::min<size_t>(workers, (n + grain - 1) / grain), body);
 }
 
-// distinct_matches (:434-454) as a count: links[a] = #{b : popcount(h[a] ^ h[b]) < bound}, a itself included.
+// distinct_matches (:434-454) as a count: links[a] = sum of mult[b] over {b : popcount(h[a] ^ h[b]) < bound}, a itself
+// included (h holds distinct hashes, mult how often each occurs among the candidates).
 // The relation is symmetric, so this equals the size of the set the reference builds for a.  Written as a dense
 // c x c loop over a contiguous array so that the compiler vectorises it for whatever the host CPU offers.
 #if defined(__SANITIZE_THREAD__)
@@ -151,11 +152,11 @@ __attribute__((target_clones("avx512vpopcntdq", "avx2", "default")))
 #else  // g++ (the sanitizer builds) names the AVX-512 VPOPCNTDQ clone by architecture
 __attribute__((target_clones("arch=icelake-server", "avx2", "default")))
 #endif
-void count_links(const uint32_t *h, size_t c, uint32_t bound, uint32_t *links) {
+void count_links_weighted(const uint32_t *h, const uint32_t *mult, size_t c, uint32_t bound, uint32_t *links) {
   for (size_t a = 0; a < c; a++) {
     const uint32_t ha = h[a];
     uint32_t count = 0;
-    for (size_t b = 0; b < c; b++) count += (uint32_t)__builtin_popcount(ha ^ h[b]) < bound ? 1u : 0u;
+    for (size_t b = 0; b < c; b++) count += (uint32_t)__builtin_popcount(ha ^ h[b]) < bound ? mult[b] : 0u;
     links[a] = count;
   }
 }
@@ -363,9 +364,30 @@ Status Comparator::best_matches(size_t num_videos, const PairEntries &pair_entri
         }
       }
     }
-    std::vector<uint32_t> hashes(cand.size()), links(cand.size(), 0);
-    for (size_t k = 0; k < cand.size(); k++) hashes[k] = cand[k].match_hash;
-    count_links(hashes.data(), hashes.size(), bound, links.data());
+    // links[k] = #{b : popcount(h_k ^ h_b) < bound} (:434-454).  A library's candidates of one video are mostly runs
+    // over the same shared segment and their simhashes repeat: the c x c comparison is done over the DISTINCT hashes,
+    // weighted by how often each occurs -- the same counts, at u x u + c log c instead of c x c.
+    std::vector<uint32_t> links(cand.size(), 0);
+    {
+      std::vector<std::pair<uint32_t, uint32_t>> order(cand.size());  // (hash, candidate)
+      for (size_t k = 0; k < cand.size(); k++) order[k] = {cand[k].match_hash, (uint32_t)k};
+      std::sort(order.begin(), order.end());
+      std::vector<uint32_t> distinct, mult, weighted;
+      for (size_t k = 0; k < order.size(); k++) {
+        if (k == 0 || order[k].first != order[k - 1].first) {
+          distinct.push_back(order[k].first);
+          mult.push_back(0);
+        }
+        mult.back()++;
+      }
+      weighted.assign(distinct.size(), 0);
+      count_links_weighted(distinct.data(), mult.data(), distinct.size(), bound, weighted.data());
+      size_t u = 0;
+      for (size_t k = 0; k < order.size(); k++) {
+        if (k && order[k].first != order[k - 1].first) u++;
+        links[order[k].second] = weighted[u];
+      }
+    }
 
     VideoResult &vr = (*per_video)[v];
     vr.has_result = true;  // Some(best) even if neither side is found (:514)
@@ -583,14 +605,57 @@ Status Comparator::results_from_runs(const std::vector<const FrameHashesData *> 
   EpilogueTrace trace;
   const size_t buckets = np * regions;
   std::vector<uint64_t> start(buckets + 1, 0);
-  for (size_t q = 0; q < num_runs; q++)
-    if (wanted(runs[q].problem)) start[runs[q].problem + 1]++;
-  for (size_t b = 0; b < buckets; b++) start[b + 1] += start[b];
-  std::vector<NeedleHipRun> sorted(start[buckets]);
-  {
+  std::vector<NeedleHipRun> sorted;
+  // Counting sort, one slice of the BUCKET range per host thread: a thread reads all runs twice (count, then place)
+  // and touches only its own buckets and its own stretch of the output, so there is nothing to synchronise; a
+  // library's few million runs are ~100 MB, read at memory speed, while the serial form spent its time on 2 x that
+  // many random accesses into a 16 MB offset table.
+  const unsigned slices = num_runs >= (1u << 16) ? std::max(1u, host_workers((uint64_t)num_runs * 64)) : 1u;
+  if (slices <= 1) {
+    for (size_t q = 0; q < num_runs; q++)
+      if (wanted(runs[q].problem)) start[runs[q].problem + 1]++;
+    for (size_t b = 0; b < buckets; b++) start[b + 1] += start[b];
+    sorted.resize(start[buckets]);
     std::vector<uint64_t> fill(start.begin(), start.end() - 1);
     for (size_t q = 0; q < num_runs; q++)
       if (wanted(runs[q].problem)) sorted[fill[runs[q].problem]++] = runs[q];
+  } else {
+    std::vector<uint64_t> slice_total(slices + 1, 0);
+    auto slice_lo = [&](unsigned t) { return (size_t)((uint64_t)buckets * t / slices); };
+    parallel_chunks(slices, 1, slices, [&](size_t t0, size_t t1) {
+      for (size_t t = t0; t < t1; t++) {
+        const size_t lo = slice_lo((unsigned)t), hi = slice_lo((unsigned)t + 1);
+        uint64_t total = 0;
+        for (size_t q = 0; q < num_runs; q++) {
+          const uint32_t b = runs[q].problem;
+          if (b >= lo && b < hi && wanted(b)) {
+            start[b + 1]++;  // bucket b's count lives at b + 1; slot hi belongs to this slice (bucket hi - 1), lo to the previous
+            total++;
+          }
+        }
+        slice_total[t + 1] = total;
+      }
+    });
+    for (unsigned t = 0; t < slices; t++) slice_total[t + 1] += slice_total[t];
+    sorted.resize(slice_total[slices]);
+    parallel_chunks(slices, 1, slices, [&](size_t t0, size_t t1) {
+      for (size_t t = t0; t < t1; t++) {
+        const size_t lo = slice_lo((unsigned)t), hi = slice_lo((unsigned)t + 1);
+        if (lo == hi) continue;
+        // counts at [lo + 1, hi] -> end offsets, in place; then walk the runs again and fill from a private cursor
+        uint64_t run = slice_total[t];
+        std::vector<uint64_t> cursor(hi - lo);
+        for (size_t b = lo; b < hi; b++) {
+          cursor[b - lo] = run;
+          run += start[b + 1];
+          start[b + 1] = run;
+        }
+        for (size_t q = 0; q < num_runs; q++) {
+          const uint32_t b = runs[q].problem;
+          if (b >= lo && b < hi && wanted(b)) sorted[cursor[b - lo]++] = runs[q];
+        }
+      }
+    });
   }
   trace.lap("bucket runs", sorted.size());
   // Heap entries pair by pair (both regions of a pair by the same thread: entries.extend(opening);
@@ -609,14 +674,14 @@ Status Comparator::results_from_runs(const std::vector<const FrameHashesData *> 
       for (size_t r = 0; r < regions; r++) {
         const uint64_t lo = start[p * regions + r], hi = start[p * regions + r + 1];
         if (hi == lo) continue;
-        std::sort(sorted.begin() + lo, sorted.begin() + hi, [](const NeedleHipRun &a, const NeedleHipRun &b) {
-          return a.src_end != b.src_end ? a.src_end > b.src_end : a.dst_end > b.dst_end;
-        });
+        if (hi - lo > 1)
+          std::sort(sorted.begin() + lo, sorted.begin() + hi, [](const NeedleHipRun &a, const NeedleHipRun &b) {
+            return a.src_end != b.src_end ? a.src_end > b.src_end : a.dst_end > b.dst_end;
+          });
         entries_from_runs(&sorted[lo], hi - lo, r == 0 ? fh[i]->opening : fh[i]->ending,
                           r == 0 ? fh[j]->opening : fh[j]->ending, fh[i]->hash_duration, fh[j]->hash_duration,
                           r == 0, &tmp);
-        std::copy(tmp.begin(), tmp.end(), pair_entries.entries.begin() + out);
-        out += tmp.size();
+        for (const HeapEntry &e : tmp) pair_entries.entries[out++] = e;
       }
       pair_entries.count[p] = (uint32_t)(out - pair_entries.first[p]);
       if (++j == n) j = ++i + 1;
