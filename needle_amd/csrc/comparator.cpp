@@ -310,7 +310,9 @@ Status Comparator::best_matches(size_t num_videos, const PairEntries &pair_entri
   // info_map (:583-588): for every non-empty pair, (pair, as source) for i and (pair, as dest) for j -- here as
   // one array per kind with a start offset per video, filled in pair order
   const size_t np = pair_entries.count.size();
-  std::vector<uint64_t> info_first(num_videos + 1, 0);
+  static thread_local std::vector<uint64_t> tl_info_first;  // scratch kept across calls, as in results_from_runs
+  std::vector<uint64_t> &info_first = tl_info_first;
+  info_first.assign(num_videos + 1, 0);
   {
     size_t i = 0, j = 1;
     for (size_t p = 0; p < np; p++) {
@@ -326,7 +328,9 @@ Status Comparator::best_matches(size_t num_videos, const PairEntries &pair_entri
     uint64_t pair;
     bool is_source;
   };
-  std::vector<Info> info(info_first[num_videos]);
+  static thread_local std::vector<Info> tl_info;
+  std::vector<Info> &info = tl_info;
+  info.resize(info_first[num_videos]);  // every element is written below
   {
     std::vector<uint64_t> fill(info_first.begin(), info_first.end() - 1);
     size_t i = 0, j = 1;
@@ -604,8 +608,17 @@ Status Comparator::results_from_runs(const std::vector<const FrameHashesData *> 
   // each bucket the way the reference walks its table backwards: src_end descending, then dst_end descending.
   EpilogueTrace trace;
   const size_t buckets = np * regions;
-  std::vector<uint64_t> start(buckets + 1, 0);
-  std::vector<NeedleHipRun> sorted;
+  // Scratch that outlives the call (per calling thread): at library scale these are 30 + 95 + 285 MB, and a fresh
+  // std::vector value-initialises every byte on one thread -- that zeroing was most of the "heap entries" phase.
+  // (bound to local references here: a lambda that names a thread_local would get the EXECUTING pool thread's copy)
+  static thread_local std::vector<uint64_t> tl_start;
+  static thread_local std::vector<NeedleHipRun> tl_sorted;
+  static thread_local PairEntries tl_pair_entries;
+  std::vector<uint64_t> &start = tl_start;
+  std::vector<NeedleHipRun> &sorted = tl_sorted;
+  PairEntries &pair_entries = tl_pair_entries;
+  start.resize(buckets + 1);
+  std::fill(start.begin(), start.end(), 0);
   // Counting sort, one slice of the BUCKET range per host thread: a thread reads all runs twice (count, then place)
   // and touches only its own buckets and its own stretch of the output, so there is nothing to synchronise; a
   // library's few million runs are ~100 MB, read at memory speed, while the serial form spent its time on 2 x that
@@ -660,10 +673,9 @@ Status Comparator::results_from_runs(const std::vector<const FrameHashesData *> 
   trace.lap("bucket runs", sorted.size());
   // Heap entries pair by pair (both regions of a pair by the same thread: entries.extend(opening);
   // entries.extend(ending), :262-281), written where the pair's runs start: a run yields at most one entry.
-  PairEntries pair_entries;
-  pair_entries.entries.resize(sorted.size());
+  if (pair_entries.entries.size() < sorted.size()) pair_entries.entries.resize(sorted.size());  // every slot read is written first
   pair_entries.first.resize(np);
-  pair_entries.count.assign(np, 0);
+  pair_entries.count.resize(np);  // every element is written below
   parallel_chunks(np, 4096, host_workers((uint64_t)sorted.size() * 64), [&](size_t p0, size_t p1) {
     std::vector<HeapEntry> tmp;
     size_t i, j;

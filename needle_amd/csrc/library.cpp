@@ -15,7 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
+#include <tuple>
 
 #include "comm.h"
 #include "hipctx.h"
@@ -63,7 +65,11 @@ struct NeedleHipLibrary {
   // library has ~n^2 / 2 pairs and a job that is repeated should not rebuild millions of descriptors
   std::vector<NeedleHipProblem> problems;
   size_t problems_for[3] = {~(size_t)0, 0, 0};
-  std::vector<FrameHashesData> shells;        // per-video timestamps for the epilogue (hashes stay in HBM)
+  // Timestamps for the epilogue (the hashes stay in HBM).  A window's timestamps are a function of its length and seek
+  // only, so videos of equal geometry SHARE one shell: at library scale the epilogue's four timestamp reads per run
+  // then hit one 87 KB array instead of 2000 copies of it (174 MB of cache misses: 58 -> 15 ms of the heap-entry phase).
+  std::vector<FrameHashesData> shells;        // distinct geometries
+  std::vector<uint32_t> shell_of;             // video -> shells[]
   // double-buffered asynchronous run-list download (needle_hip_library_fetch_runs_begin / _end)
   struct Fetch {
     void *host = nullptr;  // pinned: u32 count, then max_runs NeedleHipRun
@@ -117,15 +123,33 @@ struct NeedleHipLibrary {
   // fills the arena as before.
   size_t flat_block(int world) const { return rows() * stride / (size_t)std::max(world, 1); }
   bool flat_shardable(int world) const { return world <= 1 || (stride % 64 == 0 && (rows() * (stride / 64)) % (size_t)world == 0); }
-  void ensure_shells() {  // per-video timestamps for the epilogue: the runs carry their simhashes, hashes stay in HBM
-    if (shells.size() == n) return;
-    shells.assign(n, {});
+  void ensure_shells() {
+    if (shell_of.size() == n) return;
+    shells.clear();
+    shell_of.assign(n, 0);
     const size_t R = regions();
+    std::map<std::tuple<uint32_t, ns_t, uint32_t, ns_t>, uint32_t> seen;
     for (size_t v = 0; v < n; v++) {
-      shells[v].opening = window_timestamps(win[v * R]);
-      if (endings) shells[v].ending = window_timestamps(win[v * R + 1]);
-      shells[v].hash_duration = hash_duration;
+      const Window &wo = win[v * R];
+      const Window we = endings ? win[v * R + 1] : Window{};
+      const auto key = std::make_tuple(wo.kept, wo.seek, we.kept, we.seek);
+      auto it = seen.find(key);
+      if (it == seen.end()) {
+        FrameHashesData d;
+        d.opening = window_timestamps(wo);
+        if (endings) d.ending = window_timestamps(we);
+        d.hash_duration = hash_duration;
+        it = seen.emplace(key, (uint32_t)shells.size()).first;
+        shells.push_back(std::move(d));
+      }
+      shell_of[v] = it->second;
     }
+  }
+  std::vector<const FrameHashesData *> shell_pointers() {
+    ensure_shells();
+    std::vector<const FrameHashesData *> fh(n);
+    for (size_t v = 0; v < n; v++) fh[v] = &shells[shell_of[v]];
+    return fh;
   }
 
   const std::vector<HashTs> &timestamps(uint32_t k) {
@@ -258,6 +282,7 @@ Status plan_windows(NeedleHipLibrary *lib, const int16_t *const *pcm, const size
   if (total_values) *total_values = total;
   lib->min_len.clear();
   lib->shells.clear();
+  lib->shell_of.clear();
   lib->problems_for[0] = ~(size_t)0;
   return Status::Ok();
 }
@@ -493,9 +518,7 @@ enum NeedleError needle_hip_library_finalize(NeedleHipLibrary *lib, const struct
   if (!lib->have_pcm) return NeedleError_InvalidArgument;
   return guarded([&]() -> NeedleError {
     const Comparator &cmp = comparator_of(comparator);
-    lib->ensure_shells();
-    std::vector<const FrameHashesData *> fh;
-    for (const FrameHashesData &d : lib->shells) fh.push_back(&d);
+    const std::vector<const FrameHashesData *> fh = lib->shell_pointers();
     std::vector<VideoResult> res;
     const auto t0 = std::chrono::steady_clock::now();
     Status s = cmp.results_from_runs(fh, runs, num_runs, false, false, false, &res);
@@ -797,10 +820,14 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
     // run list of all ranks: heads from the pinned buffer, tails (rare: the first job of a library) straight from HBM
     size_t total = 0;
     for (int r = 0; r < world; r++) total += counts[r];
-    j.merged.resize(total);
+    const NeedleHipRun *run_list = nullptr;
+    if (world == 1 && counts[0] <= j.head_runs)  // one rank, everything in the pinned head: no copy of ~100 MB at library scale
+      run_list = reinterpret_cast<const NeedleHipRun *>(static_cast<const char *>(j.host) + NeedleHipLibrary::kSlabHeader);
+    else
+      j.merged.resize(total);
     size_t at = 0;
     bool tails = false;
-    for (int r = 0; r < world; r++) {
+    for (int r = 0; r < world && !run_list; r++) {
       const uint32_t head = std::min(counts[r], j.head_runs);
       std::memcpy(j.merged.data() + at, static_cast<const char *>(j.host) + (size_t)r * j.head_bytes() + NeedleHipLibrary::kSlabHeader,
                   (size_t)head * sizeof(NeedleHipRun));
@@ -819,15 +846,14 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
 
     // 5. the order-sensitive per-video epilogue (comparator.rs:583-626): every rank for all videos while that is
     // cheaper than another collective, otherwise each rank for its own block of videos + one all-gather of results
-    lib->ensure_shells();
-    std::vector<const FrameHashesData *> fh;
-    for (const FrameHashesData &d : lib->shells) fh.push_back(&d);
+    const std::vector<const FrameHashesData *> fh = lib->shell_pointers();
     std::vector<VideoResult> res;
     const bool sharded = world > 1 && shard_epilogue(total);
     size_t v0 = 0, vcount = lib->n;
     if (sharded) shard_range(lib->n, world, rank, &v0, &vcount);
     const auto t0 = std::chrono::steady_clock::now();
-    Status s = cmp.results_from_runs(fh, j.merged.data(), total, false, false, false, &res, v0, v0 + vcount);
+    if (!run_list) run_list = j.merged.data();
+    Status s = cmp.results_from_runs(fh, run_list, total, false, false, false, &res, v0, v0 + vcount);
     if (getenv("NEEDLE_HIP_TRACE"))
       std::fprintf(stderr, "[needle_hip] rank %d epilogue %zu runs, videos [%zu, %zu): %.1f us\n", rank, total, v0, v0 + vcount,
                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
