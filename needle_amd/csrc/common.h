@@ -117,7 +117,11 @@ struct StreamSpan {
 
 Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan> &streams, int channels,
                               uint32_t step, uint32_t *d_items, bool sync, double *d_chroma_dbg = nullptr,
-                              double *d_feat_dbg = nullptr, size_t descriptor_slot = 0);
+                              double *d_feat_dbg = nullptr, size_t descriptor_slot = 0, int pipe = -1);
+// (pipe 0 / 1: the caller keeps two calls in flight, e.g. the two job slots of a library.  The f32 STFT of such a call
+// runs on the CU-masked stream of hipctx.hip into workspace `pipe`, so that it overlaps whatever the previous call still
+// has queued on the library stream; everything behind it stays on the library stream.  -1: everything on the library
+// stream, one workspace.)
 // Host PCM -> kept items in DEVICE memory (d_items + item_off[i]), uploads and kernels overlapped: the streams are
 // uploaded in order on the upload stream and fingerprinted group by group (about NEEDLE_HIP_LAUNCH_GROUP_BYTES of
 // PCM each) on the library stream as they land.  The PCM is not kept.  On return every copy out of host memory has

@@ -396,6 +396,18 @@ struct FpWorkspace {
   DeviceBuffer<float> energy;
   DeviceBuffer<uint32_t> cert_ctl, chunk_list;
   DeviceBuffer<CertItem> item_list;
+  // the same set twice more for calls that are pipelined two deep (gpu_fingerprint_device's `pipe`): the STFT of call
+  // k + 1 writes its chroma while the certification / recomputation / fix-up of call k still read theirs
+  struct Pipe {
+    DeviceBuffer<double> chroma;
+    DeviceBuffer<float> energy;
+    DeviceBuffer<uint32_t> cert_ctl, chunk_list;
+    DeviceBuffer<CertItem> item_list;
+    hipEvent_t stft_done = nullptr;   // recorded on the STFT stream behind the first pass
+    hipEvent_t consumed = nullptr;    // recorded on the library stream behind the last reader of this set
+    hipEvent_t descriptors = nullptr; // recorded on the library stream behind a descriptor upload the STFT must see
+    bool consumed_valid = false;
+  } pipes[2];
   CertStats *stats = nullptr;                     // device
   uint64_t items_total = 0, chunks_total = 0;     // host: what the device counts are fractions of
 };
@@ -417,7 +429,7 @@ FpWorkspace *workspace() {
 
 Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan> &spans, int channels,
                               uint32_t step, uint32_t *d_items, bool sync, double *d_chroma_dbg,
-                              double *d_feat_dbg, size_t descriptor_slot) {
+                              double *d_feat_dbg, size_t descriptor_slot, int pipe) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   if (channels != 1 && channels != 2)
     return Status::Make(NeedleError_InvalidArgument, "fingerprint: channels must be 1 or 2");
@@ -465,10 +477,30 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       end++;
     }
     if (frames > 0) {
-      if (!(s = ws->chroma.reserve(frames * kBands)).ok()) return s;
-      if (!(s = ws->feat.reserve(std::max<uint64_t>(rows, 1) * kBands)).ok()) return s;
-      FpWorkspace::Descriptors &desc = ws->slot(chunk++);
-      if (!(s = desc.upload.put(&desc.streams, &desc.stage, meta, stream)).ok()) return s;
+      // Pipelined call (pipe 0 / 1) small enough to be ONE chunk, with a CU-masked stream available: its f32 STFT goes
+      // to that stream and its own workspace; otherwise everything stays on the library stream.
+      const char *mode_env0 = getenv("NEEDLE_HIP_STFT");
+      hipStream_t stft = (pipe == 0 || pipe == 1) && begin == 0 && end == spans.size() && d_chroma_dbg == nullptr &&
+                                 d_feat_dbg == nullptr && tiles > 0 && !(mode_env0 && std::strcmp(mode_env0, "f64") == 0) &&
+                                 getenv("NEEDLE_HIP_SEPARATE_CLASSIFY") == nullptr && frames <= (1u << 21)
+                             ? stft_stream()
+                             : nullptr;
+      FpWorkspace::Pipe *pp = stft ? &ws->pipes[pipe] : nullptr;
+      if (pp) {
+        // ... and only while the OTHER pipe still has work queued: a call that is alone on the device keeps all CUs
+        // (same workspace and events, the first pass simply stays on the library stream)
+        const FpWorkspace::Pipe &other = ws->pipes[pipe ^ 1];
+        const bool busy = other.consumed_valid && hipEventQuery(other.consumed) == hipErrorNotReady;
+        (void)hipGetLastError();
+        if (!busy) stft = stream;
+      }
+      DeviceBuffer<double> &chroma_buf = pp ? pp->chroma : ws->chroma;
+      if (!(s = chroma_buf.reserve(frames * kBands)).ok()) return s;
+      if (!pp && !(s = ws->feat.reserve(std::max<uint64_t>(rows, 1) * kBands)).ok()) return s;
+      // (a pipelined call gets descriptor slots of its own: the other pipe's table must stay resident)
+      FpWorkspace::Descriptors &desc = ws->slot(pp ? FpWorkspace::kDescriptorSlots - 2 + (size_t)pipe : chunk++);
+      bool uploaded = false;
+      if (!(s = desc.upload.put(&desc.streams, &desc.stage, meta, stream, &uploaded)).ok()) return s;
       const int n = (int)meta.size();
       if (!ws->lds_attr_set) {
         const void *variants[4] = {reinterpret_cast<const void *>(stft_chroma_kernel<1, 0, false>),
@@ -511,45 +543,69 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
         constexpr uint32_t kChunkPairs = 2;  // 634 four-pair chunks per 28 x 24 min job are two rounds of the 512 workgroup slots; two-pair chunks fit one
         const uint64_t nchunks = (pairs + kChunkPairs - 1) / kChunkPairs;
         const size_t ctl_words = sizeof(CertWork) / 4 + (size_t)((nchunks + 31) / 32);
-        if (!(s = ws->energy.reserve(frames * stft::kEnergyParts)).ok() || !(s = ws->cert_ctl.reserve(ctl_words)).ok() ||
-            !(s = ws->chunk_list.reserve(nchunks)).ok() || !(s = ws->item_list.reserve(std::max<uint64_t>(kept, 1))).ok())
+        DeviceBuffer<float> &energy_buf = pp ? pp->energy : ws->energy;
+        DeviceBuffer<uint32_t> &ctl_buf = pp ? pp->cert_ctl : ws->cert_ctl, &chunk_buf = pp ? pp->chunk_list : ws->chunk_list;
+        DeviceBuffer<CertItem> &item_buf = pp ? pp->item_list : ws->item_list;
+        if (!(s = energy_buf.reserve(frames * stft::kEnergyParts)).ok() || !(s = ctl_buf.reserve(ctl_words)).ok() ||
+            !(s = chunk_buf.reserve(nchunks)).ok() || !(s = item_buf.reserve(std::max<uint64_t>(kept, 1))).ok())
           return s;
+        if (pp) {
+          for (hipEvent_t *e : {&pp->stft_done, &pp->consumed, &pp->descriptors})
+            if (!*e) NEEDLE_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+          // the STFT may start once the previous user of this workspace has read it to the end, and -- only if the
+          // descriptor table was uploaded just now -- once that copy has executed (an unconditional wait on the library
+          // stream would put the STFT behind the whole previous job, which is the one thing this is here to avoid)
+          if (pp->consumed_valid) NEEDLE_HIP_TRY(hipStreamWaitEvent(stft, pp->consumed, 0));
+          if (uploaded) {
+            NEEDLE_HIP_TRY(hipEventRecord(pp->descriptors, stream));
+            NEEDLE_HIP_TRY(hipStreamWaitEvent(stft, pp->descriptors, 0));
+          }
+        }
         if (!ws->stats) {
           NEEDLE_HIP_TRY(hipMalloc((void **)&ws->stats, sizeof(CertStats)));
           NEEDLE_HIP_TRY(hipMemsetAsync(ws->stats, 0, sizeof(CertStats), stream));
         }
-        NEEDLE_HIP_TRY(hipMemsetAsync(ws->cert_ctl.ptr, 0, ctl_words * 4, stream));
-        CertWork *work = reinterpret_cast<CertWork *>(ws->cert_ctl.ptr);
-        uint32_t *bitmap = ws->cert_ctl.ptr + sizeof(CertWork) / 4;
+        NEEDLE_HIP_TRY(hipMemsetAsync(ctl_buf.ptr, 0, ctl_words * 4, stream));
+        CertWork *work = reinterpret_cast<CertWork *>(ctl_buf.ptr);
+        uint32_t *bitmap = ctl_buf.ptr + sizeof(CertWork) / 4;
         {
-          KernelTimer timer("stft_chroma32");
+          hipStream_t on = pp ? stft : stream;
+          KernelTimer timer("stft_chroma32", on);
           const uint32_t ppb = pairs_per_block((uint64_t)kStft32WavesPerSimd * (uint64_t)cus);
           const uint32_t grid = (uint32_t)(((pairs + ppb - 1) / ppb + 7) / 8 * 8);  // multiple of 8: see the XCD mapping
-          if (!(s = launch_stft_chroma32(channels, grid, stream, d_pcm, desc.streams.ptr, n, tab.tw32, tab.win32, tab.bin_slot,
-                                         tab.fold_tab, ws->chroma.ptr, ws->energy.ptr, (uint32_t)pairs, ppb)).ok())
+          if (!(s = launch_stft_chroma32(channels, grid, on, d_pcm, desc.streams.ptr, n, tab.tw32, tab.win32, tab.bin_slot,
+                                         tab.fold_tab, chroma_buf.ptr, energy_buf.ptr, (uint32_t)pairs, ppb)).ok())
             return s;
+        }
+        if (pp) {  // everything behind the first pass stays on the library stream, behind the STFT's event
+          NEEDLE_HIP_TRY(hipEventRecord(pp->stft_done, stft));
+          NEEDLE_HIP_TRY(hipStreamWaitEvent(stream, pp->stft_done, 0));
         }
         {
           KernelTimer timer("features_cert");
           hipLaunchKernelGGL(features_classify_cert_kernel, dim3((uint32_t)((tiles + 3) / 4)), dim3(256), 0, stream,
-                             ws->chroma.ptr, ws->energy.ptr, desc.streams.ptr, n, tab.thr, step, items_per_tile, d_items,
-                             (uint32_t)tiles, cert_k, kChunkPairs, work, bitmap, ws->chunk_list.ptr, ws->item_list.ptr);
+                             chroma_buf.ptr, energy_buf.ptr, desc.streams.ptr, n, tab.thr, step, items_per_tile, d_items,
+                             (uint32_t)tiles, cert_k, kChunkPairs, work, bitmap, chunk_buf.ptr, item_buf.ptr);
         }
         {
           KernelTimer timer("stft_fallback");
           const uint32_t grid = (uint32_t)std::min<uint64_t>(2ull * (uint64_t)cus, nchunks);
-          const stft::ChunkList list{ws->chunk_list.ptr, &work->chunk_count};
+          const stft::ChunkList list{chunk_buf.ptr, &work->chunk_count};
           auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm, desc.streams.ptr, n,
-                               tab.tw, tab.wcos, tab.wconst, tab.bin_slot, tab.fold_tab, ws->chroma.ptr, (uint32_t)pairs,
+                               tab.tw, tab.wcos, tab.wconst, tab.bin_slot, tab.fold_tab, chroma_buf.ptr, (uint32_t)pairs,
                                kChunkPairs, list);
           };
           if (channels == 1) launch(stft_chroma_kernel<1, 0, true>); else launch(stft_chroma_kernel<2, 0, true>);
         }
         {
           KernelTimer timer("fixup_items");
-          hipLaunchKernelGGL(fixup_items_kernel, dim3(64), dim3(256), 0, stream, ws->chroma.ptr, tab.thr, work,
-                             ws->item_list.ptr, d_items, ws->stats);
+          hipLaunchKernelGGL(fixup_items_kernel, dim3(64), dim3(256), 0, stream, chroma_buf.ptr, tab.thr, work,
+                             item_buf.ptr, d_items, ws->stats);
+        }
+        if (pp) {
+          NEEDLE_HIP_TRY(hipEventRecord(pp->consumed, stream));
+          pp->consumed_valid = true;
         }
         ws->items_total += kept;
         ws->chunks_total += nchunks;

@@ -32,6 +32,7 @@ Status ensure_device();
 hipStream_t library_stream();
 hipStream_t download_stream();  // result downloads, ordered behind the library stream with events
 hipStream_t upload_stream();    // PCM uploads of the streaming analyzer; kernels follow on the library stream behind events
+hipStream_t stft_stream();    // CU-masked stream for a pipelined job's f32 STFT, or nullptr (hipctx.hip)
 
 template <typename T>
 struct DeviceBuffer {
@@ -93,12 +94,15 @@ template <class T>
 struct DescriptorUpload {
   std::vector<T> resident;     // what dst holds (or will hold, by stream order)
   const T *resident_at = nullptr;
-  Status put(DeviceBuffer<T> *dst, PinnedStage *stage, const std::vector<T> &items, hipStream_t stream) {
+  Status put(DeviceBuffer<T> *dst, PinnedStage *stage, const std::vector<T> &items, hipStream_t stream,
+             bool *uploaded = nullptr) {
+    if (uploaded) *uploaded = false;
     Status s = dst->reserve(items.size());
     if (!s.ok()) return s;
     if (dst->ptr == resident_at && resident.size() == items.size() &&
         std::memcmp(resident.data(), items.data(), items.size() * sizeof(T)) == 0)
       return Status::Ok();
+    if (uploaded) *uploaded = true;
     if (!(s = stage->acquire(items.size() * sizeof(T))).ok()) return s;
     std::memcpy(stage->ptr, items.data(), items.size() * sizeof(T));
     NEEDLE_HIP_TRY(hipMemcpyAsync(dst->ptr, stage->ptr, items.size() * sizeof(T), hipMemcpyHostToDevice, stream));
@@ -113,9 +117,10 @@ struct DescriptorUpload {
 // set_kernel_timing; elapsed time is read
 // lazily (after a sync) by needle_hip_last_kernel_ms.
 struct KernelTimer {
-  explicit KernelTimer(const char *name);
+  explicit KernelTimer(const char *name, hipStream_t stream = nullptr);  // nullptr: the library stream
   ~KernelTimer();
   const char *name;
+  hipStream_t stream;
   bool active = false;
 };
 double kernel_ms(const std::string &name);

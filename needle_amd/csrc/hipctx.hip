@@ -131,6 +131,40 @@ hipStream_t download_stream() {
   return s;
 }
 
+// The f32 STFT of a job that is pipelined behind another one goes here: a stream confined (CU mask) to all but a few
+// of the device's CUs.  The kernels that follow the STFT in a job -- certification, f64 recomputation, fix-up, scan,
+// simhash -- are short and latency-bound: alone they leave the chip mostly idle (0.13 of a 0.62 ms job at 28 x 24 min).
+// With the NEXT job's STFT confined to its share of the CUs and running on its own queue, those kernels find the
+// reserved CUs free and run underneath it.  (Stream priorities alone do not do this: a retiring STFT workgroup frees
+// 35 KB of LDS and the dispatcher refills the slot before a 61 KB kernel ever fits -- NOTES §4.3, round 2.)
+// nullptr: no such stream (NEEDLE_HIP_STFT_RESERVE_CUS=0, or the runtime refuses the mask).
+hipStream_t stft_stream() {
+  static std::map<int, hipStream_t> streams;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = streams.find(dev);
+  if (it != streams.end()) return it->second;
+  hipStream_t s = nullptr;
+  int cus = 0, reserve = 32;
+  if (const char *e = getenv("NEEDLE_HIP_STFT_RESERVE_CUS")) reserve = atoi(e);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (reserve > 0 && cus >= 4 * reserve) {
+    // every (cus / reserve)-th CU stays out of the mask: the reserved ones are spread over the XCDs / shader engines
+    // whatever the bit order means on this part
+    std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0);
+    const int every = cus / reserve;
+    for (int c = 0; c < cus; c++)
+      if (c % every != every - 1) mask[(size_t)c / 32] |= 1u << (c % 32);
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      s = nullptr;
+    }
+  }
+  streams[dev] = s;
+  return s;
+}
+
 // Host -> device PCM copies of the streaming analyzer go here, so that the fingerprint kernels of the streams that
 // have landed (library stream, behind an event) run underneath the copies of the streams that follow.
 hipStream_t upload_stream() {
@@ -146,8 +180,8 @@ hipStream_t upload_stream() {
   return s;
 }
 
-KernelTimer::KernelTimer(const char *n) : name(n) {
-  hipStream_t s = library_stream();
+KernelTimer::KernelTimer(const char *n, hipStream_t on) : name(n), stream(on ? on : library_stream()) {
+  hipStream_t s = stream;
   std::lock_guard<std::mutex> lock(g_mu);
   active = timing_selection().on(name);
   if (!active) return;
@@ -163,7 +197,7 @@ KernelTimer::KernelTimer(const char *n) : name(n) {
 
 KernelTimer::~KernelTimer() {
   if (!active) return;
-  hipStream_t s = library_stream();
+  hipStream_t s = stream;
   std::lock_guard<std::mutex> lock(g_mu);
   TimerEvents &t = g_timers[timer_key(name)];
   (void)hipEventRecord(t.stop[t.cur], s);

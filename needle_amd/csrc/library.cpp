@@ -575,9 +575,19 @@ void for_rows_of_block(const NeedleHipLibrary *lib, int world, int rank, F &&f) 
 }
 
 // Fingerprints this rank's block: per row the sub-window of PCM its columns depend on, hashes straight to their places.
-NeedleError analyze_flat_block(NeedleHipLibrary *lib, int world, int rank) {
-  if (world <= 1) return needle_hip_library_analyze(lib, 0, lib->n, false);
+NeedleError analyze_flat_block(NeedleHipLibrary *lib, int world, int rank, int slot) {
   std::vector<StreamSpan> spans;
+  if (world <= 1) {
+    for (size_t row = 0; row < lib->rows(); row++) {
+      const Window &w = lib->win[row];
+      if (w.pcm_off == ~0ull)
+        return report(Status::Make(NeedleError_InvalidArgument, "video " + std::to_string(row / lib->regions()) + " has no PCM on this rank"));
+      spans.push_back(StreamSpan{w.pcm_off, w.values, (uint64_t)row * lib->stride});
+    }
+    // `slot`: the job slot is the pipeline depth -- job k + 1's STFT may overlap the tail of job k (common.h)
+    Status s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->arena, false, nullptr, nullptr, 0, slot);
+    return s.ok() ? NeedleError_Ok : report(s);
+  }
   Status bad;
   for_rows_of_block(lib, world, rank, [&](size_t row, size_t c0, size_t c1) {
     const Window &w = lib->win[row];
@@ -594,7 +604,7 @@ NeedleError analyze_flat_block(NeedleHipLibrary *lib, int world, int rank) {
   });
   if (!bad.ok()) return report(bad);
   if (spans.empty()) return NeedleError_Ok;
-  Status s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->arena, false);
+  Status s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->arena, false, nullptr, nullptr, 0, slot);
   return s.ok() ? NeedleError_Ok : report(s);
 }
 
@@ -764,7 +774,7 @@ enum NeedleError needle_hip_library_job_begin(NeedleHipLibrary *lib, const struc
     // 1. fingerprint this rank's block of HASHES (NeedleHipLibrary::flat_block) into the arena (analyzer.rs:437-445
     // across GPUs).  (After needle_hip_library_stream_pcm the rows are already there: the PCM was fingerprinted as it
     // was uploaded.)
-    NeedleError e = lib->pcm_resident ? analyze_flat_block(lib, world, rank) : NeedleError_Ok;
+    NeedleError e = lib->pcm_resident ? analyze_flat_block(lib, world, rank, slot) : NeedleError_Ok;
     if (e != NeedleError_Ok) return e;
     // 2. every rank gets every hash: one in-place all-gather of the equal blocks, in stream order
     if (comm_get()) {
