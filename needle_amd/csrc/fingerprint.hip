@@ -406,7 +406,7 @@ struct FpWorkspace {
     hipEvent_t stft_done = nullptr;   // recorded on the STFT stream behind the first pass
     hipEvent_t consumed = nullptr;    // recorded on the library stream behind the last reader of this set
     hipEvent_t descriptors = nullptr; // recorded on the library stream behind a descriptor upload the STFT must see
-    bool consumed_valid = false;
+    bool consumed_valid = false, stft_recorded = false;
   } pipes[2];
   CertStats *stats = nullptr;                     // device
   uint64_t items_total = 0, chunks_total = 0;     // host: what the device counts are fractions of
@@ -556,6 +556,11 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
           // descriptor table was uploaded just now -- once that copy has executed (an unconditional wait on the library
           // stream would put the STFT behind the whole previous job, which is the one thing this is here to avoid)
           if (pp->consumed_valid) NEEDLE_HIP_TRY(hipStreamWaitEvent(stft, pp->consumed, 0));
+          // ... and once the OTHER pipe's first pass is through: two STFTs side by side only slow each other down and
+          // leave both tails to run alone afterwards (seen in a kernel trace: pairs of 0.67 / 0.76 ms STFTs, then 0.2 ms
+          // of tail kernels on an idle chip); what is wanted beside an STFT is the previous call's TAIL
+          if (ws->pipes[pipe ^ 1].stft_done && ws->pipes[pipe ^ 1].stft_recorded)
+            NEEDLE_HIP_TRY(hipStreamWaitEvent(stft, ws->pipes[pipe ^ 1].stft_done, 0));
           if (uploaded) {
             NEEDLE_HIP_TRY(hipEventRecord(pp->descriptors, stream));
             NEEDLE_HIP_TRY(hipStreamWaitEvent(stft, pp->descriptors, 0));
@@ -579,6 +584,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
         }
         if (pp) {  // everything behind the first pass stays on the library stream, behind the STFT's event
           NEEDLE_HIP_TRY(hipEventRecord(pp->stft_done, stft));
+          pp->stft_recorded = true;
           NEEDLE_HIP_TRY(hipStreamWaitEvent(stream, pp->stft_done, 0));
         }
         {

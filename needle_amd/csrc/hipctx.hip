@@ -146,16 +146,20 @@ hipStream_t stft_stream() {
   auto it = streams.find(dev);
   if (it != streams.end()) return it->second;
   hipStream_t s = nullptr;
-  int cus = 0, reserve = 32;
+  // OFF unless NEEDLE_HIP_STFT_RESERVE_CUS names a number of CUs to keep out of the STFT's reach.  Measured at 28 x 24
+  // min (profiles/NOTES.md, round 3): with 32 reserved the next job's STFT does run beside the previous job's tail, but
+  // it takes 0.578 instead of 0.477 ms (224 CUs, and the tail kernels -- unconfined -- still take slots on them), the tail
+  // 0.40 instead of 0.13 ms, and a job 0.595 instead of 0.606 ms: 2 %, for a reported STFT time 20 % worse.  Not worth
+  // being the default; kept for measurements.
+  int cus = 0, reserve = 0;
   if (const char *e = getenv("NEEDLE_HIP_STFT_RESERVE_CUS")) reserve = atoi(e);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (reserve > 0 && cus >= 4 * reserve) {
-    // every (cus / reserve)-th CU stays out of the mask: the reserved ones are spread over the XCDs / shader engines
-    // whatever the bit order means on this part
+    // Bit i of the mask is CU i / 8 of XCD i % 8 on this part (tools/cu_mask_probe.hip: a one-bit mask confines one
+    // XCD to one CU -- and an XCD whose bits are ALL clear is not confined at all, so "every 8th bit" reserves
+    // nothing).  The low cus - reserve bits therefore keep reserve / 8 CUs of every XCD out of the STFT's reach.
     std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0);
-    const int every = cus / reserve;
-    for (int c = 0; c < cus; c++)
-      if (c % every != every - 1) mask[(size_t)c / 32] |= 1u << (c % 32);
+    for (int c = 0; c < cus - reserve; c++) mask[(size_t)c / 32] |= 1u << (c % 32);
     if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
       (void)hipGetLastError();
       s = nullptr;

@@ -66,6 +66,24 @@ int main() {
     for (unsigned v : h) used += v != 0;
     std::printf("stream %c: workgroups landed on %d distinct CUs\n", which ? 'B' : 'A', used);
   }
+  // the mask's bit order: where do the workgroups of a stream with ONE bit set land?
+  for (int bit : {0, 1, 2, 3, 7, 8, 9, 15, 16, 31, 32, 33, 63, 64, 128, 255}) {
+    if (bit >= cus) continue;
+    std::vector<uint32_t> one(words, 0);
+    one[bit / 32] = 1u << (bit % 32);
+    hipStream_t so;
+    if (hipExtStreamCreateWithCUMask(&so, words, one.data()) != hipSuccess) { std::printf("bit %d: refused\n", bit); continue; }
+    CK(hipMemset(hist, 0, 4096 * 4));
+    hipLaunchKernelGGL(where, dim3(64), dim3(64), 0, so, hist);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned> h(4096);
+    CK(hipMemcpy(h.data(), hist, 4096 * 4, hipMemcpyDeviceToHost));
+    std::printf("mask bit %3d ->", bit);
+    for (int i = 0; i < 4096; i++)
+      if (h[i]) std::printf(" xcc %d se %d sh %d cu %d (%u wgs)", i / 256, (i / 32) % 8, (i / 16) % 2, i % 16, h[i]);
+    std::printf("\n");
+    CK(hipStreamDestroy(so));
+  }
   // together: a small kernel chain on B while A runs a chip-filling kernel
   hipEventRecord(a, s0);
   hipStreamWaitEvent(sa, a, 0);

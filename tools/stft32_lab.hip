@@ -34,6 +34,7 @@ struct Lab {
   uint32_t *d_fold_tab = nullptr;
   std::vector<double> ref;
   hipEvent_t a, b;
+  hipStream_t stream = nullptr;  // LAB_RESERVE_CUS=n: a stream whose CU mask leaves n CUs out (hipctx.hip stft_stream)
 };
 
 static void setup(Lab &L) {
@@ -104,15 +105,15 @@ struct Variant {
 
 template <int WAVES, int LAB>
 static void launch_variant(Lab &L, uint32_t grid, uint32_t ppb) {
-  hipLaunchKernelGGL((stft::stft_chroma32_kernel<1, WAVES, LAB>), dim3(grid), dim3(256), core::kLds2Slots * sizeof(cf), 0, L.d_pcm,
+  hipLaunchKernelGGL((stft::stft_chroma32_kernel<1, WAVES, LAB>), dim3(grid), dim3(256), core::kLds2Slots * sizeof(cf), L.stream, L.d_pcm,
                      L.d_streams, L.eps, L.d_tw, L.d_win, L.d_bin_slot, L.d_fold_tab, L.d_chroma, L.d_energy, L.total_pairs, ppb);
 }
 
 static void time_once(Lab &L, Variant &v, bool record) {
   const uint32_t grid = (uint32_t)(((L.total_pairs + v.ppb - 1) / v.ppb + 7) / 8 * 8);
-  CK(hipEventRecord(L.a));
+  CK(hipEventRecord(L.a, L.stream));
   v.launch(L, grid, v.ppb);
-  CK(hipEventRecord(L.b));
+  CK(hipEventRecord(L.b, L.stream));
   CK(hipEventSynchronize(L.b));
   CK(hipGetLastError());
   float t;
@@ -136,6 +137,14 @@ int main(int argc, char **argv) {
   Lab L;
   if (argc > 2) L.eps = std::atoi(argv[2]);
   setup(L);
+  if (const char *e = getenv("LAB_RESERVE_CUS")) {
+    int cus = 0, reserve = atoi(e);
+    CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0);
+    for (int c = 0; c < cus - reserve; c++) mask[(size_t)c / 32] |= 1u << (c % 32);
+    CK(hipExtStreamCreateWithCUMask(&L.stream, (uint32_t)mask.size(), mask.data()));
+    std::printf("launching on a stream confined to %d of %d CUs\n", cus - reserve, cus);
+  }
   using namespace needle::stft;
   const int reps = argc > 1 ? std::atoi(argv[1]) : 40;
   std::vector<Variant> vs = {
