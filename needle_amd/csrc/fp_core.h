@@ -436,6 +436,24 @@ template <class C> NEEDLE_HD void dif2_publish(int t, C *lds, const C *r) {
   for (int j = 10; j < 16; j++) lds_put(lds, o + j, r[out16(j)]);
 }
 
+// stage 2 from values already in r (a caller that loads them itself), publish stores as in dif2_streamed
+template <int MODE = 0, class C>
+NEEDLE_HD void dif2_from_registers(int t, C *lds, C *r) {
+  constexpr bool P = (MODE & kPlainFft) != 0;
+  const int o = dif2_base(t);
+  fft16_head(r);
+  fft16_tail<0, NoHook, P>(r);
+  fft16_tail<1, NoHook, P>(r);
+  lds_put(lds, o + 12, r[3]);
+  lds_put(lds, o + 13, r[7]);
+  fft16_tail<2, NoHook, P>(r);
+  lds_put(lds, o + 10, r[10]);
+  lds_put(lds, o + 14, r[11]);
+  fft16_tail<3, NoHook, P>(r);
+  lds_put(lds, o + 11, r[14]);
+  lds_put(lds, o + 15, r[15]);
+}
+
 // stage 2 with the publish stores streamed out the same way (j = 12, 13 are outputs of tails 0 and 1, j = 10, 14 of
 // tail 2, j = 11, 15 of tail 3)
 template <int MODE = 0, class C>

@@ -84,6 +84,7 @@ struct NeedleHipLibrary {
   // into this rank's slab and the all-gather fills in the others in place.
   struct Job {
     DeviceBuffer<uint8_t> d_slabs;
+    DeviceBuffer<uint8_t> d_heads;  // world > 1: [world][head_bytes], what the all-gather of run lists fills
     uint32_t slab_runs = 0, head_runs = 0;
     int world = 0;
     void *host = nullptr;
@@ -617,7 +618,7 @@ Status job_buffers(NeedleHipLibrary *lib, NeedleHipLibrary::Job &j, int world) {
     j.slab_runs = lib->slab_runs;
     j.world = world;
     j.d_slabs.release();
-    Status s = j.d_slabs.reserve(j.slab_bytes() * (size_t)world);
+    Status s = j.d_slabs.reserve(j.slab_bytes());  // this rank's slab only: the other ranks' runs arrive as heads
     if (!s.ok()) return s;
   }
   // the one-trip download: everything the last job needed plus a margin, the whole slab while that is small
@@ -626,6 +627,10 @@ Status job_buffers(NeedleHipLibrary *lib, NeedleHipLibrary::Job &j, int world) {
   if (j.slab_bytes() * (size_t)world <= (1u << 20)) head = j.slab_runs;
   j.head_runs = head;
   const size_t want = j.head_bytes() * (size_t)world;
+  if (world > 1) {
+    Status s = j.d_heads.reserve(want);
+    if (!s.ok()) return s;
+  }
   if (want > j.host_bytes) {
     if (j.host) (void)hipHostFree(j.host);
     j.host = nullptr;
@@ -641,7 +646,7 @@ NeedleError job_search_and_gather(NeedleHipLibrary *lib, const NeedleAudioCompar
   const int world = comm_world(), rank = comm_rank();
   size_t pfirst = 0, pcount = 0;
   shard_range(pair_count(lib->n), world, rank, &pfirst, &pcount);
-  uint8_t *mine = j.d_slabs.ptr + (size_t)rank * j.slab_bytes();
+  uint8_t *mine = j.d_slabs.ptr;
   NeedleError e = needle_hip_library_search(lib, comparator, pfirst, pcount,
                                             reinterpret_cast<NeedleHipRun *>(mine + NeedleHipLibrary::kSlabHeader), j.slab_runs,
                                             reinterpret_cast<uint32_t *>(mine), false);
@@ -649,15 +654,19 @@ NeedleError job_search_and_gather(NeedleHipLibrary *lib, const NeedleAudioCompar
   hipStream_t stream = library_stream(), down = download_stream();
   if (hipEventRecord(j.searched, stream) != hipSuccess || hipStreamWaitEvent(down, j.searched, 0) != hipSuccess)
     return report(Status::Make(NeedleError_Unknown, "stream ordering failed"));
-  Status s = comm_all_gather(kSide, mine, j.d_slabs.ptr, j.slab_bytes(), down);
-  if (!s.ok()) return report(s);
-  // count + head of every slab to pinned memory: one plain asynchronous copy per slab.  (A single hipMemcpy2DAsync did
-  // the same in one call but was observed, ROCm 7.2, to execute inside the call -- 7.5 ms for 4.4 MB in a HIP API trace,
-  // behind the kernels already queued -- which made every job's enqueue wait for the previous job's scan.)
-  for (int r = 0; r < world; r++)
-    if (hipMemcpyAsync(static_cast<char *>(j.host) + (size_t)r * j.head_bytes(), j.d_slabs.ptr + (size_t)r * j.slab_bytes(),
-                       j.head_bytes(), hipMemcpyDeviceToHost, down) != hipSuccess)
-      return report(Status::Make(NeedleError_Unknown, "asynchronous run download failed"));
+  // What travels is the HEAD of every rank's slab -- its count and as many runs as the last job needed plus a margin
+  // (job_buffers) -- not the slab's capacity: at BASELINE.json configs[4] on 8 GPUs a slab is 24 MB per rank and the
+  // runs found 13 MB.  The heads land side by side in d_heads and come down in ONE copy; a rank whose count exceeds the
+  // head is handled like a slab overflow in job_end (every rank sees every count): the head grows, the job's scan
+  // and gather are repeated, the size sticks.  One rank: the head is copied straight out of the slab.
+  const uint8_t *src = mine;
+  if (world > 1) {
+    Status s = comm_all_gather(kSide, mine, j.d_heads.ptr, j.head_bytes(), down);
+    if (!s.ok()) return report(s);
+    src = j.d_heads.ptr;
+  }
+  if (hipMemcpyAsync(j.host, src, j.head_bytes() * (size_t)world, hipMemcpyDeviceToHost, down) != hipSuccess)
+    return report(Status::Make(NeedleError_Unknown, "asynchronous run download failed"));
   if (hipEventRecord(j.done, down) != hipSuccess)
     return report(Status::Make(NeedleError_Unknown, "asynchronous run download failed"));
   return NeedleError_Ok;
@@ -812,9 +821,17 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
         counts[r] = *reinterpret_cast<const uint32_t *>(static_cast<const char *>(j.host) + (size_t)r * j.head_bytes());
         most = std::max(most, counts[r]);
       }
-      if (most <= j.slab_runs) {
+      if (most <= j.slab_runs && (world == 1 || most <= j.head_runs)) {
         lib->last_max_count = most;
         break;
+      }
+      if (most <= j.slab_runs) {  // world > 1 and some rank's list is longer than the head that was gathered
+        lib->last_max_count = most;
+        Status s = job_buffers(lib, j, world);  // head_runs from last_max_count
+        if (!s.ok()) return report(s);
+        NeedleError e = job_search_and_gather(lib, comparator, j);
+        if (e != NeedleError_Ok) return e;
+        continue;
       }
       // Some rank found more runs than a slab holds (every rank sees the same counts, so every rank takes this
       // branch): grow and repeat the scan of this job -- the scan is deterministic and the arena still holds the
@@ -837,7 +854,7 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
       j.merged.resize(total);
     size_t at = 0;
     bool tails = false;
-    for (int r = 0; r < world && !run_list; r++) {
+    for (int r = 0; r < world && !run_list; r++) {  // (tails beyond the head: one rank only, out of its own slab)
       const uint32_t head = std::min(counts[r], j.head_runs);
       std::memcpy(j.merged.data() + at, static_cast<const char *>(j.host) + (size_t)r * j.head_bytes() + NeedleHipLibrary::kSlabHeader,
                   (size_t)head * sizeof(NeedleHipRun));

@@ -105,7 +105,7 @@ struct Variant {
 
 template <int WAVES, int LAB>
 static void launch_variant(Lab &L, uint32_t grid, uint32_t ppb) {
-  hipLaunchKernelGGL((stft::stft_chroma32_kernel<1, WAVES, LAB>), dim3(grid), dim3(256), core::kLds2Slots * sizeof(cf), L.stream, L.d_pcm,
+  hipLaunchKernelGGL((stft::stft_chroma32_kernel<1, WAVES, LAB>), dim3(grid), dim3(256), (core::kLds2Slots + 240) * sizeof(cf), L.stream, L.d_pcm,
                      L.d_streams, L.eps, L.d_tw, L.d_win, L.d_bin_slot, L.d_fold_tab, L.d_chroma, L.d_energy, L.total_pairs, ppb);
 }
 
@@ -153,6 +153,11 @@ int main(int argc, char **argv) {
       {"2 waves/SIMD", launch_variant<2, 0>, true, 16},
       {"window re-read per pair, 3 waves/SIMD", launch_variant<3, kLab32WinLoad>, true, 16},
       {"window re-read per pair, 4 waves/SIMD", launch_variant<4, kLab32WinLoad>, true, 16},
+      {"stage inputs as single ds_read_b64 (asm)", launch_variant<3, kLab32AsmReads>, true, 16},
+      {"stage-1 twiddles from LDS [j][n0], 3 waves/SIMD", launch_variant<3, kLab32Tw1Lds>, true, 16},
+      {"stage-1 twiddles from LDS, 4 waves/SIMD", launch_variant<4, kLab32Tw1Lds>, true, 16},
+      {"stage-1 twiddles from LDS + window re-read, 4 waves", launch_variant<4, kLab32Tw1Lds | kLab32WinLoad>, true, 16},
+      {"stage-1 twiddles from LDS + window re-read, 3 waves", launch_variant<3, kLab32Tw1Lds | kLab32WinLoad>, true, 16},
       {"no energy partials", launch_variant<3, kLab32NoEnergy>, true, 16},
       {"no barrier 1", launch_variant<3, kLab32NoB1>, false, 16},
       {"no barrier 2", launch_variant<3, kLab32NoB2>, false, 16},
