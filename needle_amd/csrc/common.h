@@ -117,7 +117,10 @@ struct StreamSpan {
 
 Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan> &streams, int channels,
                               uint32_t step, uint32_t *d_items, bool sync, double *d_chroma_dbg = nullptr,
-                              double *d_feat_dbg = nullptr, size_t descriptor_slot = 0, int pipe = -1);
+                              double *d_feat_dbg = nullptr, size_t descriptor_slot = 0, int pipe = -1,
+                              uint32_t *zero_word = nullptr, bool *zeroed = nullptr);
+// (zero_word: a device word the caller wants cleared behind the fingerprinting -- the run counter of the scan that
+// follows -- by the last kernel of the call instead of a memset dispatch; *zeroed says whether that happened.)
 // (pipe 0 / 1: the caller keeps two calls in flight, e.g. the two job slots of a library.  The f32 STFT of such a call
 // runs on the CU-masked stream of hipctx.hip into workspace `pipe`, so that it overlaps whatever the previous call still
 // has queued on the library stream; everything behind it stays on the library stream.  -1: everything on the library
@@ -155,7 +158,8 @@ Status gpu_fingerprint_streamed(const std::vector<size_t> &num_values, const Pcm
                                 int rate = kSampleRate);
 Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
                                const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
-                               NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync);
+                               NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync,
+                               bool count_is_zero = false);
 Status gpu_hamming_runs_host(const uint32_t *hashes, size_t num_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
                              const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
                              std::vector<NeedleHipRun> *runs);

@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256) void features_classify_cert_kernel(
 __global__ __launch_bounds__(256) void fixup_items_kernel(const double *__restrict__ chroma,
                                                           const core::ClassifierThresholds *__restrict__ thr,
                                                           const CertWork *__restrict__ work, const CertItem *__restrict__ item_list,
-                                                          uint32_t *__restrict__ items, CertStats *__restrict__ stats) {
+                                                          uint32_t *__restrict__ items, CertStats *__restrict__ stats,
+                                                          uint32_t *__restrict__ zero_word) {
   __shared__ double tiles[4][16 * kFeatPitch];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t n = work->item_count;
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(256) void fixup_items_kernel(const double *__restri
     wave_lds_fence();  // the next item of this wave overwrites the tile
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (zero_word) *zero_word = 0u;  // the run counter of the scan that follows (a memset dispatch less in front of it)
     atomicAdd(&stats->items_recomputed, (unsigned long long)n);
     atomicAdd(&stats->chunks_recomputed, (unsigned long long)work->chunk_count);
   }
@@ -429,8 +431,10 @@ FpWorkspace *workspace() {
 
 Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan> &spans, int channels,
                               uint32_t step, uint32_t *d_items, bool sync, double *d_chroma_dbg,
-                              double *d_feat_dbg, size_t descriptor_slot, int pipe) {
+                              double *d_feat_dbg, size_t descriptor_slot, int pipe, uint32_t *zero_word, bool *zeroed_out) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
+  bool zeroed = false;  // *zero_word was cleared by the LAST kernel enqueued here (only then is it still zero for the caller)
+  if (zeroed_out) *zeroed_out = false;
   if (channels != 1 && channels != 2)
     return Status::Make(NeedleError_InvalidArgument, "fingerprint: channels must be 1 or 2");
   if (step == 0) return Status::Make(NeedleError_InvalidArgument, "fingerprint: step must be >= 1");
@@ -570,7 +574,6 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
           NEEDLE_HIP_TRY(hipMalloc((void **)&ws->stats, sizeof(CertStats)));
           NEEDLE_HIP_TRY(hipMemsetAsync(ws->stats, 0, sizeof(CertStats), stream));
         }
-        NEEDLE_HIP_TRY(hipMemsetAsync(ctl_buf.ptr, 0, ctl_words * 4, stream));
         CertWork *work = reinterpret_cast<CertWork *>(ctl_buf.ptr);
         uint32_t *bitmap = ctl_buf.ptr + sizeof(CertWork) / 4;
         {
@@ -579,7 +582,8 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
           const uint32_t ppb = pairs_per_block((uint64_t)kStft32WavesPerSimd * (uint64_t)cus);
           const uint32_t grid = (uint32_t)(((pairs + ppb - 1) / ppb + 7) / 8 * 8);  // multiple of 8: see the XCD mapping
           if (!(s = launch_stft_chroma32(channels, grid, on, d_pcm, desc.streams.ptr, n, tab.tw32, tab.win32, tab.bin_slot,
-                                         tab.fold_tab, chroma_buf.ptr, energy_buf.ptr, (uint32_t)pairs, ppb)).ok())
+                                         tab.fold_tab, chroma_buf.ptr, energy_buf.ptr, (uint32_t)pairs, ppb, ctl_buf.ptr,
+                                         (uint32_t)ctl_words)).ok())
             return s;
         }
         if (pp) {  // everything behind the first pass stays on the library stream, behind the STFT's event
@@ -607,7 +611,8 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
         {
           KernelTimer timer("fixup_items");
           hipLaunchKernelGGL(fixup_items_kernel, dim3(64), dim3(256), 0, stream, chroma_buf.ptr, tab.thr, work,
-                             item_buf.ptr, d_items, ws->stats);
+                             item_buf.ptr, d_items, ws->stats, zero_word);
+          zeroed = zero_word != nullptr;
         }
         if (pp) {
           NEEDLE_HIP_TRY(hipEventRecord(pp->consumed, stream));
@@ -619,6 +624,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
         begin = end;
         continue;
       }
+      zeroed = false;
       {
         KernelTimer timer("stft_chroma");
         const uint32_t ppb = pairs_per_block(2ull * (uint64_t)cus);
@@ -659,6 +665,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
     }
     begin = end;
   }
+  if (zeroed_out) *zeroed_out = zeroed;
   if (sync) NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
   return Status::Ok();
 }

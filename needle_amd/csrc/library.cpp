@@ -99,6 +99,7 @@ struct NeedleHipLibrary {
   uint32_t slab_runs = 0;      // per-rank run capacity of the next job (grows on overflow)
   uint32_t last_max_count = 0;  // largest per-rank run count of the last finished job: sizes the one-trip download
   size_t arena_rows = 0;       // rows the arena was allocated with
+  const uint32_t *count_zeroed = nullptr;  // a run counter the last kernel of this job's analyze has just cleared (job_begin)
   ~NeedleHipLibrary() {
     for (Fetch &f : fetch) {
       if (f.host) (void)hipHostFree(f.host);
@@ -454,8 +455,10 @@ enum NeedleError needle_hip_library_search(NeedleHipLibrary *lib, const struct N
           hipStreamWaitEvent(library_stream(), f.done, 0) != hipSuccess)
         return report(Status::Make(NeedleError_Unknown, "stream wait failed"));
     const auto t_built = std::chrono::steady_clock::now();
+    const bool count_is_zero = lib->count_zeroed == d_count;
+    lib->count_zeroed = nullptr;
     Status s = gpu_hamming_runs_device(lib->arena, seqs.data(), seqs.size(), problems.data(), problems.size(),
-                                       cmp.hash_match_threshold(), d_runs, capacity, d_count, sync);
+                                       cmp.hash_match_threshold(), d_runs, capacity, d_count, sync, count_is_zero);
     if (getenv("NEEDLE_HIP_TRACE"))
       std::fprintf(stderr, "[needle_hip] search enqueue: %zu problems built in %.2f ms, launched in %.2f ms\n",
                    problems.size(), std::chrono::duration<double, std::milli>(t_built - t_enter).count(),
@@ -576,8 +579,10 @@ void for_rows_of_block(const NeedleHipLibrary *lib, int world, int rank, F &&f) 
 }
 
 // Fingerprints this rank's block: per row the sub-window of PCM its columns depend on, hashes straight to their places.
-NeedleError analyze_flat_block(NeedleHipLibrary *lib, int world, int rank, int slot) {
+NeedleError analyze_flat_block(NeedleHipLibrary *lib, int world, int rank, int slot, uint32_t *zero_word) {
   std::vector<StreamSpan> spans;
+  bool zeroed = false;
+  lib->count_zeroed = nullptr;
   if (world <= 1) {
     for (size_t row = 0; row < lib->rows(); row++) {
       const Window &w = lib->win[row];
@@ -586,7 +591,9 @@ NeedleError analyze_flat_block(NeedleHipLibrary *lib, int world, int rank, int s
       spans.push_back(StreamSpan{w.pcm_off, w.values, (uint64_t)row * lib->stride});
     }
     // `slot`: the job slot is the pipeline depth -- job k + 1's STFT may overlap the tail of job k (common.h)
-    Status s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->arena, false, nullptr, nullptr, 0, slot);
+    Status s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->arena, false, nullptr, nullptr, 0, slot,
+                                      zero_word, &zeroed);
+    if (s.ok() && zeroed) lib->count_zeroed = zero_word;
     return s.ok() ? NeedleError_Ok : report(s);
   }
   Status bad;
@@ -605,7 +612,9 @@ NeedleError analyze_flat_block(NeedleHipLibrary *lib, int world, int rank, int s
   });
   if (!bad.ok()) return report(bad);
   if (spans.empty()) return NeedleError_Ok;
-  Status s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->arena, false, nullptr, nullptr, 0, slot);
+  Status s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->arena, false, nullptr, nullptr, 0, slot,
+                                    zero_word, &zeroed);
+  if (s.ok() && zeroed) lib->count_zeroed = zero_word;
   return s.ok() ? NeedleError_Ok : report(s);
 }
 
@@ -780,10 +789,19 @@ enum NeedleError needle_hip_library_job_begin(NeedleHipLibrary *lib, const struc
       return report(Status::Make(NeedleError_InvalidArgument,
                                  "the hash arena does not divide into this communicator's blocks: call needle_hip_library_set_pcm "
                                  "after needle_hip_comm_init (or adopt an arena of rows x stride with rows * stride / 64 a multiple of the world size)"));
+    // (the run slabs first: the analyze step's last kernel clears this job's run counter)
+    if (lib->slab_runs == 0 && getenv("NEEDLE_HIP_SLAB_RUNS"))  // tests: a slab that overflows
+      lib->slab_runs = round_up4((uint64_t)std::max(4, atoi(getenv("NEEDLE_HIP_SLAB_RUNS"))));
+    if (lib->slab_runs == 0)
+      lib->slab_runs = round_up4(std::max<uint64_t>(1024, 4 * (uint64_t)shard_block(pair_count(lib->n), world) * lib->regions()));
+    Status sb = job_buffers(lib, j, world);
+    if (!sb.ok()) return report(sb);
     // 1. fingerprint this rank's block of HASHES (NeedleHipLibrary::flat_block) into the arena (analyzer.rs:437-445
     // across GPUs).  (After needle_hip_library_stream_pcm the rows are already there: the PCM was fingerprinted as it
     // was uploaded.)
-    NeedleError e = lib->pcm_resident ? analyze_flat_block(lib, world, rank, slot) : NeedleError_Ok;
+    lib->count_zeroed = nullptr;
+    NeedleError e = lib->pcm_resident ? analyze_flat_block(lib, world, rank, slot, reinterpret_cast<uint32_t *>(j.d_slabs.ptr))
+                                      : NeedleError_Ok;
     if (e != NeedleError_Ok) return e;
     // 2. every rank gets every hash: one in-place all-gather of the equal blocks, in stream order
     if (comm_get()) {
@@ -793,12 +811,6 @@ enum NeedleError needle_hip_library_job_begin(NeedleHipLibrary *lib, const struc
       if (!s.ok()) return report(s);
     }
     // 3. + 4. scan this rank's pair range (comparator.rs:549-564 across GPUs), gather the run lists
-    if (lib->slab_runs == 0 && getenv("NEEDLE_HIP_SLAB_RUNS"))  // tests: a slab that overflows
-      lib->slab_runs = round_up4((uint64_t)std::max(4, atoi(getenv("NEEDLE_HIP_SLAB_RUNS"))));
-    if (lib->slab_runs == 0)
-      lib->slab_runs = round_up4(std::max<uint64_t>(1024, 4 * (uint64_t)shard_block(pair_count(lib->n), world) * lib->regions()));
-    Status s = job_buffers(lib, j, world);
-    if (!s.ok()) return report(s);
     if ((e = job_search_and_gather(lib, comparator, j)) != NeedleError_Ok) return e;
     j.pending = true;
     return NeedleError_Ok;

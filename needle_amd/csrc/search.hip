@@ -631,12 +631,12 @@ SearchWorkspace *workspace() {
 
 Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
                                const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
-                               NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync) {
+                               NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync, bool count_is_zero) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   Status s = ensure_device();
   if (!s.ok()) return s;
   hipStream_t stream = library_stream();
-  NEEDLE_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
+  if (!count_is_zero) NEEDLE_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
   const int mode[3] = {getenv("NEEDLE_HIP_GENERIC_SEARCH") != nullptr, getenv("NEEDLE_HIP_BAND_SEARCH") != nullptr,
                        getenv("NEEDLE_HIP_BANDS_PER_WAVE") ? std::max(1, atoi(getenv("NEEDLE_HIP_BANDS_PER_WAVE"))) : 0};
   SearchWorkspace *ws = workspace();

@@ -106,7 +106,8 @@ struct Variant {
 template <int WAVES, int LAB>
 static void launch_variant(Lab &L, uint32_t grid, uint32_t ppb) {
   hipLaunchKernelGGL((stft::stft_chroma32_kernel<1, WAVES, LAB>), dim3(grid), dim3(256), (core::kLds2Slots + 240) * sizeof(cf), L.stream, L.d_pcm,
-                     L.d_streams, L.eps, L.d_tw, L.d_win, L.d_bin_slot, L.d_fold_tab, L.d_chroma, L.d_energy, L.total_pairs, ppb);
+                     L.d_streams, L.eps, L.d_tw, L.d_win, L.d_bin_slot, L.d_fold_tab, L.d_chroma, L.d_energy, L.total_pairs, ppb,
+                     (uint32_t *)nullptr, 0u);
 }
 
 static void time_once(Lab &L, Variant &v, bool record) {
