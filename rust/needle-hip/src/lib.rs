@@ -485,6 +485,26 @@ pub mod multi_gpu {
             Ok(Library { raw, num_videos })
         }
 
+        /// The videos `[first, first + count)` whose PCM rank `rank` of `world_size` has to hold: the fingerprinting
+        /// is cut by hashes (equal blocks of the arena), not by videos, so no rank idles; a pure function of the
+        /// library's parameters and the stream lengths (`needle_hip_library_rank_videos`).
+        pub fn rank_videos(&self, num_values: &[usize], channels: usize, world_size: usize, rank: usize) -> Result<(usize, usize)> {
+            assert!(num_values.len() == self.num_videos);
+            let (mut first, mut count) = (0usize, 0usize);
+            unsafe {
+                check(ffi::needle_hip_library_rank_videos(
+                    self.raw,
+                    num_values.as_ptr(),
+                    channels as c_int,
+                    world_size as c_int,
+                    rank as c_int,
+                    &mut first,
+                    &mut count,
+                ))?
+            };
+            Ok((first, count))
+        }
+
         /// `pcm[v]` is `None` for the videos another rank owns; `num_values[v]` is known to every rank.
         /// `resident`: keep the PCM in HBM (repeatable analyze) instead of streaming it through.
         pub fn load_pcm(&mut self, pcm: &[Option<&[i16]>], num_values: &[usize], channels: usize, resident: bool) -> Result<()> {
