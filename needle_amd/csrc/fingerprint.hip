@@ -259,8 +259,11 @@ __device__ __forceinline__ float feature_row_cert(const double *__restrict__ in,
     for (int c = 0; c < kBands; c++) out[c] = 0.0;
     return sigma == __builtin_inff() ? sigma : 0.0f;
   }
+  // one reciprocal instead of twelve divisions: a feature may differ from the f64 pipeline's by an ulp, 10^9 times less
+  // than the radius an ACCEPTED item clears; every other item is recomputed by fixup_items_kernel with the divisions
+  const double inv = 1.0 / norm;
 #pragma unroll
-  for (int c = 0; c < kBands; c++) out[c] = v[c] / norm;
+  for (int c = 0; c < kBands; c++) out[c] = v[c] * inv;
   return sigma;
 }
 
@@ -276,11 +279,12 @@ __device__ __forceinline__ uint32_t classify_window_cert(const double *w, const 
   bool unc = false;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    const double ratio = (1.0 + a[i]) / (1.0 + b[i]);
-    const double t0 = thr->e[i][0], t1 = thr->e[i][1], t2 = thr->e[i][2];
-    const unsigned q = ratio < t1 ? (ratio < t0 ? 0u : 1u) : (ratio < t2 ? 2u : 3u);
-    // |log ratio - t| <= r  <=  |ratio - e^t| <= e^t (r + r^2)   (rr = r + r^2, r < 1)
-    unc = unc || fabs(ratio - t0) <= t0 * rr || fabs(ratio - t1) <= t1 * rr || fabs(ratio - t2) <= t2 * rr;
+    // ratio < e^t  <=>  1 + a < e^t (1 + b)  (b >= 0): no division -- see feature_row_cert for why an ulp is harmless here
+    const double num = 1.0 + a[i], den = 1.0 + b[i];
+    const double d0 = thr->e[i][0] * den, d1 = thr->e[i][1] * den, d2 = thr->e[i][2] * den;
+    const unsigned q = num < d1 ? (num < d0 ? 0u : 1u) : (num < d2 ? 2u : 3u);
+    // |log ratio - t| <= r  <=  |ratio - e^t| <= e^t (r + r^2)  <=>  |num - e^t den| <= e^t den (r + r^2)   (rr = r + r^2, r < 1)
+    unc = unc || fabs(num - d0) <= d0 * rr || fabs(num - d1) <= d1 * rr || fabs(num - d2) <= d2 * rr;
     bits = (bits << 2) | (q ^ (q >> 1));
   }
   *uncertain = unc;

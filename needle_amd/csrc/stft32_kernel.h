@@ -62,6 +62,8 @@ enum : int {
   kLab32NoFold = 32,    // no fold reads / tree / chroma store
   kLab32NoPower = 64,   // no partner reads, powers, power stores
   kLab32AsmReads = 512, // the 2 x 16 stage inputs as single ds_read_b64 (lds_read16_single) instead of the compiler's ds_read2_b64
+  kLab32NoConflict = 1024,  // power stores and fold reads on a trivially conflict-free (and wrong) slot pattern: the
+                            // upper bound of what a conflict-free power image could buy
   kLab32Tw1Lds = 256,   // stage-1 twiddle powers from a [15][16] table behind the LDS image instead of 30 registers
   kLab32Clock = 128,    // thread 0 stamps s_memtime / s_memrealtime around the pair loop into `energy` (as 4 x u64 per
                         // workgroup): the clock the kernel really ran at = d memtime / d memrealtime x 100 MHz
@@ -111,7 +113,8 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
     }
     inv.w[j >> 1] = core::pack_slots(idx[0], idx[1]);
   }
-  const uint32_t fold_entry = t < kBands * core::kClassLanes ? fold_tab[t] : core::energy_fold_entry(t - kBands * core::kClassLanes);
+  uint32_t fold_entry = t < kBands * core::kClassLanes ? fold_tab[t] : core::energy_fold_entry(t - kBands * core::kClassLanes);
+  if (LAB & kLab32NoConflict) fold_entry = (uint32_t)(17 * min(4 * (t & 63), 246) + (t >> 6)) | (10u << 16);
   if (t == 0) core::lds_put(lds, core::kPowerZeroSlot, cf{0.0f, 0.0f});  // first read after the loop's barriers
   // LAB: W^(16 n0 j) at kTw1Base + 16 (j - 1) + n0: the 16 lanes of a group read 16 consecutive slots (conflict-free),
   // the wave's four groups the same ones (broadcast)
@@ -258,7 +261,10 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
       for (int j = 0; j < core::kBinsPerThread; j++) core::dif_power_of(r[core::out16(j)], yp[j], &pwa[j], &pwb[j]);
 #pragma unroll
       for (int j = 0; j < core::kBinsPerThread; j++)
-        core::lds_put_bytes(lds, (j & 1) ? core::slot_bytes<1>(inv.w[j >> 1]) : core::slot_bytes<0>(inv.w[j >> 1]), cf{pwa[j], pwb[j]});
+        if (LAB & kLab32NoConflict)
+          core::lds_put(lds, core::dif2_base(tt) + j, cf{pwa[j], pwb[j]});
+        else
+          core::lds_put_bytes(lds, (j & 1) ? core::slot_bytes<1>(inv.w[j >> 1]) : core::slot_bytes<0>(inv.w[j >> 1]), cf{pwa[j], pwb[j]});
     } else {
       asm volatile("" ::"v"(r[0].x), "v"(r[5].y), "v"(r[10].x), "v"(r[15].y));
     }
