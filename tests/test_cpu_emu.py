@@ -78,3 +78,28 @@ def test_diagonal_scan_loop_matches_oracle_dp(emu):
                                            [(int(h), i) for i, h in enumerate(s)], [(int(h), i) for i, h in enumerate(t)], 0, 0)
         want = sorted((e["src_end_idx"], e["dst_end_idx"], e["score"]) for e in ents if e["score"] >= min_len)
         assert got == want
+
+
+def test_f32_first_pass_schedule_chroma_and_energy(emu):
+    """stft_chroma32_kernel's per-thread code stepped on the CPU (same schedule, f32 arithmetic, table window and
+    twiddles): its chroma is the oracle's within f32 round-off, and the four energy partials the fourth wave folds
+    add up to the sum of squares of the windowed frame (times the kernel's 1/2 input scale, squared)."""
+    emu.emu_stft_chroma_pair_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    e = synth.make_episode(2, 40.0, 10.0)
+    pcm = e.pcm[: 20 * 11025]
+    _, chroma, _, _ = O.fingerprint(pcm, debug=True)
+    window = 0.5 * (0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(4096) / 4095)) / 32767.0
+    a, b = np.zeros(12), np.zeros(12)
+    ea, eb = np.zeros(4, dtype=np.float32), np.zeros(4, dtype=np.float32)
+    for f in (0, 1, 77, len(chroma) - 2):
+        fa = np.ascontiguousarray(pcm[f * 1365: f * 1365 + 4096])
+        fb = np.ascontiguousarray(pcm[(f + 1) * 1365: (f + 1) * 1365 + 4096])
+        emu.emu_stft_chroma_pair_f32(fa.ctypes.data, fb.ctypes.data, 1, a.ctypes.data, b.ctypes.data, ea.ctypes.data, eb.ctypes.data)
+        assert a[0] >= 0, f"layout check failed with code {a[0]}"
+        assert np.max(np.abs(a - chroma[f])) / chroma[f].max() < 2e-6
+        assert np.max(np.abs(b - chroma[f + 1])) / chroma[f + 1].max() < 2e-6
+        assert abs(float(ea.sum()) / float(((fa * window) ** 2).sum()) - 1.0) < 1e-5
+        assert abs(float(eb.sum()) / float(((fb * window) ** 2).sum()) - 1.0) < 1e-5
+    # odd frame count: frame B absent -> its energy is exactly zero
+    emu.emu_stft_chroma_pair_f32(fa.ctypes.data, None, 1, a.ctypes.data, None, ea.ctypes.data, eb.ctypes.data)
+    assert float(eb.sum()) == 0.0 and np.max(np.abs(a - chroma[len(chroma) - 2])) / chroma[len(chroma) - 2].max() < 2e-6
