@@ -292,3 +292,30 @@ def test_skip_files_are_checked_video_by_video_in_order(tmp_path, capfd):
     assert out.rstrip().endswith("Skipping due to existing skip file...")
     assert out.count("* Opening - ") == 2 and len(blocks) >= 3
     assert os.path.exists(os.path.splitext(a)[0] + ".needle.skip.json")
+
+
+def test_bench_line_carries_the_contract(tmp_path):
+    """`python bench.py` (N = 1) on a small library: ONE JSON line with the contract's keys, a roofline block for the
+    dominant kernel (HIP events in the timed region), an honest scan roofline (issued evaluations against the ceiling
+    measured in the run: a fraction <= 1), the certified dtype with its fallback share, device clocks, a CPU baseline
+    that cross-checked the GPU's hashes and results."""
+    line, _ = _bench(["--episodes", "6", "--minutes", "3", "--intro-seconds", "40", "--steps", "4", "--warmup", "2",
+                      "--search-only-episodes", "8"], {})
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 4 and line["warmup"] == 2 and line["vs_baseline"] is None
+    assert "workload" in line["config"] and line["data"] == "synthetic" and line["detected"] == 6
+    r = line["roofline"]
+    assert 0 < r["frac"] < 1 and r["achieved"] > 0 and r["avg_launch_ms"] > 0 and r["kernel"] in ("stft_chroma32", "hamming_runs")
+    if r["kernel"] == "stft_chroma32":                           # the dominant kernel at BASELINE's sizes
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    else:                                                        # a library this small is dominated by the scan's latency:
+        assert r["bound"] == "int valu" and r["unit"] == "lane-instructions/s" and "hbm" in r   # never labelled HBM-bound
+    rs = line["roofline_search"]
+    assert rs["unit"] == "lane-instructions/s" and 0 < rs["frac"] <= 1.0 and rs["pruning_factor"] > 1
+    assert line["dtype"].startswith("f64-certified") and 0 <= line["fallback_frac"]["items"] < 0.05
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["gpu_matches_oracle"] is True
+    assert line["device_state"]["source"] and "end_to_end" in line and "search_only" in line
+    assert 0 < line["search_only"]["roofline"]["frac"] <= 1.0
