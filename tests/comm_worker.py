@@ -28,13 +28,15 @@ def gpu_main(out, n, seconds):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     rdzv = rendezvous.init_comm(capi, rank, world, int(os.environ.get("LOCAL_RANK", "0")),
                                 key=os.environ["NEEDLE_TEST_RDZV_KEY"])
-    total = int(round(seconds * synth.RATE))
-    lib = capi.Library(n)
+    # NEEDLE_TEST_RAGGED: episode k lasts seconds + 3.7 k; NEEDLE_TEST_HASH_DURATION: another step between kept hashes
+    secs = [seconds + (3.7 * k if os.environ.get("NEEDLE_TEST_RAGGED") else 0.0) for k in range(n)]
+    totals = [int(round(v * synth.RATE)) for v in secs]
+    lib = capi.Library(n, hash_duration=float(os.environ.get("NEEDLE_TEST_HASH_DURATION", "0.3")))
     if os.environ.get("NEEDLE_TEST_ENDINGS"):
         lib.include_endings()
-    first, count = lib.rank_videos([total] * n, world, rank)      # the episodes this rank's block of hashes depends on
-    mine = {k: synth.make_episode(k, seconds, 20.0) for k in range(first, first + count)}
-    lib.set_pcm([mine[k].pcm if k in mine else None for k in range(n)], [total] * n)
+    first, count = lib.rank_videos(totals, world, rank)           # the episodes this rank's block of hashes depends on
+    mine = {k: synth.make_episode(k, secs[k], 20.0) for k in range(first, first + count)}
+    lib.set_pcm([mine[k].pcm if k in mine else None for k in range(n)], totals)
     cmp = capi.Comparator([f"ep{k}.wav" for k in range(n)], min_opening_duration=10,
                           include_endings=bool(os.environ.get("NEEDLE_TEST_ENDINGS")))
     jobs = []

@@ -167,6 +167,27 @@ def test_ranks_with_endings_over_host_transport(tmp_path):
             assert job["results"] == want
 
 
+@pytest.mark.parametrize("world,hash_duration,step", [(3, 0.3, 2), (4, 0.15, 1), (3, 0.4, 3)])
+def test_hash_sharding_with_ragged_lengths_and_other_steps(tmp_path, world, hash_duration, step):
+    """The ranks' blocks of hashes cut rows of DIFFERENT lengths at arbitrary columns, and the sub-window a block needs
+    depends on the step between kept hashes (hash k <- frames k step .. k step + 19): episodes of 60 .. 82 s, steps 1,
+    2 and 3, three and four ranks on one GPU; every rank ends up with the hashes one rank computes alone = the oracle's."""
+    n = 7
+    eps = [synth.make_episode(k, 60.0 + 3.7 * k, 20.0) for k in range(n)]
+    hd = O.duration_from_secs_f32(hash_duration)
+    ref = [O.FrameHashes(O.step_and_timestamp(O.fingerprint(e.pcm[: len(e.pcm) // 2]), hd), [], hd, "") for e in eps]
+    assert len(ref[0].opening) == -(-O.num_items(len(eps[0].pcm) // 2) // step)
+    want = O.run_with_frame_hashes(O.Comparator(min_opening_duration=10 * NS), ref)
+    got = launch("gpu", world, str(tmp_path / "h"), [n, 60.0], local_ranks=[0] * world,
+                 extra_env={"NEEDLE_HIP_COMM": "host", "NEEDLE_TEST_RAGGED": "1", "NEEDLE_TEST_HASH_DURATION": str(hash_duration)})
+    for g in got:
+        assert g["stft_ms"] > 0
+        for v in range(n):
+            assert g["hashes"][v] == [h for h, _ in ref[v].opening], (g["rank"], v)
+        for job in g["jobs"]:
+            assert job["results"] == _as_json(want)
+
+
 def test_rccl_communicator_with_one_rank(lib7, tmp_path):
     """librccl loaded on demand, ncclCommInitRank, and -- forced -- every collective of a job through ncclAllGather
     with a single rank: the RCCL call path on a one-GPU box."""
