@@ -421,6 +421,121 @@ NEEDLE_HD void dif1_streamed(int t, C base1, C *lds, C *r) {
   dif1_streamed_pw<MODE>(t, pw, lds, r);
 }
 
+// ---- twiddles on the CONSUMER side, folded into the first layer (f32 first pass) -------------------------------------
+// Decimation in frequency multiplies output j of a stage-0 butterfly by W^{t j} and output j of a stage-1 butterfly by
+// W^{16 n0 j}.  Seen from the thread that READS a value: input n1 of the stage-1 thread (b, n0) carries
+// W^{n0 b} (W^{16 b})^{n1}, and with the factor W^{n0 b}, common to all its inputs, moved through to its outputs (the
+// transform is linear), input n0 of the stage-2 thread (b, c) carries (W^{b + 16 c})^{n0}:
+//   stage 1, thread (b, n0):  input k times g1^k,  g1 = W_4096^{16 b};   stage 2, thread (b, c):  input k times g2^k,
+//   g2 = W_4096^{b + 16 c};   NO multiplication on the producer side: a stage stores its butterfly outputs as they are.
+// In the first layer (4-point DFTs over inputs n2, 4 + n2, 8 + n2, 12 + n2) a twiddle w = gamma (1, tau) costs two FMAs
+// for u = (1, tau) x and its scale rides on the FMAs that replace the layer's additions: 36 instructions per stage on
+// top of the 64 additions instead of 60 (15 complex multiplies).  gamma = cos is never exactly zero in the tables (cosl
+// of a rounded pi / 2), only tiny; tau is then huge and gamma tau comes out as the sine it stands for.
+// Per thread and stage 30 constants, built on the host in double (build_twiddle_row) and rounded once:
+//   column 0: tau2 gamma2 tau1 tau3 rho gamma1;  columns 1..3: w0.re w0.im tau2 gamma2 tau1 tau3 rho gamma1.
+// (The f64 kernel tried this in round 2 and ran 7 % slower -- profiles/NOTES.md §4.1; the f32 pass is VALU-bound.)
+constexpr int kTwRow = 30;
+template <typename T>
+inline void build_twiddle_row(const cd *tw4096, int m, T *row) {  // g = W_4096^m
+  int o = 0;
+  for (int n2 = 0; n2 < 4; n2++) {
+    const cd w0 = tw4096[(m * n2) & 4095], w1 = tw4096[(m * (4 + n2)) & 4095], w2 = tw4096[(m * (8 + n2)) & 4095],
+             w3 = tw4096[(m * (12 + n2)) & 4095];
+    if (n2 != 0) {
+      row[o++] = (T)w0.x;
+      row[o++] = (T)w0.y;
+    }
+    row[o++] = (T)(w2.y / w2.x);
+    row[o++] = (T)w2.x;
+    row[o++] = (T)(w1.y / w1.x);
+    row[o++] = (T)(w3.y / w3.x);
+    row[o++] = (T)(w3.x / w1.x);
+    row[o++] = (T)w1.x;
+  }
+}
+template <int N2, class C>
+NEEDLE_HD void head_col_tw(C *a, const typename C::real *row) {
+  typedef typename C::real T;
+  const T *k = row + (N2 == 0 ? 0 : 6 + 8 * (N2 - 1));
+  const C A0 = N2 == 0 ? a[0] : cmulf(a[N2], C{k[0], k[1]});
+  const int o = N2 == 0 ? 0 : 2;
+  const T tau2 = k[o], g2 = k[o + 1], tau1 = k[o + 2], tau3 = k[o + 3], rho = k[o + 4], g1 = k[o + 5];
+  const C x1 = a[4 + N2], x2 = a[8 + N2], x3 = a[12 + N2];
+  const C u2 = C{fmad(-tau2, x2.y, x2.x), fmad(tau2, x2.x, x2.y)};
+  const C E0 = C{fmad(g2, u2.x, A0.x), fmad(g2, u2.y, A0.y)}, E1 = C{fmad(-g2, u2.x, A0.x), fmad(-g2, u2.y, A0.y)};
+  const C u1 = C{fmad(-tau1, x1.y, x1.x), fmad(tau1, x1.x, x1.y)};
+  const C u3 = C{fmad(-tau3, x3.y, x3.x), fmad(tau3, x3.x, x3.y)};
+  const C v = C{fmad(rho, u3.x, u1.x), fmad(rho, u3.y, u1.y)}, vp = C{fmad(-rho, u3.x, u1.x), fmad(-rho, u3.y, u1.y)};
+  bfly4_tail(E0, E1, v, vp, g1, a[N2], a[4 + N2], a[8 + N2], a[12 + N2]);
+}
+template <class C>
+NEEDLE_HD void fft16_head_tw(C *a, const typename C::real *row) {
+  head_col_tw<0>(a, row);
+  head_col_tw<1>(a, row);
+  head_col_tw<2>(a, row);
+  head_col_tw<3>(a, row);
+}
+// First layer of stage 0 with the WINDOW folded in: the inputs are (sample of frame A, sample of frame B) still without
+// it; the real window value of each input rides on the layer's FMAs (4 multiplies + 8 FMAs + 8 additions per column
+// instead of 8 multiplies + 16 additions).
+template <int N2, class C>
+NEEDLE_HD void head_col_win(C *a, const typename C::real *w, C x0, C x1, C x2, C x3) {  // w = window at inputs n2, 4+n2, 8+n2, 12+n2
+  typedef typename C::real T;
+  const C A0 = C{w[0] * x0.x, w[0] * x0.y};
+  const T w1 = w[1], w2 = w[2], w3 = w[3];
+  const C E0 = C{fmad(w2, x2.x, A0.x), fmad(w2, x2.y, A0.y)}, E1 = C{fmad(-w2, x2.x, A0.x), fmad(-w2, x2.y, A0.y)};
+  const C p3 = C{w3 * x3.x, w3 * x3.y};
+  const C e2 = C{fmad(w1, x1.x, p3.x), fmad(w1, x1.y, p3.y)}, d = C{fmad(w1, x1.x, -p3.x), fmad(w1, x1.y, -p3.y)};
+  const C e3 = C{d.y, -d.x};
+  a[N2] = cadd(E0, e2);
+  a[4 + N2] = cadd(E1, e3);
+  a[8 + N2] = csub(E0, e2);
+  a[12 + N2] = csub(E1, e3);
+}
+// the four tails of a stage, outputs stored UNMULTIPLIED to slots o + pitch j right behind each tail
+template <class C>
+NEEDLE_HD void dif_tails_store_raw(int o, int pitch, C *lds, C *r) {
+  fft16_tail<0, NoHook, false>(r);
+#pragma unroll
+  for (int k2 = 0; k2 < 4; k2++) lds_put(lds, o + pitch * (0 + 4 * k2), r[0 + k2]);
+  fft16_tail<1, NoHook, false>(r);
+#pragma unroll
+  for (int k2 = 0; k2 < 4; k2++) lds_put(lds, o + pitch * (1 + 4 * k2), r[4 + k2]);
+  fft16_tail<2, NoHook, false>(r);
+#pragma unroll
+  for (int k2 = 0; k2 < 4; k2++) lds_put(lds, o + pitch * (2 + 4 * k2), r[8 + k2]);
+  fft16_tail<3, NoHook, false>(r);
+#pragma unroll
+  for (int k2 = 0; k2 < 4; k2++) lds_put(lds, o + pitch * (3 + 4 * k2), r[12 + k2]);
+}
+// stage 1 and stage 2 in the consumer-side form (row1 / row2: this thread's 30 constants of the stage)
+template <class C>
+NEEDLE_HD void dif1_consumer(int t, const typename C::real *row1, C *lds, C *r) {
+  const int o = dif1_base(t);
+#pragma unroll
+  for (int k = 0; k < 16; k++) r[k] = lds_get(lds, o + 17 * k);
+  fft16_head_tw(r, row1);
+  dif_tails_store_raw(o, 17, lds, r);
+}
+template <class C>
+NEEDLE_HD void dif2_consumer(int t, const typename C::real *row2, C *lds, C *r) {
+  const int o = dif2_base(t);
+#pragma unroll
+  for (int k = 0; k < 16; k++) r[k] = lds_get(lds, o + k);
+  fft16_head_tw(r, row2);
+  fft16_tail<0, NoHook, false>(r);
+  fft16_tail<1, NoHook, false>(r);
+  lds_put(lds, o + 12, r[3]);
+  lds_put(lds, o + 13, r[7]);
+  fft16_tail<2, NoHook, false>(r);
+  lds_put(lds, o + 10, r[10]);
+  lds_put(lds, o + 14, r[11]);
+  fft16_tail<3, NoHook, false>(r);
+  lds_put(lds, o + 11, r[14]);
+  lds_put(lds, o + 15, r[15]);
+}
+
 // stage 2: afterwards r[out16(j)] = Z[dif_bin_of(t, j)]
 template <class C> NEEDLE_HD void dif2(int t, const C *lds, C *r) {
   const int o = dif2_base(t);

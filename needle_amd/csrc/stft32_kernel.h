@@ -64,6 +64,9 @@ enum : int {
   kLab32AsmReads = 512, // the 2 x 16 stage inputs as single ds_read_b64 (lds_read16_single) instead of the compiler's ds_read2_b64
   kLab32NoConflict = 1024,  // power stores and fold reads on a trivially conflict-free (and wrong) slot pattern: the
                             // upper bound of what a conflict-free power image could buy
+  kLab32ConsumerTw = 2048,  // twiddles on the consumer side in tan form + the window folded into stage 0's first layer
+                            // (fp_core.h head_col_tw / head_col_win): 64 VALU instructions fewer per pair; rows built
+                            // in-kernel from the f32 table here (timing only)
   kLab32Tw1Lds = 256,   // stage-1 twiddle powers from a [15][16] table behind the LDS image instead of 30 registers
   kLab32Clock = 128,    // thread 0 stamps s_memtime / s_memrealtime around the pair loop into `energy` (as 4 x u64 per
                         // workgroup): the clock the kernel really ran at = d memtime / d memrealtime x 100 MHz
@@ -101,6 +104,29 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
   if (!(LAB & kLab32WinLoad)) {
 #pragma unroll
     for (int k = 0; k < 16; k++) win[k] = win32[t + 256 * k];
+  }
+  float row1[core::kTwRow], row2[core::kTwRow];
+  if (LAB & kLab32ConsumerTw) {
+    auto build = [&](int m, float *row) {
+      int o = 0;
+#pragma unroll
+      for (int n2 = 0; n2 < 4; n2++) {
+        const cf w0 = tw32[(m * n2) & 4095], w1 = tw32[(m * (4 + n2)) & 4095], w2 = tw32[(m * (8 + n2)) & 4095],
+                 w3 = tw32[(m * (12 + n2)) & 4095];
+        if (n2 != 0) {
+          row[o++] = w0.x;
+          row[o++] = w0.y;
+        }
+        row[o++] = w2.y / w2.x;
+        row[o++] = w2.x;
+        row[o++] = w1.y / w1.x;
+        row[o++] = w3.y / w3.x;
+        row[o++] = w3.x / w1.x;
+        row[o++] = w1.x;
+      }
+    };
+    build(16 * core::thread_k0(t), row1);
+    build(core::thread_k0(t) + 16 * (t & 15), row2);
   }
   core::Words4 inv;
 #pragma unroll
@@ -199,7 +225,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
         sb = ((int)(int16_t)rb[k] + (rb[k] >> 16)) / 2;
       }
       const float w = (LAB & kLab32WinLoad) ? win32[tt + 256 * k] : win[k];
-      const cf x{(float)sa * w, (float)sb * w};
+      const cf x = (LAB & kLab32ConsumerTw) ? cf{(float)sa, (float)sb} : cf{(float)sa * w, (float)sb * w};
       r[k] = x;
       if (!(LAB & kLab32NoEnergy)) {
         ea = core::fmad(x.x, x.x, ea);
@@ -230,9 +256,30 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
       eb = 0.0f;
     }
     if (!(LAB & kLab32NoB1)) lds_barrier(); else wave_lds_fence();  // every thread has read its share of the previous pair's powers and energy partials
-    core::dif0_streamed_pw<0>(tt, pw0, lds, r);
+    if (LAB & kLab32ConsumerTw) {
+      cf x[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) x[k] = r[k];
+      float w4[4];
+#pragma unroll
+      for (int n2 = 0; n2 < 4; n2++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) w4[q] = win[4 * q + n2];
+        if (n2 == 0) core::head_col_win<0>(r, w4, x[0], x[4], x[8], x[12]);
+        if (n2 == 1) core::head_col_win<1>(r, w4, x[1], x[5], x[9], x[13]);
+        if (n2 == 2) core::head_col_win<2>(r, w4, x[2], x[6], x[10], x[14]);
+        if (n2 == 3) core::head_col_win<3>(r, w4, x[3], x[7], x[11], x[15]);
+      }
+      core::dif_tails_store_raw(core::dif0_base(tt), 272, lds, r);
+    } else {
+      core::dif0_streamed_pw<0>(tt, pw0, lds, r);
+    }
     if (!(LAB & kLab32NoB2)) lds_barrier(); else wave_lds_fence();  // stage 0 -> 1 crosses waves
-    if (LAB & kLab32AsmReads) {
+    if (LAB & kLab32ConsumerTw) {
+      core::dif1_consumer(tt, row1, lds, r);
+      wave_lds_fence();
+      core::dif2_consumer(tt, row2, lds, r);
+    } else if (LAB & kLab32AsmReads) {
       lds_read16_single<17>(lds, core::dif1_base(tt), r);
       core::fft16_head(r);
       core::dif_tails_store<0>(core::dif1_base(tt), 17, pw1, lds, r);
@@ -247,7 +294,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
     } else {
       core::dif1_streamed_pw<0>(tt, pw1, lds, r);
     }
-    if (!(LAB & kLab32AsmReads)) {
+    if (!(LAB & (kLab32AsmReads | kLab32ConsumerTw))) {
       wave_lds_fence();  // stage 1 -> 2 stays inside 16 consecutive lanes
       core::dif2_streamed<0>(tt, lds, r);
     }

@@ -155,6 +155,7 @@ int main(int argc, char **argv) {
       {"window re-read per pair, 3 waves/SIMD", launch_variant<3, kLab32WinLoad>, true, 16},
       {"window re-read per pair, 4 waves/SIMD", launch_variant<4, kLab32WinLoad>, true, 16},
       {"stage inputs as single ds_read_b64 (asm)", launch_variant<3, kLab32AsmReads>, true, 16},
+      {"consumer-side twiddles (tan form) + window folded in", launch_variant<3, kLab32ConsumerTw>, true, 16},
       {"power stores / fold reads conflict-free (wrong slots)", launch_variant<3, kLab32NoConflict>, false, 16},
       {"conflict-free power image + single reads", launch_variant<3, kLab32NoConflict | kLab32AsmReads>, false, 16},
       {"stage-1 twiddles from LDS [j][n0], 3 waves/SIMD", launch_variant<3, kLab32Tw1Lds>, true, 16},
