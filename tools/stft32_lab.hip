@@ -103,9 +103,10 @@ struct Variant {
   double diff = -1.0;
 };
 
+static size_t g_lds_bytes = (core::kLds2Slots + 240) * sizeof(cf);  // LAB_LDS_BYTES: more, to cap the workgroups per CU
 template <int WAVES, int LAB>
 static void launch_variant(Lab &L, uint32_t grid, uint32_t ppb) {
-  hipLaunchKernelGGL((stft::stft_chroma32_kernel<1, WAVES, LAB>), dim3(grid), dim3(256), (core::kLds2Slots + 240) * sizeof(cf), L.stream, L.d_pcm,
+  hipLaunchKernelGGL((stft::stft_chroma32_kernel<1, WAVES, LAB>), dim3(grid), dim3(256), g_lds_bytes, L.stream, L.d_pcm,
                      L.d_streams, L.eps, L.d_tw, L.d_win, L.d_bin_slot, L.d_fold_tab, L.d_chroma, L.d_energy, L.total_pairs, ppb,
                      (uint32_t *)nullptr, 0u);
 }
@@ -138,6 +139,10 @@ int main(int argc, char **argv) {
   Lab L;
   if (argc > 2) L.eps = std::atoi(argv[2]);
   setup(L);
+  if (const char *e = getenv("LAB_LDS_BYTES")) {
+    g_lds_bytes = (size_t)atol(e);
+    std::printf("dynamic LDS per workgroup: %zu bytes -> %d workgroups per CU by LDS\n", g_lds_bytes, (int)(163840 / g_lds_bytes));
+  }
   if (const char *e = getenv("LAB_RESERVE_CUS")) {
     int cus = 0, reserve = atoi(e);
     CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
