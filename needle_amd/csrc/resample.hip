@@ -50,6 +50,11 @@ struct Design {
   void *d_quad_info = nullptr;  // [ceil(L / 4)] QuadInfo (resample_quad_kernel)
   float *d_coef_plain = nullptr;  // [L][T] as designed (resample_dec_kernel reads row 0)
   int row_len = 0, steps = 0, quad_pad = 0, delta = 0;
+  // resample_mfma_kernel (resample_mfma.h): [nblocks][mfma_steps][64] B operands, the blocks' window starts
+  float *d_coef_b = nullptr;
+  int *d_block_k0 = nullptr;
+  std::vector<int> block_k0;
+  int mfma_steps = 0, nblocks = 0;  // mfma_steps 0: the kernel does not apply
 };
 
 double bessel_i0(double x) {
@@ -671,6 +676,8 @@ __global__ __launch_bounds__(THREADS) void resample_dec_kernel(const int16_t *__
     if (tile_base + i < st.n_out) out[st.out_off + tile_base + i] = out_tile[i];
 }
 
+#include "resample_mfma.h"
+
 }  // namespace
 
 size_t resample_out_len(size_t n_in, int rate) {
@@ -755,6 +762,39 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
       }
       NEEDLE_HIP_TRY(hipMalloc(&d->d_quad_info, info.size() * sizeof(QuadInfo)));
       NEEDLE_HIP_TRY(hipMemcpy(d->d_quad_info, info.data(), info.size() * sizeof(QuadInfo), hipMemcpyHostToDevice));
+      // resample_mfma_kernel: per block of sixteen outputs of a row, where the union of their windows starts and the
+      // coefficient of every (sample of the union, output) pair as the MFMA's B operand
+      if (d->M % 4 == 0 && d->M >= kRowModeMinM && d->L >= 16) {
+        auto cp = [&](int o) { return (int)((long long)o * d->M / d->L); };
+        d->nblocks = (d->L + 15) / 16;
+        int need = 0;
+        for (int b = 0; b < d->nblocks; b++) need = std::max(need, cp(std::min(16 * b + 15, d->L - 1)) - cp(16 * b) + d->T);
+        for (int bucket : {12, 20, 36, 52})
+          if (d->mfma_steps == 0 && 4 * bucket >= need) d->mfma_steps = bucket;
+      }
+      if (d->mfma_steps) {
+        const int S = d->mfma_steps;
+        std::vector<float> cb((size_t)d->nblocks * S * 64, 0.f);
+        d->block_k0.assign(d->nblocks, 0);
+        for (int b = 0; b < d->nblocks; b++) {
+          const int c0 = (int)((long long)16 * b * d->M / d->L);
+          d->block_k0[b] = c0 + d->delta;
+          for (int j = 0; j < 16; j++) {
+            const int o = 16 * b + j;
+            if (o >= d->L) continue;
+            const long long pm = (long long)o * d->M;
+            const int cpo = (int)(pm / d->L), phase = (int)(pm - (long long)cpo * d->L);
+            for (int t = 0; t < d->T; t++) {
+              const int k = cpo - c0 + t;  // sample of the union this tap meets
+              cb[((size_t)b * S + (size_t)(k >> 2)) * 64 + (size_t)(16 * (k & 3) + j)] = d->coef[(size_t)phase * d->T + t];
+            }
+          }
+        }
+        NEEDLE_HIP_TRY(hipMalloc((void **)&d->d_coef_b, cb.size() * sizeof(float)));
+        NEEDLE_HIP_TRY(hipMemcpy(d->d_coef_b, cb.data(), cb.size() * sizeof(float), hipMemcpyHostToDevice));
+        NEEDLE_HIP_TRY(hipMalloc((void **)&d->d_block_k0, d->block_k0.size() * sizeof(int)));
+        NEEDLE_HIP_TRY(hipMemcpy(d->d_block_k0, d->block_k0.data(), d->block_k0.size() * sizeof(int), hipMemcpyHostToDevice));
+      }
     }
   }
   // Decimation steps of 64 samples or more use the row layout; there the kernel with four consecutive outputs per
@@ -779,6 +819,22 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
   constexpr int kDecThreads = 256;
   const int dec_q = d->L == 1 && d->T == 32 * d->M ? (d->M == 4 ? 5 : d->M == 2 ? 6 : 0) : 0;
   const bool dec = dec_q != 0 && getenv("NEEDLE_HIP_RESAMPLE_V1") == nullptr;
+  // matrix-core kernel (resample_mfma.h): one wave per block of sixteen outputs of a row, at most `mf_waves` per
+  // workgroup; a tile's blocks are cut into `mf_splits` workgroups.  NEEDLE_HIP_RESAMPLE_QUAD forces the DPP kernel.
+  const int mf_max_waves = mfma_rs::kConsumers;
+  const int mf_splits = d->mfma_steps ? (d->nblocks + mf_max_waves - 1) / mf_max_waves : 1;
+  const int mf_waves = d->mfma_steps ? (d->nblocks + mf_splits - 1) / mf_splits : 1;
+  int mf_groups = 0;
+  for (int sp = 0; d->mfma_steps && sp < mf_splits; sp++) {
+    const int b0 = sp * mf_waves, b1 = std::min(b0 + mf_waves, d->nblocks);
+    if (b0 >= b1) { mf_groups = 1 << 30; break; }  // an empty split: not this kernel
+    const int start = d->block_k0[b0] & ~3;
+    mf_groups = std::max(mf_groups, (d->block_k0[b1 - 1] + 4 * d->mfma_steps - start + 3) >> 2);
+  }
+  const int mf_buffer_floats = mfma_rs::kStagedGroups * 4 * mfma_rs::kRows;
+  const size_t mf_lds = (size_t)2 * mf_buffer_floats * sizeof(float);  // double-buffered
+  const bool mfma = quad && d->mfma_steps != 0 && mf_groups <= mfma_rs::kStagedGroups &&
+                    mf_lds <= 160 * 1024 && getenv("NEEDLE_HIP_RESAMPLE_QUAD") == nullptr;
   const uint64_t tile_outputs = dec ? (uint64_t)kDecThreads * dec_q : quad ? (uint64_t)kQuadRows * d->L : (uint64_t)d->n * d->L;
   std::vector<RsStream> meta;
   uint64_t blocks = 0;
@@ -790,7 +846,7 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
     m.n_out = resample_out_len(sp.n_in, rate);
     m.block_base = (uint32_t)blocks;
     m.pad = 0;
-    blocks += (m.n_out + tile_outputs - 1) / tile_outputs * (quad && !dec ? (uint64_t)quad_splits : 1);
+    blocks += (m.n_out + tile_outputs - 1) / tile_outputs * (dec ? 1 : mfma ? (uint64_t)mf_splits : quad ? (uint64_t)quad_splits : 1);
     if (m.n_out) meta.push_back(m);
   }
   if (blocks > 0x7FFFFFFFull) return Status::Make(NeedleError_InvalidArgument, "resample: batch too large for one launch");
@@ -818,6 +874,96 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
       } else {
         if (channels == 1) launch(resample_dec_kernel<1, 2, 6, kDecThreads>); else launch(resample_dec_kernel<2, 2, 6, kDecThreads>);
       }
+      NEEDLE_HIP_TRY(hipGetLastError());
+      if (sync) NEEDLE_HIP_TRY(hipStreamSynchronize(library_stream()));
+      return Status::Ok();
+    }
+    if (mfma) {
+      mfma_rs::Geom mg;
+      mg.L = d->L; mg.M = d->M; mg.half = d->T / 2; mg.delta = d->delta;
+      mg.nblocks = d->nblocks; mg.blocks_per_wg = mf_waves; mg.splits = mf_splits;
+      int cus = 256;
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      // Wave roles.  The waves of a workgroup go to the four SIMDs in turn, so waves w, w + 4, w + 8, w + 12 share one.
+      // Measured (profiles/r03_resample_mfma.log): whatever a staging wave issues -- conversions or bare loads --
+      // adds its time to the MFMA time of the SIMD it sits on instead of hiding under it, and on a SIMD with two or
+      // three multiplying waves it barely gets a turn (blocks first, staging waves last: 0.57 ms; the staging waves on
+      // SIMDs with one multiplying wave: 0.44).  Hence: three SIMDs with three multiplying waves each and nothing else,
+      // the fourth with the tenth block's wave and the three staging waves; waves 12-14 leave at once.
+      // NEEDLE_HIP_RESAMPLE_LAYOUT=0 (tuning): blocks first, then the staging waves.
+      static const unsigned char by_simd[16] = {0, 1, 2, 9, 3, 4, 5, 0x80, 6, 7, 8, 0x81, 0xFF, 0xFF, 0xFF, 0x82};
+      const bool naive = getenv("NEEDLE_HIP_RESAMPLE_LAYOUT") && atoi(getenv("NEEDLE_HIP_RESAMPLE_LAYOUT")) == 0;
+      for (int w = 0; w < 16; w++) {
+        unsigned char r = naive ? (w < mf_waves ? (unsigned char)w : w < mf_waves + mfma_rs::kProducers ? (unsigned char)(0x80 + w - mf_waves) : 0xFF)
+                                : by_simd[w];
+        if (r < 0x80 && r >= mf_waves) r = 0xFF;  // fewer blocks than multiplying waves
+        mg.role[w] = r;
+      }
+      const int mf_total_waves = 16;
+      const int mf_threads = mf_total_waves * 64;
+      int per_cu = 1;
+      if (const char *e = getenv("NEEDLE_HIP_RESAMPLE_WG_PER_CU")) per_cu = std::max(1, atoi(e));  // tuning
+      // persistent workgroups: a multiple of the splits, so that a workgroup keeps its blocks (and B registers)
+      uint64_t grid = std::min<uint64_t>(blocks, (uint64_t)cus * per_cu);
+      grid = std::max<uint64_t>(mf_splits, grid / mf_splits * mf_splits);
+      auto launch = [&](auto kernel) -> Status {
+        static std::map<std::pair<int, const void *>, size_t> announced;  // largest dynamic LDS size per device and kernel
+        size_t &have = announced[{dev, reinterpret_cast<const void *>(kernel)}];
+        if (have < mf_lds) {
+          NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)mf_lds));
+          have = mf_lds;
+        }
+        KernelTimer timer("resample");
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)grid), dim3(mf_threads), mf_lds, stream, d_in, w.first->ptr,
+                           (int)meta.size(), d->d_coef_b, d->d_block_k0, mg, (uint32_t)blocks, mf_buffer_floats, d_out);
+        return Status::Ok();
+      };
+      using namespace mfma_rs;
+      const bool mono = channels == 1;
+#ifdef NEEDLE_HIP_LAB_BUILD
+      const int mlab = getenv("NEEDLE_HIP_RESAMPLE_LAB") ? atoi(getenv("NEEDLE_HIP_RESAMPLE_LAB")) : 0;
+#else
+      const int mlab = 0;  // the product has no wrong-result variants
+#endif
+      if (mlab && !mono && d->mfma_steps == 52) {
+#ifdef NEEDLE_HIP_LAB_BUILD
+        switch (mlab) {
+          case 1: s = launch(resample_mfma_kernel<2, 52, 1>); break;
+          case 2: s = launch(resample_mfma_kernel<2, 52, 2>); break;
+          case 3: s = launch(resample_mfma_kernel<2, 52, 3>); break;
+          case 4: s = launch(resample_mfma_kernel<2, 52, 4>); break;
+          case 7: s = launch(resample_mfma_kernel<2, 52, 7>); break;
+          case 8: s = launch(resample_mfma_kernel<2, 52, 8>); break;
+          case 12: s = launch(resample_mfma_kernel<2, 52, 12>); break;
+          case 15: s = launch(resample_mfma_kernel<2, 52, 15>); break;
+          case 33: s = launch(resample_mfma_kernel<2, 52, 33>); break;
+          case 64: s = launch(resample_mfma_kernel<2, 52, 64>); break;
+          case 68: s = launch(resample_mfma_kernel<2, 52, 68>); break;
+          case 37: s = launch(resample_mfma_kernel<2, 52, 37>); break;
+          case 6: s = launch(resample_mfma_kernel<2, 52, 6>); break;
+          default: {
+            unsigned long long zero[8] = {}, got[8];
+            NEEDLE_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_rs_clock), zero, sizeof zero));
+            s = launch(resample_mfma_kernel<2, 52, 16>);
+            NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+            NEEDLE_HIP_TRY(hipMemcpyFromSymbol(got, HIP_SYMBOL(g_rs_clock), sizeof got));
+            const double n = (double)std::max<unsigned long long>(got[5], 1);
+            fprintf(stderr, "resample_mfma block 0, ticks per tile over %llu tiles: multiply %.0f + barrier %.0f | staging pass "
+                            "%.0f + barrier %.0f\n", got[5], got[0] / n, got[1] / n, got[2] / n, got[4] / n);
+            break;
+          }
+        }
+#endif
+      } else {
+        switch (d->mfma_steps) {
+          case 12: s = mono ? launch(resample_mfma_kernel<1, 12>) : launch(resample_mfma_kernel<2, 12>); break;
+          case 20: s = mono ? launch(resample_mfma_kernel<1, 20>) : launch(resample_mfma_kernel<2, 20>); break;
+          case 36: s = mono ? launch(resample_mfma_kernel<1, 36>) : launch(resample_mfma_kernel<2, 36>); break;
+          default: s = mono ? launch(resample_mfma_kernel<1, 52>) : launch(resample_mfma_kernel<2, 52>); break;
+        }
+      }
+      if (!s.ok()) return s;
       NEEDLE_HIP_TRY(hipGetLastError());
       if (sync) NEEDLE_HIP_TRY(hipStreamSynchronize(library_stream()));
       return Status::Ok();
@@ -977,6 +1123,11 @@ Status gpu_resample_host(const std::vector<const int16_t *> &pcm, const std::vec
                                     hipMemcpyHostToDevice, stream));
   s = gpu_resample_device(d_in.ptr, spans, channels, rate, d_out.ptr, false);
   if (!s.ok()) return s;
+  // measurement (tools/bench_resample.py): the kernel again on the resident input, so that the timed launch follows
+  // another launch and not the copies
+  if (const char *e = getenv("NEEDLE_HIP_RESAMPLE_REPEAT"))
+    for (int k = 0; k < atoi(e); k++)
+      if (!(s = gpu_resample_device(d_in.ptr, spans, channels, rate, d_out.ptr, false)).ok()) return s;
   std::vector<int16_t> host(std::max<uint64_t>(out_total, 1));
   NEEDLE_HIP_TRY(hipMemcpyAsync(host.data(), d_out.ptr, out_total * sizeof(int16_t), hipMemcpyDeviceToHost, stream));
   NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
