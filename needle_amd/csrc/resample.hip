@@ -775,10 +775,12 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
       if (d->mfma_steps) {
         const int S = d->mfma_steps;
         std::vector<float> cb((size_t)d->nblocks * S * 64, 0.f);
-        d->block_k0.assign(d->nblocks, 0);
+        d->block_k0.assign((size_t)2 * d->nblocks, 0);  // window starts, then the steps a block needs (a multiple of 4)
         for (int b = 0; b < d->nblocks; b++) {
           const int c0 = (int)((long long)16 * b * d->M / d->L);
           d->block_k0[b] = c0 + d->delta;
+          const int c_last = (int)((long long)std::min(16 * b + 15, d->L - 1) * d->M / d->L);
+          d->block_k0[d->nblocks + b] = std::min(S, ((c_last - c0 + d->T + 3) / 4 + 3) & ~3);
           for (int j = 0; j < 16; j++) {
             const int o = 16 * b + j;
             if (o >= d->L) continue;
@@ -831,9 +833,13 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
     const int start = d->block_k0[b0] & ~3;
     mf_groups = std::max(mf_groups, (d->block_k0[b1 - 1] + 4 * d->mfma_steps - start + 3) >> 2);
   }
-  const int mf_buffer_floats = mfma_rs::kStagedGroups * 4 * mfma_rs::kRows;
+  // a row of the LDS image: the groups the staging threads of the row move, or all the groups its blocks read if more
+  const int mf_row_groups = std::max(mfma_rs::kCovered, mf_groups);
+  const int mf_buffer_floats = mf_row_groups * 4 * mfma_rs::kRows;
   const size_t mf_lds = (size_t)2 * mf_buffer_floats * sizeof(float);  // double-buffered
-  const bool mfma = quad && d->mfma_steps != 0 && mf_groups <= mfma_rs::kStagedGroups &&
+  const bool mfma = quad && d->mfma_steps != 0 && (mf_groups <= mfma_rs::kCovered ||  // longer rows: the rest is the start of the next row (one split only)
+                     (mf_splits == 1 && mf_groups - d->M / 4 <= mfma_rs::kCovered && mfma_rs::kCovered >= d->M / 4 &&
+                      mf_groups - mfma_rs::kCovered <= 64 * mfma_rs::kProducers)) &&
                     mf_lds <= 160 * 1024 && getenv("NEEDLE_HIP_RESAMPLE_QUAD") == nullptr;
   const uint64_t tile_outputs = dec ? (uint64_t)kDecThreads * dec_q : quad ? (uint64_t)kQuadRows * d->L : (uint64_t)d->n * d->L;
   std::vector<RsStream> meta;
@@ -882,6 +888,12 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
       mfma_rs::Geom mg;
       mg.L = d->L; mg.M = d->M; mg.half = d->T / 2; mg.delta = d->delta;
       mg.nblocks = d->nblocks; mg.blocks_per_wg = mf_waves; mg.splits = mf_splits;
+      mg.m_groups = d->M / 4;
+      mg.dup_lo = mg.dup_hi = 0;
+      if (mf_groups > mfma_rs::kCovered) {
+        mg.dup_lo = mfma_rs::kCovered - mg.m_groups;
+        mg.dup_hi = mf_groups - mg.m_groups;
+      }
       int cus = 256;
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
       // Wave roles.  The waves of a workgroup go to the four SIMDs in turn, so waves w, w + 4, w + 8, w + 12 share one.
@@ -905,6 +917,7 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
       if (const char *e = getenv("NEEDLE_HIP_RESAMPLE_WG_PER_CU")) per_cu = std::max(1, atoi(e));  // tuning
       // persistent workgroups: a multiple of the splits, so that a workgroup keeps its blocks (and B registers)
       uint64_t grid = std::min<uint64_t>(blocks, (uint64_t)cus * per_cu);
+      if (const char *e = getenv("NEEDLE_HIP_RESAMPLE_GRID")) grid = std::max(1, atoi(e));  // tests: few workgroups, many tiles each
       grid = std::max<uint64_t>(mf_splits, grid / mf_splits * mf_splits);
       auto launch = [&](auto kernel) -> Status {
         static std::map<std::pair<int, const void *>, size_t> announced;  // largest dynamic LDS size per device and kernel
@@ -939,18 +952,25 @@ Status gpu_resample_device(const int16_t *d_in, const std::vector<ResampleSpan> 
           case 15: s = launch(resample_mfma_kernel<2, 52, 15>); break;
           case 33: s = launch(resample_mfma_kernel<2, 52, 33>); break;
           case 64: s = launch(resample_mfma_kernel<2, 52, 64>); break;
+          case 128: s = launch(resample_mfma_kernel<2, 52, 128>); break;
+          case 132: s = launch(resample_mfma_kernel<2, 52, 132>); break;
           case 68: s = launch(resample_mfma_kernel<2, 52, 68>); break;
           case 37: s = launch(resample_mfma_kernel<2, 52, 37>); break;
           case 6: s = launch(resample_mfma_kernel<2, 52, 6>); break;
           default: {
-            unsigned long long zero[8] = {}, got[8];
+            unsigned long long zero[40] = {}, got[40];
             NEEDLE_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_rs_clock), zero, sizeof zero));
             s = launch(resample_mfma_kernel<2, 52, 16>);
             NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
             NEEDLE_HIP_TRY(hipMemcpyFromSymbol(got, HIP_SYMBOL(g_rs_clock), sizeof got));
-            const double n = (double)std::max<unsigned long long>(got[5], 1);
-            fprintf(stderr, "resample_mfma block 0, ticks per tile over %llu tiles: multiply %.0f + barrier %.0f | staging pass "
-                            "%.0f + barrier %.0f\n", got[5], got[0] / n, got[1] / n, got[2] / n, got[4] / n);
+            const double n = (double)std::max<unsigned long long>(got[32], 1);
+            fprintf(stderr, "resample_mfma block 0, s_memtime ticks per tile (work + barrier) over %llu tiles, by wave:", got[32]);
+            for (int w = 0; w < 16; w++)
+              if (mg.role[w] != 0xFF)
+                fprintf(stderr, " %s%d %.0f+%.0f", mg.role[w] >= 0x80 ? "stage" : "blk", mg.role[w] & 0x7F, got[2 * w] / n, got[2 * w + 1] / n);
+            fprintf(stderr, "\n  block 0: prologue %.1f us, loop %.1f us; last block entered %.1f us after block 0 and ended %.1f us after it\n",
+                    (got[34] - got[33]) / 100.0, (got[35] - got[34]) / 100.0, ((double)got[36] - (double)got[33]) / 100.0,
+                    ((double)got[37] - (double)got[35]) / 100.0);
             break;
           }
         }

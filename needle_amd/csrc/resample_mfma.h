@@ -31,8 +31,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kRows = 16;        // rows of a tile = the M dimension of the MFMA
 constexpr int kProducers = 3;    // waves of a workgroup that stage samples; the others multiply
 constexpr int kConsumers = 10;   // multiplying waves of a workgroup at most (see the role layout in resample.hip)
-constexpr int kPrefetch = 19;    // groups a staging thread holds in registers for the tile after the next
-constexpr int kStagedGroups = kPrefetch * 4 * kProducers;  // groups of a row a staging pass moves (>= the groups read)
+constexpr int kPrefetch = 14;    // groups of its row a staging thread holds in registers for the tile after the next
+constexpr int kCovered = kPrefetch * 4 * kProducers;  // groups of a row the staging threads of that row move themselves
 
 struct Geom {
   int L, M, half, delta;
@@ -42,6 +42,11 @@ struct Geom {
   // what wave w of a workgroup does: 0..15 multiplies block jb0 + role[w], 0x80 + k is staging wave k, 0xFF leaves at once
   // (waves w, w + 4, w + 8 ... share a SIMD: the layout decides which waves compete for one)
   unsigned char role[16];
+  // A row's groups from kCovered on are the next row's groups dup_lo .. dup_hi - 1 (rows lie M samples apart): whoever
+  // converts one of those writes it to both places; the last row's come from the sixteen rows' successor ("row 16"),
+  // one extra group for the first dup_hi - dup_lo staging threads.  dup_hi = 0: every row fits kCovered groups.
+  int m_groups;        // M / 4
+  int dup_lo, dup_hi;
 };
 
 // k0[b]: first sample of block b's window union, counted from the row's origin (input sample row * M - half + 1 -
@@ -72,8 +77,10 @@ __device__ __forceinline__ float4 group_f32(typename Raw<CH>::type v) {
   if constexpr (CH == 1) {
     return float4{(float)(int16_t)v.x, (float)(v.x >> 16), (float)(int16_t)v.y, (float)(v.y >> 16)};
   } else {
-    auto mix = [](int w) { return __builtin_truncf((float)((int)(int16_t)w + (w >> 16)) * 0.5f); };
-    return float4{mix(v.x), mix(v.y), mix(v.z), mix(v.w)};
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    auto sum = [](int w) { return (float)((int)(int16_t)w + (w >> 16)); };
+    const v2f lo = v2f{sum(v.x), sum(v.y)} * 0.5f, hi = v2f{sum(v.z), sum(v.w)} * 0.5f;  // (v_pk_mul_f32)
+    return float4{__builtin_truncf(lo.x), __builtin_truncf(lo.y), __builtin_truncf(hi.x), __builtin_truncf(hi.y)};
   }
 }
 
@@ -85,56 +92,100 @@ struct TileSrc {
   bool fast;           // the tile lies inside its stream and the stream is 16-byte aligned: staged by aligned groups
 };
 
-__device__ __forceinline__ bool tile_is_fast(const int16_t *src, uint64_t n_in, long long first0, int M) {
-  const long long tile_last = first0 + (long long)(kRows - 1) * M + 4ll * kStagedGroups;
+__device__ __forceinline__ bool tile_is_fast(const int16_t *src, uint64_t n_in, long long first0, const Geom &geo) {
+  const long long tile_last = first0 + max((long long)(kRows - 1) * geo.M + 4ll * kCovered, (long long)kRows * geo.M + 4ll * geo.dup_hi);
   return (reinterpret_cast<uintptr_t>(src) & 15) == 0 && first0 >= 0 && tile_last <= (long long)n_in;
 }
 
+// what a staging thread carries from the loads of a tile to its LDS writes
+template <int CH>
+struct Staged {
+  typename Raw<CH>::type v[kPrefetch];
+  typename Raw<CH>::type tail;  // its group of "row 16"
+};
+
 // One pass of a staging thread over its groups: group u of tile `cur` goes from its register to LDS (the wait is for that
-// load only), and the same register receives group u of tile `next` at once -- a thread always has kPrefetch loads in
-// flight, and the memory pipeline never drains while a tile is written.  (Separate passes -- write everything, then
-// issue everything -- left HBM idle for the writes and the barrier: 40 % of the time.)  LAB: 1 no loads, 2 no writes.
+// load only), and the same register receives group u of tile `next` at once -- a thread always has its loads in flight,
+// each with a whole tile period to arrive, and the memory pipeline never drains while a tile is written.  (Separate
+// passes -- write everything, then issue everything -- left HBM idle for the writes and the barrier: 40 % of the time.)
+// Every thread moves exactly kPrefetch groups of its row, g0 + u gstep: no clamps and no conditions, so the loads are
+// one address register plus immediate offsets.  A sample is converted ONCE: the part of a row's window that is the
+// start of the next row's is written to both (the conversions are VALU work on a SIMD that also multiplies, and there
+// they add to the MFMA time; staging every row's whole window converted 1.4 samples per sample).
+// LAB: 1 no loads, 2 no writes.
 template <int CH, int LAB>
-__device__ __forceinline__ void stage_pass(typename Raw<CH>::type (&v)[kPrefetch], float *lds,
-                                           const int16_t *__restrict__ in, const TileSrc *cur, const TileSrc *next, int M,
+__device__ __forceinline__ void stage_pass(Staged<CH> &sg, float *lds, const int16_t *__restrict__ in, bool have_cur,
+                                           const TileSrc cur, bool have_next, const TileSrc next, const Geom &geo,
                                            int groups, int pt) {
   using raw_t = typename Raw<CH>::type;
-  const int row = pt & 15, g0 = pt >> 4, gstep = 4 * kProducers;
-  const uint32_t row_groups = (uint32_t)(row * M) >> 2;  // M is a multiple of 4
-  // Every thread moves exactly kPrefetch groups, g0 + u gstep: no clamps and no conditions, so the loads are one
-  // address register plus immediate offsets (no VALU work that would have to squeeze in between the other waves' MFMAs)
-  // and the buffer has kStagedGroups groups per row whether or not the blocks read the last ones.
-  auto write = [&](int u) {
-    const int g = g0 + u * gstep;
-    const float4 f = group_f32<CH>(v[u]);
-    float *dst = lds + (size_t)(4 * g) * kRows + row;
-    dst[0] = f.x; dst[kRows] = f.y; dst[2 * kRows] = f.z; dst[3 * kRows] = f.w;
+  const int row = pt & 15, g0 = pt >> 4;
+  constexpr int gstep = 4 * kProducers;
+  const uint32_t row_groups = (uint32_t)(row * geo.M) >> 2;  // M is a multiple of 4
+  // LDS stores as single ds_write_b32 with the slot's distance as the instruction's 16-bit offset: one address register for
+  // all slots (the compiler's ds_write2_b32 reaches 1 KB, so it kept an address per slot -- and spilled them)
+  const uint32_t lds_at = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float *)lds;
+  const uint32_t own_at = lds_at + (uint32_t)((4 * g0) * kRows + row) * 4u;
+  const uint32_t dup_at = own_at - 4u + (uint32_t)(4 * geo.m_groups * kRows) * 4u;  // the row before, M samples later
+#define NEEDLE_RS_PUT(at, f, off)                                                                                      \
+  do {                                                                                                                 \
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(at), "v"((f).x), "n"((off)) : "memory");                         \
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(at), "v"((f).y), "n"((off) + kRows * 4) : "memory");             \
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(at), "v"((f).z), "n"((off) + 2 * kRows * 4) : "memory");         \
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(at), "v"((f).w), "n"((off) + 3 * kRows * 4) : "memory");         \
+  } while (0)
+  const int tail_count = geo.dup_hi - geo.dup_lo;  // > 0: rows are longer than kCovered groups
+  const bool dup_row = row >= 1;
+#define NEEDLE_RS_WRITE(u)                                                                                             \
+  do {                                                                                                                 \
+    const float4 f = group_f32<CH>(sg.v[u]);                                                                            \
+    NEEDLE_RS_PUT(own_at, f, (u) * gstep * 4 * kRows * 4);                                                              \
+    if ((u) * gstep < geo.dup_hi && ((u) + 1) * gstep > geo.dup_lo) { /* (uniform: the slot meets the duplicated range) */ \
+      const int g = g0 + (u) * gstep;                                                                                   \
+      if (dup_row && g >= geo.dup_lo && g < geo.dup_hi) NEEDLE_RS_PUT(dup_at, f, (u) * gstep * 4 * kRows * 4);          \
+    }                                                                                                                   \
+  } while (0)
+  auto write_tail = [&]() {
+    if (tail_count > 0) {
+      const float4 f = group_f32<CH>(sg.tail);
+      const uint32_t at = lds_at + (uint32_t)(4 * (geo.dup_lo + pt + geo.m_groups) * kRows + kRows - 1) * 4u;
+      if (pt < tail_count) NEEDLE_RS_PUT(at, f, 0);
+    }
   };
-  const bool cur_fast = cur && cur->fast, next_fast = next && next->fast;
+  // (the tiles by value and flags, not by pointer: a pointer that may be null keeps both structures in scratch memory)
+  const bool cur_fast = have_cur && cur.fast, next_fast = have_next && next.fast;
   // (derived from the kernel argument in every path, so that the loads are global_load, not flat_load)
-  const raw_t *base = reinterpret_cast<const raw_t *>(in + (next_fast ? next->in_off + (uint64_t)CH * next->first0 : 0)) + row_groups;
-  if (cur_fast && next_fast) {  // the steady state: straight-line code, so that the wait before write u is vmcnt(kPrefetch - 1)
+  const raw_t *tile_base = reinterpret_cast<const raw_t *>(in + (next_fast ? next.in_off + (uint64_t)CH * next.first0 : 0));
+  const raw_t *base = tile_base + row_groups;
+  const raw_t *tail_at = tile_base + (uint32_t)(kRows * geo.m_groups + geo.dup_lo + min(pt, max(tail_count, 1) - 1));
+  if (cur_fast && next_fast) {  // the steady state
 #pragma unroll
     for (int u = 0; u < kPrefetch; u++) {
-      if (!(LAB & 2)) write(u);
-      else asm volatile("" ::"v"(v[u].x), "v"(v[u].y));  // (lab: the loads stay although nothing reads them)
-      if (!(LAB & 1)) v[u] = base[g0 + u * gstep];
-      else if (LAB & 32) asm volatile("v_mov_b32 %0, %1" : "=v"(v[u].x) : "v"(pt + u));  // (lab: values the compiler cannot fold)
+      if (!(LAB & 2)) NEEDLE_RS_WRITE(u);
+      else asm volatile("" ::"v"(sg.v[u].x), "v"(sg.v[u].y));  // (lab: the loads stay although nothing reads them)
+      if (LAB & 128) sg.v[u] = tile_base[pt + 64 * kProducers * u];  // (lab: the same bytes per tile, fully coalesced)
+      else if (!(LAB & 1)) sg.v[u] = base[g0 + u * gstep];
+      else if (LAB & 32) asm volatile("v_mov_b32 %0, %1" : "=v"(sg.v[u].x) : "v"(pt + u));  // (lab: values the compiler cannot fold)
     }
+    if (!(LAB & 2)) write_tail();
+    if (tail_count > 0 && !(LAB & 1)) sg.tail = *tail_at;
     return;
   }
   if (cur_fast && !(LAB & 2)) {
 #pragma unroll
-    for (int u = 0; u < kPrefetch; u++) write(u);
-  } else if (cur && !cur_fast && !(LAB & 2)) {  // first / last tiles of a stream, unaligned streams: sample by sample
-    const long long from = cur->first0 + (long long)row * M;
+    for (int u = 0; u < kPrefetch; u++) NEEDLE_RS_WRITE(u);
+    write_tail();
+  } else if (have_cur && !cur_fast && !(LAB & 2)) {  // first / last tiles of a stream, unaligned streams: sample by sample
+    const long long from = cur.first0 + (long long)row * geo.M;
     for (int m = g0; m < 4 * groups; m += gstep)
-      lds[(size_t)m * kRows + row] = (float)downmixed<CH>(in + cur->in_off, cur->n_in, from + m);
+      lds[(size_t)m * kRows + row] = (float)downmixed<CH>(in + cur.in_off, cur.n_in, from + m);
   }
   if (next_fast && !(LAB & 1)) {
 #pragma unroll
-    for (int u = 0; u < kPrefetch; u++) v[u] = base[g0 + u * gstep];
+    for (int u = 0; u < kPrefetch; u++) sg.v[u] = base[g0 + u * gstep];
+    if (tail_count > 0) sg.tail = *tail_at;
   }
+#undef NEEDLE_RS_WRITE
+#undef NEEDLE_RS_PUT
 }
 
 // The workgroup barrier of this kernel: LDS traffic of the wave complete, then s_barrier -- and NOT __syncthreads(),
@@ -142,15 +193,12 @@ __device__ __forceinline__ void stage_pass(typename Raw<CH>::type (&v)[kPrefetch
 // flight, that is the point of them.
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// One MFMA step per sample group with the A operands read `kAhead` steps in front of their use: the chain of dependent
-// MFMAs (40 cycles each) then never waits for the LDS.
-constexpr int kAhead = 8;
+// LAB & 16: s_memtime ticks every wave of block 0 spends working and at the barrier: [2 w] work, [2 w + 1] barrier of wave w,
+// [32] tiles, [33..35] s_memrealtime (100 MHz) of block 0's first multiplying wave at entry, after the prologue barrier, at the end;
+// [36..37] the same wave of the LAST block: entry and end
+__device__ unsigned long long g_rs_clock[40];
 
-// LAB & 16: s_memtime ticks block 0 spends per phase: [0] multiply, [1] multiplying waves at the barrier, [2] a staging
-// pass, [4] staging waves at the barrier, [5] tiles
-__device__ unsigned long long g_rs_clock[8];
-
-// gridDim.x is a multiple of geo.splits; block_k0 has geo.nblocks entries; coef_b is [nblocks][STEPS][64].
+// gridDim.x is a multiple of geo.splits; block_k0 is [2][nblocks]: window starts, then steps; coef_b is [nblocks][STEPS][64].
 // blockDim.x = 1024: what each of the sixteen waves does is geo.role.
 // LAB (timing experiments, wrong results; NEEDLE_HIP_LAB_BUILD only): 1 no global loads, 2 no LDS writes, 4 no MFMA loop,
 // 8 no output stores, 16 clocks, 32 (with 1) opaque values in place of the loads: the conversions stay
@@ -163,6 +211,8 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int my_role = geo.role[wave];
   if (my_role == 0xFF) return;
+  const bool stamp = (LAB & 16) && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && my_role == 0 && lane == 0;
+  if (stamp) g_rs_clock[blockIdx.x == 0 ? 33 : 36] = __builtin_amdgcn_s_memrealtime();
   const bool producer = my_role >= 0x80;  // wave-uniform
   const int pt = 64 * (my_role & 0x7F) + lane;  // a staging thread's index
   const int split = (int)(blockIdx.x % (uint32_t)geo.splits);
@@ -200,9 +250,11 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(
     // MFMA + 0.35 ms of staging = 0.58 ms).
     __builtin_amdgcn_s_setprio(3);
     // period t: tile t + 1 goes from registers to buffer (t + 1) & 1 while the loads of tile t + 2 take its place
-    typename Raw<CH>::type v[kPrefetch];
-    if (LAB & 1)
-      for (int u = 0; u < kPrefetch; u++) v[u] = typename Raw<CH>::type{};
+    Staged<CH> sg;
+    if (LAB & 1) {
+      for (int u = 0; u < kPrefetch; u++) sg.v[u] = typename Raw<CH>::type{};
+      sg.tail = typename Raw<CH>::type{};
+    }
     Cursor cur;
     auto source = [&](uint32_t t) {
       uint64_t tile;
@@ -211,27 +263,31 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(
       ts.in_off = cur.st.in_off;
       ts.n_in = cur.st.n_in;
       ts.first0 = first_of((LAB & 64) ? (tile & 31) + 1 : tile);  // (lab 64: every load hits the L2)
-      ts.fast = (LAB & 1) || tile_is_fast(in + ts.in_off, ts.n_in, ts.first0, geo.M);
+      ts.fast = (LAB & 1) || tile_is_fast(in + ts.in_off, ts.n_in, ts.first0, geo);
       return ts;
     };
     TileSrc a = source(0), nx = a;
-    stage_pass<CH, LAB>(v, lds, in, nullptr, &a, geo.M, groups, pt);
+    stage_pass<CH, LAB>(sg, lds, in, false, a, true, a, geo, groups, pt);
     if (my_tiles > 1) nx = source(1);
-    stage_pass<CH, LAB>(v, lds, in, &a, my_tiles > 1 ? &nx : nullptr, geo.M, groups, pt);
+    stage_pass<CH, LAB>(sg, lds, in, true, a, my_tiles > 1, nx, geo, groups, pt);
     wg_barrier();
+    unsigned long long work = 0, wait = 0;
     for (uint32_t t = 0; t < my_tiles; t++) {
       const unsigned long long c0 = (LAB & 16) ? __builtin_amdgcn_s_memtime() : 0;
       if (t + 1 < my_tiles) {
         a = nx;
         if (t + 2 < my_tiles) nx = source(t + 2);
-        stage_pass<CH, LAB>(v, lds + ((t + 1) & 1) * buffer_floats, in, &a, t + 2 < my_tiles ? &nx : nullptr, geo.M, groups, pt);
+        stage_pass<CH, LAB>(sg, lds + ((t + 1) & 1) * buffer_floats, in, true, a, t + 2 < my_tiles, nx, geo, groups, pt);
       }
       const unsigned long long c2 = (LAB & 16) ? __builtin_amdgcn_s_memtime() : 0;
       wg_barrier();
-      if ((LAB & 16) && blockIdx.x == 0 && pt == 0) {
+      if (LAB & 16) {
         const unsigned long long c3 = __builtin_amdgcn_s_memtime();
-        g_rs_clock[2] += c2 - c0; g_rs_clock[4] += c3 - c2; g_rs_clock[5] += 1;
+        work += c2 - c0; wait += c3 - c2;
       }
+    }
+    if ((LAB & 16) && blockIdx.x == 0 && lane == 0) {
+      g_rs_clock[2 * wave] = work; g_rs_clock[2 * wave + 1] = wait; g_rs_clock[32] = my_tiles;
     }
     return;
   }
@@ -240,32 +296,36 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(
 #pragma unroll
   for (int s = 0; s < STEPS; s++) b[s] = live ? coef_b[((size_t)jb * STEPS + s) * 64 + lane] : 0.f;
   const int a_off = (live ? (block_k0[jb] - region_start) * kRows : 0) + lane;
+  const int my_steps = live ? block_k0[geo.nblocks + jb] : 0;  // (the table's second half: steps per block, multiples of 4)
   const bool p_live = 16 * jb + (lane & 15) < geo.L;
   const int out_at = 4 * (lane >> 4) * geo.L + 16 * jb + (lane & 15);
   Cursor cur;
   uint64_t tile;
   locate(cur, blockIdx.x, tile);
   wg_barrier();
+  if (stamp && blockIdx.x == 0) g_rs_clock[34] = __builtin_amdgcn_s_memrealtime();
+  unsigned long long work = 0, wait = 0;
   for (uint32_t t = 0; t < my_tiles; t++) {
     const unsigned long long c0 = (LAB & 16) ? __builtin_amdgcn_s_memtime() : 0;
     if (live) {
       const RsStream st = cur.st;
       const float *a_ptr = lds + (t & 1) * buffer_floats + a_off;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      constexpr int kSteps = (LAB & 4) ? kAhead : STEPS;
-      float a[kSteps];
+      // Chunks of four steps, the next chunk's A operands read while this one is multiplied; a block whose windows
+      // span fewer samples (the last one of a row: L % 16 outputs) stops early.
+      float a[2][4];
 #pragma unroll
-      for (int s = 0; s < kSteps; s++) a[s] = a_ptr[64 * s];
+      for (int k = 0; k < 4; k++) a[0][k] = a_ptr[64 * k];
 #pragma unroll
-      for (int s = 0; s < kSteps; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
-      // the schedule: kAhead reads, then a read per MFMA, then the last kAhead MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
+      for (int c = 0; c < STEPS / 4; c++) {
+        if (4 * c >= my_steps || ((LAB & 4) && c >= 2)) break;  // uniform
+        if (c + 1 < STEPS / 4) {
 #pragma unroll
-      for (int s = 0; s < kSteps - kAhead; s++) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          for (int k = 0; k < 4; k++) a[(c + 1) & 1][k] = a_ptr[64 * (4 * (c + 1) + k)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c & 1][k], b[4 * c + k], acc, 0, 0, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
       // outputs: lane (j = lane & 15, rows 4 (lane >> 4) .. + 3); only a stream's last tile needs the bounds check
       const uint64_t tile_first = tile * (uint64_t)(kRows * geo.L);
       int16_t *dst = out + st.out_off + tile_first;
@@ -280,11 +340,15 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(
     if (t + 1 < my_tiles) locate(cur, blockIdx.x + (t + 1) * gridDim.x, tile);
     const unsigned long long c1 = (LAB & 16) ? __builtin_amdgcn_s_memtime() : 0;
     wg_barrier();  // every wave is done with this buffer; the next one is complete
-    if ((LAB & 16) && blockIdx.x == 0 && my_role == 0 && lane == 0) {
+    if (LAB & 16) {
       const unsigned long long c2 = __builtin_amdgcn_s_memtime();
-      g_rs_clock[0] += c1 - c0; g_rs_clock[1] += c2 - c1;
+      work += c1 - c0; wait += c2 - c1;
     }
   }
+  if ((LAB & 16) && blockIdx.x == 0 && lane == 0) {
+    g_rs_clock[2 * wave] = work; g_rs_clock[2 * wave + 1] = wait;
+  }
+  if (stamp) g_rs_clock[blockIdx.x == 0 ? 35 : 37] = __builtin_amdgcn_s_memrealtime();
 }
 
 }  // namespace mfma_rs

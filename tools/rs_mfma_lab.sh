@@ -12,5 +12,5 @@ timeout -k 10 100 python tools/bench_resample.py 2>&1
 export NEEDLE_CAPI_LIB=needle_amd/lib/ab/rslab.so
 for lab in ${LABS:-3 4 33 2 15}; do
   echo "---- LAB $lab"
-  NEEDLE_HIP_RESAMPLE_LAB=$lab timeout -k 10 100 python tools/bench_resample.py 2>&1 | grep "48000 Hz x2\|ticks per tile" | tail -4
+  NEEDLE_HIP_RESAMPLE_LAB=$lab timeout -k 10 100 python tools/bench_resample.py 2>&1 | grep "48000 Hz x2\|ticks per tile\|block 0:" | tail -5
 done
