@@ -21,6 +21,11 @@
 //    coalesced load per row and reads them back as broadcast LDS reads: a broadcast vector-memory load returns
 //    16 bytes to every lane whatever the addresses (16 cycles of the CU's L1 path per 4 taps), a broadcast LDS
 //    read costs 4.
+//
+// Four kernels, chosen by rate (gpu_resample_device): integer decimation with scalar coefficients (44.1 / 22.05 kHz),
+// the matrix-core kernel of resample_mfma.h (decimation steps M >= 64 with M % 4 == 0 and rows that fit: 48, 32, 24,
+// 16, 8 kHz), the DPP-operand kernel with four outputs per lane (the other row-layout rates: 96 kHz, and the above
+// with NEEDLE_HIP_RESAMPLE_QUAD=1), and the general kernel described above.  All four are the same arithmetic.
 #include "hipctx.h"
 
 #include <algorithm>

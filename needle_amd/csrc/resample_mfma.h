@@ -208,7 +208,7 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(
     const float *__restrict__ coef_b, const int *__restrict__ block_k0, Geom geo, uint32_t total_blocks, int buffer_floats,
     int16_t *__restrict__ out) {
   extern __shared__ float lds[];  // two buffers of [sample][row]
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // (uniform, and known to be)
   const int my_role = geo.role[wave];
   if (my_role == 0xFF) return;
   const bool stamp = (LAB & 16) && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && my_role == 0 && lane == 0;
