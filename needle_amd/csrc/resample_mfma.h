@@ -1,4 +1,4 @@
-// Resampler on the matrix cores: the kernel for decimation steps M >= 64 with M % 4 == 0 (48, 32, 16, 8, 96 kHz ...).
+// Resampler on the matrix cores: the kernel for decimation steps M >= 64 with M % 4 == 0 (48, 32, 24, 16, 8 kHz ...).
 // Included by resample.hip only (it uses that file's RsStream and the down-mix helper).
 //
 // Specification and oracle are unchanged (oracle/ora_resample.h): every output is a chain of f32 fused multiply-adds in
@@ -18,10 +18,12 @@
 // compile-time offset, because the samples lie in LDS transposed, [sample][row]: lane l = 16 k + i of step s reads word
 // 64 s + l of the block's window -- consecutive lanes, consecutive words, no bank conflict.
 //
-// Staging: thread t takes row t % 16 and every (blockDim / 16)-th group of four samples of it: one 8- or 16-byte load,
-// down-mix, four ds_write_b32 sixteen words apart (the 32 lanes of an LDS lane group then differ in the row -- 16
-// banks -- and in two groups: 2-way, which costs a store nothing).  The loads of the NEXT tile are issued before the
-// MFMA loop of this one and written to LDS after it, so a workgroup's HBM round trip lies under its own arithmetic.
+// Staging is the job of kProducers waves of the workgroup (the others multiply): thread pt of them takes row pt % 16 and
+// every (4 kProducers)-th group of four samples of it: one 8- or 16-byte load, down-mix, four ds_write_b32 sixteen words
+// apart (the 32 lanes of an LDS lane group then differ in the row -- 16 banks -- and in two groups: 2-way, which costs a
+// store nothing).  LDS holds two tiles: while tile t is multiplied, tile t + 1 goes from the staging threads' registers
+// to the other buffer and the loads of tile t + 2 take its place in the registers (stage_pass), one barrier per tile.
+// Which SIMD a wave runs on matters more than anything else here: see the role layout in resample.hip.
 #pragma once
 
 namespace mfma_rs {
