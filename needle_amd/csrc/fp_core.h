@@ -39,6 +39,38 @@ template <class C> NEEDLE_HD C cmulf(C a, C b) {
   return C{fmad(a.x, b.x, -(a.y * b.y)), fmad(a.x, b.y, a.y * b.x)};
 }
 template <class C> NEEDLE_HD C mul_neg_i(C a) { return C{a.y, -a.x}; }
+// The forms the 16-point transform is made of (one definition of WHAT is computed; NEEDLE_PK_F32 below only changes the
+// instructions that compute it):
+//   axpy(s, v, e) = e + s v        arot(s, v, e) = e + s (-i v)        (both as fused multiply-adds per component)
+//   addrot(e, v)  = e + (-i v)     subrot(e, v)  = e - (-i v)
+//   rot_m(v)      = v + (-i v) = (x + y, y - x)       rot_p(v) = v + i v = (x - y, x + y)
+template <class C> NEEDLE_HD C axpy(typename C::real s, C v, C e) { return C{fmad(s, v.x, e.x), fmad(s, v.y, e.y)}; }
+template <class C> NEEDLE_HD C arot(typename C::real s, C v, C e) { return C{fmad(s, v.y, e.x), fmad(-s, v.x, e.y)}; }
+template <class C> NEEDLE_HD C addrot(C e, C v) { return C{e.x + v.y, e.y - v.x}; }
+template <class C> NEEDLE_HD C subrot(C e, C v) { return C{e.x - v.y, e.y + v.x}; }
+template <class C> NEEDLE_HD C rot_m(C v) { return C{v.x + v.y, v.y - v.x}; }
+template <class C> NEEDLE_HD C rot_p(C v) { return C{v.x - v.y, v.x + v.y}; }
+
+#if defined(__HIP_DEVICE_COMPILE__) && defined(NEEDLE_PK_F32)
+// The same per-component operations on cf as two-component vector operations, which the compiler issues as the packed
+// instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: one instruction for the real and the imaginary part, swaps and
+// signs in the operand modifiers).  Every component sees exactly the operation of the generic form above: same results.
+typedef float pk2f __attribute__((ext_vector_type(2)));
+NEEDLE_HD pk2f pk(cf a) { return pk2f{a.x, a.y}; }
+NEEDLE_HD cf unpk(pk2f a) { return cf{a.x, a.y}; }
+template <> NEEDLE_HD cf cadd<cf>(cf a, cf b) { return unpk(pk(a) + pk(b)); }
+template <> NEEDLE_HD cf csub<cf>(cf a, cf b) { return unpk(pk(a) - pk(b)); }
+template <> NEEDLE_HD cf cmulf<cf>(cf a, cf b) {
+  const pk2f t = pk2f{a.y, a.y} * pk2f{b.y, b.x};
+  return unpk(__builtin_elementwise_fma(pk2f{a.x, a.x}, pk(b), pk2f{-t.x, t.y}));
+}
+template <> NEEDLE_HD cf axpy<cf>(float s, cf v, cf e) { return unpk(__builtin_elementwise_fma(pk2f{s, s}, pk(v), pk(e))); }
+template <> NEEDLE_HD cf arot<cf>(float s, cf v, cf e) { return unpk(__builtin_elementwise_fma(pk2f{s, -s}, pk2f{v.y, v.x}, pk(e))); }
+template <> NEEDLE_HD cf addrot<cf>(cf e, cf v) { return unpk(pk(e) + pk2f{v.y, -v.x}); }
+template <> NEEDLE_HD cf subrot<cf>(cf e, cf v) { return unpk(pk(e) - pk2f{v.y, -v.x}); }
+template <> NEEDLE_HD cf rot_m<cf>(cf v) { return unpk(pk(v) + pk2f{v.y, -v.x}); }
+template <> NEEDLE_HD cf rot_p<cf>(cf v) { return unpk(pk(v) + pk2f{-v.y, v.x}); }
+#endif
 
 constexpr int kThreads = 256;    // threads per frame pair
 constexpr int kMinBin = 10;      // max(1, round(4096*28/11025))
@@ -60,11 +92,11 @@ NEEDLE_HD int thread_pad_slot(int t) { return 17 * t + 16; }  // window recurren
 NEEDLE_HD int pidx(int i) { return i + (i >> 4); }
 
 template <class C> NEEDLE_HD void bfly4(C &a0, C &a1, C &a2, C &a3) {
-  C e0 = cadd(a0, a2), e1 = csub(a0, a2), e2 = cadd(a1, a3), e3 = mul_neg_i(csub(a1, a3));
+  C e0 = cadd(a0, a2), e1 = csub(a0, a2), e2 = cadd(a1, a3), d = csub(a1, a3);
   a0 = cadd(e0, e2);
-  a1 = cadd(e1, e3);
+  a1 = addrot(e1, d);
   a2 = csub(e0, e2);
-  a3 = csub(e1, e3);
+  a3 = subrot(e1, d);
 }
 
 // 16-point forward DFT in place.  Output X[k], k = k1 + 4 k2, is left in a[4 k1 + k2]; out16(j) gives the
@@ -131,50 +163,50 @@ NEEDLE_HD void fft16_tail(C *a, HOOK hook = HOOK()) {
     a[4 * K1] = cadd(E0, v);
     a[4 * K1 + 2] = csub(E0, v);
     hook(2);
-    a[4 * K1 + 1] = C{E1.x + vp.y, E1.y - vp.x};
-    a[4 * K1 + 3] = C{E1.x - vp.y, E1.y + vp.x};
+    a[4 * K1 + 1] = addrot(E1, vp);
+    a[4 * K1 + 3] = subrot(E1, vp);
     hook(3);
     return;
   } else if (K1 == 1) {  // w = (1, W1, W2, W3)
     const C b0 = a[4], b1 = a[5], b2 = a[6], b3 = a[7];
-    const C u2 = C{b2.x + b2.y, b2.y - b2.x};  // W2 b2 = h u2
-    E0 = C{fmad(h, u2.x, b0.x), fmad(h, u2.y, b0.y)};
-    E1 = C{fmad(-h, u2.x, b0.x), fmad(-h, u2.y, b0.y)};
+    const C u2 = rot_m(b2);  // W2 b2 = h u2
+    E0 = axpy(h, u2, b0);
+    E1 = axpy(-h, u2, b0);
     hook(0);
-    const C u1 = C{fmad(t8, b1.y, b1.x), fmad(-t8, b1.x, b1.y)};    // W1 b1 = c u1
-    const C u3 = C{fmad(ct8, b3.y, b3.x), fmad(-ct8, b3.x, b3.y)};  // W3 b3 = s u3 = c t8 u3
-    v = C{fmad(t8, u3.x, u1.x), fmad(t8, u3.y, u1.y)};
-    vp = C{fmad(-t8, u3.x, u1.x), fmad(-t8, u3.y, u1.y)};
+    const C u1 = arot(t8, b1, b1);    // W1 b1 = c u1
+    const C u3 = arot(ct8, b3, b3);   // W3 b3 = s u3 = c t8 u3
+    v = axpy(t8, u3, u1);
+    vp = axpy(-t8, u3, u1);
     g = c;
   } else if (K1 == 2) {  // w = (1, W2, W4, W6)
     const C b0 = a[8], b1 = a[9], b2 = a[10], b3 = a[11];
-    E0 = C{b0.x + b2.y, b0.y - b2.x};  // W4 = -i
-    E1 = C{b0.x - b2.y, b0.y + b2.x};
+    E0 = addrot(b0, b2);  // W4 = -i
+    E1 = subrot(b0, b2);
     hook(0);
-    const C u1 = C{b1.x + b1.y, b1.y - b1.x};  // W2 b1 = h u1
-    const C n3 = C{b3.x - b3.y, b3.x + b3.y};  // W6 b3 = -h n3
-    v = C{u1.x - n3.x, u1.y - n3.y};
-    vp = C{u1.x + n3.x, u1.y + n3.y};
+    const C u1 = rot_m(b1);  // W2 b1 = h u1
+    const C n3 = rot_p(b3);  // W6 b3 = -h n3
+    v = csub(u1, n3);
+    vp = cadd(u1, n3);
     g = h;
   } else {  // K1 == 3: w = (1, W3, W6, W9)
     const C b0 = a[12], b1 = a[13], b2 = a[14], b3 = a[15];
-    const C n2 = C{b2.x - b2.y, b2.x + b2.y};  // W6 b2 = -h n2
-    E0 = C{fmad(-h, n2.x, b0.x), fmad(-h, n2.y, b0.y)};
-    E1 = C{fmad(h, n2.x, b0.x), fmad(h, n2.y, b0.y)};
+    const C n2 = rot_p(b2);  // W6 b2 = -h n2
+    E0 = axpy(-h, n2, b0);
+    E1 = axpy(h, n2, b0);
     hook(0);
-    const C u1 = C{fmad(ct8, b1.y, b1.x), fmad(-ct8, b1.x, b1.y)};  // W3 b1 = s u1
-    const C u3 = C{fmad(t8, b3.y, b3.x), fmad(-t8, b3.x, b3.y)};    // W9 b3 = -c u3 = -s ct8 u3
-    v = C{fmad(-ct8, u3.x, u1.x), fmad(-ct8, u3.y, u1.y)};
-    vp = C{fmad(ct8, u3.x, u1.x), fmad(ct8, u3.y, u1.y)};
+    const C u1 = arot(ct8, b1, b1);  // W3 b1 = s u1
+    const C u3 = arot(t8, b3, b3);   // W9 b3 = -c u3 = -s ct8 u3
+    v = axpy(-ct8, u3, u1);
+    vp = axpy(ct8, u3, u1);
     g = s;
   }
   hook(1);
   // E2 = g v and E3 = -i g v' are never formed: the outputs are E0 +- g v and E1 +- g (-i v')
-  a[4 * K1] = C{fmad(g, v.x, E0.x), fmad(g, v.y, E0.y)};
-  a[4 * K1 + 2] = C{fmad(-g, v.x, E0.x), fmad(-g, v.y, E0.y)};
+  a[4 * K1] = axpy(g, v, E0);
+  a[4 * K1 + 2] = axpy(-g, v, E0);
   hook(2);
-  a[4 * K1 + 1] = C{fmad(g, vp.y, E1.x), fmad(-g, vp.x, E1.y)};
-  a[4 * K1 + 3] = C{fmad(-g, vp.y, E1.x), fmad(g, vp.x, E1.y)};
+  a[4 * K1 + 1] = arot(g, vp, E1);
+  a[4 * K1 + 3] = arot(-g, vp, E1);
   hook(3);
 }
 template <class C> NEEDLE_HD void fft16(C *a) {
