@@ -346,10 +346,16 @@ enum NeedleError needle_hip_library_stream_pcm(NeedleHipLibrary *lib, const int1
     std::vector<const int16_t *> src;
     std::vector<size_t> len;
     std::vector<uint64_t> rows;
+    const auto t0 = std::chrono::steady_clock::now();
     Status s = plan_windows(lib, pcm, num_values, channels, false, &src, &len, nullptr, &rows, nullptr);
     if (!s.ok()) return report(s);
     for (uint64_t &r : rows) r *= lib->stride;  // kept items of a window go straight to its arena row
+    const auto t1 = std::chrono::steady_clock::now();
     if (!(s = gpu_fingerprint_streamed_device(src, len, channels, lib->step, lib->arena, rows)).ok()) return report(s);
+    if (getenv("NEEDLE_HIP_TRACE"))
+      std::fprintf(stderr, "[needle_hip] stream_pcm: windows planned in %.2f ms, %zu windows streamed in %.2f ms\n",
+                   std::chrono::duration<double, std::milli>(t1 - t0).count(), src.size(),
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     lib->have_pcm = true;
     lib->pcm_resident = false;
     return NeedleError_Ok;
