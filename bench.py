@@ -470,6 +470,9 @@ def main() -> None:
     ap.add_argument("--episodes", type=int, default=28)
     ap.add_argument("--minutes", type=float, default=24.0)
     ap.add_argument("--intro-seconds", type=float, default=90.0)
+    ap.add_argument("--preheat", type=int, default=80,
+                    help="untimed jobs run BEFORE the W warm-up steps: a step is 0.6 ms, so 5 warm-up steps are 3 ms, and the "
+                         "device needs ~30 ms of load before its kernels run at their steady rate (DESIGN.md section 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / search_only / roofline_search")
     ap.add_argument("--search-only-episodes", type=int, default=280)
@@ -580,6 +583,11 @@ def main() -> None:
     # HIP events around every kernel cost 3 % of a step (one more packet between dependent dispatches each), so
     # the timed region carries them for the dominant kernel only -- the one `roofline` is about, found in the
     # warm-up where all kernels are timed; the other kernels' times come from a few untimed steps afterwards.
+    for i in range(max(0, args.preheat)):                   # the same count on every rank (a job has collectives)
+        step(False)
+    barrier()
+    for k in warm_ms:
+        warm_ms[k] = 0.0
     capi.set_kernel_timing("all")
     for i in range(args.warmup):
         step(False)
@@ -670,7 +678,11 @@ def main() -> None:
                        "parallelism": "1 gpu" if world == 1 else
                        f"{world} ranks, one process per GPU: equal blocks of hashes + pair ranges, 2 all-gathers per job "
                        f"inside libneedle_capi.so ({capi.comm_backend()})",
-                       "comm": capi.comm_backend()},
+                       "comm": capi.comm_backend(),
+                       "preheat_jobs": max(0, args.preheat),
+                       "preheat_note": "untimed jobs in front of the W warm-up steps (a step is ~0.6 ms; the device needs "
+                                       "~30 ms under load before kernels run at their steady rate: --preheat 0 with "
+                                       "--steps 20 --warmup 5 measures 590 k, with 50 warm-up steps 641 k)"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": traffic_source,
