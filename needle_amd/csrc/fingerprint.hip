@@ -291,15 +291,18 @@ __device__ __forceinline__ uint32_t classify_window_cert(const double *w, const 
   return bits;
 }
 
-__global__ __launch_bounds__(256) void features_classify_cert_kernel(
+// kCertWaves waves per workgroup, each with a tile of its own and no barrier between them: two, so that five workgroups
+// (30 KB of LDS each) fit a CU -- the kernel is latency-bound and now needs 150 VGPRs, not 376 (fp_core.h WindowStep).
+constexpr int kCertWaves = 2;
+__global__ __launch_bounds__(64 * kCertWaves) void features_classify_cert_kernel(
     const double *__restrict__ chroma, const float *__restrict__ energy, const FpStream *__restrict__ streams, int num_streams,
     const core::ClassifierThresholds *__restrict__ thr, uint32_t step, uint32_t items_per_tile, uint32_t *__restrict__ items,
     uint32_t total_tiles, float cert_k, uint32_t chunk_pairs, CertWork *__restrict__ work, uint32_t *__restrict__ chunk_bitmap,
     uint32_t *__restrict__ chunk_list, CertItem *__restrict__ item_list) {
-  __shared__ double tiles[4][kTileRowsMax * kFeatPitch];
-  __shared__ float sigmas[4][kTileRowsMax];
+  __shared__ double tiles[kCertWaves][kTileRowsMax * kFeatPitch];
+  __shared__ float sigmas[kCertWaves][kTileRowsMax];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t g = blockIdx.x * 4 + wave;
+  const uint32_t g = blockIdx.x * kCertWaves + wave;
   if (g >= total_tiles) return;  // wave-uniform; the waves of a workgroup never wait for each other
   const int si = find_stream<&FpStream::tile_base>(streams, num_streams, g);
   const FpStream st = streams[si];
@@ -597,7 +600,8 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
         }
         {
           KernelTimer timer("features_cert");
-          hipLaunchKernelGGL(features_classify_cert_kernel, dim3((uint32_t)((tiles + 3) / 4)), dim3(256), 0, stream,
+          hipLaunchKernelGGL(features_classify_cert_kernel, dim3((uint32_t)((tiles + kCertWaves - 1) / kCertWaves)),
+                             dim3(64 * kCertWaves), 0, stream,
                              chroma_buf.ptr, energy_buf.ptr, desc.streams.ptr, n, tab.thr, step, items_per_tile, d_items,
                              (uint32_t)tiles, cert_k, kChunkPairs, work, bitmap, chunk_buf.ptr, item_buf.ptr);
         }

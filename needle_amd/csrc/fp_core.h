@@ -856,6 +856,17 @@ template <int R, int C, int PITCH>
 struct WindowStep {
   static NEEDLE_HD void run(const double *w, double *a, double *b) {
     CellStep<R, C, 0>::run(w[R * PITCH + C], a, b);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The 32 sums are pinned at the end of every row (an empty asm that "uses" them): without this the compiler loads all
+    // 192 cells of the window first and adds afterwards -- 384 registers for the cells alone, 376 VGPRs, one wave per
+    // SIMD.  The sums themselves, and their order, are unchanged.
+    if (C == 11) {
+      asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                        "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+      asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]),
+                        "+v"(b[8]), "+v"(b[9]), "+v"(b[10]), "+v"(b[11]), "+v"(b[12]), "+v"(b[13]), "+v"(b[14]), "+v"(b[15]));
+    }
+#endif
     WindowStep<(C == 11) ? R + 1 : R, (C == 11) ? 0 : C + 1, PITCH>::run(w, a, b);
   }
 };
