@@ -175,20 +175,21 @@ class DeviceTelemetry:
         return out
 
 
-def cpu_baseline(eps, results_gpu, hashes_gpu):
-    """The oracle on the host cores (rank 0, N = 1 only): same episodes, same pairs, reference cost
-    structure.  Bounded: the whole 28-episode job when the core count makes it ~<= 30 s, else a prefix of
-    the pair list, scaled.  Also cross-checks the GPU's hashes and results against it."""
+def cpu_baseline(windows, n_total, results_gpu, hashes_gpu, whole_job):
+    """The oracle on the host cores (rank 0, N = 1 only): same episodes, same pairs, reference cost structure.
+    `windows`: the opening-window PCM of a SAMPLE of the job's episodes (all of them when whole_job), n_total the job's
+    episode count.  Bounded to ~30 s: analyze the sample, search as many of its pairs as the budget allows, scale both
+    legs to the whole job.  Cross-checks the GPU's hashes of the sampled episodes (and, when the whole job was run,
+    its results) against the oracle's."""
     import numpy as np
     from oracle import oracle as O
     threads = usable_cpus()
     hd = O.duration_from_secs_f32(0.3)
-    windows = [e.pcm[: len(e.pcm) // 2] for e in eps]
     t0 = time.perf_counter()
     fhs = O.analyze_batch(windows, 1, hd, threads=threads)
-    t_analyze = time.perf_counter() - t0
-    n = len(eps)
-    pairs_total = n * (n - 1) // 2
+    t_analyze = (time.perf_counter() - t0) * n_total / len(windows)
+    n = len(windows)
+    pairs_total = n_total * (n_total - 1) // 2
     # ~0.1 core-seconds per 24-min pair: keep the search leg under ~25 s of wall
     est_pair_s = 0.1 * (len(fhs[0].opening) / 2897.0) ** 2
     budget_pairs = int(25.0 * threads / max(est_pair_s, 1e-6))
@@ -202,13 +203,13 @@ def cpu_baseline(eps, results_gpu, hashes_gpu):
     t_search_full = t_search * pairs_total / max(sample_pairs, 1)
     value = pairs_total / (t_analyze + t_search_full)
     # second CPU number, so the ratio is not inflated by the reference's allocation pattern: the
-    # same scan without the table, one pass per diagonal, all pairs over all threads; same analyze stage
+    # same scan without the table, one pass per diagonal, all sampled pairs over all threads; same analyze stage
     seqs = [np.array([h for h, _ in f.opening], dtype=np.uint32) for f in fhs]
     t0 = time.perf_counter()
     opt_runs, _ = O.diagonal_runs_all_pairs(seqs, 10, 82, threads=threads)
-    t_opt = time.perf_counter() - t0
+    t_opt = (time.perf_counter() - t0) * pairs_total / max(n * (n - 1) // 2, 1)
     parity = all(hashes_gpu[v].tolist() == [h for h, _ in fhs[v].opening] for v in range(n))
-    if k == n:
+    if whole_job and k == n:
         got = [None if r is None else (r.opening, r.ending) for r in results_gpu]
         want = [None if r is None else (r.opening, r.ending) for r in res]
         parity = parity and got == want
@@ -216,14 +217,14 @@ def cpu_baseline(eps, results_gpu, hashes_gpu):
         "value": round(value, 3), "unit": "episode-pairs/s", "cores": threads, "kind": "port",
         "cpu_model": cpu_model(),
         "sample": f"oracle (C restatement of analyzer.rs/comparator.rs + chromaprint in f64, not the Rust binary): "
-                  f"analyze all {n} episodes in {t_analyze:.2f} s, search {sample_pairs}/{pairs_total} pairs in "
-                  f"{t_search:.2f} s (scaled to all pairs), {threads} threads, PCM in host memory",
-        "analyze_s": round(t_analyze, 3), "search_s_scaled": round(t_search_full, 3),
+                  f"analyze {n} of {n_total} episodes, search {sample_pairs} of {pairs_total} pairs in "
+                  f"{t_search:.2f} s (both legs scaled to the whole job), {threads} threads, PCM in host memory",
+        "analyze_s_scaled": round(t_analyze, 3), "search_s_scaled": round(t_search_full, 3),
         "gpu_matches_oracle": bool(parity),
         "optimised_cpu_variant": {"value": round(pairs_total / (t_analyze + t_opt), 3), "unit": "episode-pairs/s",
-                                  "search_s": round(t_opt, 4), "runs": int(opt_runs),
-                                  "what": "same analyze stage + table-free diagonal scan of all pairs (min run 82), "
-                                          f"{threads} threads, without the per-video epilogue"},
+                                  "search_s_scaled": round(t_opt, 4), "runs_in_sample": int(opt_runs),
+                                  "what": "same analyze stage + table-free diagonal scan of the sampled pairs (min run 82), "
+                                          f"{threads} threads, scaled, without the per-video epilogue"},
     }
 
 
@@ -296,18 +297,19 @@ def search_only(capi, synth, episodes, minutes, reps=5):
     t_prep = time.perf_counter()
     half = minutes * 60.0 / 2
     tmp = tempfile.mkdtemp(prefix="needle_bench_search_")
-    paths = []
-    batch = 28
-    for b0 in range(0, episodes, batch):
-        ks = range(b0, min(episodes, b0 + batch))
-        # only the opening half of each episode is ever hashed: synthesise that half (shared intro inside it)
-        eps = [synth.make_episode(k, half, 90.0 if half > 400 else half / 4) for k in ks]
-        batch_paths = [os.path.join(tmp, f"episode-{k:04d}.wav") for k in ks]
-        paths += batch_paths
-        # the product's own writer: Analyzer::run_pcm with the whole (half-)stream as the opening window,
-        # persist = True -> <video>.needle.dat next to each video path
-        capi.Analyzer.from_files(batch_paths).with_opening_search_percentage(1.0).run_pcm(
-            [e.pcm for e in eps], channels=1, persist=True)
+    paths = [os.path.join(tmp, f"episode-{k:04d}.wav") for k in range(episodes)]
+    # Only the opening half of each episode is ever hashed: that half is generated in HBM (synth.DeviceLibrary),
+    # fingerprinted there, and every video's FrameHashes is written with the product's own writer
+    # (needle_hip_library_frame_hashes + needle_hip_frame_hashes_write -> <video>.needle.dat, data.rs layout).
+    samples = int(round(half * RATE))
+    gen = synth.DeviceLibrary(episodes, samples, 90.0 if half > 400 else half / 4)
+    src = capi.Library(episodes, opening_search_percentage=1.0)
+    src.set_pcm_device(gen.pointers(), [samples] * episodes)
+    gen.free()
+    src.analyze(0, episodes, sync=True)
+    for k, p in enumerate(paths):
+        src.frame_hashes(k).write(os.path.splitext(p)[0] + ".needle.dat")
+    del src, gen
     prep_s = time.perf_counter() - t_prep
     cmp = capi.Comparator(paths)
     capi.set_kernel_timing("hamming_runs,simhash_runs")
@@ -473,6 +475,10 @@ def main() -> None:
     ap.add_argument("--preheat", type=int, default=80,
                     help="untimed jobs run BEFORE the W warm-up steps: a step is 0.6 ms, so 5 warm-up steps are 3 ms, and the "
                          "device needs ~30 ms of load before its kernels run at their steady rate (DESIGN.md section 5)")
+    ap.add_argument("--device-synth", action="store_true",
+                    help="generate every rank's episodes in HBM (needle_amd.synth.DeviceLibrary) instead of on the host: what "
+                         "makes BASELINE.json configs[4] (--episodes 2000 --minutes 45) fit a bench run; the opening half of "
+                         "each episode is generated and is the whole search window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / search_only / roofline_search")
     ap.add_argument("--search-only-episodes", type=int, default=280)
@@ -522,19 +528,36 @@ def main() -> None:
 
     n = args.episodes
     total_samples = int(round(args.minutes * 60.0 * RATE))
-    lib = capi.Library(n)
     # every rank needs every length (metadata), but only the PCM its share of the fingerprinting depends on: the hashes
     # of all episodes are cut into `world` equal blocks (3.5 episodes' worth each for 28 on 8), and rank_videos names
     # the episodes a rank's block meets
-    first, count = lib.rank_videos([total_samples] * n, world, rank)
-    mine = {k: synth.make_episode(k, args.minutes * 60.0, args.intro_seconds) for k in range(first, first + count)}
-    if world == 1:
-        eps = [mine[k] for k in range(n)]
-    lib.set_pcm([mine[k].pcm if k in mine else None for k in range(n)], [total_samples] * n)
+    t_setup = time.perf_counter()
+    eps = None
+    if args.device_synth:
+        window_samples = int(round(args.minutes * 60.0 / 2 * RATE))
+        lib = capi.Library(n, opening_search_percentage=1.0)
+        first, count = lib.rank_videos([window_samples] * n, world, rank)
+        gen = synth.DeviceLibrary(count, window_samples, args.intro_seconds, first_episode=first)
+        ptrs = gen.pointers()
+        # a bounded sample for the CPU baseline / cross-check, read back before the generator's buffer goes
+        sample_ids = list(range(min(n, 40))) if (world == 1 and not args.no_cpu_baseline) else []
+        sample_pcm = [gen.episode(k) for k in sample_ids]
+        lib.set_pcm_device([ptrs[k - first] if first <= k < first + count else None for k in range(n)], [window_samples] * n)
+        gen.free()
+        del gen
+        windows = [window_samples] * n
+    else:
+        lib = capi.Library(n)
+        first, count = lib.rank_videos([total_samples] * n, world, rank)
+        mine = {k: synth.make_episode(k, args.minutes * 60.0, args.intro_seconds) for k in range(first, first + count)}
+        if world == 1:
+            eps = [mine[k] for k in range(n)]
+        lib.set_pcm([mine[k].pcm if k in mine else None for k in range(n)], [total_samples] * n)
+        windows = [total_samples // 2] * n
+    setup_s = time.perf_counter() - t_setup
     cmp = capi.Comparator([f"episode-{k:04d}.wav" for k in range(n)])
     cmp.handle()
     n_pairs = lib.num_pairs()
-    windows = [total_samples // 2] * n
     kept = [capi.lib().needle_hip_fingerprint_num_kept(w, 2) for w in windows]
 
     # default arithmetic: f32 first pass + certification + f64 recomputation of what could not be certified (include/
@@ -583,7 +606,36 @@ def main() -> None:
     # HIP events around every kernel cost 3 % of a step (one more packet between dependent dispatches each), so
     # the timed region carries them for the dominant kernel only -- the one `roofline` is about, found in the
     # warm-up where all kernels are timed; the other kernels' times come from a few untimed steps afterwards.
-    for i in range(max(0, args.preheat)):                   # the same count on every rank (a job has collectives)
+    def rank0_says(x: float) -> float:                       # a decision every rank must take alike (a job has collectives)
+        return float(capi.comm_all_gather(np.array([x], dtype=np.float64))[0, 0]) if world > 1 else x
+
+    # First the COLD figure: W + K steps straight after set-up with nothing in front -- what `--preheat 0` measures and
+    # what a driver that trusts its own --warmup sees.  It doubles as the start of the preheat.  Skipped when one job is
+    # long enough (> 20 ms) that the device's ramp-up (~30 ms under load) cannot matter.
+    step(False)
+    barrier()                                                # first job: slabs grow, tables are built, scan repeated
+    t0 = time.perf_counter()
+    step(False)
+    barrier()
+    probe_ms = rank0_says(1e3 * (time.perf_counter() - t0))
+    cold = None
+    preheat_jobs = 0
+    if args.preheat > 0 and probe_ms <= 20.0:
+        for i in range(args.warmup):
+            step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(False)
+        barrier()
+        cold_s = time.perf_counter() - t0
+        if world > 1:
+            cold_s = float(capi.comm_all_gather(np.array([cold_s], dtype=np.float64)).max())
+        cold = {"value": round(n_pairs / (cold_s / args.steps), 2), "ms_per_step": round(1e3 * cold_s / args.steps, 4),
+                "what": f"the same {args.warmup} + {args.steps} steps run first, two untimed jobs after set-up and nothing else "
+                        "in front (the --preheat 0 figure); `value` is the steady state reached after the preheat jobs"}
+        preheat_jobs = max(0, args.preheat - args.warmup - args.steps)
+    for i in range(preheat_jobs):
         step(False)
     barrier()
     for k in warm_ms:
@@ -647,7 +699,7 @@ def main() -> None:
         achieved = abytes / (avg[dominant] * 1e-3) / 1e9 if avg[dominant] > 0 else 0.0
         traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes/launch from rocprofv3 PMC passes (N = 1 launch shape)
-        if os.path.exists(tpath) and world == 1:
+        if os.path.exists(tpath) and world == 1 and n == 28 and args.minutes == 24.0:
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(dominant)
@@ -669,20 +721,27 @@ def main() -> None:
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64-certified (f32 first pass)" if certified else "f64",
             "data": "synthetic",
-            "config": {"workload": f"{n} episodes x {args.minutes:g} min synthetic mono s16 PCM @ 11025 Hz, PCM RESIDENT IN HBM "
-                                   f"before the timed region (host->device copy excluded: see end_to_end), "
-                                   f"{args.intro_seconds:g} s shared intro, opening window 50 %, hash 0.3 s, "
-                                   f"threshold 10, min opening 20 s; analyze+search, {n_pairs} pairs "
-                                   f"(BASELINE.json configs[1]; configs[3] sharding when n_gpus > 1)",
+            "config": {"workload": (f"{n} episodes x {args.minutes:g} min synthetic mono s16 PCM @ 11025 Hz, PCM RESIDENT IN HBM "
+                                    f"before the timed region (host->device copy excluded: see end_to_end), "
+                                    f"{args.intro_seconds:g} s shared intro, opening window 50 %, hash 0.3 s, "
+                                    f"threshold 10, min opening 20 s; analyze+search, {n_pairs} pairs "
+                                    + ("(BASELINE.json configs[4]'s library: 2000 x 45 min, full O(N^2) search; PCM generated in HBM, "
+                                       "the streamed-from-pinned form is tools/library_stream_device.py)"
+                                       if (n, args.minutes) == (2000, 45.0) else
+                                       "(BASELINE.json configs[1]; configs[3] sharding when n_gpus > 1)"
+                                       if (n, args.minutes) == (28, 24.0) else "(not one of BASELINE.json's configurations)")),
                        "episodes": n, "pairs": n_pairs, "hashes_per_episode": kept[0],
                        "parallelism": "1 gpu" if world == 1 else
                        f"{world} ranks, one process per GPU: equal blocks of hashes + pair ranges, 2 all-gathers per job "
                        f"inside libneedle_capi.so ({capi.comm_backend()})",
                        "comm": capi.comm_backend(),
-                       "preheat_jobs": max(0, args.preheat),
-                       "preheat_note": "untimed jobs in front of the W warm-up steps (a step is ~0.6 ms; the device needs "
-                                       "~30 ms under load before kernels run at their steady rate: --preheat 0 with "
-                                       "--steps 20 --warmup 5 measures 590 k, with 50 warm-up steps 641 k)"},
+                       "preheat_jobs": (2 + args.warmup + args.steps + preheat_jobs) if cold else 2,
+                       "preheat_note": "untimed jobs in front of the W warm-up steps, the cold measurement's own steps "
+                                       "included (a step is ~0.6 ms; the device needs ~30 ms under load before kernels run "
+                                       "at their steady rate); `cold` is the figure without them.  Jobs longer than 20 ms "
+                                       "get two untimed jobs and no cold figure",
+                       "setup_s": round(setup_s, 2), "synth": "device (HBM)" if args.device_synth else "host"},
+            "cold": cold,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": traffic_source,
@@ -715,16 +774,24 @@ def main() -> None:
                                                 "note": "integer-VALU-bound by construction (~1450 ops per byte): the HBM fraction says nothing"})
             except capi.NeedleError as e:
                 out["roofline_search"] = {"error": str(e)}
-        if world == 1 and not args.no_extras:
+        out["comm_bytes_per_job"] = dict(lib.job_comm_bytes(0), what="received per rank in one steady-state job: all-gather of "
+                                         "hash rows (the arena's equal blocks), all-gather of run-list heads (count + the last "
+                                         "job's largest list + margin, per rank), all-gather of per-video results when the "
+                                         "epilogue is sharded; scans_repeated = overflows met (0 in the steady state)")
+        out["host_threads_per_rank"] = capi.host_threads()
+        if world == 1 and not args.no_extras and eps is not None:
             out["end_to_end"] = end_to_end(capi, eps, cmp, n_pairs)
+        if world == 1 and not args.no_extras:
             so = search_only(capi, synth, args.search_only_episodes, 24.0)
             if "roofline_search" in out and "peak" in out["roofline_search"]:
                 so["roofline"] = search_roofline(out["roofline_search"]["ceiling_cells_per_s"], so.pop("issued_evals"),
                                                  so["table_cells"], so["scan_kernel_ms"])
             out["search_only"] = so
         if world == 1 and not args.no_cpu_baseline:
-            hashes = [lib.frame_hashes(v).opening_data()[0] for v in range(n)]
-            out["cpu_baseline"] = cpu_baseline(eps, state["results"], hashes)
+            if eps is not None:
+                sample_ids, sample_pcm = list(range(n)), [e.pcm[: len(e.pcm) // 2] for e in eps]
+            hashes = [lib.frame_hashes(v).opening_data()[0] for v in sample_ids]
+            out["cpu_baseline"] = cpu_baseline(sample_pcm, n, state["results"], hashes, whole_job=len(sample_ids) == n)
         if sup_dir:                                              # supervisor 0 prints it once the attempt has succeeded
             tmp = os.path.join(sup_dir, f".result.{attempt}.tmp")
             with open(tmp, "w") as f:

@@ -104,6 +104,26 @@ enum NeedleError needle_hip_fingerprint_device(const int16_t *d_pcm, const uint6
  * on the current device since the last reset; waits for the library stream. */
 enum NeedleError needle_hip_fingerprint_cert_stats(uint64_t counts[4], bool reset);
 
+/* Audit of that first pass.  The acceptance radius is an EMPIRICAL guard, not a proven bound: K = 64
+ * times the error scale S, where the worst |log v32 - log v64| / S ever observed is 1.8.  This makes the claim checkable on
+ * any input: both transforms -- the f32 first pass and the f64 kernel -- run over the same resident PCM into buffers of
+ * their own and every kept item is examined on the device with the certification kernel's own functions and K.
+ *   items                : kept items examined
+ *   accepted             : items the first pass accepted (emitted from f32 chroma)
+ *   accepted_mismatches  : accepted items whose f32 bits differ from the f64 pipeline's item (each one a hole: must be 0)
+ *   mismatches           : items of `d_items` (what the product emitted for these streams) that differ from the f64 item
+ *   max_error_over_s     : max over accepted items and their 16 classifiers of |log v32 - log v64| / S (compare with K)
+ *   max_s                : largest S among accepted items
+ * Same stream description as needle_hip_fingerprint_device; synchronous; allocates 2 x 96 B per frame while it runs. */
+typedef struct NeedleHipCertAudit {
+  uint64_t items, accepted, accepted_mismatches, mismatches;
+  double max_error_over_s, max_s;
+} NeedleHipCertAudit;
+enum NeedleError needle_hip_fingerprint_audit_device(const int16_t *d_pcm, const uint64_t *pcm_offsets,
+                                                     const uint64_t *num_values, size_t num_streams, int channels,
+                                                     uint32_t step, const uint32_t *d_items, const uint64_t *item_offsets,
+                                                     NeedleHipCertAudit *audit);
+
 /* Test hook: intermediate stages of one stream, copied to the host.  chroma [frames][12] (energy per
  * pitch class per FFT frame), features [frames-4][12] (FIR-filtered, L2-normalised). NULLs allowed. */
 enum NeedleError needle_hip_fingerprint_debug(const int16_t *pcm, size_t num_values, int channels,
@@ -280,6 +300,10 @@ enum NeedleError needle_hip_library_fetch_runs_end(NeedleHipLibrary *library, in
 enum NeedleError needle_hip_library_finalize(NeedleHipLibrary *library, const struct NeedleAudioComparator *comparator,
                                              const NeedleHipRun *runs, size_t num_runs,
                                              NeedleHipSearchResult *results);
+/* needle_hip_fingerprint_audit_device over the hashes this rank's share of the fingerprinting produced (all of them
+ * without a communicator): the library's resident PCM through both transforms, compared with the arena's rows.  Call after
+ * a job (or needle_hip_library_analyze) has filled the arena; needs set_pcm / set_pcm_device (resident PCM). */
+enum NeedleError needle_hip_library_audit(NeedleHipLibrary *library, NeedleHipCertAudit *audit);
 /* Copies one video's FrameHashes out of the library after analyze (+gather). */
 enum NeedleError needle_hip_library_frame_hashes(NeedleHipLibrary *library, size_t index, FrameHashes **output);
 
@@ -332,6 +356,19 @@ enum NeedleError needle_hip_library_job_begin(NeedleHipLibrary *library, const s
                                               int slot);
 enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *library, const struct NeedleAudioComparator *comparator,
                                             int slot, NeedleHipSearchResult *results, size_t *num_runs);
+/* The complete run list (all pairs, all ranks' shares in rank order) the epilogue of the job that finished last in
+ * `slot` worked from: host memory of the library, valid until the slot's next job_begin.  For checkers and callers
+ * that want the segments themselves ("the final cross-shard pair list"), not only the per-video results. */
+enum NeedleError needle_hip_library_job_runs(const NeedleHipLibrary *library, int slot, const NeedleHipRun **runs,
+                                             size_t *num_runs);
+/* What the collectives of that job moved, as received per rank: bytes[0] hash rows (all-gather of the arena's blocks),
+ * bytes[1] run-list heads (every gather of the job, repeats included), bytes[2] per-video results of a sharded
+ * epilogue; bytes[3] = scans repeated because a slab or a head overflowed (0 in the steady state). */
+enum NeedleError needle_hip_library_job_comm_bytes(const NeedleHipLibrary *library, int slot, uint64_t bytes[4]);
+/* Host threads this process uses for its parallel host phases (epilogue, file reads, upload staging): the CPUs usable
+ * by the process (affinity, cgroup quota) divided by the rank processes of the node once a communicator is up
+ * (LOCAL_WORLD_SIZE if the launcher exports it, else the world size); NEEDLE_HOST_THREADS overrides. */
+int needle_hip_host_threads(void);
 
 #ifdef __cplusplus
 }

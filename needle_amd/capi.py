@@ -93,7 +93,8 @@ NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_comm_all_gather_host", "needle_hip_comm_shard", "needle_hip_library_job_begin",
     "needle_hip_library_job_end", "needle_hip_library_stream_pcm", "needle_hip_host_alloc",
     "needle_hip_host_alloc_free", "needle_hip_int_valu_ceiling",
-    "needle_hip_comparator_results_from_runs"]
+    "needle_hip_comparator_results_from_runs", "needle_hip_library_job_runs", "needle_hip_library_job_comm_bytes",
+    "needle_hip_host_threads", "needle_hip_fingerprint_audit_device", "needle_hip_library_audit"]
 
 _LIB = None
 
@@ -263,6 +264,12 @@ def scan_issued_evaluations(reset: bool = False) -> int:
     lib().needle_hip_scan_issued_evaluations.argtypes = [C.POINTER(C.c_uint64), C.c_bool]
     check(lib().needle_hip_scan_issued_evaluations(C.byref(v), reset))
     return int(v.value)
+
+
+def host_threads() -> int:
+    """Host threads this process uses for its parallel host phases (needle_hip_host_threads)."""
+    lib().needle_hip_host_threads.restype = C.c_int
+    return int(lib().needle_hip_host_threads())
 
 
 def int_valu_ceiling() -> float:
@@ -637,6 +644,27 @@ def comm_shard(units: int, world: int, rank: int) -> Tuple[int, int]:
     return first.value, count.value
 
 
+class CCertAudit(C.Structure):
+    _fields_ = [("items", C.c_uint64), ("accepted", C.c_uint64), ("accepted_mismatches", C.c_uint64),
+                ("mismatches", C.c_uint64), ("max_error_over_s", C.c_double), ("max_s", C.c_double)]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def fingerprint_audit_device(d_pcm: int, pcm_offsets, num_values, channels: int, step: int, d_items: int, item_offsets) -> dict:
+    """needle_hip_fingerprint_audit_device: f32 first pass vs f64 kernel over the same resident PCM."""
+    n = len(num_values)
+    a = CCertAudit()
+    u64 = C.c_uint64 * n
+    lib().needle_hip_fingerprint_audit_device.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_size_t,
+                                                          C.c_int, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64),
+                                                          C.POINTER(CCertAudit)]
+    check(lib().needle_hip_fingerprint_audit_device(d_pcm, u64(*pcm_offsets), u64(*num_values), n, channels, step, d_items,
+                                                    u64(*item_offsets), C.byref(a)))
+    return a.as_dict()
+
+
 # ---- HBM-resident library (bench / multi-GPU) -----------------------------------------------------------------
 class Library:
     """NeedleHipLibrary: PCM resident in HBM, padded device hash arena, pair-sharded search."""
@@ -740,6 +768,29 @@ class Library:
         found = C.c_size_t(0)
         check(lib().needle_hip_library_job_end(self._h, comparator._h or comparator.handle(), slot, res, C.byref(found)))
         return _results(res, self.n), found.value
+
+    def audit(self) -> dict:
+        """Both transforms over this rank's resident PCM, every kept item compared on the device (needle_hip_library_audit)."""
+        a = CCertAudit()
+        lib().needle_hip_library_audit.argtypes = [C.c_void_p, C.POINTER(CCertAudit)]
+        check(lib().needle_hip_library_audit(self._h, C.byref(a)))
+        return a.as_dict()
+
+    def job_runs(self, slot: int = 0) -> np.ndarray:
+        """The complete run list of the job that finished last in `slot` (a copy; needle_hip_library_job_runs)."""
+        ptr, total = C.c_void_p(), C.c_size_t(0)
+        lib().needle_hip_library_job_runs.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        check(lib().needle_hip_library_job_runs(self._h, slot, C.byref(ptr), C.byref(total)))
+        out = np.zeros(total.value, dtype=RUN_DTYPE)
+        if total.value:
+            C.memmove(out.ctypes.data, ptr.value, out.nbytes)
+        return out
+
+    def job_comm_bytes(self, slot: int = 0) -> dict:
+        b = (C.c_uint64 * 4)()
+        lib().needle_hip_library_job_comm_bytes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+        check(lib().needle_hip_library_job_comm_bytes(self._h, slot, b))
+        return {"hash_rows": int(b[0]), "run_heads": int(b[1]), "results": int(b[2]), "scans_repeated": int(b[3])}
 
     def __del__(self):
         if getattr(self, "_h", None):

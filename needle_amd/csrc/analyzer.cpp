@@ -210,7 +210,7 @@ Status Analyzer::run(ns_t hash_duration, bool persist, bool threading, std::vect
     const std::pair<int, int> key{p.info.channels, p.info.sample_rate};
     if (std::find(keys.begin(), keys.end(), key) == keys.end()) keys.push_back(key);
   }
-  const unsigned readers = threading ? std::min(usable_cpus(), 16u) : 1u;
+  const unsigned readers = threading ? std::min(host_threads(), 16u) : 1u;
   const size_t per = include_endings_ ? 2 : 1;
   for (const std::pair<int, int> &key : keys) {
     std::vector<const Pending *> group;

@@ -484,6 +484,24 @@ enum NeedleError needle_hip_fingerprint_device(const int16_t *d_pcm, const uint6
   });
 }
 
+enum NeedleError needle_hip_fingerprint_audit_device(const int16_t *d_pcm, const uint64_t *pcm_offsets, const uint64_t *num_values,
+                                                     size_t num_streams, int channels, uint32_t step, const uint32_t *d_items,
+                                                     const uint64_t *item_offsets, NeedleHipCertAudit *audit) {
+  if (!d_pcm || !pcm_offsets || !num_values || !d_items || !item_offsets || !audit) return NeedleError_NullArgument;
+  return guarded([&]() -> NeedleError {
+    std::vector<StreamSpan> spans(num_streams);
+    for (size_t i = 0; i < num_streams; i++) spans[i] = StreamSpan{pcm_offsets[i], num_values[i], item_offsets[i]};
+    uint64_t c[4] = {0, 0, 0, 0};
+    Status s = gpu_fingerprint_audit_device(d_pcm, spans, channels, step, d_items, c, &audit->max_error_over_s, &audit->max_s);
+    if (!s.ok()) return report(s);
+    audit->items = c[0];
+    audit->accepted = c[1];
+    audit->accepted_mismatches = c[2];
+    audit->mismatches = c[3];
+    return NeedleError_Ok;
+  });
+}
+
 enum NeedleError needle_hip_fingerprint_debug(const int16_t *pcm, size_t num_values, int channels, double *chroma,
                                               double *features) {
   if (!pcm) return NeedleError_NullArgument;

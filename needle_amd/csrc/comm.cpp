@@ -141,6 +141,14 @@ Status nccl_status(const RcclApi &api, ncclResult_t r, const char *what) {
 }
 }  // namespace
 
+// Rank processes sharing this node's CPUs: the launcher's LOCAL_WORLD_SIZE when it exports one (torchrun does), else the
+// world size (this transport is single-node).  Sizes every rank's host thread pool (common.h host_threads()).
+unsigned node_ranks(int world) {
+  if (const char *e = getenv("LOCAL_WORLD_SIZE"))
+    if (atoi(e) > 0) return (unsigned)atoi(e);
+  return (unsigned)std::max(world, 1);
+}
+
 Comm *comm_get() { return g_comm; }
 int comm_rank() { return g_comm ? g_comm->rank : 0; }
 int comm_world() { return g_comm ? g_comm->world : 1; }
@@ -232,6 +240,7 @@ Status comm_init(const uint8_t id[128], int rank, int world) {
       return s;
     }
     g_comm = c;
+    set_node_ranks(node_ranks(world));
     return Status::Ok();
   }
 
@@ -278,6 +287,7 @@ Status comm_init(const uint8_t id[128], int rank, int world) {
   } else {
     c->nccl[kSide] = c->nccl[kData];
   }
+  set_node_ranks(node_ranks(world));
   return Status::Ok();
 }
 
@@ -286,6 +296,7 @@ void comm_finalize() {
   Comm *c = g_comm;
   if (!c) return;
   g_comm = nullptr;
+  set_node_ranks(1);
   (void)hipDeviceSynchronize();
   if (c->host) {
     if (c->shm) munmap(c->shm, c->shm_bytes);

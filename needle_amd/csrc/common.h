@@ -64,6 +64,11 @@ std::string format_f32_json(float v);                                           
 // Host CPUs this process may use: hardware threads capped by its affinity mask and by the cgroup CPU quota (a
 // container can see every core of the machine and be granted a few CPUs of time).
 unsigned usable_cpus();
+// This process's share of them: usable_cpus() divided by the rank processes of this node (set_node_ranks(), called by
+// the communicator with max(world, LOCAL_WORLD_SIZE); 1 without a communicator), at least 1.  Eight ranks on a 16-CPU
+// share get two epilogue threads each instead of 8 x 16 threads on 16 CPUs.  NEEDLE_HOST_THREADS overrides it.
+unsigned host_threads();
+void set_node_ranks(unsigned ranks);
 
 // ---- chromaprint-facing constants -------------------------------------------------
 constexpr int kSampleRate = 11025;
@@ -169,6 +174,9 @@ Status gpu_int_valu_ceiling(double *cells_per_second);
 Status gpu_scan_issued_evaluations(uint64_t *lane_evaluations, bool reset);
 // certified f32 first pass of the fingerprinter: {items, items recomputed in f64, chunks of frame pairs, chunks recomputed}
 Status gpu_fingerprint_cert_stats(uint64_t out[4], bool reset);
+// audit of that first pass: both transforms over the same PCM, every kept item compared on the device (fingerprint.hip)
+Status gpu_fingerprint_audit_device(const int16_t *d_pcm, const std::vector<StreamSpan> &spans, int channels, uint32_t step,
+                                    const uint32_t *d_items, uint64_t out[4], double *max_ratio, double *max_sigma);
 
 // ---- resampler front-end (resample.hip) -------------------------------------------------------------------
 struct ResampleSpan {

@@ -34,8 +34,7 @@ struct EpilogueTrace {  // NEEDLE_HIP_TRACE=1: phase times of the host epilogue 
 };
 
 unsigned host_workers(uint64_t work) {  // NEEDLE_HOST_THREADS=1 forces the sequential path
-  unsigned hw = usable_cpus();
-  if (const char *e = std::getenv("NEEDLE_HOST_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));
+  const unsigned hw = host_threads();  // this rank's share of the node's CPUs (common.h)
   return (work < (1u << 22) || hw <= 1) ? 1u : std::min(hw, 64u);
 }
 
@@ -714,8 +713,7 @@ Status Comparator::run(bool analyze, bool display, bool use_skip_files, bool wri
     // `threading` they go to host threads (a library is thousands of small files), and the error reported is the
     // one the sequential walk would have hit first.
     std::vector<Status> status(videos_.size());
-    unsigned workers = threading ? std::min(usable_cpus(), 16u) : 1u;
-    if (const char *e = std::getenv("NEEDLE_HOST_THREADS")) workers = (unsigned)std::max(1, std::atoi(e));
+    const unsigned workers = threading ? std::min(host_threads(), 16u) : 1u;
     parallel_chunks(videos_.size(), 16, videos_.size() >= 64 ? workers : 1u, [&](size_t b, size_t e) {
       for (size_t v = b; v < e; v++)
         status[v] = frame_hashes_read(with_extension(videos_[v], FRAME_HASH_DATA_FILE_NAME), &data[v]);

@@ -364,6 +364,69 @@ __global__ __launch_bounds__(256) void fixup_items_kernel(const double *__restri
   }
 }
 
+// ---- audit of the certified first pass -----------------------------------------------------------------------------
+// Not part of a job: needle_hip_fingerprint_audit_device / needle_hip_library_audit run BOTH transforms over the same
+// resident PCM -- stft_chroma32_kernel into one chroma buffer, stft_chroma_kernel (f64) into another -- and this kernel
+// then looks at every kept item with the certification kernel's own functions: the acceptance decision from the f32
+// chroma (feature_row_cert, classify_window_cert, the same K), the f64 pipeline's item from the f64 chroma
+// (feature_row, classify_window), and for every ACCEPTED item the quantity the radius is a bound on,
+//     max over the 16 classifiers of |log v32 - log v64| / S,      v = (1 + a) / (1 + b),
+// reduced to a maximum over the batch.  Counts: accepted items whose f32 bits differ from the f64 item (each one a
+// hole in the guarantee: must be 0), and items of the product's own output `items` that differ from the f64 item.
+struct AuditCounts {
+  unsigned long long items, accepted, accepted_wrong, final_wrong;
+  unsigned long long max_ratio_bits, max_sigma_bits;  // doubles >= 0 compare like their bit patterns
+};
+__global__ __launch_bounds__(64) void audit_items_kernel(const double *__restrict__ chroma32, const float *__restrict__ energy,
+                                                         const double *__restrict__ chroma64, const FpStream *__restrict__ streams,
+                                                         int num_streams, const core::ClassifierThresholds *__restrict__ thr,
+                                                         uint32_t step, uint32_t items_per_tile, const uint32_t *__restrict__ items,
+                                                         uint32_t total_tiles, float cert_k, AuditCounts *__restrict__ out) {
+  __shared__ double tile32[kTileRowsMax * kFeatPitch], tile64[kTileRowsMax * kFeatPitch];
+  __shared__ float sig[kTileRowsMax];
+  const uint32_t lane = threadIdx.x, g = blockIdx.x;
+  if (g >= total_tiles) return;
+  const int si = find_stream<&FpStream::tile_base>(streams, num_streams, g);
+  const FpStream st = streams[si];
+  const uint32_t k0 = (g - st.tile_base) * items_per_tile;
+  const uint32_t count = min(items_per_tile, st.kept - k0);
+  const uint32_t x0 = k0 * step;
+  const uint32_t rows = (count - 1) * step + 16;
+  const uint64_t row0 = (uint64_t)st.frame_base + x0;
+  for (uint32_t r = lane; r < rows; r += 64) {
+    sig[r] = feature_row_cert(chroma32 + (row0 + r) * kBands, energy + (row0 + r) * stft::kEnergyParts, cert_k, tile32 + r * kFeatPitch);
+    feature_row(chroma64 + (row0 + r) * kBands, tile64 + r * kFeatPitch);
+  }
+  wave_lds_fence();
+  if (lane >= count) return;
+  float s_max = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; r++) s_max = fmaxf(s_max, sig[lane * step + r]);
+  bool unc = false;
+  const double r = (double)cert_k * (double)s_max;
+  const uint32_t bits32 = classify_window_cert<kFeatPitch>(tile32 + lane * step * kFeatPitch, thr, r + r * r, &unc);
+  unc = unc || !(r < 0.25);
+  const uint32_t bits64 = core::classify_window<kFeatPitch>(tile64 + lane * step * kFeatPitch, thr);
+  atomicAdd(&out->items, 1ull);
+  if (items[st.item_off + k0 + lane] != bits64) atomicAdd(&out->final_wrong, 1ull);
+  if (unc) return;
+  atomicAdd(&out->accepted, 1ull);
+  if (bits32 != bits64) atomicAdd(&out->accepted_wrong, 1ull);
+  double a32[16], b32[16], a64[16], b64[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) a32[i] = b32[i] = a64[i] = b64[i] = 0.0;
+  core::WindowStep<0, 0, kFeatPitch>::run(tile32 + lane * step * kFeatPitch, a32, b32);
+  core::WindowStep<0, 0, kFeatPitch>::run(tile64 + lane * step * kFeatPitch, a64, b64);
+  double err = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+    err = fmax(err, fabs(log((1.0 + a32[i]) / (1.0 + b32[i])) - log((1.0 + a64[i]) / (1.0 + b64[i]))));
+  // S = 0: silence or rows under the norm cut in both pipelines -- every feature is exactly zero, err must be too
+  const double ratio = s_max > 0.0f ? err / (double)s_max : (err > 0.0 ? __builtin_inf() : 0.0);
+  atomicMax(&out->max_ratio_bits, (unsigned long long)__double_as_longlong(ratio));
+  atomicMax(&out->max_sigma_bits, (unsigned long long)__double_as_longlong((double)s_max));
+}
+
 // ---- kernel 3: 16 classifiers over a 16x12 window, one thread per kept item ----------------------------------
 __global__ __launch_bounds__(256) void classify_kernel(const double *__restrict__ feat,
                                                        const FpStream *__restrict__ streams, int num_streams,
@@ -697,6 +760,112 @@ Status gpu_fingerprint_cert_stats(uint64_t out[4], bool reset) {
   out[2] = ws->chunks_total;
   out[3] = host.chunks_recomputed;
   if (reset) ws->items_total = ws->chunks_total = 0;
+  return Status::Ok();
+}
+
+// Audit (include/needle_hip.h needle_hip_fingerprint_audit_device): both transforms over the same resident PCM, every
+// kept item compared on the device.  out = {items, accepted by the first pass, accepted items whose f32 bits are not the
+// f64 item, items of d_items that are not the f64 item}; *max_ratio = max |log v32 - log v64| / S over accepted items.
+Status gpu_fingerprint_audit_device(const int16_t *d_pcm, const std::vector<StreamSpan> &spans, int channels, uint32_t step,
+                                    const uint32_t *d_items, uint64_t out[4], double *max_ratio, double *max_sigma) {
+  std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
+  if (channels != 1 && channels != 2) return Status::Make(NeedleError_InvalidArgument, "fingerprint: channels must be 1 or 2");
+  if (step == 0) return Status::Make(NeedleError_InvalidArgument, "fingerprint: step must be >= 1");
+  Status s = ensure_device();
+  if (!s.ok()) return s;
+  FpTables tab;
+  if (!(s = get_tables(&tab)).ok()) return s;
+  hipStream_t stream = library_stream();
+  // buffers of its own, freed on return: an audit must not disturb the workspaces of jobs in flight
+  DeviceBuffer<double> chroma32, chroma64;
+  DeviceBuffer<float> energy;
+  DeviceBuffer<uint32_t> ctl;
+  DeviceBuffer<FpStream> d_streams;
+  DeviceBuffer<AuditCounts> d_counts;
+  if (!(s = d_counts.reserve(1)).ok() || !(s = ctl.reserve(64)).ok()) return s;
+  NEEDLE_HIP_TRY(hipMemsetAsync(d_counts.ptr, 0, sizeof(AuditCounts), stream));
+  float cert_k = 64.0f;
+  if (const char *e = getenv("NEEDLE_HIP_CERT_K")) cert_k = std::max(0.0f, (float)atof(e));
+  int cus = 256;
+  {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cus = std::max(cus, 1);
+  }
+  {
+    const void *variants[2] = {reinterpret_cast<const void *>(stft_chroma_kernel<1, 0, false>),
+                               reinterpret_cast<const void *>(stft_chroma_kernel<2, 0, false>)};
+    for (const void *fn : variants)
+      NEEDLE_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(core::kLds2Slots * sizeof(cd))));
+  }
+  const uint64_t kMaxFramesPerChunk = 4u << 20;
+  const uint32_t items_per_tile = (uint32_t)std::min<uint64_t>(64, (uint64_t)(kTileRowsMax - 16) / step + 1);
+  size_t begin = 0;
+  while (begin < spans.size()) {
+    std::vector<FpStream> meta;
+    uint64_t frames = 0, rows = 0, kept = 0, pairs = 0, tiles = 0;
+    size_t end = begin;
+    while (end < spans.size()) {
+      const size_t samples = spans[end].num_values / (size_t)channels;
+      const uint64_t f = num_frames(samples);
+      if (!meta.empty() && frames + f > kMaxFramesPerChunk) break;
+      if (f > 0xFFFFFFF0ull) return Status::Make(NeedleError_InvalidArgument, "fingerprint: stream too long");
+      FpStream m;
+      m.pcm_off = spans[end].pcm_off;
+      m.item_off = spans[end].item_off;
+      m.frames = (uint32_t)f;
+      m.frame_base = (uint32_t)frames;
+      m.fir_rows = f >= (uint64_t)kFirTaps ? (uint32_t)(f - (kFirTaps - 1)) : 0;
+      m.fir_base = (uint32_t)rows;
+      m.kept = (uint32_t)num_kept(samples, step);
+      m.kept_base = (uint32_t)kept;
+      m.pair_base = (uint32_t)pairs;
+      m.tile_base = (uint32_t)tiles;
+      tiles += (m.kept + items_per_tile - 1) / items_per_tile;
+      pairs += (m.frames + 1) / 2;
+      frames += m.frames;
+      rows += m.fir_rows;
+      kept += m.kept;
+      meta.push_back(m);
+      end++;
+    }
+    if (frames > 0 && tiles > 0) {
+      if (!(s = chroma32.reserve(frames * kBands)).ok() || !(s = chroma64.reserve(frames * kBands)).ok() ||
+          !(s = energy.reserve(frames * stft::kEnergyParts)).ok() || !(s = d_streams.reserve(meta.size())).ok())
+        return s;
+      NEEDLE_HIP_TRY(hipStreamSynchronize(stream));  // the previous chunk still reads d_streams; `meta` is pageable
+      NEEDLE_HIP_TRY(hipMemcpyAsync(d_streams.ptr, meta.data(), meta.size() * sizeof(FpStream), hipMemcpyHostToDevice, stream));
+      NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+      const int n = (int)meta.size();
+      const uint32_t grid = (uint32_t)(((pairs + kPairsPerBlock - 1) / kPairsPerBlock + 7) / 8 * 8);
+      if (!(s = launch_stft_chroma32(channels, grid, stream, d_pcm, d_streams.ptr, n, tab.tw32, tab.win32, tab.bin_slot, tab.fold_tab,
+                                     chroma32.ptr, energy.ptr, (uint32_t)pairs, kPairsPerBlock, ctl.ptr, 4)).ok())
+        return s;
+      auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm, d_streams.ptr, n, tab.tw,
+                           tab.wcos, tab.wconst, tab.bin_slot, tab.fold_tab, chroma64.ptr, (uint32_t)pairs, (uint32_t)kPairsPerBlock,
+                           stft::ChunkList{nullptr, nullptr});
+      };
+      if (channels == 1) launch(stft_chroma_kernel<1, 0, false>); else launch(stft_chroma_kernel<2, 0, false>);
+      hipLaunchKernelGGL(audit_items_kernel, dim3((uint32_t)tiles), dim3(64), 0, stream, chroma32.ptr, energy.ptr, chroma64.ptr,
+                         d_streams.ptr, n, tab.thr, step, items_per_tile, d_items, (uint32_t)tiles, cert_k, d_counts.ptr);
+      NEEDLE_HIP_TRY(hipGetLastError());
+    }
+    begin = end;
+  }
+  AuditCounts host;
+  NEEDLE_HIP_TRY(hipMemcpyAsync(&host, d_counts.ptr, sizeof(host), hipMemcpyDeviceToHost, stream));
+  NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+  out[0] = host.items;
+  out[1] = host.accepted;
+  out[2] = host.accepted_wrong;
+  out[3] = host.final_wrong;
+  double ratio = 0.0, sigma = 0.0;
+  std::memcpy(&ratio, &host.max_ratio_bits, sizeof(double));
+  std::memcpy(&sigma, &host.max_sigma_bits, sizeof(double));
+  if (max_ratio) *max_ratio = ratio;
+  if (max_sigma) *max_sigma = sigma;
   return Status::Ok();
 }
 

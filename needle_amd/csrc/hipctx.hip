@@ -457,7 +457,7 @@ Status gpu_upload_pcm(const std::vector<const int16_t *> &pcm, const std::vector
     std::memcpy(dst, pcm[stream_index] + first, count * sizeof(int16_t));
     return Status::Ok();
   };
-  unsigned threads = std::min(usable_cpus(), 16u);
+  unsigned threads = std::min(host_threads(), 16u);
   if (const char *e = getenv("NEEDLE_HIP_UPLOAD_THREADS")) threads = (unsigned)std::max(1, atoi(e));
   return gpu_upload_pcm_streamed(num_values, dev_off, read, threads, d_pcm, stream, issued_cb);
 }

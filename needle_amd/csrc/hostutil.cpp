@@ -16,6 +16,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -508,6 +509,16 @@ unsigned usable_cpus() {
     if (quota > 0 && period > 0) n = std::min(n, (unsigned)std::max(1L, quota / period));
   }
   return n;
+}
+
+namespace {
+std::atomic<unsigned> g_node_ranks{1};
+}
+void set_node_ranks(unsigned ranks) { g_node_ranks.store(std::max(1u, ranks)); }
+unsigned host_threads() {
+  if (const char *e = std::getenv("NEEDLE_HOST_THREADS")) return (unsigned)std::max(1, std::atoi(e));
+  static const unsigned usable = usable_cpus();  // the cgroup files do not change under a running process
+  return std::max(1u, usable / g_node_ranks.load());
 }
 
 }  // namespace needle

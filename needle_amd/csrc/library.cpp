@@ -92,6 +92,9 @@ struct NeedleHipLibrary {
     hipEvent_t searched = nullptr, done = nullptr;
     bool pending = false;
     std::vector<NeedleHipRun> merged;
+    const NeedleHipRun *last_runs = nullptr;  // the complete run list of the job that finished last in this slot
+    size_t last_total = 0;
+    uint64_t comm_bytes[4] = {0, 0, 0, 0};  // received per rank in this job: hash rows, run heads, results; scans repeated
     size_t slab_bytes() const { return kSlabHeader + (size_t)slab_runs * sizeof(NeedleHipRun); }
     size_t head_bytes() const { return kSlabHeader + (size_t)head_runs * sizeof(NeedleHipRun); }
   } job[2];
@@ -584,23 +587,17 @@ void for_rows_of_block(const NeedleHipLibrary *lib, int world, int rank, F &&f) 
   }
 }
 
-// Fingerprints this rank's block: per row the sub-window of PCM its columns depend on, hashes straight to their places.
-NeedleError analyze_flat_block(NeedleHipLibrary *lib, int world, int rank, int slot, uint32_t *zero_word) {
-  std::vector<StreamSpan> spans;
-  bool zeroed = false;
-  lib->count_zeroed = nullptr;
+// The streams this rank's share of the fingerprinting is made of: whole windows without a communicator, otherwise per row
+// of its block the sub-window of PCM the block's columns depend on, hashes straight to their places.
+Status block_spans(const NeedleHipLibrary *lib, int world, int rank, std::vector<StreamSpan> *spans) {
   if (world <= 1) {
     for (size_t row = 0; row < lib->rows(); row++) {
       const Window &w = lib->win[row];
       if (w.pcm_off == ~0ull)
-        return report(Status::Make(NeedleError_InvalidArgument, "video " + std::to_string(row / lib->regions()) + " has no PCM on this rank"));
-      spans.push_back(StreamSpan{w.pcm_off, w.values, (uint64_t)row * lib->stride});
+        return Status::Make(NeedleError_InvalidArgument, "video " + std::to_string(row / lib->regions()) + " has no PCM on this rank");
+      spans->push_back(StreamSpan{w.pcm_off, w.values, (uint64_t)row * lib->stride});
     }
-    // `slot`: the job slot is the pipeline depth -- job k + 1's STFT may overlap the tail of job k (common.h)
-    Status s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->arena, false, nullptr, nullptr, 0, slot,
-                                      zero_word, &zeroed);
-    if (s.ok() && zeroed) lib->count_zeroed = zero_word;
-    return s.ok() ? NeedleError_Ok : report(s);
+    return Status::Ok();
   }
   Status bad;
   for_rows_of_block(lib, world, rank, [&](size_t row, size_t c0, size_t c1) {
@@ -613,13 +610,23 @@ NeedleError analyze_flat_block(NeedleHipLibrary *lib, int world, int rank, int s
     // hashes c0 .. c1-1 = raw items c0 step .. (c1 - 1) step = frames c0 step .. (c1 - 1) step + 19
     const uint64_t x0 = (uint64_t)c0 * lib->step, frames = (uint64_t)(c1 - 1 - c0) * lib->step + 20;
     const uint64_t samples = (frames - 1) * (uint64_t)kHop + (uint64_t)kFrameSize;
-    spans.push_back(StreamSpan{w.pcm_off + x0 * (uint64_t)kHop * (uint64_t)lib->channels, samples * (uint64_t)lib->channels,
-                               (uint64_t)row * lib->stride + c0});
+    spans->push_back(StreamSpan{w.pcm_off + x0 * (uint64_t)kHop * (uint64_t)lib->channels, samples * (uint64_t)lib->channels,
+                                (uint64_t)row * lib->stride + c0});
   });
-  if (!bad.ok()) return report(bad);
+  return bad;
+}
+
+// Fingerprints this rank's block.
+NeedleError analyze_flat_block(NeedleHipLibrary *lib, int world, int rank, int slot, uint32_t *zero_word) {
+  std::vector<StreamSpan> spans;
+  bool zeroed = false;
+  lib->count_zeroed = nullptr;
+  Status s = block_spans(lib, world, rank, &spans);
+  if (!s.ok()) return report(s);
   if (spans.empty()) return NeedleError_Ok;
-  Status s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->arena, false, nullptr, nullptr, 0, slot,
-                                    zero_word, &zeroed);
+  // `slot`: the job slot is the pipeline depth -- job k + 1's STFT may overlap the tail of job k (common.h)
+  s = gpu_fingerprint_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->arena, false, nullptr, nullptr, 0, slot,
+                             zero_word, &zeroed);
   if (s.ok() && zeroed) lib->count_zeroed = zero_word;
   return s.ok() ? NeedleError_Ok : report(s);
 }
@@ -638,8 +645,10 @@ Status job_buffers(NeedleHipLibrary *lib, NeedleHipLibrary::Job &j, int world) {
   }
   // the one-trip download: everything the last job needed plus a margin, the whole slab while that is small
   uint32_t head = lib->last_max_count ? round_up4((uint64_t)lib->last_max_count + lib->last_max_count / 8 + 64) : 4096u;
+  const char *forced = lib->last_max_count ? nullptr : getenv("NEEDLE_HIP_HEAD_RUNS");  // tests: a first head that overflows
+  if (forced) head = round_up4((uint64_t)std::max(4, atoi(forced)));
   head = std::min(head, j.slab_runs);
-  if (j.slab_bytes() * (size_t)world <= (1u << 20)) head = j.slab_runs;
+  if (!forced && j.slab_bytes() * (size_t)world <= (1u << 20)) head = j.slab_runs;
   j.head_runs = head;
   const size_t want = j.head_bytes() * (size_t)world;
   if (world > 1) {
@@ -679,6 +688,7 @@ NeedleError job_search_and_gather(NeedleHipLibrary *lib, const NeedleAudioCompar
     Status s = comm_all_gather(kSide, mine, j.d_heads.ptr, j.head_bytes(), down);
     if (!s.ok()) return report(s);
     src = j.d_heads.ptr;
+    j.comm_bytes[1] += j.head_bytes() * (uint64_t)world;
   }
   if (hipMemcpyAsync(j.host, src, j.head_bytes() * (size_t)world, hipMemcpyDeviceToHost, down) != hipSuccess)
     return report(Status::Make(NeedleError_Unknown, "asynchronous run download failed"));
@@ -791,6 +801,9 @@ enum NeedleError needle_hip_library_job_begin(NeedleHipLibrary *lib, const struc
     NeedleHipLibrary::Job &j = lib->job[slot];
     if (j.pending) return report(Status::Make(NeedleError_InvalidArgument, "job slot still pending"));
     const int world = comm_world(), rank = comm_rank();
+    j.last_runs = nullptr;
+    j.last_total = 0;
+    std::fill(j.comm_bytes, j.comm_bytes + 4, 0);
     if (!lib->flat_shardable(world))
       return report(Status::Make(NeedleError_InvalidArgument,
                                  "the hash arena does not divide into this communicator's blocks: call needle_hip_library_set_pcm "
@@ -815,6 +828,7 @@ enum NeedleError needle_hip_library_job_begin(NeedleHipLibrary *lib, const struc
       Status s = comm_all_gather(kData, reinterpret_cast<const uint8_t *>(lib->arena) + (size_t)rank * block_bytes, lib->arena,
                                  block_bytes, library_stream());
       if (!s.ok()) return report(s);
+      j.comm_bytes[0] += block_bytes * (uint64_t)world;
     }
     // 3. + 4. scan this rank's pair range (comparator.rs:549-564 across GPUs), gather the run lists
     if ((e = job_search_and_gather(lib, comparator, j)) != NeedleError_Ok) return e;
@@ -849,6 +863,7 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
         if (!s.ok()) return report(s);
         NeedleError e = job_search_and_gather(lib, comparator, j);
         if (e != NeedleError_Ok) return e;
+        j.comm_bytes[3]++;
         continue;
       }
       // Some rank found more runs than a slab holds (every rank sees the same counts, so every rank takes this
@@ -860,6 +875,7 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
       if (!s.ok()) return report(s);
       NeedleError e = job_search_and_gather(lib, comparator, j);
       if (e != NeedleError_Ok) return e;
+      j.comm_bytes[3]++;
     }
     j.pending = false;
     // run list of all ranks: heads from the pinned buffer, tails (rare: the first job of a library) straight from HBM
@@ -898,6 +914,8 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
     if (sharded) shard_range(lib->n, world, rank, &v0, &vcount);
     const auto t0 = std::chrono::steady_clock::now();
     if (!run_list) run_list = j.merged.data();
+    j.last_runs = run_list;
+    j.last_total = total;
     Status s = cmp.results_from_runs(fh, run_list, total, false, false, false, &res, v0, v0 + vcount);
     if (getenv("NEEDLE_HIP_TRACE"))
       std::fprintf(stderr, "[needle_hip] rank %d epilogue %zu runs, videos [%zu, %zu): %.1f us\n", rank, total, v0, v0 + vcount,
@@ -919,6 +937,7 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
       for (size_t k = 0; k < vcount; k++)
         fill_c_result(res[v0 + k], reinterpret_cast<NeedleHipSearchResult *>(mine.data() + sizeof(Block)) + k);
     Status g = comm_all_gather_host(mine.data(), all.data(), block_bytes);
+    j.comm_bytes[2] += block_bytes * (uint64_t)world;
     if (!s.ok()) return report(s);
     if (!g.ok()) return report(g);
     for (int r = 0; r < world; r++) {
@@ -929,6 +948,45 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
       shard_range(lib->n, world, r, &f, &c);
       std::memcpy(results + f, blk + sizeof(Block), c * sizeof(NeedleHipSearchResult));
     }
+    return NeedleError_Ok;
+  });
+}
+
+enum NeedleError needle_hip_library_job_runs(const NeedleHipLibrary *lib, int slot, const NeedleHipRun **runs, size_t *num_runs) {
+  if (!lib || !runs || !num_runs) return NeedleError_NullArgument;
+  if (slot < 0 || slot > 1 || lib->job[slot].pending || (!lib->job[slot].last_runs && lib->job[slot].last_total))
+    return NeedleError_InvalidArgument;
+  *runs = lib->job[slot].last_runs;
+  *num_runs = lib->job[slot].last_total;
+  return NeedleError_Ok;
+}
+
+enum NeedleError needle_hip_library_job_comm_bytes(const NeedleHipLibrary *lib, int slot, uint64_t bytes[4]) {
+  if (!lib || !bytes) return NeedleError_NullArgument;
+  if (slot < 0 || slot > 1) return NeedleError_InvalidArgument;
+  std::copy(lib->job[slot].comm_bytes, lib->job[slot].comm_bytes + 4, bytes);
+  return NeedleError_Ok;
+}
+
+int needle_hip_host_threads(void) { return (int)host_threads(); }
+
+enum NeedleError needle_hip_library_audit(NeedleHipLibrary *lib, NeedleHipCertAudit *audit) {
+  if (!lib || !audit) return NeedleError_NullArgument;
+  if (!lib->have_pcm || !lib->pcm_resident) return NeedleError_InvalidArgument;
+  return guarded([&]() -> NeedleError {
+    std::vector<StreamSpan> spans;
+    Status s = block_spans(lib, comm_world(), comm_rank(), &spans);
+    if (!s.ok()) return report(s);
+    uint64_t c[4] = {0, 0, 0, 0};
+    *audit = NeedleHipCertAudit{};
+    if (spans.empty()) return NeedleError_Ok;
+    s = gpu_fingerprint_audit_device(lib->d_pcm.ptr, spans, lib->channels, lib->step, lib->arena, c, &audit->max_error_over_s,
+                                     &audit->max_s);
+    if (!s.ok()) return report(s);
+    audit->items = c[0];
+    audit->accepted = c[1];
+    audit->accepted_mismatches = c[2];
+    audit->mismatches = c[3];
     return NeedleError_Ok;
   });
 }

@@ -3,6 +3,10 @@ tests/test_comm_cpu.py and the -m gpu tests in tests/test_gpu_multi.py.
 
   gpu <out> <n> <seconds> : needle_hip_comm_init + Library.set_pcm (own block) + 3 pipelined job_begin/_end;
                             writes every job's results, the run count and every video's hashes.
+  lib <out> <n> <minutes> : BASELINE.json configs[4]'s shape between ranks: this rank's share of n episodes of `minutes`
+                            (opening half) generated in HBM (synth.DeviceLibrary), three pipelined jobs; writes the
+                            results, the run count, a digest of the SORTED complete run list of every job, what the
+                            job's collectives moved, the host threads this rank used and its epilogue wait.
   cpu <out> <n>           : no device.  The exchange + sharded-epilogue logic on host data: run lists of this
                             rank's pair range (from the oracle's table-free scan -- the checker standing in for the
                             scan kernel, tests only) are all-gathered twice, through torch.distributed/gloo and
@@ -54,6 +58,58 @@ def gpu_main(out, n, seconds):
         json.dump({"rank": rank, "backend": capi.comm_backend(), "world": capi.comm_world_size(),
                    "videos_held": [first, count], "stft_ms": stft_ms,
                    "jobs": [{"results": _res(r), "runs": k} for r, k in jobs], "hashes": hashes}, f)
+    capi.comm_barrier()
+    capi.comm_finalize()
+    rdzv.close()
+
+
+def run_digest(runs):
+    """Order-free digest of a complete run list: within a rank's slab the order is whatever the atomics produced."""
+    import hashlib
+    keys = np.stack([runs[f].astype(np.uint32) for f in ("problem", "src_end", "dst_end", "len", "src_match_hash",
+                                                         "dst_match_hash")], axis=1)
+    keys = keys[np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))]
+    return hashlib.sha256(np.ascontiguousarray(keys).tobytes()).hexdigest()
+
+
+def lib_main(out, n, minutes):
+    import time
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    rdzv = rendezvous.init_comm(capi, rank, world, int(os.environ.get("LOCAL_RANK", "0")),
+                                key=os.environ["NEEDLE_TEST_RDZV_KEY"])
+    samples = int(round(minutes * 60.0 / 2 * synth.RATE))
+    lib = capi.Library(n, opening_search_percentage=1.0)
+    first, count = lib.rank_videos([samples] * n, world, rank)
+    gen = synth.DeviceLibrary(count, samples, 90.0, first_episode=first)
+    ptrs = gen.pointers()
+    lib.set_pcm_device([ptrs[k - first] if first <= k < first + count else None for k in range(n)], [samples] * n)
+    gen.free()
+    cmp = capi.Comparator([f"episode-{k:04d}.wav" for k in range(n)])
+    jobs = []
+
+    def end(slot):
+        t0 = time.perf_counter()
+        res, found = lib.job_end(cmp, slot)
+        wait_ms = 1e3 * (time.perf_counter() - t0)
+        jobs.append({"results": _res(res), "runs": found, "digest": run_digest(lib.job_runs(slot)),
+                     "comm": lib.job_comm_bytes(slot), "end_ms": wait_ms})
+
+    lib.job_begin(cmp, 0)
+    lib.job_begin(cmp, 1)
+    end(0)
+    lib.job_begin(cmp, 0)
+    end(1)
+    end(0)
+    d_arena, stride = lib.hash_arena()
+    arena = np.zeros(n * stride, dtype=np.uint32)
+    capi.check(capi.lib().needle_hip_memcpy_d2h(arena.ctypes.data, d_arena, arena.nbytes))
+    import hashlib
+    kept = int(capi.lib().needle_hip_fingerprint_num_kept(samples, 2))      # the padding beyond it depends on the world size
+    with open(f"{out}.{rank}", "w") as f:
+        json.dump({"rank": rank, "backend": capi.comm_backend(), "world": capi.comm_world_size(),
+                   "videos_held": [first, count], "host_threads": capi.host_threads(), "jobs": jobs, "audit": lib.audit(),
+                   "arena_digest": hashlib.sha256(np.ascontiguousarray(arena.reshape(n, stride)[:, :kept]).tobytes()).hexdigest(),
+                   "stride": stride}, f)
     capi.comm_barrier()
     capi.comm_finalize()
     rdzv.close()
@@ -147,5 +203,7 @@ def _res_json(rs):
 if __name__ == "__main__":
     if sys.argv[1] == "gpu":
         gpu_main(sys.argv[2], int(sys.argv[3]), float(sys.argv[4]))
+    elif sys.argv[1] == "lib":
+        lib_main(sys.argv[2], int(sys.argv[3]), float(sys.argv[4]))
     else:
         cpu_main(sys.argv[2], int(sys.argv[3]))

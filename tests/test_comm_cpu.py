@@ -69,9 +69,11 @@ def _host_comm_rank(rank, world, key, slot_bytes, q):
         for r in range(world):
             ok = ok and np.array_equal(got[r], (np.arange(size, dtype=np.uint8) * (r + 3) + r).astype(np.uint8))
         capi.comm_barrier()
+    threads = capi.host_threads()                      # this rank's share of the node's CPUs while the communicator is up
     capi.comm_finalize()
+    ok = ok and capi.host_threads() >= threads         # back to every usable CPU without one
     rdzv.close()
-    q.put((rank, bool(ok)))
+    q.put((rank, bool(ok), threads) if os.environ.get("NEEDLE_TEST_REPORT_THREADS") else (rank, bool(ok)))
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -87,6 +89,30 @@ def test_host_staged_communicator_between_processes(world):
         p.join(timeout=60)
     assert got == [(r, True) for r in range(world)]
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("needle_comm_")]      # unlinked once everybody attached
+
+
+def test_eight_ranks_share_the_hosts_cpus(monkeypatch):
+    """Every rank sizes its host pools (epilogue, readers, upload staging) to usable CPUs / ranks of the node: eight
+    ranks of one node never run more host threads than the node gives this job.  LOCAL_WORLD_SIZE,
+    which torchrun exports, wins over the world size; NEEDLE_HOST_THREADS wins over both."""
+    usable = capi.host_threads()
+    assert usable == min(len(os.sched_getaffinity(0)), usable) >= 1 and capi.comm_world_size() == 1
+    monkeypatch.setenv("NEEDLE_TEST_REPORT_THREADS", "1")
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = uuid.uuid4().hex
+    procs = [ctx.Process(target=_host_comm_rank, args=(r, world, key, 4096, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [g[:2] for g in got] == [(r, True) for r in range(world)]
+    threads = [g[2] for g in got]
+    assert threads == [max(1, usable // world)] * world and sum(threads) <= max(usable, world)
+    monkeypatch.setenv("NEEDLE_HOST_THREADS", "3")
+    assert capi.host_threads() == 3
 
 
 @pytest.mark.parametrize("world,n", [(2, 7), (3, 8)])

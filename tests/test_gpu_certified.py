@@ -205,3 +205,57 @@ def test_first_pass_error_stays_an_order_of_magnitude_inside_the_radius(monkeypa
     assert all(g.tolist() == w.tolist() for g, w in zip(tight, want))
     _mode(monkeypatch)
     assert all(g.tolist() == w.tolist() for g, w in zip(capi.fingerprint(pcms, step=1), want))
+
+
+def test_audit_finds_what_the_radius_prevents(adversarial, monkeypatch):
+    """needle_hip_library_audit is the on-device check that certified == f64 (both transforms over the same resident
+    PCM, every kept item).  With the product's radius the constructed near-threshold inputs audit clean -- every item was
+    refused by the first pass and recomputed; with NEEDLE_HIP_CERT_K=0 (accept everything) the same audit reports
+    accepted items whose f32 bits are wrong and a product output that differs from the f64 pipeline: the audit is not
+    vacuous either."""
+    pcms = [p for lo, hi, *_ in adversarial for p in (lo, hi)]
+    n = len(pcms)
+
+    def audited(k):
+        _mode(monkeypatch, k=k)
+        lib = capi.Library(n, opening_search_percentage=1.0)
+        lib.set_pcm(pcms, [len(p) for p in pcms])
+        lib.analyze()
+        return lib.audit()
+
+    a = audited(None)
+    assert a["items"] == n and a["accepted"] == 0 and a["mismatches"] == 0 and a["accepted_mismatches"] == 0, a
+    b = audited(0)
+    assert b["items"] == n and b["accepted"] == n and b["accepted_mismatches"] >= 1 and b["mismatches"] >= 1, b
+    _mode(monkeypatch)
+
+
+def test_audit_on_audio_and_hostile_signals(monkeypatch):
+    """On audio the accepted items' |log v32 - log v64| / S stays under ~2 (the gate measured 1.8) against K = 64; on
+    signals built to inflate the f32 error (strong out-of-band tones over weak in-band ones) S grows with it and the
+    ratio stays bounded too; nothing that was accepted differs from the f64 item."""
+    _mode(monkeypatch)
+    eps = synth.make_library(6, 240.0, 30.0)
+    lib = capi.Library(len(eps))
+    lib.set_pcm([e.pcm for e in eps], [len(e.pcm) for e in eps])
+    lib.analyze()
+    a = lib.audit()
+    assert a["mismatches"] == 0 and a["accepted_mismatches"] == 0 and 0 < a["max_error_over_s"] <= 8.0, a
+    assert a["accepted"] > 0.99 * a["items"]
+    rng = np.random.default_rng(5)
+    n = 30 * 11025
+    t = np.arange(n) / 11025.0
+    zoo = [30 * np.sin(2 * np.pi * 440 * t) + 30000 * np.sin(2 * np.pi * 5000.0 * t),
+           300 * np.sin(2 * np.pi * 440 * t) + 30000,
+           rng.standard_normal(n) * 3 + 30000 * np.sin(2 * np.pi * 5100 * t),
+           30000 * np.sin(2 * np.pi * (20 * t + 0.5 * 390 * t * t)),
+           np.where(np.sin(2 * np.pi * 220 * t) >= 0, 32767.0, -32768.0),
+           rng.standard_normal(n) * 1.0, np.zeros(n),
+           12000 * np.sin(2 * np.pi * 523.25 * t) + rng.standard_normal(n) * 0.7]
+    pcms = [np.clip(np.rint(v), -32768, 32767).astype(np.int16) for v in zoo]
+    lib = capi.Library(len(pcms), opening_search_percentage=1.0)
+    lib.set_pcm(pcms, [len(p) for p in pcms])
+    lib.analyze()
+    z = lib.audit()
+    print("audit audio:", a, "zoo:", z)
+    assert z["mismatches"] == 0 and z["accepted_mismatches"] == 0 and z["max_error_over_s"] <= 16.0, z

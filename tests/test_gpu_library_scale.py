@@ -135,6 +135,13 @@ def test_config4_full_size_on_one_gpu():
         clock = 0.123 / (1365 / 11025.0)
         assert abs(start / 1e9 - off * clock) < 4.0 and abs(end / 1e9 - (off + 90.0) * clock) < 4.0, (v, start, end, off)
 
+    # the certified first pass audited over ALL 2000 episodes: the f64 kernel over the same resident PCM, every one of the
+    # 10.9 M kept items compared on the device (the oracle checks below can only sample)
+    audit = lib.audit()
+    print("audit 2000 x 45 min:", audit)
+    assert audit["items"] == n * 5441 and audit["mismatches"] == 0 and audit["accepted_mismatches"] == 0
+    assert audit["accepted"] > 0.99 * audit["items"] and audit["max_error_over_s"] <= 8.0
+
     # every video's kept hashes in one copy of the arena
     d_arena, stride = lib.hash_arena()
     kept = 5441
@@ -178,3 +185,68 @@ def test_config4_full_size_on_one_gpu():
     sel = sorted(set([0, n - 1] + rng.choice(n, size=min(22, n), replace=False).tolist()))
     want_sel = O.run_selected_videos(O.Comparator(), gpu_hashes, [ts] * n, hd, sel, threads=threads)
     assert [None if r is None else (r.opening, r.ending) for r in want_sel] == [got_all[v] for v in sel]
+
+
+RANKS_EPISODES = int(os.environ.get("NEEDLE_TEST_RANKS_EPISODES", "400"))
+
+
+@pytest.mark.parametrize("world,env", [
+    (4, {"NEEDLE_HIP_SLAB_RUNS": "2048"}),                       # slab overflow on the first job: grow + rescan + regather
+    (5, {"NEEDLE_HIP_HEAD_RUNS": "64", "NEEDLE_HIP_SHARD_EPILOGUE": "0"}),   # head overflow; unsharded epilogue on every rank
+])
+def test_config4_shape_between_ranks_on_one_gpu(tmp_path, world, env):
+    """BASELINE.json configs[4]'s shape with world > 1: 400 episodes x 45 min, 79 800 pairs, 5 441
+    hashes per episode, every rank a real process on device 0 over the host-staged transport, PCM generated in HBM per
+    rank for the episodes needle_hip_library_rank_videos names.  Exercised at the size that triggers them: hash-block
+    sharding that cuts rows mid-episode, the run-slab overflow (grow + rescan + regather) or the head overflow, the
+    sharded epilogue (> 2^17 runs: its extra gather) and the unsharded one, two jobs in flight.  Every rank's results,
+    run count, complete run list (order-free digest) and hash arena equal the single-rank job's.  (Five ranks is what a
+    one-GPU box allows beside the test process: its guard stops a run with more than 6 processes on the GPU.)"""
+    from tests.comm_worker import run_digest
+    from tests.test_comm_cpu import launch
+    import hashlib
+    assert capi.device_count() > 0
+    n = RANKS_EPISODES
+    samples = int(round(MINUTES * 60.0 / 2 * 11025))
+    gen = synth.DeviceLibrary(n, samples, 90.0)
+    lib = capi.Library(n, opening_search_percentage=1.0)
+    lib.set_pcm_device(gen.pointers(), [samples] * n)
+    gen.free()
+    cmp = capi.Comparator([f"episode-{k:04d}.wav" for k in range(n)])
+    lib.job_begin(cmp, 0)
+    res, found = lib.job_end(cmp, 0)
+    want_results = [None if r is None else [None if x is None else list(x) for x in (r.opening, r.ending)] for r in res]
+    want_digest = run_digest(lib.job_runs(0))
+    assert lib.job_comm_bytes(0) == {"hash_rows": 0, "run_heads": 0, "results": 0, "scans_repeated": 0}
+    d_arena, stride = lib.hash_arena()
+    arena = np.zeros(n * stride, dtype=np.uint32)
+    capi.check(capi.lib().needle_hip_memcpy_d2h(arena.ctypes.data, d_arena, arena.nbytes))
+    kept = int(capi.lib().needle_hip_fingerprint_num_kept(samples, 2))
+    want_arena = hashlib.sha256(np.ascontiguousarray(arena.reshape(n, stride)[:, :kept]).tobytes()).hexdigest()
+    assert kept == 5441 and found >= n * (n - 1) // 2
+    assert n < 300 or found >= (1 << 17)                          # the size at which the epilogue is sharded by default
+    assert sum(1 for r in res if r is not None and r.opening is not None) == n
+    del lib, gen                                                  # the ranks need the device's memory and process slots
+
+    got = launch("lib", world, str(tmp_path / f"w{world}"), [n, MINUTES], local_ranks=[0] * world,
+                 extra_env=dict(env, NEEDLE_HIP_COMM="host"), timeout=900)
+    usable = _cpus()
+    for g in got:
+        assert g["backend"] == "host" and g["world"] == world and g["videos_held"][1] >= n // world
+        assert g["host_threads"] == max(1, usable // world)       # the node's CPUs are divided between the ranks
+        assert g["arena_digest"] == want_arena, g["rank"]         # rows computed by other ranks included
+        for k, job in enumerate(g["jobs"]):
+            assert job["runs"] == found and job["digest"] == want_digest, (g["rank"], k)
+            assert job["results"] == want_results, (g["rank"], k)
+            c = job["comm"]
+            assert c["hash_rows"] == n * g["stride"] * 4          # one all-gather of the arena's equal blocks
+            assert c["run_heads"] >= 24 * found                   # every rank receives every run once (+ margins)
+            sharded = env.get("NEEDLE_HIP_SHARD_EPILOGUE") != "0" and found >= (1 << 17)
+            assert (c["results"] > 0) == sharded
+        # the first job met the overflow that was forced and repeated its scan; the steady state repeats nothing
+        assert g["jobs"][0]["comm"]["scans_repeated"] >= 1 and g["jobs"][2]["comm"]["scans_repeated"] == 0
+        assert g["jobs"][2]["comm"]["run_heads"] < 3 * 24 * found + world * 4096
+        a = g["audit"]                                            # this rank's block of hashes, f32 first pass vs f64 kernel
+        assert a["mismatches"] == 0 and a["accepted_mismatches"] == 0 and a["max_error_over_s"] <= 8.0
+    assert sum(g["host_threads"] for g in got) <= max(usable, world)
+    assert sum(g["audit"]["items"] for g in got) == n * kept      # the blocks tile the library: every hash audited once

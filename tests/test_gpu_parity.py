@@ -387,6 +387,13 @@ def test_config2_full_size_parity(lib28):
         assert len(h) == 2897
         assert h.tolist() == [x for x, _ in ref[v].opening], f"episode {v}"
         assert ts.tolist() == [t for _, t in ref[v].opening]
+    # the first pass audited on the device: the f64 kernel over the same resident PCM, every kept item compared
+    # (needle_hip_library_audit).  Accepted items must all be the f64 item; what the radius K S = 64 S is a guard against
+    # -- |log v32 - log v64| / S of an accepted item -- must stay an order of magnitude inside it.
+    audit = lib.audit()
+    print("audit 28 x 24 min:", audit)
+    assert audit["items"] == n * 2897 and audit["mismatches"] == 0 and audit["accepted_mismatches"] == 0
+    assert audit["accepted"] > 0.99 * audit["items"] and audit["max_error_over_s"] <= 8.0
     cmp = capi.Comparator([f"ep{k}.wav" for k in range(n)])
     cmp.handle()
     cap = 1 << 16
