@@ -52,6 +52,31 @@ pub struct NeedleHipSearchResult {
     pub ending_end_ns: u64,
 }
 
+/// One matched segment of a pair (`NeedleHipRun`, include/needle_hip.h): what
+/// `Comparator::longest_common_hash_match` pushes per maximal run (comparator.rs:196-229).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]
+pub struct NeedleHipRun {
+    pub problem: u32,
+    pub src_end: u32,
+    pub dst_end: u32,
+    pub len: u32,
+    pub src_match_hash: u32,
+    pub dst_match_hash: u32,
+}
+
+/// Result of `needle_hip_library_audit` (f32 first pass vs the f64 kernel over the same resident PCM).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct NeedleHipCertAudit {
+    pub items: u64,
+    pub accepted: u64,
+    pub accepted_mismatches: u64,
+    pub mismatches: u64,
+    pub max_error_over_s: f64,
+    pub max_s: f64,
+}
+
 extern "C" {
     // ---- needle.h ------------------------------------------------------------------------------------
     pub fn needle_error_to_str(error: NeedleError) -> *const c_char;
@@ -215,6 +240,17 @@ extern "C" {
         index: usize,
         output: *mut *mut FrameHashes,
     ) -> NeedleError;
+    /// The complete run list of the job that finished last in `slot`; valid until the slot's next `job_begin`.
+    pub fn needle_hip_library_job_runs(
+        library: *const NeedleHipLibrary,
+        slot: c_int,
+        runs: *mut *const NeedleHipRun,
+        num_runs: *mut usize,
+    ) -> NeedleError;
+    /// `{hash rows, run heads, results}` bytes received in the job's all-gathers, `[3]` = scans repeated.
+    pub fn needle_hip_library_job_comm_bytes(library: *const NeedleHipLibrary, slot: c_int, bytes: *mut u64) -> NeedleError;
+    pub fn needle_hip_library_audit(library: *mut NeedleHipLibrary, audit: *mut NeedleHipCertAudit) -> NeedleError;
+    pub fn needle_hip_host_threads() -> c_int;
     pub fn needle_hip_host_alloc(host_ptr: *mut *mut c_void, bytes: usize) -> NeedleError;
     pub fn needle_hip_host_alloc_free(host_ptr: *mut c_void) -> NeedleError;
 }

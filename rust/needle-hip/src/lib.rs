@@ -543,6 +543,23 @@ pub mod multi_gpu {
         }
     }
 
+    impl Library {
+        /// The matched segments of every pair -- all ranks' shares -- that the last `run` worked from (a copy).
+        pub fn last_runs(&self) -> Result<Vec<ffi::NeedleHipRun>> {
+            let (mut ptr, mut n) = (std::ptr::null(), 0usize);
+            unsafe { check(ffi::needle_hip_library_job_runs(self.raw, 0, &mut ptr, &mut n))? };
+            Ok(if n == 0 { Vec::new() } else { unsafe { std::slice::from_raw_parts(ptr, n) }.to_vec() })
+        }
+
+        /// Both transforms (f32 first pass, f64 kernel) over this rank's resident PCM, every kept item compared on the
+        /// device: `mismatches` and `accepted_mismatches` must be 0 (`needle_hip_library_audit`).
+        pub fn audit(&mut self) -> Result<ffi::NeedleHipCertAudit> {
+            let mut a = ffi::NeedleHipCertAudit::default();
+            unsafe { check(ffi::needle_hip_library_audit(self.raw, &mut a))? };
+            Ok(a)
+        }
+    }
+
     impl Drop for Library {
         fn drop(&mut self) {
             unsafe { ffi::needle_hip_library_free(self.raw) }

@@ -382,3 +382,33 @@ def test_pair_index_map_matches_the_enumeration(tmp_path):
                     "-L" + libdir, "-lneedle_capi", "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "pair_at ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_rust_ffi_signatures_and_struct_layouts_match_the_headers(tmp_path):
+    """The first `cargo build` of rust/needle-hip on a machine with a toolchain should be a formality: every extern
+    declaration of ffi.rs has the argument and return types of the C prototype (needle-capi/src/lib.rs:346-637 is the
+    surface the 13 reference symbols come from), every #[repr(C)] struct the size and field offsets gcc gives the C
+    struct, NeedleError the header's variants in order."""
+    from tests import rust_ffi_check as R
+    assert R.c_type_to_rust("const char *const *paths") == "*const *const c_char"
+    assert R.c_type_to_rust("const char *const **videos") == "*mut *const *const c_char"
+    assert R.c_type_to_rust("struct NeedleAudioAnalyzer **output") == "*mut *mut NeedleAudioAnalyzer"
+    assert R.c_type_to_rust("const struct NeedleAudioComparator **output") == "*mut *const NeedleAudioComparator"
+    assert R.c_type_to_rust("uint64_t counts[4]") == "*mut u64" and R.c_type_to_rust("const uint8_t id[128]") == "*const u8"
+    protos = R.c_prototypes()
+    fns, structs, variants = R.rust_declarations()
+    assert len(fns) >= 50 and len(protos) >= len(fns)
+    for name, (params, ret) in fns.items():
+        assert name in protos, name
+        want_params, want_ret = protos[name]
+        assert params == want_params, (name, params, want_params)
+        assert ret == want_ret, (name, ret, want_ret)
+    assert variants == R.header_error_variants() and len(variants) == 12
+    sized = {k: v for k, v in structs.items() if v}              # opaque handles have no fields
+    assert {"NeedleHipSearchResult", "NeedleHipRun", "NeedleHipCertAudit"} <= set(sized)
+    c = R.c_layout(sized, str(tmp_path))
+    for name, fields in sized.items():
+        offsets, size = R.rust_layout(fields)
+        assert c[(name, "size")] == size, (name, size, c[(name, "size")])
+        for f, off in offsets:
+            assert c[(name, f)] == off, (name, f, off, c[(name, f)])

@@ -250,3 +250,85 @@ def test_config4_shape_between_ranks_on_one_gpu(tmp_path, world, env):
         assert a["mismatches"] == 0 and a["accepted_mismatches"] == 0 and a["max_error_over_s"] <= 8.0
     assert sum(g["host_threads"] for g in got) <= max(usable, world)
     assert sum(g["audit"]["items"] for g in got) == n * kept      # the blocks tile the library: every hash audited once
+
+
+def test_config3_at_its_stated_count_280_files(tmp_path, capfd):
+    """BASELINE.json configs[2] at its stated count: 280 episodes x 24 min as real .needle.dat files (written by the
+    product from audio generated in HBM), then needle_audio_comparator_run(analyze=false, display) -- the reference's
+    `needle search` -- over the files.  Checked: what it prints for every video against comparator.rs:524-629 through the
+    oracle (table-free pair function; each of the sampled videos depends on its 279 pairs), and the COMPLETE run list of
+    the 39 060 pairs (same files, read back) against the oracle's table-free scan of all pairs."""
+    assert capi.device_count() > 0
+    n, threads = int(os.environ.get("NEEDLE_TEST_CONFIG3_EPISODES", "280")), _cpus()
+    samples = int(round(24 * 60.0 / 2 * 11025))
+    gen = synth.DeviceLibrary(n, samples, 90.0)
+    src = capi.Library(n, opening_search_percentage=1.0)
+    src.set_pcm_device(gen.pointers(), [samples] * n)
+    gen.free()
+    src.analyze(0, n, sync=True)
+    paths = [str(tmp_path / f"episode-{k:04d}.wav") for k in range(n)]
+    for k, p in enumerate(paths):
+        src.frame_hashes(k).write(p[:-4] + ".needle.dat")
+    del src, gen
+    capfd.readouterr()
+    capi.Comparator(paths).run(analyze=False, display=True)
+    out = capfd.readouterr().out
+    blocks = [b for b in out.strip("\n").split("\n\n")]
+    assert len(blocks) == n and all(b.splitlines()[0] == p for b, p in zip(blocks, paths))
+    assert sum("* Opening - \"" in b for b in blocks) == n         # planted truth: every episode carries the shared intro
+
+    fhs = [capi.FrameHashes.from_path(p[:-4] + ".needle.dat") for p in paths]
+    hashes = [f.opening_data()[0] for f in fhs]
+    ts = [f.opening_data()[1].astype(np.uint64) for f in fhs]
+    assert all(len(h) == 2897 for h in hashes)
+    hd = O.duration_from_secs_f32(0.3)
+    sel = sorted(set([0, 1, n // 2, n - 1] + np.random.default_rng(3).choice(n, size=min(36, n), replace=False).tolist()))
+    want = O.run_selected_videos(O.Comparator(), hashes, ts, hd, sel, threads=threads)
+    for v, w in zip(sel, want):
+        o = f'* Opening - "{O.format_time(w.opening[0])}"-"{O.format_time(w.opening[1])}"' if w and w.opening else "* Opening - N/A"
+        assert blocks[v].splitlines()[1:] == ([o, "* Ending - N/A"] if w else ["No opening or ending found."]), v
+
+    # the complete run list of all pairs, GPU scan vs the oracle's table-free scan (min run 82 = 20 s at 0.246 s per hash)
+    pairs = [(i, j, 82) for i in range(n) for j in range(i + 1, n)]
+    runs = capi.hamming_runs(hashes, pairs, 10)
+    total, ref = O.diagonal_runs_all_pairs(hashes, 10, 82, threads=threads, capacity=4 * len(runs) + 1024)
+    got = np.stack([runs["problem"], runs["src_end"], runs["dst_end"], runs["len"]], axis=1).astype(np.uint32)
+    assert total == len(got) >= len(pairs)
+    assert np.array_equal(got[np.lexsort((got[:, 2], got[:, 1], got[:, 0]))], ref[np.lexsort((ref[:, 2], ref[:, 1], ref[:, 0]))])
+
+
+def test_config4_streamed_from_pinned_host_pcm(monkeypatch):
+    """BASELINE.json configs[4] as worded -- "analyze streamed from host-pinned PCM" -- at 1000 episodes x 45 min:
+    29.8 GB of opening-window PCM in pinned host memory (filled from the device generator, so the same audio as the
+    resident form), needle_hip_library_stream_pcm in calls of 250 episodes each through the 2 GiB staging arena, then
+    the full O(N^2) search.  The hash arena and the results must equal the resident job's over the same audio."""
+    assert capi.device_count() > 0
+    n = int(os.environ.get("NEEDLE_TEST_STREAMED_EPISODES", "1000"))
+    samples = int(round(MINUTES * 60.0 / 2 * 11025))
+    gen = synth.DeviceLibrary(n, samples, 90.0)
+    lib = capi.Library(n, opening_search_percentage=1.0)
+    lib.set_pcm_device(gen.pointers(), [samples] * n)
+    cmp = capi.Comparator([f"episode-{k:04d}.wav" for k in range(n)])
+    lib.job_begin(cmp, 0)
+    want, found = lib.job_end(cmp, 0)
+    d_arena, stride = lib.hash_arena()
+    want_arena = np.zeros(n * stride, dtype=np.uint32)
+    capi.check(capi.lib().needle_hip_memcpy_d2h(want_arena.ctypes.data, d_arena, want_arena.nbytes))
+    del lib
+    pinned = [capi.PinnedArray(samples) for _ in range(n)]
+    for k, p in enumerate(pinned):                              # device -> pinned host: the caller's decoded PCM
+        capi.check(capi.lib().needle_hip_memcpy_d2h(p.ptr, gen.pointers()[k], 2 * samples))
+    gen.free()
+    streamed = capi.Library(n, opening_search_percentage=1.0)
+    for first in range(0, n, 250):                               # a decoder hands over a batch at a time
+        batch = [pinned[k].array if first <= k < first + 250 else None for k in range(n)]
+        streamed.stream_pcm(batch, [samples] * n)
+    streamed.job_begin(cmp, 0)
+    got, found2 = streamed.job_end(cmp, 0)
+    d_arena, stride2 = streamed.hash_arena()
+    got_arena = np.zeros(n * stride2, dtype=np.uint32)
+    capi.check(capi.lib().needle_hip_memcpy_d2h(got_arena.ctypes.data, d_arena, got_arena.nbytes))
+    assert stride2 == stride and np.array_equal(got_arena, want_arena)
+    assert found2 == found >= n * (n - 1) // 2
+    assert [None if r is None else (r.opening, r.ending) for r in got] == [None if r is None else (r.opening, r.ending) for r in want]
+    assert sum(1 for r in got if r is not None and r.opening is not None) == n
