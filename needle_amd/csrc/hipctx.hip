@@ -153,6 +153,18 @@ hipStream_t stft_stream() {
   // being the default; kept for measurements.
   int cus = 0, reserve = 0;
   if (const char *e = getenv("NEEDLE_HIP_STFT_RESERVE_CUS")) reserve = atoi(e);
+  // NEEDLE_HIP_STFT_SHARE=1 (round 4 experiment): a plain second stream, no CU mask -- the next job's STFT shares every CU
+  // with the previous job's tail kernels, and room for those is made by capping the STFT's workgroups per CU through its
+  // dynamic LDS size instead (NEEDLE_HIP_STFT_LDS_BYTES, fingerprint32.hip)
+  if (const char *e = getenv("NEEDLE_HIP_STFT_SHARE"))
+    if (atoi(e) != 0 && reserve == 0) {
+      if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        s = nullptr;
+      }
+      streams[dev] = s;
+      return s;
+    }
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (reserve > 0 && cus >= 4 * reserve) {
     // Bit i of the mask is CU i / 8 of XCD i % 8 on this part (tools/cu_mask_probe.hip: a one-bit mask confines one

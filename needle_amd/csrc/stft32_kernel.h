@@ -68,6 +68,8 @@ enum : int {
                             // (fp_core.h head_col_tw / head_col_win): 64 VALU instructions fewer per pair; rows built
                             // in-kernel from the f32 table here (timing only)
   kLab32Tw1Lds = 256,   // stage-1 twiddle powers from a [15][16] table behind the LDS image instead of 30 registers
+  kLab32FormatLoad = 4096,  // mono: samples through tbuffer_load_format_x [16, SSCALED] -- the s16 -> f32 conversion happens in
+                            // the load (exact: tools/format_load_probe.hip) and the 32 v_cvt_f32_i32 per pair go away
   kLab32Clock = 128,    // thread 0 stamps s_memtime / s_memrealtime around the pair loop into `energy` (as 4 x u64 per
                         // workgroup): the clock the kernel really ran at = d memtime / d memrealtime x 100 MHz
 };
@@ -170,7 +172,37 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
   };
   using reg_t = int;
   reg_t ra[16], rb[16];
+  constexpr bool kFormatLoad = (LAB & kLab32FormatLoad) != 0 && CH == 1;
+  typedef int rsrc_t __attribute__((ext_vector_type(4)));
+  const int voff = 2 * t;  // byte offset of this thread's first sample inside a frame
   auto issue_loads = [&](const PairSrc &p) {
+    if (kFormatLoad) {
+      // One buffer resource per pair, based at frame A (uniform: SGPRs), stride 0, no clamp that matters; frame B is the
+      // same resource at soffset = one hop.  The instruction offset reaches 4095 bytes, so samples 8 x 256 and up take
+      // 4096 more through soffset.  Values arrive as (float)s16; the registers are the integer ones, reinterpreted.
+      const uint64_t a = (uint64_t)(uintptr_t)p.a;
+      rsrc_t rs;
+      rs.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+      rs.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) & 0xffff;
+      rs.z = 0x7fffffff;
+      rs.w = 4 | (5 << 3) | (6 << 6) | (7 << 9) | (3 << 12) | (2 << 15);
+      const int b_lo = __builtin_amdgcn_readfirstlane(p.has_b ? kHop * 2 : 0), b_hi = b_lo + 4096, a_hi = 4096;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        asm volatile("tbuffer_load_format_x %0, %1, %2, 0 format:[BUF_DATA_FORMAT_16,BUF_NUM_FORMAT_SSCALED] offen offset:%3"
+                     : "=v"(ra[k]) : "v"(voff), "s"(rs), "n"(512 * k) : "memory");
+        asm volatile("tbuffer_load_format_x %0, %1, %2, %4 format:[BUF_DATA_FORMAT_16,BUF_NUM_FORMAT_SSCALED] offen offset:%3"
+                     : "=v"(rb[k]) : "v"(voff), "s"(rs), "n"(512 * k), "s"(b_lo) : "memory");
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        asm volatile("tbuffer_load_format_x %0, %1, %2, %4 format:[BUF_DATA_FORMAT_16,BUF_NUM_FORMAT_SSCALED] offen offset:%3"
+                     : "=v"(ra[8 + k]) : "v"(voff), "s"(rs), "n"(512 * k), "s"(a_hi) : "memory");
+        asm volatile("tbuffer_load_format_x %0, %1, %2, %4 format:[BUF_DATA_FORMAT_16,BUF_NUM_FORMAT_SSCALED] offen offset:%3"
+                     : "=v"(rb[8 + k]) : "v"(voff), "s"(rs), "n"(512 * k), "s"(b_hi) : "memory");
+      }
+      return;
+    }
     const raw_t *qa = reinterpret_cast<const raw_t *>(p.a), *qb = reinterpret_cast<const raw_t *>(p.b);
     int tt = t;
     asm volatile("" : "+v"(tt));  // an opaque INDEX keeps these global (not flat) loads inside the loop (stft_kernel.h)
@@ -179,6 +211,20 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
       ra[k] = (reg_t)qa[tt + 256 * k];
       rb[k] = (reg_t)qb[tt + 256 * k];
     }
+  };
+  // the asm loads are invisible to the compiler's wait-count bookkeeping: their consumer waits for them itself
+  auto loads_landed = [&]() {
+    if (!kFormatLoad) return;
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]), "+v"(ra[8]),
+                   "+v"(ra[9]), "+v"(ra[10]), "+v"(ra[11]), "+v"(ra[12]), "+v"(ra[13]), "+v"(ra[14]), "+v"(ra[15])
+                 :
+                 : "memory");
+    asm volatile(""
+                 : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7]), "+v"(rb[8]),
+                   "+v"(rb[9]), "+v"(rb[10]), "+v"(rb[11]), "+v"(rb[12]), "+v"(rb[13]), "+v"(rb[14]), "+v"(rb[15])
+                 :
+                 : "memory");
   };
   constexpr int kFoldHalf = core::kClassLaneMax / 2;
   auto fold_tree_store = [&](cf acc, const PairSrc &p, int tt, bool store) {
@@ -215,6 +261,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
     asm volatile("" : "+v"(tt));
     cf r[16];
     float ea = 0.0f, eb = 0.0f;
+    loads_landed();
     auto convert = [&](int k) {
       int sa, sb;
       if (CH == 1) {
@@ -225,7 +272,8 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
         sb = ((int)(int16_t)rb[k] + (rb[k] >> 16)) / 2;
       }
       const float w = (LAB & kLab32WinLoad) ? win32[tt + 256 * k] : win[k];
-      const cf x = (LAB & kLab32ConsumerTw) ? cf{(float)sa, (float)sb} : cf{(float)sa * w, (float)sb * w};
+      const float fa = kFormatLoad ? __int_as_float(sa) : (float)sa, fb = kFormatLoad ? __int_as_float(sb) : (float)sb;
+      const cf x = (LAB & kLab32ConsumerTw) ? cf{fa, fb} : cf{fa * w, fb * w};
       r[k] = x;
       if (!(LAB & kLab32NoEnergy)) {
         ea = core::fmad(x.x, x.x, ea);

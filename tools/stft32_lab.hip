@@ -160,6 +160,8 @@ int main(int argc, char **argv) {
       {"window re-read per pair, 3 waves/SIMD", launch_variant<3, kLab32WinLoad>, true, 16},
       {"window re-read per pair, 4 waves/SIMD", launch_variant<4, kLab32WinLoad>, true, 16},
       {"stage inputs as single ds_read_b64 (asm)", launch_variant<3, kLab32AsmReads>, true, 16},
+      {"samples converted in the load (tbuffer format load)", launch_variant<3, kLab32FormatLoad>, true, 16},
+      {"format loads + single ds_read_b64 (asm)", launch_variant<3, kLab32FormatLoad | kLab32AsmReads>, true, 16},
       {"consumer-side twiddles (tan form) + window folded in", launch_variant<3, kLab32ConsumerTw>, true, 16},
       {"power stores / fold reads conflict-free (wrong slots)", launch_variant<3, kLab32NoConflict>, false, 16},
       {"conflict-free power image + single reads", launch_variant<3, kLab32NoConflict | kLab32AsmReads>, false, 16},
@@ -178,6 +180,15 @@ int main(int argc, char **argv) {
       {"product, 8 pairs per workgroup", launch_variant<3, 0>, true, 8},
       {"product, 32 pairs per workgroup", launch_variant<3, 0>, true, 32},
   };
+  if (const char *only = getenv("LAB_ONLY")) {  // "0,2,18": run these variants only (counter passes)
+    std::vector<Variant> keep;
+    for (const char *p = only; *p;) {
+      const size_t i = (size_t)std::strtoul(p, const_cast<char **>(&p), 10);
+      if (i < vs.size()) keep.push_back(vs[i]);
+      while (*p == ',') p++;
+    }
+    vs = keep;
+  }
   for (int i = 0; i < 30; i++) time_once(L, vs[0], false);  // warm-up: the first launches run at a lower clock
   for (Variant &v : vs) check_variant(L, v);
   for (int r = 0; r < reps; r++)
