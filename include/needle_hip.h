@@ -67,6 +67,11 @@ enum NeedleError needle_hip_int_valu_ceiling(double *cells_per_second);
  * lanes, inside the table or not.  This returns the sum since the last reset (waits for the library stream):
  * issued evaluations per second of the UNCOUNTED kernel against needle_hip_int_valu_ceiling() is a fraction <= 1. */
 enum NeedleError needle_hip_scan_issued_evaluations(uint64_t *lane_evaluations, bool reset);
+/* The same counting launches, two figures: counts[0] = the issued lane evaluations above, counts[1] = diagonals that
+ * passed the head rows of a window (summed over all windows) and had to be finished -- what a cheaper head costs.  The
+ * window shape itself (rows per aligned window W, head rows H; default 8, 3) can be chosen among the instantiated ones
+ * with NEEDLE_HIP_SCAN_SHAPE="W,H" (W in 4, 8, 16; H in 2..4): every shape emits the same runs (tools/scan_shape_sweep.py). */
+enum NeedleError needle_hip_scan_counts(uint64_t counts[2], bool reset);
 
 /* ---- fingerprint: the chromaprint Context replacement -------------------------------------------
  * Replaces chromaprint::Context::{start,feed,finish,get_fingerprint_raw,get_delay,get_item_duration,

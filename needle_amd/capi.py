@@ -94,7 +94,8 @@ NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_library_job_end", "needle_hip_library_stream_pcm", "needle_hip_host_alloc",
     "needle_hip_host_alloc_free", "needle_hip_int_valu_ceiling",
     "needle_hip_comparator_results_from_runs", "needle_hip_library_job_runs", "needle_hip_library_job_comm_bytes",
-    "needle_hip_host_threads", "needle_hip_fingerprint_audit_device", "needle_hip_library_audit"]
+    "needle_hip_host_threads", "needle_hip_fingerprint_audit_device", "needle_hip_library_audit",
+    "needle_hip_scan_counts"]
 
 _LIB = None
 
@@ -264,6 +265,14 @@ def scan_issued_evaluations(reset: bool = False) -> int:
     lib().needle_hip_scan_issued_evaluations.argtypes = [C.POINTER(C.c_uint64), C.c_bool]
     check(lib().needle_hip_scan_issued_evaluations(C.byref(v), reset))
     return int(v.value)
+
+
+def scan_counts(reset: bool = False) -> Tuple[int, int]:
+    """(issued lane evaluations, diagonals that survived the head rows) of the counting scan launches."""
+    c = (C.c_uint64 * 2)()
+    lib().needle_hip_scan_counts.argtypes = [C.POINTER(C.c_uint64), C.c_bool]
+    check(lib().needle_hip_scan_counts(c, reset))
+    return int(c[0]), int(c[1])
 
 
 def host_threads() -> int:

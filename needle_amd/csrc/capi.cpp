@@ -432,6 +432,14 @@ enum NeedleError needle_hip_scan_issued_evaluations(uint64_t *lane_evaluations, 
   });
 }
 
+enum NeedleError needle_hip_scan_counts(uint64_t counts[2], bool reset) {
+  if (!counts) return NeedleError_NullArgument;
+  return guarded([&]() -> NeedleError {
+    Status s = gpu_scan_issued_evaluations(&counts[0], reset, &counts[1]);
+    return s.ok() ? NeedleError_Ok : report(s);
+  });
+}
+
 enum NeedleError needle_hip_int_valu_ceiling(double *cells_per_second) {
   if (!cells_per_second) return NeedleError_NullArgument;
   return guarded([&]() -> NeedleError {

@@ -476,6 +476,7 @@ struct FpWorkspace {
     DeviceBuffer<uint32_t> cert_ctl, chunk_list;
     DeviceBuffer<CertItem> item_list;
     hipEvent_t stft_done = nullptr;   // recorded on the STFT stream behind the first pass
+    hipEvent_t recomputed = nullptr;  // recorded on the library stream behind the f64 recomputation of the listed chunks
     hipEvent_t consumed = nullptr;    // recorded on the library stream behind the last reader of this set
     hipEvent_t descriptors = nullptr; // recorded on the library stream behind a descriptor upload the STFT must see
     bool consumed_valid = false, stft_recorded = false;
@@ -624,7 +625,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
             !(s = chunk_buf.reserve(nchunks)).ok() || !(s = item_buf.reserve(std::max<uint64_t>(kept, 1))).ok())
           return s;
         if (pp) {
-          for (hipEvent_t *e : {&pp->stft_done, &pp->consumed, &pp->descriptors})
+          for (hipEvent_t *e : {&pp->stft_done, &pp->consumed, &pp->descriptors, &pp->recomputed})
             if (!*e) NEEDLE_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
           // the STFT may start once the previous user of this workspace has read it to the end, and -- only if the
           // descriptor table was uploaded just now -- once that copy has executed (an unconditional wait on the library
@@ -633,8 +634,16 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
           // ... and once the OTHER pipe's first pass is through: two STFTs side by side only slow each other down and
           // leave both tails to run alone afterwards (seen in a kernel trace: pairs of 0.67 / 0.76 ms STFTs, then 0.2 ms
           // of tail kernels on an idle chip); what is wanted beside an STFT is the previous call's TAIL
-          if (ws->pipes[pipe ^ 1].stft_done && ws->pipes[pipe ^ 1].stft_recorded)
-            NEEDLE_HIP_TRY(hipStreamWaitEvent(stft, ws->pipes[pipe ^ 1].stft_done, 0));
+          // Shared-CU overlap (NEEDLE_HIP_STFT_SHARE, hipctx.hip): behind the other pipe's f64 RECOMPUTATION instead.  That
+          // kernel's workgroup (68 KB of LDS, ~250 VGPRs) does not fit the hole a retiring first-pass workgroup leaves
+          // (35 KB, 163 VGPRs): started beside a first pass it waits for all of it (kernel trace, profiles/NOTES.md round 4);
+          // the kernels behind it (fix-up, scan, simhash) and the certification kernel do fit and run beside it.
+          const FpWorkspace::Pipe &other = ws->pipes[pipe ^ 1];
+          static const bool share = getenv("NEEDLE_HIP_STFT_SHARE") && atoi(getenv("NEEDLE_HIP_STFT_SHARE")) != 0;
+          if (share && other.recomputed && other.stft_recorded)
+            NEEDLE_HIP_TRY(hipStreamWaitEvent(stft, other.recomputed, 0));
+          else if (other.stft_done && other.stft_recorded)
+            NEEDLE_HIP_TRY(hipStreamWaitEvent(stft, other.stft_done, 0));
           if (uploaded) {
             NEEDLE_HIP_TRY(hipEventRecord(pp->descriptors, stream));
             NEEDLE_HIP_TRY(hipStreamWaitEvent(stft, pp->descriptors, 0));
@@ -679,6 +688,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
           };
           if (channels == 1) launch(stft_chroma_kernel<1, 0, true>); else launch(stft_chroma_kernel<2, 0, true>);
         }
+        if (pp) NEEDLE_HIP_TRY(hipEventRecord(pp->recomputed, stream));
         {
           KernelTimer timer("fixup_items");
           hipLaunchKernelGGL(fixup_items_kernel, dim3(64), dim3(256), 0, stream, chroma_buf.ptr, tab.thr, work,

@@ -65,7 +65,18 @@ hipStream_t library_stream() {
   auto it = g_streams.find(dev);
   if (it != g_streams.end()) return it->second;
   hipStream_t s = nullptr;
-  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+  // NEEDLE_HIP_LIBRARY_PRIORITY=1 (experiment, with NEEDLE_HIP_STFT_SHARE): the library stream at the highest priority, so
+  // that the tail kernels of job k are dispatched into the slots the next job's retiring STFT workgroups free
+  const char *prio = getenv("NEEDLE_HIP_LIBRARY_PRIORITY");
+  if (prio && atoi(prio) != 0) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) != hipSuccess) {
+      (void)hipGetLastError();
+      s = nullptr;
+    }
+  }
+  if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
   g_streams[dev] = s;
   return s;
 }
@@ -158,7 +169,9 @@ hipStream_t stft_stream() {
   // dynamic LDS size instead (NEEDLE_HIP_STFT_LDS_BYTES, fingerprint32.hip)
   if (const char *e = getenv("NEEDLE_HIP_STFT_SHARE"))
     if (atoi(e) != 0 && reserve == 0) {
-      if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) {
         (void)hipGetLastError();
         s = nullptr;
       }

@@ -29,13 +29,21 @@ constexpr int kSampleHead = 3;                  // rows of a window evaluated be
 // Which rows: the first, a middle and the last one of the window.  Neighbouring rows of a diagonal are correlated in
 // audio (a note lasts several hashes): between unrelated synthetic episodes three CONSECUTIVE cells all match with
 // probability 0.7 %, the cells of rows {0, W/2, W-1} with 0.15 % -- 4.5 times fewer diagonals to finish afterwards.
-__host__ __device__ constexpr int head_row(int k, int W) { return k == 0 ? 0 : (k == 1 ? W / 2 : W - 1); }
-__host__ __device__ constexpr bool is_head_row(int s, int W) { return s == 0 || s == W / 2 || s == W - 1; }
-// k-th row of the window that is NOT a head row (k = 0 .. W - kSampleHead - 1)
-__host__ __device__ constexpr int tail_row(int k, int W) {
+// H head rows of a window of W: H = 3 (the default) takes rows {0, W/2, W-1}; other counts are spread evenly over the
+// window (H = 2: {0, W-1}; H = 4: {0, (W-1)/3, 2(W-1)/3, W-1}) -- tools/scan_shape_sweep.py measures the choices.
+__host__ __device__ constexpr int head_row(int k, int W, int H = kSampleHead) {
+  return H == 3 ? (k == 0 ? 0 : (k == 1 ? W / 2 : W - 1)) : (k * (W - 1)) / (H - 1);
+}
+__host__ __device__ constexpr bool is_head_row(int s, int W, int H = kSampleHead) {
+  for (int k = 0; k < H; k++)
+    if (head_row(k, W, H) == s) return true;
+  return false;
+}
+// k-th row of the window that is NOT a head row (k = 0 .. W - H - 1)
+__host__ __device__ constexpr int tail_row(int k, int W, int H = kSampleHead) {
   int seen = 0;
   for (int s = 0; s < W; s++) {
-    if (is_head_row(s, W)) continue;
+    if (is_head_row(s, W, H)) continue;
     if (seen == k) return s;
     seen++;
   }
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(256) void hamming_runs_band_kernel(const uint32_t *
 // cell lies inside the table, on the padding or repeats another lane's) and adds the total to *eval_groups when it
 // leaves -- the numerator of an honest roofline: issued cell evaluations per second against the measured
 // integer-VALU ceiling, <= 1 by construction, unlike the cells of the reference's table the scan merely COVERS.
-template <int R, int W, bool COUNT = false>
+template <int R, int W, bool COUNT = false, int H = kSampleHead>
 __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_t *__restrict__ hashes,
                                                                    const SearchProblem *__restrict__ problems,
                                                                    int num_problems, uint32_t threshold,
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
                                                                    int bands_per_wave, int sparse_max,
                                                                    unsigned long long *__restrict__ eval_groups) {
   constexpr int B = 64 * R;
-  unsigned long long groups = 0;  // COUNT only
+  unsigned long long groups = 0, survived = 0;  // COUNT only
   extern __shared__ uint32_t lds[];
   int lo = 0, hi = num_problems - 1;
   while (lo < hi) {
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
   int k0 = (i_start - 1 + P - 1) / P;
   for (int w0 = 1 + k0 * P; w0 + W - 1 <= i_end; w0 += P) {
     // the W + R - 1 destination hashes this lane's R diagonals meet in rows w0 .. w0+W-1; the rows are taken in
-    // two parts: after kSampleHead of them (head_row) hardly any of the wave's 64 R diagonals still matches on
+    // two parts: after H of them (head_row) hardly any of the wave's 64 R diagonals still matches on
     // unrelated audio, and then the rest of the window is skipped -- nothing can pass that has already failed
     uint32_t E[W + R - 1];
 #pragma unroll
@@ -331,12 +339,12 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
 #pragma unroll
     for (int r = 0; r < R; r++) ok[r] = true;
 #pragma unroll
-    for (int k = 0; k < kSampleHead; k++) {
-      const int s = head_row(k, W);
+    for (int k = 0; k < H; k++) {
+      const int s = head_row(k, W, H);
 #pragma unroll
       for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv[s] ^ E[s + r]) <= threshold);
     }
-    if (COUNT) groups += kSampleHead * R;
+    if (COUNT) groups += H * R;
     // exact resolution of one diagonal whose W window cells all match, by the whole wave (d is wave-uniform)
     auto resolve = [&](const int d) {
       const int ilo = d < 0 ? 1 - d : 1;
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
     // is self-similar (sustained notes: a diagonal that matched three rows running is likely to match the next
     // one), a few of the wave's 64 R diagonals do survive, and walking the remaining rows for all of them would
     // cost 64 R cells per row to test those few.  Up to sparse_max survivors are therefore finished one at a time,
-    // the W - kSampleHead remaining cells of a diagonal side by side in as many lanes; more than that (sustained
+    // the W - H remaining cells of a diagonal side by side in as many lanes; more than that (sustained
     // sounds, silence) goes on row by row as before.  Both paths test exactly the same cells.
     unsigned long long alive[R];
     int survivors = 0;
@@ -397,16 +405,17 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
       alive[r] = __ballot(ok[r]);
       survivors += __popcll(alive[r]);
     }
+    if (COUNT) survived += (unsigned long long)survivors;
     if (survivors == 0) continue;
     if (survivors <= sparse_max) {
-      // lane k (k < W - kSampleHead) takes the k-th remaining row; lanes beyond repeat the last of them
-      constexpr int kTail = W - kSampleHead;
-      uint32_t sv_tail = sv[tail_row(kTail - 1, W)];
-      int tail_off = tail_row(kTail - 1, W);
+      // lane k (k < W - H) takes the k-th remaining row; lanes beyond repeat the last of them
+      constexpr int kTail = W - H;
+      uint32_t sv_tail = sv[tail_row(kTail - 1, W, H)];
+      int tail_off = tail_row(kTail - 1, W, H);
 #pragma unroll
       for (int k = kTail - 2; k >= 0; k--) {
-        sv_tail = lane == k ? sv[tail_row(k, W)] : sv_tail;
-        tail_off = lane == k ? tail_row(k, W) : tail_off;
+        sv_tail = lane == k ? sv[tail_row(k, W, H)] : sv_tail;
+        tail_off = lane == k ? tail_row(k, W, H) : tail_off;
       }
 #pragma unroll
       for (int r = 0; r < R; r++) {
@@ -424,12 +433,12 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
       continue;
     }
 #pragma unroll
-    for (int k = 0; k < W - kSampleHead; k++) {
-      const int s = tail_row(k, W);
+    for (int k = 0; k < W - H; k++) {
+      const int s = tail_row(k, W, H);
 #pragma unroll
       for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv[s] ^ E[s + r]) <= threshold);
     }
-    if (COUNT) groups += (W - kSampleHead) * R;
+    if (COUNT) groups += (W - H) * R;
     // ---- candidates: resolved one at a time by the whole wave ----
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -442,7 +451,10 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
     }
   }
   }  // bands of this wave
-  if (COUNT && lane == 0) atomicAdd(eval_groups, groups);
+  if (COUNT && lane == 0) {
+    atomicAdd(eval_groups, groups);
+    atomicAdd(eval_groups + 1, survived);  // diagonals that passed the head rows, over all windows
+  }
 }
 
 // ---- simhash of every emitted run (comparator.rs:149-153,226-229) -----------------------------------------------
@@ -489,6 +501,34 @@ __global__ __launch_bounds__(256) void simhash_runs_kernel(const uint32_t *__res
 
 // What a launch needs besides its inputs: the device descriptors, the grid and the kernel choice.  Kept with the
 // inputs it was derived from, so that a job that is run again (a library has ~n^2 / 2 pairs) rebuilds nothing.
+// The sampled scan's window shape: rows per aligned window W and head rows H.  (8, 3) unless NEEDLE_HIP_SCAN_SHAPE="W,H"
+// names another of the instantiated ones (tools/scan_shape_sweep.py; every shape tests the same cells of a candidate
+// and emits the same runs -- the shapes differ in how many cells they look at before giving a window up).
+struct ScanShape {
+  int w = kSampleW, h = kSampleHead;
+};
+ScanShape scan_shape() {
+  ScanShape sh;
+  if (const char *e = getenv("NEEDLE_HIP_SCAN_SHAPE")) {
+    int w = 0, h = 0;
+    if (std::sscanf(e, "%d,%d", &w, &h) == 2 && (w == 4 || w == 8 || w == 16) && h >= 2 && h <= 4 && h < w) {
+      sh.w = w;
+      sh.h = h;
+    }
+  }
+  return sh;
+}
+using SampledKernel = void (*)(const uint32_t *, const SearchProblem *, int, uint32_t, NeedleHipRun *, uint32_t, uint32_t *, int, int,
+                               unsigned long long *);
+template <bool COUNT>
+SampledKernel sampled_kernel(ScanShape sh) {
+#define NEEDLE_SHAPE(W_, H_) \
+  if (sh.w == W_ && sh.h == H_) return hamming_runs_sampled_kernel<kBandR, W_, COUNT, H_>;
+  NEEDLE_SHAPE(4, 2) NEEDLE_SHAPE(4, 3) NEEDLE_SHAPE(8, 2) NEEDLE_SHAPE(8, 4) NEEDLE_SHAPE(16, 2) NEEDLE_SHAPE(16, 3) NEEDLE_SHAPE(16, 4)
+#undef NEEDLE_SHAPE
+  return hamming_runs_sampled_kernel<kBandR, kSampleW, COUNT, kSampleHead>;
+}
+
 struct SearchPlan {
   std::vector<NeedleHipSeq> seqs;          // inputs ...
   std::vector<NeedleHipProblem> problems;
@@ -541,7 +581,7 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     uint32_t smallest = 0xFFFFFFFFu;
     for (const SearchProblem &m : meta) smallest = std::min(smallest, m.min_len);
     const bool generic_only = mode[0] != 0;
-    const bool sampled = !generic_only && smallest >= (uint32_t)(2 * kSampleW - 1 + 8) && mode[1] == 0;
+    const bool sampled = !generic_only && smallest >= (uint32_t)(2 * scan_shape().w - 1 + 8) && mode[1] == 0;
     const bool fast = !generic_only && !sampled && smallest >= (uint32_t)(kBandR * kBandU);
     // What a pair needs in LDS under the chosen kernel.  A pair beyond the CU's 160 KiB (a window of more than ~2.7 h
     // of audio at step 1) goes to the end of the table and is scanned from HBM by the unstaged kernel: one such
@@ -658,10 +698,14 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_band_kernel<kBandR, kBandU>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_sampled_kernel<kBandR, kSampleW, false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_sampled_kernel<kBandR, kSampleW, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      for (int w : {4, 8, 16})
+        for (int h : {2, 3, 4}) {
+          if (h >= w) continue;
+          NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sampled_kernel<false>(ScanShape{w, h})),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sampled_kernel<true>(ScanShape{w, h})),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
       ws->lds_attr_set = true;
     }
     const int staged = (int)plan.staged, oversize = (int)(meta.size() - plan.staged);
@@ -672,16 +716,16 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
         if (const char *e = getenv("NEEDLE_HIP_SPARSE_MAX")) sparse_max = std::max(0, atoi(e));  // tests, tuning: 0 = row by row
         if (getenv("NEEDLE_HIP_SCAN_COUNT")) {  // diagnostic: the same scan, counting what it issues
           if (!ws->eval_groups) {
-            NEEDLE_HIP_TRY(hipMalloc((void **)&ws->eval_groups, sizeof(unsigned long long)));
-            NEEDLE_HIP_TRY(hipMemsetAsync(ws->eval_groups, 0, sizeof(unsigned long long), stream));
+            NEEDLE_HIP_TRY(hipMalloc((void **)&ws->eval_groups, 2 * sizeof(unsigned long long)));
+            NEEDLE_HIP_TRY(hipMemsetAsync(ws->eval_groups, 0, 2 * sizeof(unsigned long long), stream));
           }
-          hipLaunchKernelGGL((hamming_runs_sampled_kernel<kBandR, kSampleW, true>), dim3((uint32_t)blocks), dim3(256),
-                             lds_bytes, stream, d_hashes, ws->problems.ptr, staged, threshold, d_runs, capacity, d_count,
-                             bands_per_wave, sparse_max, ws->eval_groups);
+          hipLaunchKernelGGL(sampled_kernel<true>(scan_shape()), dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
+                             ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,
+                             ws->eval_groups);
         } else {
-          hipLaunchKernelGGL((hamming_runs_sampled_kernel<kBandR, kSampleW, false>), dim3((uint32_t)blocks), dim3(256),
-                             lds_bytes, stream, d_hashes, ws->problems.ptr, staged, threshold, d_runs, capacity, d_count,
-                             bands_per_wave, sparse_max, (unsigned long long *)nullptr);
+          hipLaunchKernelGGL(sampled_kernel<false>(scan_shape()), dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
+                             ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,
+                             (unsigned long long *)nullptr);
         }
       }
       else if (fast)
@@ -709,19 +753,20 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
 
 // Cell evaluations ISSUED by the sampled scan's counting launches (NEEDLE_HIP_SCAN_COUNT=1) since the last reset:
 // groups of xor / popcount / compare over a wave's 64 lanes, times 64.
-Status gpu_scan_issued_evaluations(uint64_t *lane_evaluations, bool reset) {
+Status gpu_scan_issued_evaluations(uint64_t *lane_evaluations, bool reset, uint64_t *head_survivors) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   Status s = ensure_device();
   if (!s.ok()) return s;
   SearchWorkspace *ws = workspace();
-  unsigned long long groups = 0;
+  unsigned long long groups[2] = {0, 0};
   hipStream_t stream = library_stream();
   if (ws->eval_groups) {
-    NEEDLE_HIP_TRY(hipMemcpyAsync(&groups, ws->eval_groups, sizeof(groups), hipMemcpyDeviceToHost, stream));
-    if (reset) NEEDLE_HIP_TRY(hipMemsetAsync(ws->eval_groups, 0, sizeof(unsigned long long), stream));
+    NEEDLE_HIP_TRY(hipMemcpyAsync(groups, ws->eval_groups, sizeof(groups), hipMemcpyDeviceToHost, stream));
+    if (reset) NEEDLE_HIP_TRY(hipMemsetAsync(ws->eval_groups, 0, sizeof(groups), stream));
     NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
   }
-  *lane_evaluations = (uint64_t)groups * 64u;
+  *lane_evaluations = (uint64_t)groups[0] * 64u;
+  if (head_survivors) *head_survivors = (uint64_t)groups[1];
   return Status::Ok();
 }
 

@@ -11,6 +11,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from needle_amd import capi, synth  # noqa: E402
 
@@ -77,11 +79,16 @@ def main():
     os.environ["NEEDLE_HIP_SCAN_COUNT"] = "1"
     step(False)
     flush()
-    capi.scan_issued_evaluations(reset=True)
+    capi.scan_counts(reset=True)
     step(False)
     flush()
-    issued = capi.scan_issued_evaluations(reset=True)
+    issued, survivors = capi.scan_counts(reset=True)
     del os.environ["NEEDLE_HIP_SCAN_COUNT"]
+    import hashlib
+    runs_arr = lib.job_runs((seq[0] - 1) & 1)
+    keys = np.stack([runs_arr[f].astype(np.uint32) for f in ("problem", "src_end", "dst_end", "len", "src_match_hash", "dst_match_hash")], axis=1)
+    keys = keys[np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))]
+    digest = hashlib.sha256(np.ascontiguousarray(keys).tobytes()).hexdigest()[:16]
     ceiling = capi.int_valu_ceiling()
     pairs = n * (n - 1) // 2
     kept = capi.lib().needle_hip_fingerprint_num_kept(samples, 2)
@@ -91,7 +98,8 @@ def main():
            "pairs_per_s": round(pairs / (pipelined_ms * 1e-3), 1),
            "kernel_ms": {k: round(v / jobs, 4) for k, v in acc.items()},
            "host_ms_per_job": {k: round(1e3 * v / (2 * jobs), 3) for k, v in host.items()},
-           "runs": int(state["runs"]),
+           "runs": int(state["runs"]), "run_list_digest": digest, "scan_shape": os.environ.get("NEEDLE_HIP_SCAN_SHAPE", "8,3"),
+           "head_survivors": survivors,
            "detected": sum(1 for r in state["res"] if r is not None and r.opening is not None),
            "fallback": {"items": cs["items_recomputed"] / max(cs["items"], 1), "chunks": cs["chunks_recomputed"] / max(cs["chunks"], 1)},
            "scan_roofline": {"issued_cell_evaluations": issued, "lane_instructions_per_s": round(3.0 * issued / (scan_ms * 1e-3), 1),
