@@ -563,7 +563,7 @@ def main() -> None:
     # default arithmetic: f32 first pass + certification + f64 recomputation of what could not be certified (include/
     # needle_hip.h); NEEDLE_HIP_STFT=f64 runs stft_chroma + features_classify instead.  Kernels that did not run read 0.
     kernel_names = ["stft_chroma32", "features_cert", "stft_fallback", "fixup_items", "stft_chroma", "features_classify",
-                    "hamming_runs", "simhash_runs"]
+                    "hamming_runs", "simhash_runs", "epilogue_buckets", "epilogue_entries", "epilogue_best_match"]
     kernel_ms = {k: 0.0 for k in kernel_names}      # timed region: the dominant kernel only (see below)
     warm_ms = {k: 0.0 for k in kernel_names}        # warm-up: all kernels, to find the dominant one
     extra_ms = {k: 0.0 for k in kernel_names}       # untimed steps after the timed region: all kernels (breakdown)

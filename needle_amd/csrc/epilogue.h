@@ -1,0 +1,39 @@
+// Device form of the per-video epilogue of a library job (epilogue.hip); the host form is comparator.cpp.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/needle_hip.h"
+#include "common.h"
+
+namespace needle {
+
+struct EpilogueJob {
+  int slot = 0;                      // job slot: two jobs in flight keep two workspaces
+  uint32_t n = 0;                    // videos
+  uint32_t regions = 1;              // of the COMPARATOR: NeedleHipRun.problem = pair * regions + region
+  uint32_t rows_per_video = 1;       // of the library's hash arena: row = video * rows_per_video + region
+  uint32_t v0 = 0, v1 = 0;           // results wanted for videos [v0, v1)
+  uint32_t threshold = 0;
+  bool include_endings = false;
+  ns_t min_opening_duration = 0, min_ending_duration = 0, time_padding = 0, hash_duration = 0;
+  // the run list: num_segments slabs (own slab, or the gathered heads in rank order), each `header_bytes` of header
+  // (word 0 = runs found) followed by up to segment_capacity runs
+  const uint8_t *segment_base[64] = {nullptr};
+  int num_segments = 0;
+  uint32_t segment_capacity = 0, header_bytes = 32;
+  uint64_t max_runs = 0;             // upper bound of the runs in all segments (sizes the workspaces)
+  // per arena row: hashes kept, offset of its (un-seeked) timestamps in `ts`, seek added to each of them
+  const std::vector<uint32_t> *row_len = nullptr, *row_ts = nullptr;
+  const std::vector<uint64_t> *row_seek = nullptr, *ts = nullptr;
+};
+
+// Enqueues the epilogue kernels on `stream` behind whatever fills the segments, then the copies of results[n] and of the
+// failure count (videos whose padding / hash duration exceed the match end: the reference panics) into HOST memory
+// (pinned: the copies are asynchronous).  Counts beyond a segment's capacity are clamped: the host redoes such a job.
+Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHipSearchResult *host_results, uint32_t *host_failed);
+
+}  // namespace needle

@@ -1,0 +1,544 @@
+// The order-sensitive epilogue of a library job ON THE DEVICE: from the complete run list of all pairs to one
+// SearchResult per video (needle/src/audio/comparator.rs:191-249 validity + BinaryHeap order, :405-515 find_best_match,
+// :583-626 per-video walk), bit for bit what comparator.cpp computes on host threads.  At BASELINE.json configs[4]
+// (2000 x 45 min: 3.95 M runs, ~3 950 candidates per video) the host form takes 68 ms on 16 threads -- and every rank of
+// an 8-GPU job has a sixteenth of those threads -- while the work is 3e10 popcount-compares and a few small sorts.
+//
+//   bucket_count / scan / bucket_scatter : counting sort of the runs by problem (pair * regions + region)
+//   pair_entries   : one thread per bucket -- the reference's reverse table walk order (src_end, then dst_end, descending),
+//                    the duration validity tests (:212-223), std's BinaryHeap::push (append + sift up on the derived
+//                    lexicographic Ord, :22-35) -> the bucket's entries in the heap's backing-array order (:249)
+//   best_match     : one workgroup per video -- its pairs in lexicographic order, openings before endings inside a
+//                    pair (:414-431) = the candidate numbering; links[k] = #{b : popcount(h_k ^ h_b) < bound} over ALL
+//                    its candidates by brute force (:434-454); score = -(links * 0.3f + secs * 0.7f) in unfused f32
+//                    (:469); arg-min over (score, index) (:473-475); padding and hash duration (:479-481)
+//
+// Nothing here approximates: ties are broken by the candidate index exactly as the sorted (f32, usize) list of the
+// reference breaks them.  tests: the GPU suite and tools/fuzz_pipeline.py with NEEDLE_HIP_DEVICE_EPILOGUE=1.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "../../include/needle_hip.h"
+#include "epilogue.h"
+#include "hipctx.h"
+
+namespace needle {
+
+namespace {
+
+constexpr int kMaxSegments = 64;
+
+struct RunSegments {  // the run list as the ranks' slabs or gathered heads: header word 0 = runs found, runs behind it
+  const uint8_t *base[kMaxSegments];
+  uint32_t capacity[kMaxSegments];
+  uint32_t header_bytes;
+  int count;
+};
+
+struct DeviceEntry {  // ComparatorHeapEntry (:22-35) without the fields that are constant inside a bucket
+  uint64_t src_start, src_end, dst_start, dst_end;
+  uint32_t score, src_hash, dst_hash, pad;
+};
+
+struct Candidate {  // :410-432
+  uint64_t start, end;
+  uint32_t hash, is_opening;
+};
+
+struct EpilogueParams {
+  uint32_t n, regions, buckets;          // videos, comparator regions, np * regions
+  uint32_t rows_per_video;               // rows of the hash arena per video
+  uint32_t v0, v1;                       // the videos whose results are wanted
+  uint32_t bound;                        // threshold + threshold / 2 (:441)
+  uint32_t include_endings;
+  uint64_t min_duration[2];              // [0] opening, [1] ending
+  uint64_t time_padding, hash_duration;
+};
+
+__device__ __forceinline__ uint32_t segment_count(const RunSegments &s, int k) {
+  return min(*reinterpret_cast<const uint32_t *>(s.base[k]), s.capacity[k]);  // an overflowed slab is redone by the host
+}
+
+// run g of the concatenated list (segments in rank order)
+__device__ __forceinline__ bool locate_run(const RunSegments &s, uint64_t g, NeedleHipRun *out) {
+  for (int k = 0; k < s.count; k++) {
+    const uint32_t c = segment_count(s, k);
+    if (g < c) {
+      *out = reinterpret_cast<const NeedleHipRun *>(s.base[k] + s.header_bytes)[g];
+      return true;
+    }
+    g -= c;
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(256) void bucket_count_kernel(RunSegments segs, uint32_t buckets, uint32_t *__restrict__ count) {
+  uint64_t total = 0;
+  for (int k = 0; k < segs.count; k++) total += segment_count(segs, k);
+  for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+    NeedleHipRun r;
+    if (locate_run(segs, g, &r) && r.problem < buckets) atomicAdd(&count[r.problem], 1u);
+  }
+}
+
+// exclusive scan of count[0..n) into start[0..n], start[n] = total: per-block sums, one block over them, then the blocks
+constexpr int kScanBlock = 1024;
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const uint32_t *__restrict__ count, uint32_t n, uint32_t *__restrict__ sums) {
+  __shared__ uint32_t part[256];
+  const uint32_t base = blockIdx.x * kScanBlock;
+  uint32_t s = 0;
+  for (int k = 0; k < 4; k++) {
+    const uint32_t i = base + threadIdx.x * 4 + k;
+    s += i < n ? count[i] : 0u;
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) part[threadIdx.x] += part[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[blockIdx.x] = part[0];
+}
+__global__ __launch_bounds__(256) void scan_sums_kernel(uint32_t *__restrict__ sums, uint32_t blocks) {  // one workgroup
+  __shared__ uint32_t carry;
+  __shared__ uint32_t part[256];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < blocks; base += 256) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < blocks ? sums[i] : 0u;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {  // inclusive Hillis-Steele
+      const uint32_t add = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+      __syncthreads();
+      part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < blocks) sums[i] = carry + part[threadIdx.x] - v;  // exclusive
+    __syncthreads();
+    if (threadIdx.x == 255) carry += part[255];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void scan_apply_kernel(const uint32_t *__restrict__ count, uint32_t n, const uint32_t *__restrict__ sums,
+                                                         uint32_t *__restrict__ start) {
+  __shared__ uint32_t part[256];
+  const uint32_t base = blockIdx.x * kScanBlock;
+  uint32_t v[4], s = 0;
+  for (int k = 0; k < 4; k++) {
+    const uint32_t i = base + threadIdx.x * 4 + k;
+    v[k] = i < n ? count[i] : 0u;
+    s += v[k];
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const uint32_t add = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t run = sums[blockIdx.x] + part[threadIdx.x] - s;
+  for (int k = 0; k < 4; k++) {
+    const uint32_t i = base + threadIdx.x * 4 + k;
+    if (i < n) start[i] = run;
+    run += v[k];
+    if (i + 1 == n) start[n] = run;
+  }
+}
+
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(RunSegments segs, uint32_t buckets, const uint32_t *__restrict__ start,
+                                                             uint32_t *__restrict__ fill, NeedleHipRun *__restrict__ sorted) {
+  uint64_t total = 0;
+  for (int k = 0; k < segs.count; k++) total += segment_count(segs, k);
+  for (uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+    NeedleHipRun r;
+    if (locate_run(segs, g, &r) && r.problem < buckets) sorted[start[r.problem] + atomicAdd(&fill[r.problem], 1u)] = r;
+  }
+}
+
+// pairs (i, j), i < j, i-major (comparator.rs:534-545): the inverse of the numbering, exact (hostutil's pair_at)
+__device__ __forceinline__ uint64_t row_start(uint64_t n, uint64_t i) { return i * (2 * n - i - 1) / 2; }
+__device__ __forceinline__ void pair_at_device(uint64_t n, uint64_t index, uint32_t *pi, uint32_t *pj) {
+  const double b = 2.0 * (double)n - 1.0;
+  const double disc = b * b - 8.0 * (double)index;
+  uint64_t i = disc > 0.0 ? (uint64_t)((b - sqrt(disc)) / 2.0) : 0;
+  if (i + 2 > n) i = n >= 2 ? n - 2 : 0;
+  while (i > 0 && row_start(n, i) > index) i--;
+  while (i + 2 < n && row_start(n, i + 1) <= index) i++;
+  *pi = (uint32_t)i;
+  *pj = (uint32_t)(i + 1 + (index - row_start(n, i)));
+}
+
+// #[derive(Ord)] over (score, src_start, src_end, dst_start, dst_end, src_match_hash, dst_match_hash, ...): the rest of
+// the fields are equal for all entries of one bucket.  true: a > b.
+__device__ __forceinline__ bool entry_greater(const DeviceEntry &a, const DeviceEntry &b) {
+  if (a.score != b.score) return a.score > b.score;
+  if (a.src_start != b.src_start) return a.src_start > b.src_start;
+  if (a.src_end != b.src_end) return a.src_end > b.src_end;
+  if (a.dst_start != b.dst_start) return a.dst_start > b.dst_start;
+  if (a.dst_end != b.dst_end) return a.dst_end > b.dst_end;
+  if (a.src_hash != b.src_hash) return a.src_hash > b.src_hash;
+  return a.dst_hash > b.dst_hash;
+}
+
+// One thread per bucket.  row tables: length, offset of the row's timestamps in `ts` (un-seeked, shared by rows of equal
+// length), seek added to every timestamp of the row.
+__global__ __launch_bounds__(64) void pair_entries_kernel(EpilogueParams pr, const uint32_t *__restrict__ start,
+                                                          NeedleHipRun *__restrict__ sorted, const uint32_t *__restrict__ row_len,
+                                                          const uint32_t *__restrict__ row_ts, const uint64_t *__restrict__ row_seek,
+                                                          const uint64_t *__restrict__ ts, DeviceEntry *__restrict__ entries,
+                                                          uint32_t *__restrict__ valid) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= pr.buckets) return;
+  const uint32_t lo = start[b], hi = start[b + 1];
+  uint32_t out = 0;
+  if (hi > lo) {
+    // the reference walks its table backwards: i = n-1..1 and, inside, j = m-1..1 (:191-192)
+    for (uint32_t a = lo + 1; a < hi; a++) {
+      const NeedleHipRun x = sorted[a];
+      uint32_t q = a;
+      while (q > lo) {
+        const NeedleHipRun y = sorted[q - 1];
+        const bool before = y.src_end != x.src_end ? y.src_end > x.src_end : y.dst_end > x.dst_end;
+        if (before) break;
+        sorted[q] = y;
+        q--;
+      }
+      sorted[q] = x;
+    }
+    const uint32_t region = b % pr.regions;
+    uint32_t vi, vj;
+    pair_at_device(pr.n, b / pr.regions, &vi, &vj);
+    const uint32_t src_row = vi * pr.rows_per_video + region, dst_row = vj * pr.rows_per_video + region;
+    const uint32_t src_len = row_len[src_row], dst_len = row_len[dst_row];
+    const uint64_t *src_ts = ts + row_ts[src_row], *dst_ts = ts + row_ts[dst_row];
+    const uint64_t src_seek = row_seek[src_row], dst_seek = row_seek[dst_row];
+    const uint64_t min_duration = pr.min_duration[region];
+    DeviceEntry *heap = entries + lo;
+    for (uint32_t a = lo; a < hi; a++) {
+      const NeedleHipRun r = sorted[a];
+      const uint32_t i = r.src_end, j = r.dst_end, len = r.len;
+      if (len == 0 || len > i || len > j || i >= src_len || j >= dst_len) continue;
+      DeviceEntry e;
+      e.src_start = src_ts[i - len] + src_seek;  // one BEFORE the first matched cell (:206-207)
+      e.src_end = src_ts[i] + src_seek;
+      e.dst_start = dst_ts[j - len] + dst_seek;
+      e.dst_end = dst_ts[j] + dst_seek;
+      if (e.src_end < e.src_start || e.dst_end < e.dst_start) continue;
+      if (e.src_end - e.src_start < min_duration || e.dst_end - e.dst_start < min_duration) continue;  // :212-223
+      e.score = len;
+      e.src_hash = r.src_match_hash;
+      e.dst_hash = r.dst_match_hash;
+      e.pad = 0;
+      // BinaryHeap::push: append, sift up while greater than the parent
+      uint32_t pos = out++;
+      while (pos > 0) {
+        const uint32_t parent = (pos - 1) / 2;
+        const DeviceEntry p = heap[parent];
+        if (!entry_greater(e, p)) break;
+        heap[pos] = p;
+        pos = parent;
+      }
+      heap[pos] = e;
+    }
+  }
+  valid[b] = out;
+}
+
+struct BestKey {
+  float score;
+  uint32_t index;
+  uint32_t have;
+};
+__device__ __forceinline__ bool better(const BestKey &a, const BestKey &b) {  // a before b in the ascending (score, index) order
+  if (!a.have) return false;
+  if (!b.have) return true;
+  return a.score < b.score || (a.score == b.score && a.index < b.index);
+}
+
+__device__ __forceinline__ float as_secs_f32(uint64_t d) {  // Duration::as_secs_f32 (hostutil.cpp duration_as_secs_f32)
+  const float secs = (float)(d / 1000000000ull);
+  const float frac = (float)(uint32_t)(d % 1000000000ull) / 1000000000.0f;
+  return secs + frac;
+}
+
+constexpr int kHashTile = 4096;
+// One workgroup per wanted video.
+__global__ __launch_bounds__(256) void best_match_kernel(EpilogueParams pr, const uint32_t *__restrict__ start,
+                                                         const uint32_t *__restrict__ valid, const DeviceEntry *__restrict__ entries,
+                                                         Candidate *__restrict__ cand_pool, unsigned long long *__restrict__ cand_cursor,
+                                                         uint32_t *__restrict__ links_pool, NeedleHipSearchResult *__restrict__ results,
+                                                         uint32_t *__restrict__ failed) {
+  __shared__ uint32_t scan[256];
+  __shared__ uint32_t carry;
+  __shared__ unsigned long long pool_base;
+  __shared__ uint32_t tile[kHashTile];
+  __shared__ BestKey best[2][256];
+  const uint32_t v = pr.v0 + blockIdx.x, t = threadIdx.x;
+  const uint64_t n = pr.n;
+  const uint32_t slots = pr.n - 1;  // the video's pairs in lexicographic order: (q, v) for q < v, then (v, q + 1)
+  auto bucket_of = [&](uint32_t q) -> uint64_t {
+    const uint64_t p = q < v ? row_start(n, q) + (v - q - 1) : row_start(n, v) + (q - v);
+    return p * pr.regions;
+  };
+  // pass 1: candidates per pair slot -> total
+  if (t == 0) carry = 0;
+  __syncthreads();
+  uint32_t mine_total = 0;
+  for (uint32_t q = t; q < slots; q += 256) {
+    const uint64_t b = bucket_of(q);
+    mine_total += valid[b] + (pr.regions == 2 ? valid[b + 1] : 0u);
+  }
+  scan[t] = mine_total;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)t < d) scan[t] += scan[t + d];
+    __syncthreads();
+  }
+  const uint32_t c = scan[0];
+  __syncthreads();
+  NeedleHipSearchResult res;
+  memset(&res, 0, sizeof(res));
+  if (c == 0) {  // no pair of this video has an entry: the reference pushes nothing for it (:608-617)
+    if (t == 0) results[v] = res;
+    return;
+  }
+  if (t == 0) pool_base = atomicAdd(cand_cursor, (unsigned long long)c);
+  __syncthreads();
+  Candidate *cand = cand_pool + pool_base;
+  uint32_t *links = links_pool + pool_base;
+  // pass 2: candidate index of every pair slot (exclusive scan in slot order, 256 slots at a time), then the fill
+  for (uint32_t base = 0; base < slots; base += 256) {
+    const uint32_t q = base + t;
+    uint32_t cnt = 0;
+    uint64_t b = 0;
+    if (q < slots) {
+      b = bucket_of(q);
+      cnt = valid[b] + (pr.regions == 2 ? valid[b + 1] : 0u);
+    }
+    scan[t] = cnt;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const uint32_t add = (int)t >= d ? scan[t - d] : 0u;
+      __syncthreads();
+      scan[t] += add;
+      __syncthreads();
+    }
+    uint32_t at = carry + scan[t] - cnt;
+    if (cnt) {
+      const bool as_source = q >= v;
+      for (uint32_t r = 0; r < pr.regions; r++) {  // openings first, then endings (:414-431)
+        const DeviceEntry *e = entries + start[b + r];
+        const uint32_t k1 = valid[b + r];
+        for (uint32_t k = 0; k < k1; k++) {
+          Candidate cd;
+          cd.start = as_source ? e[k].src_start : e[k].dst_start;
+          cd.end = as_source ? e[k].src_end : e[k].dst_end;
+          cd.hash = as_source ? e[k].src_hash : e[k].dst_hash;
+          cd.is_opening = r == 0 ? 1u : 0u;
+          cand[at++] = cd;
+        }
+      }
+    }
+    __syncthreads();
+    if (t == 255) carry += scan[255];
+    __syncthreads();
+  }
+  __threadfence_block();
+  __syncthreads();
+  // links[k] = #{b : popcount(h_k ^ h_b) < bound}, k itself included (:434-454): all candidates against all, the b side
+  // staged through LDS a tile at a time
+  for (uint32_t k0 = 0; k0 < c; k0 += 256 * 4) {
+    uint32_t hk[4], acc[4] = {0, 0, 0, 0};
+    for (int u = 0; u < 4; u++) {
+      const uint32_t k = k0 + u * 256 + t;
+      hk[u] = k < c ? cand[k].hash : 0u;
+    }
+    for (uint32_t b0 = 0; b0 < c; b0 += kHashTile) {
+      const uint32_t len = min((uint32_t)kHashTile, c - b0);
+      __syncthreads();
+      for (uint32_t i = t; i < len; i += 256) tile[i] = cand[b0 + i].hash;
+      __syncthreads();
+      for (uint32_t i = 0; i < len; i++) {
+        const uint32_t hb = tile[i];
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] += (uint32_t)__popc(hk[u] ^ hb) < pr.bound ? 1u : 0u;
+      }
+    }
+    for (int u = 0; u < 4; u++) {
+      const uint32_t k = k0 + u * 256 + t;
+      if (k < c) links[k] = acc[u];
+    }
+  }
+  __syncthreads();
+  // score = -(count * 0.3 + secs * 0.7) in f32, no fused multiply-add (:469); ascending (score, index), first (:473-475)
+  BestKey mine[2] = {{0.f, 0u, 0u}, {0.f, 0u, 0u}};
+  for (uint32_t k = t; k < c; k += 256) {
+    const Candidate cd = cand[k];
+    const uint32_t l = links[k];
+    if (l == 0) continue;
+    const float count = (float)(long long)l;
+    const float secs = as_secs_f32(cd.end - cd.start);
+    const float a = count * 0.3f;
+    const float b = secs * 0.7f;
+    const float weighted = a + b;
+    const BestKey key = {-weighted, k, 1u};
+    const int which = cd.is_opening ? 0 : 1;
+    if (better(key, mine[which])) mine[which] = key;
+  }
+  best[0][t] = mine[0];
+  best[1][t] = mine[1];
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)t < d) {
+      if (better(best[0][t + d], best[0][t])) best[0][t] = best[0][t + d];
+      if (better(best[1][t + d], best[1][t])) best[1][t] = best[1][t + d];
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    res.has_result = true;  // Some(best) even if neither side is found (:514)
+    bool bad = false;
+    for (int which = 0; which < 2; which++) {
+      if (which == 1 && !pr.include_endings) break;  // :486
+      const BestKey w = best[which][0];
+      if (!w.have) continue;
+      const Candidate cd = cand[w.index];
+      if (cd.end < pr.time_padding || cd.end - pr.time_padding < pr.hash_duration) {  // Duration underflow panics upstream
+        bad = true;
+        break;
+      }
+      const uint64_t s = cd.start + pr.time_padding;                    // :479
+      const uint64_t e = cd.end - pr.time_padding - pr.hash_duration;   // :481
+      if (which == 0) {
+        res.has_opening = true;
+        res.opening_start_ns = s;
+        res.opening_end_ns = e;
+      } else {
+        res.has_ending = true;
+        res.ending_start_ns = s;
+        res.ending_end_ns = e;
+      }
+    }
+    if (bad) atomicAdd(failed, 1u);
+    results[v] = res;
+  }
+}
+
+struct EpilogueWorkspace {
+  DeviceBuffer<uint32_t> count, start, fill, sums, valid, links, ctl, row_len, row_ts;
+  DeviceBuffer<uint64_t> row_seek, ts;
+  DeviceBuffer<NeedleHipRun> sorted;
+  DeviceBuffer<DeviceEntry> entries;
+  DeviceBuffer<Candidate> cand;
+  DeviceBuffer<NeedleHipSearchResult> results;
+  std::vector<uint32_t> h_row_len, h_row_ts;  // what the device tables hold
+  std::vector<uint64_t> h_row_seek, h_ts;
+};
+std::mutex g_mu;
+std::map<std::pair<int, int>, EpilogueWorkspace *> g_ws;  // (device, job slot)
+
+EpilogueWorkspace *workspace(int slot) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_mu);
+  EpilogueWorkspace *&w = g_ws[{dev, slot}];
+  if (!w) w = new EpilogueWorkspace();
+  return w;
+}
+
+template <class T>
+Status upload_if_changed(DeviceBuffer<T> *dst, std::vector<T> *resident, const std::vector<T> &want, hipStream_t stream) {
+  if (dst->ptr && *resident == want) return Status::Ok();
+  Status s = dst->reserve(std::max<size_t>(want.size(), 1));
+  if (!s.ok()) return s;
+  // (pageable source: the copy is staged by the runtime before the call returns)
+  if (!want.empty()) NEEDLE_HIP_TRY(hipMemcpyAsync(dst->ptr, want.data(), want.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+  NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+  *resident = want;
+  return Status::Ok();
+}
+
+}  // namespace
+
+Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHipSearchResult *host_results, uint32_t *host_failed) {
+  if (job.num_segments < 1 || job.num_segments > kMaxSegments)
+    return Status::Make(NeedleError_InvalidArgument, "device epilogue: too many run segments");
+  const uint64_t np = (uint64_t)job.n * (job.n - 1) / 2;
+  const uint64_t buckets = np * job.regions;
+  if (job.n < 2 || buckets >= 0xFFFFFFF0ull || job.max_runs >= 0xFFFFFFF0ull)
+    return Status::Make(NeedleError_InvalidArgument, "device epilogue: library too large");
+  EpilogueWorkspace *ws = workspace(job.slot);
+  Status s;
+  // row tables: only re-uploaded when the geometry changes
+  if (!(s = upload_if_changed(&ws->row_len, &ws->h_row_len, *job.row_len, stream)).ok() ||
+      !(s = upload_if_changed(&ws->row_ts, &ws->h_row_ts, *job.row_ts, stream)).ok() ||
+      !(s = upload_if_changed(&ws->row_seek, &ws->h_row_seek, *job.row_seek, stream)).ok() ||
+      !(s = upload_if_changed(&ws->ts, &ws->h_ts, *job.ts, stream)).ok())
+    return s;
+  const size_t runs = std::max<uint64_t>(job.max_runs, 1);
+  if (!(s = ws->count.reserve(buckets)).ok() || !(s = ws->fill.reserve(buckets)).ok() || !(s = ws->start.reserve(buckets + 1)).ok() ||
+      !(s = ws->valid.reserve(buckets)).ok() || !(s = ws->sums.reserve((buckets + kScanBlock - 1) / kScanBlock + 1)).ok() ||
+      !(s = ws->sorted.reserve(runs)).ok() || !(s = ws->entries.reserve(runs)).ok() || !(s = ws->cand.reserve(2 * runs)).ok() ||
+      !(s = ws->links.reserve(2 * runs)).ok() || !(s = ws->ctl.reserve(4)).ok() || !(s = ws->results.reserve(job.n)).ok())
+    return s;
+  RunSegments segs;
+  std::memset(&segs, 0, sizeof(segs));
+  segs.count = job.num_segments;
+  segs.header_bytes = job.header_bytes;
+  for (int k = 0; k < job.num_segments; k++) {
+    segs.base[k] = job.segment_base[k];
+    segs.capacity[k] = job.segment_capacity;
+  }
+  EpilogueParams pr;
+  std::memset(&pr, 0, sizeof(pr));
+  pr.n = job.n;
+  pr.regions = job.regions;
+  pr.rows_per_video = job.rows_per_video;
+  pr.buckets = (uint32_t)buckets;
+  pr.v0 = job.v0;
+  pr.v1 = job.v1;
+  pr.bound = job.threshold + job.threshold / 2;
+  pr.include_endings = job.include_endings ? 1u : 0u;
+  pr.min_duration[0] = job.min_opening_duration;
+  pr.min_duration[1] = job.min_ending_duration;
+  pr.time_padding = job.time_padding;
+  pr.hash_duration = job.hash_duration;
+  NEEDLE_HIP_TRY(hipMemsetAsync(ws->count.ptr, 0, buckets * sizeof(uint32_t), stream));
+  NEEDLE_HIP_TRY(hipMemsetAsync(ws->fill.ptr, 0, buckets * sizeof(uint32_t), stream));
+  NEEDLE_HIP_TRY(hipMemsetAsync(ws->ctl.ptr, 0, 4 * sizeof(uint32_t), stream));
+  NEEDLE_HIP_TRY(hipMemsetAsync(ws->results.ptr, 0, (size_t)job.n * sizeof(NeedleHipSearchResult), stream));
+  const uint32_t run_grid = (uint32_t)std::min<uint64_t>(4096, (runs + 255) / 256);
+  const uint32_t scan_blocks = (uint32_t)((buckets + kScanBlock - 1) / kScanBlock);
+  {
+    KernelTimer timer("epilogue_buckets", stream);
+    hipLaunchKernelGGL(bucket_count_kernel, dim3(run_grid), dim3(256), 0, stream, segs, pr.buckets, ws->count.ptr);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(scan_blocks), dim3(256), 0, stream, ws->count.ptr, pr.buckets, ws->sums.ptr);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, stream, ws->sums.ptr, scan_blocks);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(scan_blocks), dim3(256), 0, stream, ws->count.ptr, pr.buckets, ws->sums.ptr, ws->start.ptr);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(run_grid), dim3(256), 0, stream, segs, pr.buckets, ws->start.ptr, ws->fill.ptr,
+                       ws->sorted.ptr);
+  }
+  {
+    KernelTimer timer("epilogue_entries", stream);
+    hipLaunchKernelGGL(pair_entries_kernel, dim3((pr.buckets + 63) / 64), dim3(64), 0, stream, pr, ws->start.ptr, ws->sorted.ptr,
+                       ws->row_len.ptr, ws->row_ts.ptr, ws->row_seek.ptr, ws->ts.ptr, ws->entries.ptr, ws->valid.ptr);
+  }
+  if (pr.v1 > pr.v0) {
+    KernelTimer timer("epilogue_best_match", stream);
+    hipLaunchKernelGGL(best_match_kernel, dim3(pr.v1 - pr.v0), dim3(256), 0, stream, pr, ws->start.ptr, ws->valid.ptr, ws->entries.ptr,
+                       ws->cand.ptr, reinterpret_cast<unsigned long long *>(ws->ctl.ptr), ws->links.ptr, ws->results.ptr, ws->ctl.ptr + 2);
+  }
+  NEEDLE_HIP_TRY(hipGetLastError());
+  NEEDLE_HIP_TRY(hipMemcpyAsync(host_results, ws->results.ptr, (size_t)job.n * sizeof(NeedleHipSearchResult), hipMemcpyDeviceToHost, stream));
+  NEEDLE_HIP_TRY(hipMemcpyAsync(host_failed, ws->ctl.ptr + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  return Status::Ok();
+}
+
+}  // namespace needle

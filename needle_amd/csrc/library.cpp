@@ -20,6 +20,7 @@
 #include <tuple>
 
 #include "comm.h"
+#include "epilogue.h"
 #include "hipctx.h"
 #include "needle_core.h"
 
@@ -92,6 +93,10 @@ struct NeedleHipLibrary {
     hipEvent_t searched = nullptr, done = nullptr;
     bool pending = false;
     std::vector<NeedleHipRun> merged;
+    // device epilogue (epilogue.hip): per-video results + failure count land here (pinned) behind the run download
+    void *host_results = nullptr;
+    size_t host_results_bytes = 0;
+    bool device_epilogue = false, sharded = false;
     const NeedleHipRun *last_runs = nullptr;  // the complete run list of the job that finished last in this slot
     size_t last_total = 0;
     uint64_t comm_bytes[4] = {0, 0, 0, 0};  // received per rank in this job: hash rows, run heads, results; scans repeated
@@ -103,6 +108,28 @@ struct NeedleHipLibrary {
   uint32_t last_max_count = 0;  // largest per-rank run count of the last finished job: sizes the one-trip download
   size_t arena_rows = 0;       // rows the arena was allocated with
   const uint32_t *count_zeroed = nullptr;  // a run counter the last kernel of this job's analyze has just cleared (job_begin)
+  // what the device epilogue needs to know about the arena's rows (built once per geometry: plan_windows clears them)
+  std::vector<uint32_t> row_len, row_ts;
+  std::vector<uint64_t> row_seek, ts_tables;
+  void ensure_row_tables() {
+    if (row_len.size() == rows()) return;
+    row_len.assign(rows(), 0);
+    row_ts.assign(rows(), 0);
+    row_seek.assign(rows(), 0);
+    ts_tables.clear();
+    std::map<uint32_t, uint32_t> offset_of;  // kept length -> offset of its un-seeked timestamps
+    for (size_t row = 0; row < rows(); row++) {
+      const Window &w = win[row];
+      auto it = offset_of.find(w.kept);
+      if (it == offset_of.end()) {
+        it = offset_of.emplace(w.kept, (uint32_t)ts_tables.size()).first;
+        for (const HashTs &h : timestamps(w.kept)) ts_tables.push_back(h.ts);
+      }
+      row_len[row] = w.kept;
+      row_ts[row] = it->second;
+      row_seek[row] = w.seek;
+    }
+  }
   ~NeedleHipLibrary() {
     for (Fetch &f : fetch) {
       if (f.host) (void)hipHostFree(f.host);
@@ -110,6 +137,7 @@ struct NeedleHipLibrary {
       if (f.ready) (void)hipEventDestroy(f.ready);
     }
     for (Job &j : job) {
+      if (j.host_results) (void)hipHostFree(j.host_results);
       if (j.host) (void)hipHostFree(j.host);
       if (j.done) (void)hipEventDestroy(j.done);
       if (j.searched) (void)hipEventDestroy(j.searched);
@@ -286,6 +314,7 @@ Status plan_windows(NeedleHipLibrary *lib, const int16_t *const *pcm, const size
   }
   if (total_values) *total_values = total;
   lib->min_len.clear();
+  lib->row_len.clear();
   lib->shells.clear();
   lib->shell_of.clear();
   lib->problems_for[0] = ~(size_t)0;
@@ -665,6 +694,14 @@ Status job_buffers(NeedleHipLibrary *lib, NeedleHipLibrary::Job &j, int world) {
   return Status::Ok();
 }
 
+// The per-video epilogue on the device (epilogue.hip) instead of on host threads: at library scale, where the host form
+// takes tens of milliseconds and every rank of a node has only its share of the CPUs.  Decided when the job is enqueued
+// (the run count is not known yet): by the number of sequence pairs, or NEEDLE_HIP_DEVICE_EPILOGUE=1 / 0.
+bool device_epilogue_wanted(const NeedleHipLibrary *lib, size_t comparator_regions) {
+  if (const char *e = getenv("NEEDLE_HIP_DEVICE_EPILOGUE")) return atoi(e) != 0;
+  return (uint64_t)pair_count(lib->n) * comparator_regions >= (1u << 16);
+}
+
 // scan of this rank's pair range into its slab, gather of the slabs, download of their heads: all asynchronous
 NeedleError job_search_and_gather(NeedleHipLibrary *lib, const NeedleAudioComparator *comparator, NeedleHipLibrary::Job &j) {
   const int world = comm_world(), rank = comm_rank();
@@ -692,6 +729,58 @@ NeedleError job_search_and_gather(NeedleHipLibrary *lib, const NeedleAudioCompar
   }
   if (hipMemcpyAsync(j.host, src, j.head_bytes() * (size_t)world, hipMemcpyDeviceToHost, down) != hipSuccess)
     return report(Status::Make(NeedleError_Unknown, "asynchronous run download failed"));
+  const Comparator &cmp = comparator_of(comparator);
+  const size_t Rc = cmp.include_endings() ? 2 : 1;
+  j.device_epilogue = device_epilogue_wanted(lib, Rc) && lib->n >= 2;
+  if (j.device_epilogue) {
+    // every rank for all videos, or -- more than one rank and a library large enough to pay for one more collective -- each
+    // for its own block of videos (the decision cannot wait for the run count: the pairs stand in for it)
+    j.sharded = world > 1 && (getenv("NEEDLE_HIP_SHARD_EPILOGUE") ? atoi(getenv("NEEDLE_HIP_SHARD_EPILOGUE")) != 0
+                                                                   : (uint64_t)pair_count(lib->n) * Rc >= (1u << 16));
+    const size_t want = (lib->n + 1) * sizeof(NeedleHipSearchResult);
+    if (want > j.host_results_bytes) {
+      if (j.host_results) (void)hipHostFree(j.host_results);
+      j.host_results = nullptr;
+      j.host_results_bytes = 0;
+      if (hipHostMalloc(&j.host_results, want, hipHostMallocDefault) != hipSuccess)
+        return report(Status::Make(NeedleError_Unknown, "pinned allocation failed"));
+      j.host_results_bytes = want;
+    }
+    lib->ensure_row_tables();
+    EpilogueJob ej;
+    ej.slot = (int)(&j - lib->job);
+    ej.n = (uint32_t)lib->n;
+    ej.regions = (uint32_t)Rc;
+    ej.rows_per_video = (uint32_t)lib->regions();
+    size_t v0 = 0, vcount = lib->n;
+    if (j.sharded) shard_range(lib->n, world, rank, &v0, &vcount);
+    ej.v0 = (uint32_t)v0;
+    ej.v1 = (uint32_t)(v0 + vcount);
+    ej.threshold = cmp.hash_match_threshold();
+    ej.include_endings = cmp.include_endings();
+    ej.min_opening_duration = cmp.min_opening_duration();
+    ej.min_ending_duration = cmp.min_ending_duration();
+    ej.time_padding = cmp.time_padding();
+    ej.hash_duration = lib->hash_duration;
+    ej.num_segments = world;
+    ej.header_bytes = (uint32_t)NeedleHipLibrary::kSlabHeader;
+    if (world > 1) {
+      for (int r = 0; r < world; r++) ej.segment_base[r] = j.d_heads.ptr + (size_t)r * j.head_bytes();
+      ej.segment_capacity = j.head_runs;
+    } else {
+      ej.segment_base[0] = mine;
+      ej.segment_capacity = j.slab_runs;
+    }
+    ej.max_runs = (uint64_t)ej.segment_capacity * (uint64_t)world;
+    ej.row_len = &lib->row_len;
+    ej.row_ts = &lib->row_ts;
+    ej.row_seek = &lib->row_seek;
+    ej.ts = &lib->ts_tables;
+    NeedleHipSearchResult *hr = static_cast<NeedleHipSearchResult *>(j.host_results);
+    Status s = world <= 64 ? gpu_epilogue_enqueue(ej, down, hr, reinterpret_cast<uint32_t *>(hr + lib->n))
+                           : Status::Make(NeedleError_InvalidArgument, "device epilogue: more than 64 ranks");
+    if (!s.ok()) return report(s);
+  }
   if (hipEventRecord(j.done, down) != hipSuccess)
     return report(Status::Make(NeedleError_Unknown, "asynchronous run download failed"));
   return NeedleError_Ok;
@@ -907,23 +996,34 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
 
     // 5. the order-sensitive per-video epilogue (comparator.rs:583-626): every rank for all videos while that is
     // cheaper than another collective, otherwise each rank for its own block of videos + one all-gather of results
-    const std::vector<const FrameHashesData *> fh = lib->shell_pointers();
     std::vector<VideoResult> res;
-    const bool sharded = world > 1 && shard_epilogue(total);
+    const bool sharded = j.device_epilogue ? j.sharded : (world > 1 && shard_epilogue(total));
     size_t v0 = 0, vcount = lib->n;
     if (sharded) shard_range(lib->n, world, rank, &v0, &vcount);
     const auto t0 = std::chrono::steady_clock::now();
     if (!run_list) run_list = j.merged.data();
     j.last_runs = run_list;
     j.last_total = total;
-    Status s = cmp.results_from_runs(fh, run_list, total, false, false, false, &res, v0, v0 + vcount);
+    Status s;
+    const NeedleHipSearchResult *device_results = nullptr;
+    if (j.device_epilogue) {  // computed on the device behind the gather (epilogue.hip); j.done covers its copies
+      device_results = static_cast<const NeedleHipSearchResult *>(j.host_results);
+      if (*reinterpret_cast<const uint32_t *>(device_results + lib->n) != 0)
+        s = Status::Make(NeedleError_Unknown, "overflow when subtracting durations (time_padding / hash_duration exceed the match end)");
+    } else {
+      const std::vector<const FrameHashesData *> fh = lib->shell_pointers();
+      s = cmp.results_from_runs(fh, run_list, total, false, false, false, &res, v0, v0 + vcount);
+    }
     if (getenv("NEEDLE_HIP_TRACE"))
       std::fprintf(stderr, "[needle_hip] rank %d epilogue %zu runs, videos [%zu, %zu): %.1f us\n", rank, total, v0, v0 + vcount,
                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     // an error on one rank must not leave the others waiting in the collective below: it travels with the results
     if (!sharded) {
       if (!s.ok()) return report(s);
-      for (size_t v = 0; v < lib->n; v++) fill_c_result(res[v], &results[v]);
+      if (device_results)
+        std::memcpy(results, device_results, lib->n * sizeof(NeedleHipSearchResult));
+      else
+        for (size_t v = 0; v < lib->n; v++) fill_c_result(res[v], &results[v]);
       return NeedleError_Ok;
     }
     const size_t b = shard_block(lib->n, world);
@@ -933,7 +1033,9 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
     const size_t block_bytes = sizeof(Block) + b * sizeof(NeedleHipSearchResult);
     std::vector<uint8_t> mine(block_bytes, 0), all(block_bytes * (size_t)world, 0);
     reinterpret_cast<Block *>(mine.data())->failed = s.ok() ? 0 : 1;
-    if (s.ok())
+    if (s.ok() && device_results)
+      std::memcpy(mine.data() + sizeof(Block), device_results + v0, vcount * sizeof(NeedleHipSearchResult));
+    else if (s.ok())
       for (size_t k = 0; k < vcount; k++)
         fill_c_result(res[v0 + k], reinterpret_cast<NeedleHipSearchResult *>(mine.data() + sizeof(Block)) + k);
     Status g = comm_all_gather_host(mine.data(), all.data(), block_bytes);

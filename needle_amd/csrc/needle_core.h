@@ -125,6 +125,7 @@ class Comparator {
                          bool is_opening, std::vector<HeapEntry> *out) const;
   ns_t min_opening_duration() const { return min_opening_duration_; }
   ns_t min_ending_duration() const { return min_ending_duration_; }
+  ns_t time_padding() const { return time_padding_; }
   // Run list of ALL pairs (NeedleHipRun.problem = pair_index * regions + region) -> per-video results.
   // [v0, v1): the videos whose results are wanted (a rank's block in a multi-GPU job; the other slots of
   // per_video stay empty and only the pairs that touch the block are worked on).

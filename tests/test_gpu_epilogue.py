@@ -1,0 +1,128 @@
+"""-m gpu: the per-video epilogue ON THE DEVICE (needle_amd/csrc/epilogue.hip) against the host form (comparator.cpp)
+and the oracle (comparator.rs:191-249,405-515,583-626 restated in oracle/ora_needle.c).  The device form is what a
+library-scale job uses (>= 65 536 sequence pairs, or NEEDLE_HIP_DEVICE_EPILOGUE=1); both forms see the same run list.
+What can go wrong is ORDER: the reverse table walk, BinaryHeap's backing-array order, the candidate numbering that
+breaks ties between equal (f32) scores -- so the inputs here are built to tie: the same segment planted bit-identically
+in many videos, competing segments of equal length, several runs per pair, endings, padding."""
+import numpy as np
+import pytest
+
+from needle_amd import capi, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+NS = O.NS
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert capi.device_count() > 0, "GPU tests need a HIP device (the product has no CPU fallback)"
+
+
+def _as(rs):
+    return [None if r is None else (r.opening, r.ending) for r in rs]
+
+
+def _job(lib, cmp, monkeypatch, device):
+    monkeypatch.setenv("NEEDLE_HIP_DEVICE_EPILOGUE", "1" if device else "0")
+    lib.job_begin(cmp, 0)
+    res, runs = lib.job_end(cmp, 0)
+    return _as(res), runs
+
+
+def _planted_library(rng, n, kept, endings, exact):
+    """Hash rows with shared segments: `exact` plants bit-identical copies (equal simhashes, equal lengths: ties)."""
+    rows = []
+    seg_a, seg_b, seg_c = (rng.integers(0, 2 ** 32, L, dtype=np.uint64).astype(np.uint32) for L in (110, 110, 95))
+    for v in range(n):
+        regions = []
+        for r in range(2 if endings else 1):
+            h = rng.integers(0, 2 ** 32, kept[v], dtype=np.uint64).astype(np.uint32)
+            for seg, every, base in ((seg_a, 1, 7), (seg_b, 2, 260), (seg_c, 3, 420)):
+                if v % every == 0 and base + 13 * (v % 5) + len(seg) < kept[v]:
+                    a = base + 13 * (v % 5) + 31 * r
+                    if a + len(seg) >= kept[v]:
+                        continue
+                    flips = np.zeros(len(seg), dtype=np.uint32) if exact else \
+                        (np.uint32(1) << rng.integers(0, 32, len(seg)).astype(np.uint32)) * (rng.random(len(seg)) < 0.5)
+                    h[a:a + len(seg)] = seg ^ flips
+            regions.append(h)
+        rows.append(regions)
+    return rows
+
+
+@pytest.mark.parametrize("n,endings,exact,min_s,padding,threshold", [
+    (24, False, True, 20, 0.0, 10), (24, True, True, 15, 0.0, 10), (17, False, False, 10, 0.0, 10),
+    (9, True, False, 20, 1.5, 6), (31, False, True, 25, 0.25, 12), (12, True, True, 5, 0.0, 10)])
+def test_device_epilogue_on_planted_hashes_equals_host_and_oracle(monkeypatch, n, endings, exact, min_s, padding, threshold):
+    """Hashes written straight into the library's arena (the search and the epilogue start from hashes): identical
+    segments in many videos give every pair several runs and many candidates exactly equal scores."""
+    rng = np.random.default_rng(1000 + n)
+    seconds = [170.0 + 11.0 * (v % 4) for v in range(n)]
+    lens = [int(round(s * synth.RATE)) for s in seconds]
+    lib = capi.Library(n)
+    if endings:
+        lib.include_endings()
+    lib.stream_pcm([np.zeros(v, dtype=np.int16) for v in lens], lens)      # geometry only: the rows are overwritten below
+    fhs0 = [lib.frame_hashes(v) for v in range(n)]
+    kept = [(len(f.opening_data()[0]), len(f.ending_data()[0]) if endings else 0) for f in fhs0]
+    rows = _planted_library(rng, n, [k[0] for k in kept], endings, exact)
+    d_arena, stride = lib.hash_arena()
+    R = lib.rows_per_video()
+    for v in range(n):
+        for r in range(R):
+            h = rows[v][r][: kept[v][r]] if r == 0 else rows[v][r][: kept[v][1]]
+            h = np.ascontiguousarray(h, dtype=np.uint32)
+            capi.check(capi.lib().needle_hip_memcpy_h2d(d_arena + 4 * (v * R + r) * stride, h.ctypes.data, h.nbytes))
+    cmp = capi.Comparator([f"v{v}.wav" for v in range(n)], include_endings=endings, min_opening_duration=min_s,
+                          min_ending_duration=min_s, hash_match_threshold=threshold, time_padding=padding)
+    host, runs_h = _job(lib, cmp, monkeypatch, device=False)
+    dev, runs_d = _job(lib, cmp, monkeypatch, device=True)
+    assert runs_h == runs_d > 0
+    assert dev == host
+    hd = O.duration_from_secs_f32(0.3)
+    ofh = []
+    for v in range(n):
+        f = lib.frame_hashes(v)
+        op = list(zip(f.opening_data()[0].tolist(), f.opening_data()[1].tolist()))
+        en = list(zip(f.ending_data()[0].tolist(), f.ending_data()[1].tolist())) if endings else []
+        assert [h for h, _ in op] == rows[v][0][: kept[v][0]].tolist()
+        ofh.append(O.FrameHashes(op, en, hd, ""))
+    want = O.run_with_frame_hashes(O.Comparator(include_endings=endings, hash_match_threshold=threshold,
+                                                min_opening_duration=min_s * NS, min_ending_duration=min_s * NS,
+                                                time_padding=O.duration_from_secs_f32(padding)), ofh, threads=8)
+    assert dev == _as(want)
+    assert sum(1 for r in dev if r is not None and r[0] is not None) >= n // 2
+
+
+def test_device_epilogue_on_audio_with_two_jobs_in_flight(monkeypatch):
+    eps = [synth.make_episode(k, 100.0 + 7.0 * k, 22.0, 21.0) for k in range(6)]
+    lens = [len(e.pcm) for e in eps]
+    lib = capi.Library(6).include_endings()
+    lib.set_pcm([e.pcm for e in eps], lens)
+    cmp = capi.Comparator([f"ep{k}.wav" for k in range(6)], min_opening_duration=10, min_ending_duration=10, include_endings=True)
+    host, _ = _job(lib, cmp, monkeypatch, device=False)
+    monkeypatch.setenv("NEEDLE_HIP_DEVICE_EPILOGUE", "1")
+    monkeypatch.setenv("NEEDLE_HIP_SLAB_RUNS", "4")               # (a fresh library: its first job overflows and is redone)
+    lib2 = capi.Library(6).include_endings()
+    lib2.set_pcm([e.pcm for e in eps], lens)
+    lib2.job_begin(cmp, 0)
+    lib2.job_begin(cmp, 1)
+    a = _as(lib2.job_end(cmp, 0)[0])
+    lib2.job_begin(cmp, 0)
+    b = _as(lib2.job_end(cmp, 1)[0])
+    c = _as(lib2.job_end(cmp, 0)[0])
+    assert a == b == c == host
+    assert all(r is not None and r[0] is not None and r[1] is not None for r in a)
+
+
+def test_padding_larger_than_the_match_fails_like_the_host_form(monkeypatch):
+    eps = synth.make_library(4, 90.0, 20.0)
+    lib = capi.Library(4)
+    lib.set_pcm([e.pcm for e in eps], [len(e.pcm) for e in eps])
+    cmp = capi.Comparator([f"ep{k}.wav" for k in range(4)], min_opening_duration=10, time_padding=4000.0)
+    for device in (False, True):
+        monkeypatch.setenv("NEEDLE_HIP_DEVICE_EPILOGUE", "1" if device else "0")
+        lib.job_begin(cmp, 0)
+        with pytest.raises(capi.NeedleError, match="overflow when subtracting durations"):
+            lib.job_end(cmp, 0)

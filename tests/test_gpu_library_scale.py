@@ -194,7 +194,7 @@ RANKS_EPISODES = int(os.environ.get("NEEDLE_TEST_RANKS_EPISODES", "400"))
     (4, {"NEEDLE_HIP_SLAB_RUNS": "2048"}),                       # slab overflow on the first job: grow + rescan + regather
     (5, {"NEEDLE_HIP_HEAD_RUNS": "64", "NEEDLE_HIP_SHARD_EPILOGUE": "0"}),   # head overflow; unsharded epilogue on every rank
 ])
-def test_config4_shape_between_ranks_on_one_gpu(tmp_path, world, env):
+def test_config4_shape_between_ranks_on_one_gpu(tmp_path, monkeypatch, world, env):
     """BASELINE.json configs[4]'s shape with world > 1: 400 episodes x 45 min, 79 800 pairs, 5 441
     hashes per episode, every rank a real process on device 0 over the host-staged transport, PCM generated in HBM per
     rank for the episodes needle_hip_library_rank_videos names.  Exercised at the size that triggers them: hash-block
@@ -218,6 +218,13 @@ def test_config4_shape_between_ranks_on_one_gpu(tmp_path, world, env):
     want_results = [None if r is None else [None if x is None else list(x) for x in (r.opening, r.ending)] for r in res]
     want_digest = run_digest(lib.job_runs(0))
     assert lib.job_comm_bytes(0) == {"hash_rows": 0, "run_heads": 0, "results": 0, "scans_repeated": 0}
+    # 79 800 pairs: the job above ran the per-video epilogue on the device (epilogue.hip); the host form must agree
+    monkeypatch.setenv("NEEDLE_HIP_DEVICE_EPILOGUE", "0")
+    lib.job_begin(cmp, 1)
+    res_host, found_host = lib.job_end(cmp, 1)
+    monkeypatch.delenv("NEEDLE_HIP_DEVICE_EPILOGUE")
+    assert found_host == found
+    assert [None if r is None else [None if x is None else list(x) for x in (r.opening, r.ending)] for r in res_host] == want_results
     d_arena, stride = lib.hash_arena()
     arena = np.zeros(n * stride, dtype=np.uint32)
     capi.check(capi.lib().needle_hip_memcpy_d2h(arena.ctypes.data, d_arena, arena.nbytes))

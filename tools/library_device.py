@@ -31,7 +31,7 @@ def main():
     prep_s = time.perf_counter() - t0
     cmp = capi.Comparator([f"episode-{k:05d}.wav" for k in range(n)])
     names = ["stft_chroma32", "features_cert", "stft_fallback", "fixup_items", "stft_chroma", "features_classify",
-             "hamming_runs", "simhash_runs"]
+             "hamming_runs", "simhash_runs", "epilogue_buckets", "epilogue_entries", "epilogue_best_match"]
     state = {"res": None, "runs": 0}
     pending = []
     seq = [0]
