@@ -51,6 +51,18 @@ template <class C> NEEDLE_HD C subrot(C e, C v) { return C{e.x - v.y, e.y + v.x}
 template <class C> NEEDLE_HD C rot_m(C v) { return C{v.x + v.y, v.y - v.x}; }
 template <class C> NEEDLE_HD C rot_p(C v) { return C{v.x - v.y, v.x + v.y}; }
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(NEEDLE_PK_CMUL) && !defined(NEEDLE_PK_F32)
+// Only the twiddle products in packed form (round 4): on gfx950 a v_fma_f32 with a register accumulator costs a wave 8.0
+// cycles once a second wave issues on its SIMD and a v_pk_fma_f32 8.8 for TWO of them (profiles/r04_issue_rates.log), so
+// the 2 mul + 2 fma of a complex product (25 cycles) become 1 v_pk_mul + 1 v_pk_fma (18); the additions stay scalar (a
+// packed add costs what two plain ones do, and packing everything spills: profiles/NOTES.md round 3).
+typedef float pk2f __attribute__((ext_vector_type(2)));
+template <> NEEDLE_HD cf cmulf<cf>(cf a, cf b) {
+  const pk2f t = pk2f{a.y, a.y} * pk2f{b.y, b.x};
+  const pk2f r = __builtin_elementwise_fma(pk2f{a.x, a.x}, pk2f{b.x, b.y}, pk2f{-t.x, t.y});
+  return cf{r.x, r.y};
+}
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && defined(NEEDLE_PK_F32)
 // The same per-component operations on cf as two-component vector operations, which the compiler issues as the packed
 // instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: one instruction for the real and the imaginary part, swaps and
