@@ -13,6 +13,7 @@
 #include "hipctx.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
   const int lane = (int)(threadIdx.x & 63);
   const int min_len = (int)pr.min_len;
   const int P = min_len - W + 1;  // >= W: the host selects this kernel only when min_len >= 2W - 1
+  const uint32_t bias = 31u - min(threshold, 31u);  // (the host sends thresholds of 32 and more to the generic kernel)
   // a workgroup stages the destination once and its four waves walk bands_per_wave bands each (large launches:
   // one workgroup per pair instead of one per four bands, so the staging is not repeated)
   // Bands near the corners of the table have few rows, those around the main diagonal all of them.  A workgroup
@@ -335,15 +337,23 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
     uint32_t sv[W];
 #pragma unroll
     for (int s = 0; s < W; s++) sv[s] = src[w0 + s];
+    // A cell matches iff popcount <= threshold.  One compare per cell (v_cmp to an SGPR mask + a scalar AND) is the most
+    // expensive of its three instructions on gfx950 (profiles/r04_issue_rates2.log: v_xor 4.6, v_bcnt 8.7, v_cmp 9.1
+    // cycles of a wave), so the verdicts of a diagonal's rows are gathered in a register instead: v_bcnt adds its second
+    // operand, popcount + (31 - threshold) has bit 5 set exactly when the cell does NOT match (the sum stays below 64),
+    // the rows' sums are ORed together, and ONE compare per diagonal and window reads the bit.  Same cells, same verdicts.
     bool ok[R];
+    uint32_t miss[R];  // bit 5: some row of the window so far does not match on this diagonal
 #pragma unroll
-    for (int r = 0; r < R; r++) ok[r] = true;
+    for (int r = 0; r < R; r++) miss[r] = 0u;
 #pragma unroll
     for (int k = 0; k < H; k++) {
       const int s = head_row(k, W, H);
 #pragma unroll
-      for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv[s] ^ E[s + r]) <= threshold);
+      for (int r = 0; r < R; r++) miss[r] |= (uint32_t)__popc(sv[s] ^ E[s + r]) + bias;
     }
+#pragma unroll
+    for (int r = 0; r < R; r++) ok[r] = miss[r] < 32u;
     if (COUNT) groups += H * R;
     // exact resolution of one diagonal whose W window cells all match, by the whole wave (d is wave-uniform)
     auto resolve = [&](const int d) {
@@ -407,6 +417,31 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
     }
     if (COUNT) survived += (unsigned long long)survivors;
     if (survivors == 0) continue;
+    if (sparse_max < 0) {
+      // Default.  Every cell of the window on this lane's R diagonals is already in E: a diagonal that survived the head
+      // rows in ANY lane has its remaining rows tested by all lanes straight from registers -- W - H cells per lane, no LDS
+      // round trip, no lane shuffling, nothing the next window waits for but arithmetic.  (The sparse form below re-reads
+      // the survivor's cells from LDS into neighbouring lanes: one dependent LDS latency per survivor, and with ~1.1
+      // survivors per window on audio that latency, not the arithmetic, was what a wave spent its time on.)
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        if (alive[r] == 0) continue;  // wave-uniform
+        uint32_t mm = miss[r];
+#pragma unroll
+        for (int k = 0; k < W - H; k++) {
+          const int s = tail_row(k, W, H);
+          mm |= (uint32_t)__popc(sv[s] ^ E[s + r]) + bias;
+        }
+        if (COUNT) groups += W - H;
+        unsigned long long cand = __ballot(mm < 32u);
+        while (cand) {
+          const int src_lane = __ffsll((long long)cand) - 1;
+          cand &= cand - 1;
+          resolve(D0 + src_lane * R + r);
+        }
+      }
+      continue;
+    }
     if (survivors <= sparse_max) {
       // lane k (k < W - H) takes the k-th remaining row; lanes beyond repeat the last of them
       constexpr int kTail = W - H;
@@ -436,8 +471,10 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
     for (int k = 0; k < W - H; k++) {
       const int s = tail_row(k, W, H);
 #pragma unroll
-      for (int r = 0; r < R; r++) ok[r] = ok[r] & ((uint32_t)__popc(sv[s] ^ E[s + r]) <= threshold);
+      for (int r = 0; r < R; r++) miss[r] |= (uint32_t)__popc(sv[s] ^ E[s + r]) + bias;
     }
+#pragma unroll
+    for (int r = 0; r < R; r++) ok[r] = miss[r] < 32u;
     if (COUNT) groups += (W - H) * R;
     // ---- candidates: resolved one at a time by the whole wave ----
 #pragma unroll
@@ -532,7 +569,7 @@ SampledKernel sampled_kernel(ScanShape sh) {
 struct SearchPlan {
   std::vector<NeedleHipSeq> seqs;          // inputs ...
   std::vector<NeedleHipProblem> problems;
-  int mode[3] = {0, 0, 0};                 // ... and the environment switches that steer the choice
+  int mode[4] = {0, 0, 0, 0};              // ... and the switches that steer the choice ([3]: threshold beyond the sampled kernel's bit trick)
   std::vector<SearchProblem> meta;         // derived: the pairs the chosen kernel can stage, then the oversize ones
   size_t staged = 0;                       // how many of meta go to the chosen kernel
   uint64_t oversize_blocks = 0;            // grid of the unstaged kernel over meta[staged..]
@@ -581,7 +618,7 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     uint32_t smallest = 0xFFFFFFFFu;
     for (const SearchProblem &m : meta) smallest = std::min(smallest, m.min_len);
     const bool generic_only = mode[0] != 0;
-    const bool sampled = !generic_only && smallest >= (uint32_t)(2 * scan_shape().w - 1 + 8) && mode[1] == 0;
+    const bool sampled = !generic_only && smallest >= (uint32_t)(2 * scan_shape().w - 1 + 8) && mode[1] == 0 && mode[3] == 0;
     const bool fast = !generic_only && !sampled && smallest >= (uint32_t)(kBandR * kBandU);
     // What a pair needs in LDS under the chosen kernel.  A pair beyond the CU's 160 KiB (a window of more than ~2.7 h
     // of audio at step 1) goes to the end of the table and is scanned from HBM by the unstaged kernel: one such
@@ -677,8 +714,9 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
   if (!s.ok()) return s;
   hipStream_t stream = library_stream();
   if (!count_is_zero) NEEDLE_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
-  const int mode[3] = {getenv("NEEDLE_HIP_GENERIC_SEARCH") != nullptr, getenv("NEEDLE_HIP_BAND_SEARCH") != nullptr,
-                       getenv("NEEDLE_HIP_BANDS_PER_WAVE") ? std::max(1, atoi(getenv("NEEDLE_HIP_BANDS_PER_WAVE"))) : 0};
+  const int mode[4] = {getenv("NEEDLE_HIP_GENERIC_SEARCH") != nullptr, getenv("NEEDLE_HIP_BAND_SEARCH") != nullptr,
+                       getenv("NEEDLE_HIP_BANDS_PER_WAVE") ? std::max(1, atoi(getenv("NEEDLE_HIP_BANDS_PER_WAVE"))) : 0,
+                       threshold > 31u};  // every cell matches at 32: the band / generic kernels take such a launch
   SearchWorkspace *ws = workspace();
   SearchPlan &plan = ws->plan;
   const bool reuse = plan.matches(seqs, num_seqs, problems, num_problems, mode);
@@ -712,8 +750,8 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
     if (staged > 0) {
       KernelTimer timer("hamming_runs");
       if (sampled) {
-        int sparse_max = kSparseMax;
-        if (const char *e = getenv("NEEDLE_HIP_SPARSE_MAX")) sparse_max = std::max(0, atoi(e));  // tests, tuning: 0 = row by row
+        int sparse_max = -1;  // survivors of the head rows finished from registers (the kernel's default path)
+        if (const char *e = getenv("NEEDLE_HIP_SPARSE_MAX")) sparse_max = std::max(0, atoi(e));  // tests, tuning: the LDS forms; 0 = row by row
         if (getenv("NEEDLE_HIP_SCAN_COUNT")) {  // diagnostic: the same scan, counting what it issues
           if (!ws->eval_groups) {
             NEEDLE_HIP_TRY(hipMalloc((void **)&ws->eval_groups, 2 * sizeof(unsigned long long)));
@@ -825,6 +863,32 @@ Status gpu_hamming_runs_host(const uint32_t *hashes, size_t num_hashes, const Ne
 // v_bcnt_u32_b32, v_cmp, v_cndmask -- on registers only, no memory, eight independent cells per lane and row, at the
 // occupancy that gives the highest rate.
 namespace {
+// The sampled scan's own blend (its head rows): per cell v_xor, v_bcnt (+ bias), a share of a v_or3 and of one v_cmp per
+// diagonal and three rows, the masks counted in the scalar unit -- on registers only.  Counted as 3 instructions per cell.
+template <int R>
+__global__ __launch_bounds__(256) void valu_ceiling_sampled_kernel(uint32_t *out, int rows, uint32_t threshold, uint32_t seed) {
+  uint32_t Wd[R + 2];
+#pragma unroll
+  for (int r = 0; r < R + 2; r++) Wd[r] = seed * (threadIdx.x + 1) * (r + 3) + blockIdx.x;
+  const uint32_t bias = 31u - threshold;
+  uint32_t sv = __builtin_amdgcn_readfirstlane(seed ^ blockIdx.x);
+  int total = 0;
+  for (int i = 0; i < rows; i += 3) {
+    uint32_t s0 = sv * 1664525u + 1013904223u, s1 = s0 * 1664525u + 1013904223u, s2 = s1 * 1664525u + 1013904223u;
+    sv = s2;
+    int survivors = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const uint32_t miss = ((uint32_t)__popc(s0 ^ Wd[r]) + bias) | ((uint32_t)__popc(s1 ^ Wd[r + 1]) + bias) |
+                            ((uint32_t)__popc(s2 ^ Wd[r + 2]) + bias);
+      survivors += __popcll(__ballot(miss < 32u));
+    }
+    total += survivors;
+    if (survivors == (int)seed) Wd[0] ^= 1u;  // never (seed is large): a use the compiler cannot remove
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)total + Wd[0];
+}
+
 template <int R>
 __global__ __launch_bounds__(256) void valu_ceiling_kernel(uint32_t *out, int rows, uint32_t threshold, uint32_t seed) {
   uint32_t W[R];
@@ -877,6 +941,21 @@ Status gpu_int_valu_ceiling(double *cells_per_second) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, a, b) == hipSuccess && ms > 0.f)
       best = std::max(best, (double)grid * 256 * R * rows / (ms * 1e-3));
+    // the sampled kernel's three-instruction cell, expressed in cells of four instructions so that 4 x the figure
+    // returned stays "lane-instructions per second" for either blend (bench.py's search_roofline)
+    constexpr int RS = 7;
+    hipLaunchKernelGGL(valu_ceiling_sampled_kernel<RS>, dim3(grid), dim3(256), 0, stream, out.ptr, 99, 10u, 12345678u);
+    (void)hipEventRecord(a, stream);
+    hipLaunchKernelGGL(valu_ceiling_sampled_kernel<RS>, dim3(grid), dim3(256), 0, stream, out.ptr, rows - rows % 3, 10u, 12345678u);
+    (void)hipEventRecord(b, stream);
+    if (hipEventSynchronize(b) != hipSuccess) break;
+    if (hipEventElapsedTime(&ms, a, b) == hipSuccess && ms > 0.f) {
+      const double rate3 = (double)grid * 256 * RS * (rows - rows % 3) / (ms * 1e-3);  // cells of 3 instructions per second
+      if (getenv("NEEDLE_HIP_TRACE"))
+        std::fprintf(stderr, "[needle_hip] int-VALU ceiling, %d workgroups per CU: sampled blend %.3e cells/s (x3 = %.3e lane-instructions/s), "
+                             "band blend so far %.3e cells/s (x4 = %.3e)\n", blocks_per_cu, rate3, 3.0 * rate3, best, 4.0 * best);
+      best = std::max(best, rate3 * 3.0 / 4.0);
+    }
   }
   (void)hipEventDestroy(a);
   (void)hipEventDestroy(b);

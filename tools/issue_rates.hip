@@ -16,7 +16,7 @@
 
 enum Op {
   kFmac, kAdd, kMul, kFmamk, kMulE64Neg, kPkAdd, kPkFma, kCvt, kAddDpp, kFmacDep1, kFmacDep2, kFmacBank,
-  kFmacSame, kFmacSgpr, kAddNoAcc,
+  kFmacSame, kFmacSgpr, kAddNoAcc, kXor, kBcnt, kCmpSgpr, kMax3, kCell3, kCndmask,
   kDsRead, kDsRead2, kDsWrite, kDsWrite2, kLoadShort, kMixValuLds, kMixValuLdsVmem, kMixValuOnly, kNumOps
 };
 static const char *kNames[kNumOps] = {
@@ -24,10 +24,11 @@ static const char *kNames[kNumOps] = {
     "v_mul_f32_e64 (neg modifier)", "v_pk_add_f32", "v_pk_fma_f32", "v_cvt_f32_i32_e32", "v_add_f32_dpp row_mirror",
     "v_fmac_f32 dependent, distance 1", "v_fmac_f32 dependent, distance 2", "v_fmac_f32, three sources in one VGPR bank",
     "v_fmac_f32 a_i, x, x (one VGPR read twice)", "v_fmac_f32 a_i, s0, x (SGPR multiplicand)", "v_add_f32 a_i, x, y (no accumulator read)",
+    "v_xor_b32", "v_bcnt_u32_b32", "v_cmp_le_u32_e64 -> SGPR pair", "v_max3_u32", "scan cell: v_xor + v_bcnt + v_cmp (+ s_and)", "v_cndmask_b32 (VCC)",
     "ds_read_b64 (conflict-free)", "ds_read2_b64", "ds_write_b64", "ds_write2_b64", "global_load_sshort (L2 hits)",
     "mix: 16 VALU + 1 ds_write_b64 + 1 ds_read_b64", "mix: + 0.7 global_load_sshort per 16 VALU", "mix: the 16 VALU alone"};
 // wave-instructions per iteration of each loop below
-static const int kPerIter[kNumOps] = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 64, 64, 64, 64, 64, 144, 150, 128};
+static const int kPerIter[kNumOps] = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 384, 128, 64, 64, 64, 64, 64, 144, 150, 128};
 
 template <int OP>
 __global__ __launch_bounds__(256) void rate_kernel(unsigned long long *cycles, float *sink, const short *pcm, int iters) {
@@ -110,6 +111,40 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned long long *cycles, f
       REP16(asm volatile("v_add_f32_e32 %0, %8, %9\n v_add_f32_e32 %1, %8, %9\n v_add_f32_e32 %2, %8, %9\n v_add_f32_e32 %3, %8, %9\n"
                          "v_add_f32_e32 %4, %8, %9\n v_add_f32_e32 %5, %8, %9\n v_add_f32_e32 %6, %8, %9\n v_add_f32_e32 %7, %8, %9"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y));)
+    } else if (OP == kXor) {
+      REP16(asm volatile("v_xor_b32 %0, %8, %0\n v_xor_b32 %1, %8, %1\n v_xor_b32 %2, %8, %2\n v_xor_b32 %3, %8, %3\n"
+                         "v_xor_b32 %4, %8, %4\n v_xor_b32 %5, %8, %5\n v_xor_b32 %6, %8, %6\n v_xor_b32 %7, %8, %7"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x));)
+    } else if (OP == kBcnt) {
+      REP16(asm volatile("v_bcnt_u32_b32 %0, %8, %0\n v_bcnt_u32_b32 %1, %8, %1\n v_bcnt_u32_b32 %2, %8, %2\n v_bcnt_u32_b32 %3, %8, %3\n"
+                         "v_bcnt_u32_b32 %4, %8, %4\n v_bcnt_u32_b32 %5, %8, %5\n v_bcnt_u32_b32 %6, %8, %6\n v_bcnt_u32_b32 %7, %8, %7"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x));)
+    } else if (OP == kCmpSgpr) {
+      unsigned long long m0, m1, m2, m3;
+      REP16(asm volatile("v_cmp_le_u32_e64 %0, %4, %5\n v_cmp_le_u32_e64 %1, %4, %6\n v_cmp_le_u32_e64 %2, %4, %7\n v_cmp_le_u32_e64 %3, %4, %8\n"
+                         "v_cmp_le_u32_e64 %0, %4, %9\n v_cmp_le_u32_e64 %1, %4, %10\n v_cmp_le_u32_e64 %2, %4, %11\n v_cmp_le_u32_e64 %3, %4, %12"
+                         : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3) : "v"(x), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));)
+      i0 += (int)(m0 ^ m1 ^ m2 ^ m3);
+    } else if (OP == kMax3) {
+      REP16(asm volatile("v_max3_u32 %0, %8, %9, %0\n v_max3_u32 %1, %8, %9, %1\n v_max3_u32 %2, %8, %9, %2\n v_max3_u32 %3, %8, %9, %3\n"
+                         "v_max3_u32 %4, %8, %9, %4\n v_max3_u32 %5, %8, %9, %5\n v_max3_u32 %6, %8, %9, %6\n v_max3_u32 %7, %8, %9, %7"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y));)
+    } else if (OP == kCell3) {  // eight cells: xor, popcount, compare to an SGPR mask, masks ANDed in the scalar unit
+      unsigned long long m0 = ~0ull;
+      REP16(asm volatile("v_xor_b32 %1, %9, %1\n v_bcnt_u32_b32 %1, %1, 0\n v_cmp_le_u32_e64 vcc, %1, %10\n s_and_b64 %0, %0, vcc\n"
+                         "v_xor_b32 %2, %9, %2\n v_bcnt_u32_b32 %2, %2, 0\n v_cmp_le_u32_e64 vcc, %2, %10\n s_and_b64 %0, %0, vcc\n"
+                         "v_xor_b32 %3, %9, %3\n v_bcnt_u32_b32 %3, %3, 0\n v_cmp_le_u32_e64 vcc, %3, %10\n s_and_b64 %0, %0, vcc\n"
+                         "v_xor_b32 %4, %9, %4\n v_bcnt_u32_b32 %4, %4, 0\n v_cmp_le_u32_e64 vcc, %4, %10\n s_and_b64 %0, %0, vcc\n"
+                         "v_xor_b32 %5, %9, %5\n v_bcnt_u32_b32 %5, %5, 0\n v_cmp_le_u32_e64 vcc, %5, %10\n s_and_b64 %0, %0, vcc\n"
+                         "v_xor_b32 %6, %9, %6\n v_bcnt_u32_b32 %6, %6, 0\n v_cmp_le_u32_e64 vcc, %6, %10\n s_and_b64 %0, %0, vcc\n"
+                         "v_xor_b32 %7, %9, %7\n v_bcnt_u32_b32 %7, %7, 0\n v_cmp_le_u32_e64 vcc, %7, %10\n s_and_b64 %0, %0, vcc\n"
+                         "v_xor_b32 %8, %9, %8\n v_bcnt_u32_b32 %8, %8, 0\n v_cmp_le_u32_e64 vcc, %8, %10\n s_and_b64 %0, %0, vcc"
+                         : "+s"(m0), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(i0) : "vcc");)
+      i0 += (int)m0;
+    } else if (OP == kCndmask) {
+      REP16(asm volatile("v_cndmask_b32_e32 %0, %8, %0, vcc\n v_cndmask_b32_e32 %1, %8, %1, vcc\n v_cndmask_b32_e32 %2, %8, %2, vcc\n v_cndmask_b32_e32 %3, %8, %3, vcc\n"
+                         "v_cndmask_b32_e32 %4, %8, %4, vcc\n v_cndmask_b32_e32 %5, %8, %5, vcc\n v_cndmask_b32_e32 %6, %8, %6, vcc\n v_cndmask_b32_e32 %7, %8, %7, vcc"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x) : "vcc");)
     } else if (OP == kDsRead) {
       REP8(asm volatile("ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:2048\n ds_read_b64 %2, %4 offset:4096\n ds_read_b64 %3, %4 offset:6144\n"
                         "ds_read_b64 %0, %4 offset:8192\n ds_read_b64 %1, %4 offset:10240\n ds_read_b64 %2, %4 offset:12288\n ds_read_b64 %3, %4 offset:14336\n"
@@ -158,14 +193,14 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned long long *cycles, f
 template <int OP>
 static void run(unsigned long long *d_cycles, float *d_sink, const short *d_pcm) {
   const int iters = 400;
-  for (int wgs_per_cu : {1, 2, 3, 4}) {
+  for (int wgs_per_cu : {1, 2, 3, 4, 5, 8}) {
     const int grid = 256 * wgs_per_cu;
     // 160 KiB of LDS per CU: 40 KiB per workgroup admits four, and the grid is 256 x the count wanted
     hipFuncSetAttribute(reinterpret_cast<const void *>(rate_kernel<OP>), hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024);
     std::vector<unsigned long long> h(grid);
     double best = 1e30;
     for (int rep = 0; rep < 3; rep++) {
-      rate_kernel<OP><<<grid, 256, (wgs_per_cu == 4 ? 36 : 40) * 1024>>>(d_cycles, d_sink, d_pcm, iters);
+      rate_kernel<OP><<<grid, 256, (wgs_per_cu >= 8 ? 18 : wgs_per_cu == 5 ? 30 : wgs_per_cu == 4 ? 36 : 40) * 1024>>>(d_cycles, d_sink, d_pcm, iters);
       hipMemcpy(h.data(), d_cycles, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost);
       std::sort(h.begin(), h.end());
       best = std::min(best, (double)h[grid / 2]);
@@ -180,8 +215,8 @@ int main() {
   unsigned long long *d_cycles;
   float *d_sink;
   short *d_pcm;
-  hipMalloc(&d_cycles, 1024 * sizeof(unsigned long long));
-  hipMalloc(&d_sink, 1024 * 256 * sizeof(float));
+  hipMalloc(&d_cycles, 4096 * sizeof(unsigned long long));
+  hipMalloc(&d_sink, 4096 * 256 * sizeof(float));
   hipMalloc(&d_pcm, 1 << 20);
   hipMemset(d_pcm, 1, 1 << 20);
   run<kFmac>(d_cycles, d_sink, d_pcm);
@@ -199,6 +234,12 @@ int main() {
   run<kFmacSame>(d_cycles, d_sink, d_pcm);
   run<kFmacSgpr>(d_cycles, d_sink, d_pcm);
   run<kAddNoAcc>(d_cycles, d_sink, d_pcm);
+  run<kXor>(d_cycles, d_sink, d_pcm);
+  run<kBcnt>(d_cycles, d_sink, d_pcm);
+  run<kCmpSgpr>(d_cycles, d_sink, d_pcm);
+  run<kMax3>(d_cycles, d_sink, d_pcm);
+  run<kCell3>(d_cycles, d_sink, d_pcm);
+  run<kCndmask>(d_cycles, d_sink, d_pcm);
   run<kDsRead>(d_cycles, d_sink, d_pcm);
   run<kDsRead2>(d_cycles, d_sink, d_pcm);
   run<kDsWrite>(d_cycles, d_sink, d_pcm);

@@ -1,5 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out
-LAB_ONLY=0,5,13 timeout -k 10 200 ./tools/stft32_lab 30 | tail -4
-echo "--- packed twiddle products"
-LAB_ONLY=0,5,13 timeout -k 10 200 ./tools/stft32_lab_pkc 30 | tail -4
+timeout -k 10 300 ./tools/issue_rates > gpurun_out/r04_issue_rates2.log 2>&1; echo rc=$?
+grep -a "v_xor\|v_bcnt\|v_cmp\|v_max3\|scan cell\|v_cndmask\|v_add_f32_e32" gpurun_out/r04_issue_rates2.log
