@@ -525,7 +525,8 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
     std::vector<FpStream> meta;
     uint64_t frames = 0, rows = 0, kept = 0, pairs = 0, tiles = 0;
     // items per tile of the fused feature + classify kernel: as many (up to 64) as its LDS rows cover
-    const uint32_t items_per_tile = (uint32_t)std::min<uint64_t>(64, (uint64_t)(kTileRowsMax - 16) / step + 1);
+    uint32_t items_per_tile = (uint32_t)std::min<uint64_t>(64, (uint64_t)(kTileRowsMax - 16) / step + 1);
+    if (const char *e = getenv("NEEDLE_HIP_ITEMS_PER_TILE")) items_per_tile = std::min(items_per_tile, (uint32_t)std::max(1, atoi(e)));  // tuning
     size_t end = begin;
     while (end < spans.size()) {
       const size_t samples = spans[end].num_values / (size_t)channels;
