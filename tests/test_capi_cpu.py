@@ -412,3 +412,30 @@ def test_rust_ffi_signatures_and_struct_layouts_match_the_headers(tmp_path):
         assert c[(name, "size")] == size, (name, size, c[(name, "size")])
         for f, off in offsets:
             assert c[(name, f)] == off, (name, f, off, c[(name, f)])
+
+
+def test_round4_entry_points_validate_their_arguments_without_a_device():
+    """needle_hip_library_job_runs / _job_comm_bytes / _audit and needle_hip_host_threads: NULLs, bad slots and a library
+    without PCM are refused with the reference's error codes before anything touches a device."""
+    import ctypes as C
+    L = capi.lib()
+    vp = C.c_void_p
+    ERR = {name: code for code, name in enumerate(capi.ERROR_NAMES)}
+    L.needle_hip_library_job_runs.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.needle_hip_library_job_comm_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_uint64)]
+    L.needle_hip_library_audit.argtypes = [vp, vp]
+    runs, n = vp(), C.c_size_t(7)
+    assert L.needle_hip_library_job_runs(None, 0, C.byref(runs), C.byref(n)) == ERR["NullArgument"]
+    lib = capi.Library(3)
+    assert L.needle_hip_library_job_runs(lib._h, 0, None, C.byref(n)) == ERR["NullArgument"]
+    assert L.needle_hip_library_job_runs(lib._h, 2, C.byref(runs), C.byref(n)) == ERR["InvalidArgument"]
+    assert L.needle_hip_library_job_runs(lib._h, 1, C.byref(runs), C.byref(n)) == ERR["Ok"] and n.value == 0   # no job yet
+    b = (C.c_uint64 * 4)(9, 9, 9, 9)
+    assert L.needle_hip_library_job_comm_bytes(lib._h, 0, b) == ERR["Ok"] and list(b) == [0, 0, 0, 0]
+    assert L.needle_hip_library_job_comm_bytes(lib._h, -1, b) == ERR["InvalidArgument"]
+    assert L.needle_hip_library_job_comm_bytes(lib._h, 0, None) == ERR["NullArgument"]
+    audit = capi.CCertAudit()
+    assert L.needle_hip_library_audit(None, C.byref(audit)) == ERR["NullArgument"]
+    assert L.needle_hip_library_audit(lib._h, None) == ERR["NullArgument"]
+    assert L.needle_hip_library_audit(lib._h, C.byref(audit)) == ERR["InvalidArgument"]        # no resident PCM
+    assert 1 <= capi.host_threads() <= max(1, len(os.sched_getaffinity(0)))
