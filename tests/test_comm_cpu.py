@@ -144,3 +144,22 @@ def test_rank_videos_cuts_the_hashes_not_the_videos():
     assert shares[0][0] == 0 and shares[-1][0] + shares[-1][1] == 9 and all(c >= 1 for _, c in shares)
     with pytest.raises(capi.NeedleError):
         lib.rank_videos([total] * 28, 8, 8)
+
+
+def test_config4_plan_for_eight_ranks():
+    """BASELINE.json configs[4] on 8 ranks, the parts that need no device: the hash-block plan at 5 441 hashes per episode
+    (needle_hip_library_rank_videos: 2000 episodes cut into 8 equal blocks of hashes -- every rank holds 250 or 251
+    episodes, neighbours share at most the episode on their border, the shares tile the library) and the pair plan
+    (1 999 000 pairs in 8 contiguous ranges).  The GPU suite runs this shape with 4 and 5 ranks (a one-GPU box allows no
+    more processes); the plan for 8 is the same function."""
+    n, samples = 2000, int(round(45 * 60.0 / 2 * 11025))
+    lib = capi.Library(n, opening_search_percentage=1.0)
+    shares = [lib.rank_videos([samples] * n, 8, r) for r in range(8)]
+    assert shares[0][0] == 0 and shares[-1][0] + shares[-1][1] == n
+    assert all(250 <= c <= 251 for _, c in shares), shares
+    for (f0, c0), (f1, _) in zip(shares, shares[1:]):
+        assert f0 + c0 - 1 <= f1 <= f0 + c0
+    pairs = n * (n - 1) // 2
+    ranges = [capi.comm_shard(pairs, 8, r) for r in range(8)]
+    assert sum(c for _, c in ranges) == pairs and max(c for _, c in ranges) - min(c for _, c in ranges) <= 8
+    assert all(ranges[r][0] + ranges[r][1] == ranges[r + 1][0] for r in range(7))
