@@ -50,7 +50,6 @@ __host__ __device__ constexpr int tail_row(int k, int W, int H = kSampleHead) {
   }
   return W - 1;
 }
-constexpr int kSparseMax = 6;                   // survivors of the head rows that are finished one diagonal at a time
 
 struct SearchProblem {
   uint32_t src_off, n;  // hash arena offset + length of the source sequence
