@@ -268,13 +268,13 @@ __device__ __forceinline__ float feature_row_cert(const double *__restrict__ in,
 }
 
 // classify_window + "is any of the 48 comparisons within rr (relative) of its threshold"
-template <int PITCH>
+template <int PITCH, int ODD = 0>
 __device__ __forceinline__ uint32_t classify_window_cert(const double *w, const core::ClassifierThresholds *thr, double rr,
                                                          bool *uncertain) {
   double a[16], b[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) a[i] = b[i] = 0.0;
-  core::WindowStep<0, 0, PITCH>::run(w, a, b);
+  core::WindowStep<0, 0, PITCH, ODD>::run(w, a, b);
   uint32_t bits = 0;
   bool unc = false;
 #pragma unroll
@@ -294,6 +294,10 @@ __device__ __forceinline__ uint32_t classify_window_cert(const double *w, const 
 // kCertWaves waves per workgroup, each with a tile of its own and no barrier between them: two, so that five workgroups
 // (30 KB of LDS each) fit a CU -- the kernel is latency-bound and now needs 150 VGPRs, not 376 (fp_core.h WindowStep).
 constexpr int kCertWaves = 2;
+constexpr int kHalfRows = kTileRowsMax / 2;  // SPLIT: even rows of a tile first, its odd rows from here on
+// SPLIT (chosen by the launcher when step == 2): the tile's rows lie de-interleaved in LDS (fp_core.h WindowStep ODD) --
+// same values, same additions in the same order; only where a row is kept differs.
+template <bool SPLIT>
 __global__ __launch_bounds__(64 * kCertWaves) void features_classify_cert_kernel(
     const double *__restrict__ chroma, const float *__restrict__ energy, const FpStream *__restrict__ streams, int num_streams,
     const core::ClassifierThresholds *__restrict__ thr, uint32_t step, uint32_t items_per_tile, uint32_t *__restrict__ items,
@@ -315,7 +319,8 @@ __global__ __launch_bounds__(64 * kCertWaves) void features_classify_cert_kernel
   const double *in = chroma + ((uint64_t)st.frame_base + x0) * kBands;
   const float *en = energy + ((uint64_t)st.frame_base + x0) * stft::kEnergyParts;
   for (uint32_t r = lane; r < rows; r += 64)
-    sig[r] = feature_row_cert(in + (uint64_t)r * kBands, en + (uint64_t)r * stft::kEnergyParts, cert_k, mine + r * kFeatPitch);
+    sig[r] = feature_row_cert(in + (uint64_t)r * kBands, en + (uint64_t)r * stft::kEnergyParts, cert_k,
+                              mine + (SPLIT ? (r >> 1) + (r & 1u) * kHalfRows : r) * kFeatPitch);
   wave_lds_fence();
   if (lane < count) {
     float s_max = 0.0f;
@@ -323,7 +328,8 @@ __global__ __launch_bounds__(64 * kCertWaves) void features_classify_cert_kernel
     for (int r = 0; r < 16; r++) s_max = fmaxf(s_max, sig[lane * step + r]);
     bool unc = false;
     const double r = (double)cert_k * (double)s_max;   // +inf when a row is at the norm cut
-    const uint32_t bits = classify_window_cert<kFeatPitch>(mine + lane * step * kFeatPitch, thr, r + r * r, &unc);
+    const uint32_t bits = SPLIT ? classify_window_cert<kFeatPitch, kHalfRows * kFeatPitch>(mine + lane * kFeatPitch, thr, r + r * r, &unc)
+                                : classify_window_cert<kFeatPitch>(mine + lane * step * kFeatPitch, thr, r + r * r, &unc);
     unc = unc || !(r < 0.25);                           // out of the calibrated regime: recompute
     const uint64_t out = st.item_off + k0 + lane;
     items[out] = bits;
@@ -673,8 +679,8 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
         }
         {
           KernelTimer timer("features_cert");
-          hipLaunchKernelGGL(features_classify_cert_kernel, dim3((uint32_t)((tiles + kCertWaves - 1) / kCertWaves)),
-                             dim3(64 * kCertWaves), 0, stream,
+          hipLaunchKernelGGL(step == 2 ? features_classify_cert_kernel<true> : features_classify_cert_kernel<false>,
+                             dim3((uint32_t)((tiles + kCertWaves - 1) / kCertWaves)), dim3(64 * kCertWaves), 0, stream,
                              chroma_buf.ptr, energy_buf.ptr, desc.streams.ptr, n, tab.thr, step, items_per_tile, d_items,
                              (uint32_t)tiles, cert_k, kChunkPairs, work, bitmap, chunk_buf.ptr, item_buf.ptr);
         }

@@ -864,10 +864,13 @@ template <int R, int C>
 struct CellStep<R, C, 16> {
   static NEEDLE_HD void run(double, double *, double *) {}
 };
-template <int R, int C, int PITCH>
+// ODD > 0: the window's rows are stored de-interleaved -- even rows PITCH apart from w, odd rows PITCH apart from w + ODD
+// (the certification kernel at step 2: neighbouring lanes' windows then start one row apart in each half, and a wave's
+// accesses to one cell spread over all LDS banks; row-major with two rows between lanes they hit every other bank twice).
+template <int R, int C, int PITCH, int ODD = 0>
 struct WindowStep {
   static NEEDLE_HD void run(const double *w, double *a, double *b) {
-    CellStep<R, C, 0>::run(w[R * PITCH + C], a, b);
+    CellStep<R, C, 0>::run(w[ODD ? (R >> 1) * PITCH + (R & 1) * ODD + C : R * PITCH + C], a, b);
 #if defined(__HIP_DEVICE_COMPILE__)
     // The 32 sums are pinned at the end of every row (an empty asm that "uses" them): without this the compiler loads all
     // 192 cells of the window first and adds afterwards -- 384 registers for the cells alone, 376 VGPRs, one wave per
@@ -879,11 +882,11 @@ struct WindowStep {
                         "+v"(b[8]), "+v"(b[9]), "+v"(b[10]), "+v"(b[11]), "+v"(b[12]), "+v"(b[13]), "+v"(b[14]), "+v"(b[15]));
     }
 #endif
-    WindowStep<(C == 11) ? R + 1 : R, (C == 11) ? 0 : C + 1, PITCH>::run(w, a, b);
+    WindowStep<(C == 11) ? R + 1 : R, (C == 11) ? 0 : C + 1, PITCH, ODD>::run(w, a, b);
   }
 };
-template <int PITCH>
-struct WindowStep<16, 0, PITCH> {
+template <int PITCH, int ODD>
+struct WindowStep<16, 0, PITCH, ODD> {
   static NEEDLE_HD void run(const double *, double *, double *) {}
 };
 
