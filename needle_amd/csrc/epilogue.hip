@@ -468,6 +468,7 @@ Status upload_if_changed(DeviceBuffer<T> *dst, std::vector<T> *resident, const s
 }  // namespace
 
 Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHipSearchResult *host_results, uint32_t *host_failed) {
+  std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());  // the per-device workspaces are shared, as everywhere else
   if (job.num_segments < 1 || job.num_segments > kMaxSegments)
     return Status::Make(NeedleError_InvalidArgument, "device epilogue: too many run segments");
   const uint64_t np = (uint64_t)job.n * (job.n - 1) / 2;
