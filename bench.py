@@ -293,7 +293,7 @@ def search_roofline(ceiling_cells, issued_evals, covered_cells, scan_ms):
 def search_only(capi, synth, episodes, minutes, reps=5):
     """BASELINE.json configs[2]: `episodes` x 24-min episodes as real .needle.dat files (written once by this
     analyzer from synthetic audio), then needle_audio_comparator_run(analyze=false) timed from disk: file reads,
-    upload of the hashes, scan + simhash kernels, download, epilogue."""
+    upload of the hashes, scan + simhash + epilogue kernels, download of the results."""
     t_prep = time.perf_counter()
     half = minutes * 60.0 / 2
     tmp = tempfile.mkdtemp(prefix="needle_bench_search_")
@@ -348,7 +348,8 @@ def search_only(capi, synth, episodes, minutes, reps=5):
             "scan_kernel_ms": round(sum(scan) / len(scan), 4), "simhash_kernel_ms": round(sum(simh) / len(simh), 4),
             "table_cells": float(pairs) * n_h * n_h, "prepare_s": round(prep_s, 2), "issued_evals": issued,
             "what": "needle_audio_comparator_run(analyze=false) over .needle.dat files in the page cache: read + parse, "
-                    "H2D of hashes, scan, simhash, D2H of runs, host epilogue; wall clock per call"}
+                    "H2D of hashes, scan, simhash, per-video epilogue on the device (from 16 384 sequence pairs up; the run "
+                    "list stays in HBM), D2H of the results; wall clock per call"}
 
 
 # ---- launching N ranks -----------------------------------------------------------------------------------------------

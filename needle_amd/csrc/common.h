@@ -169,6 +169,10 @@ Status gpu_hamming_runs_host(const uint32_t *hashes, size_t num_hashes, const Ne
                              const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
                              std::vector<NeedleHipRun> *runs);
 
+// Sequence pairs from which the per-video epilogue runs on the device (epilogue.hip) instead of on host threads
+// (NEEDLE_HIP_DEVICE_EPILOGUE=1 / 0 forces either): the library job and Comparator::run_with_frame_hashes alike.
+constexpr uint64_t kDeviceEpiloguePairs = 1u << 14;
+
 // Diagnostic (search.hip): cells/s of the band scan's 4-instruction cell on registers only, measured on this device.
 Status gpu_int_valu_ceiling(double *cells_per_second);
 Status gpu_scan_issued_evaluations(uint64_t *lane_evaluations, bool reset, uint64_t *head_survivors = nullptr);

@@ -17,6 +17,9 @@
 #include <unistd.h>
 
 #include "needle_core.h"
+#ifndef NEEDLE_EPILOGUE_DIRECT
+#include "epilogue.h"
+#endif
 
 namespace needle {
 
@@ -445,7 +448,18 @@ Status Comparator::best_matches(size_t num_videos, const PairEntries &pair_entri
                   [&](size_t b, size_t e) {
                     for (size_t k = b; k < e; k++) find_best(todo[k]);
                   });
+  std::vector<uint8_t> any(num_videos, 0);
+  for (size_t v = v0; v < v1; v++) any[v] = info_count(v) != 0;
+  return walk_results(num_videos, any, status, display, use_skip_files, write_skip_files, per_video, v0, v1);
+}
 
+// The part of comparator.rs:593-626 with side effects, video by video in the reference's order: skip-file check, what
+// find_best_match found (computed before, on host threads or on the device), display, skip-file write.
+Status Comparator::walk_results(size_t num_videos, const std::vector<uint8_t> &any, const std::vector<Status> &status, bool display,
+                                bool use_skip_files, bool write_skip_files, std::vector<VideoResult> *per_video, size_t v0,
+                                size_t v1) const {
+  v1 = std::min(v1, num_videos);
+  v0 = std::min(v0, v1);
   for (size_t v = v0; v < v1; v++) {
     const std::string &path = v < videos_.size() ? videos_[v] : std::string();
     if (display) std::printf("\n%s\n\n", path.c_str());  // :595-597
@@ -465,7 +479,7 @@ Status Comparator::best_matches(size_t num_videos, const PairEntries &pair_entri
         }
       }
     }
-    if (info_count(v) == 0) {
+    if (!any[v]) {
       if (display) std::printf(include_endings_ ? "No opening or ending found.\n" : "No opening found.\n");
       continue;
     }
@@ -525,13 +539,20 @@ Status Comparator::run_with_frame_hashes(const std::vector<const FrameHashesData
       total += seq.size();
     }
   std::vector<uint32_t> arena(total);
+  std::vector<uint8_t> ts_like_first(n * regions, 0);  // the row's timestamps equal video 0's of the same region (device epilogue)
   const unsigned workers = host_workers(total * 16);
   parallel_chunks(n, 8, workers, [&](size_t v0, size_t v1) {
     for (size_t v = v0; v < v1; v++)
       for (size_t r = 0; r < regions; r++) {
         const std::vector<HashTs> &seq = r == 0 ? fh[v]->opening : fh[v]->ending;
+        const std::vector<HashTs> &first = r == 0 ? fh[0]->opening : fh[0]->ending;
         uint32_t *dst = arena.data() + seqs[v * regions + r].offset;
-        for (size_t k = 0; k < seq.size(); k++) dst[k] = seq[k].hash;
+        bool same = seq.size() == first.size();
+        for (size_t k = 0; k < seq.size(); k++) {
+          dst[k] = seq[k].hash;
+          same = same && seq[k].ts == first[k].ts;
+        }
+        ts_like_first[v * regions + r] = same;
         min_len[v * regions + r] = min_run_length(seq, r == 0 ? min_opening_duration_ : min_ending_duration_);
       }
   });
@@ -574,6 +595,74 @@ Status Comparator::run_with_frame_hashes(const std::vector<const FrameHashesData
   }
   trace.lap("arena + pair table", problems.size());
   std::vector<NeedleHipRun> runs;
+#ifndef NEEDLE_EPILOGUE_DIRECT
+  // Library scale: scan AND per-video epilogue on the device (epilogue.hip), only the n results come back.  The arena's
+  // rows are the videos' windows with their own timestamps; identical timestamp tables (videos of equal length) go up once.
+  bool on_device = (uint64_t)np * regions >= kDeviceEpiloguePairs && n >= 2;
+  if (const char *e = std::getenv("NEEDLE_HIP_DEVICE_EPILOGUE")) on_device = std::atoi(e) != 0 && n >= 2;
+  if (on_device) {
+    std::vector<uint32_t> row_len(n * regions), row_ts(n * regions);
+    std::vector<uint64_t> row_seek(n * regions, 0), ts;
+    for (size_t row = 0; row < n * regions; row++) {  // a library's videos mostly share their timestamps: one table each
+      const std::vector<HashTs> &seq = row % regions == 0 ? fh[row / regions]->opening : fh[row / regions]->ending;
+      row_len[row] = (uint32_t)seq.size();
+      if (row >= regions && ts_like_first[row]) {
+        row_ts[row] = row_ts[row % regions];
+        continue;
+      }
+      row_ts[row] = (uint32_t)ts.size();
+      for (const HashTs &h : seq) ts.push_back(h.ts);
+    }
+    EpilogueJob job;
+    job.slot = 2;  // a workspace of its own, beside the two job slots of a library
+    job.n = (uint32_t)n;
+    job.regions = job.rows_per_video = (uint32_t)regions;
+    job.v0 = 0;
+    job.v1 = (uint32_t)n;
+    job.threshold = hash_match_threshold_;
+    job.include_endings = include_endings_;
+    job.min_opening_duration = min_opening_duration_;
+    job.min_ending_duration = min_ending_duration_;
+    job.time_padding = time_padding_;
+    job.hash_duration = n ? fh[0]->hash_duration : 0;
+    bool uniform = true;  // Candidate.hash_duration is per video upstream (:410-432): one value on the device
+    for (size_t v = 0; v < n; v++) uniform = uniform && fh[v]->hash_duration == job.hash_duration;
+    job.row_len = &row_len;
+    job.row_ts = &row_ts;
+    job.row_seek = &row_seek;
+    job.ts = &ts;
+    std::vector<NeedleHipSearchResult> results;
+    uint32_t failed = 0;
+    size_t found = 0;
+    if (uniform) {
+      Status s = gpu_search_results_host(arena.data(), arena.size(), seqs.data(), seqs.size(), problems.data(), problems.size(),
+                                         hash_match_threshold_, job, &results, &failed, &runs, &found);
+      if (!s.ok()) return s;
+      trace.lap("upload + scan + simhash + device epilogue", found);
+      if (failed == 0) {
+        per_video->assign(n, {});
+        std::vector<uint8_t> any(n, 0);
+        for (size_t v = 0; v < n; v++) {
+          const NeedleHipSearchResult &r = results[v];
+          any[v] = r.has_result;
+          VideoResult &vr = (*per_video)[v];
+          vr.has_result = r.has_result;
+          vr.result.has_opening = r.has_opening;
+          vr.result.has_ending = r.has_ending;
+          vr.result.opening_start = r.opening_start_ns;
+          vr.result.opening_end = r.opening_end_ns;
+          vr.result.ending_start = r.ending_start_ns;
+          vr.result.ending_end = r.ending_end_ns;
+        }
+        const std::vector<Status> status(n);
+        Status w = walk_results(n, any, status, display, use_skip_files, write_skip_files, per_video, 0, n);
+        trace.lap("display / skip files per video", n);
+        return w;
+      }
+      return results_from_runs(fh, runs.data(), runs.size(), display, use_skip_files, write_skip_files, per_video);
+    }
+  }
+#endif
   // an empty problem list still goes through the device entry point: there is no CPU path to fall to
   Status s = gpu_hamming_runs_host(arena.data(), arena.size(), seqs.data(), seqs.size(), problems.data(),
                                    problems.size(), hash_match_threshold_, &runs);

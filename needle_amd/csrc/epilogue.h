@@ -20,11 +20,12 @@ struct EpilogueJob {
   uint32_t threshold = 0;
   bool include_endings = false;
   ns_t min_opening_duration = 0, min_ending_duration = 0, time_padding = 0, hash_duration = 0;
-  // the run list: num_segments slabs (own slab, or the gathered heads in rank order), each `header_bytes` of header
-  // (word 0 = runs found) followed by up to segment_capacity runs
-  const uint8_t *segment_base[64] = {nullptr};
+  // the run list: num_segments pieces in order (a rank's slab, the gathered heads in rank order, or the buffer of a
+  // host-side search call), each a device word holding the runs found and up to segment_capacity runs
+  const uint32_t *segment_count[64] = {nullptr};
+  const NeedleHipRun *segment_runs[64] = {nullptr};
   int num_segments = 0;
-  uint32_t segment_capacity = 0, header_bytes = 32;
+  uint32_t segment_capacity = 0;
   uint64_t max_runs = 0;             // upper bound of the runs in all segments (sizes the workspaces)
   // per arena row: hashes kept, offset of its (un-seeked) timestamps in `ts`, seek added to each of them
   const std::vector<uint32_t> *row_len = nullptr, *row_ts = nullptr;
@@ -35,5 +36,14 @@ struct EpilogueJob {
 // failure count (videos whose padding / hash duration exceed the match end: the reference panics) into HOST memory
 // (pinned: the copies are asynchronous).  Counts beyond a segment's capacity are clamped: the host redoes such a job.
 Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHipSearchResult *host_results, uint32_t *host_failed);
+
+// Comparator::run_with_frame_hashes with both halves on the device (search.hip): host hash arena in, scan + simhash, the
+// epilogue above on the run list where it lies, the n per-video results out; the run list itself never crosses PCIe.
+// `job` carries everything but the segments.  *failed > 0: the caller falls back to the host epilogue (which reports the
+// video that fails, in the reference's order) -- `runs` then holds the downloaded list.
+Status gpu_search_results_host(const uint32_t *hashes, size_t num_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
+                               const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold, EpilogueJob job,
+                               std::vector<NeedleHipSearchResult> *results, uint32_t *failed, std::vector<NeedleHipRun> *runs,
+                               size_t *num_runs);
 
 }  // namespace needle

@@ -32,10 +32,10 @@ namespace {
 
 constexpr int kMaxSegments = 64;
 
-struct RunSegments {  // the run list as the ranks' slabs or gathered heads: header word 0 = runs found, runs behind it
-  const uint8_t *base[kMaxSegments];
+struct RunSegments {  // the run list in pieces: a device word with the runs found, and the runs
+  const uint32_t *found[kMaxSegments];
+  const NeedleHipRun *runs[kMaxSegments];
   uint32_t capacity[kMaxSegments];
-  uint32_t header_bytes;
   int count;
 };
 
@@ -60,7 +60,7 @@ struct EpilogueParams {
 };
 
 __device__ __forceinline__ uint32_t segment_count(const RunSegments &s, int k) {
-  return min(*reinterpret_cast<const uint32_t *>(s.base[k]), s.capacity[k]);  // an overflowed slab is redone by the host
+  return min(*s.found[k], s.capacity[k]);  // an overflowed slab is redone by the host
 }
 
 // run g of the concatenated list (segments in rank order)
@@ -68,7 +68,7 @@ __device__ __forceinline__ bool locate_run(const RunSegments &s, uint64_t g, Nee
   for (int k = 0; k < s.count; k++) {
     const uint32_t c = segment_count(s, k);
     if (g < c) {
-      *out = reinterpret_cast<const NeedleHipRun *>(s.base[k] + s.header_bytes)[g];
+      *out = s.runs[k][g];
       return true;
     }
     g -= c;
@@ -492,9 +492,9 @@ Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHi
   RunSegments segs;
   std::memset(&segs, 0, sizeof(segs));
   segs.count = job.num_segments;
-  segs.header_bytes = job.header_bytes;
   for (int k = 0; k < job.num_segments; k++) {
-    segs.base[k] = job.segment_base[k];
+    segs.found[k] = job.segment_count[k];
+    segs.runs[k] = job.segment_runs[k];
     segs.capacity[k] = job.segment_capacity;
   }
   EpilogueParams pr;

@@ -699,7 +699,7 @@ Status job_buffers(NeedleHipLibrary *lib, NeedleHipLibrary::Job &j, int world) {
 // (the run count is not known yet): by the number of sequence pairs, or NEEDLE_HIP_DEVICE_EPILOGUE=1 / 0.
 bool device_epilogue_wanted(const NeedleHipLibrary *lib, size_t comparator_regions) {
   if (const char *e = getenv("NEEDLE_HIP_DEVICE_EPILOGUE")) return atoi(e) != 0;
-  return (uint64_t)pair_count(lib->n) * comparator_regions >= (1u << 16);
+  return (uint64_t)pair_count(lib->n) * comparator_regions >= kDeviceEpiloguePairs;
 }
 
 // scan of this rank's pair range into its slab, gather of the slabs, download of their heads: all asynchronous
@@ -763,12 +763,15 @@ NeedleError job_search_and_gather(NeedleHipLibrary *lib, const NeedleAudioCompar
     ej.time_padding = cmp.time_padding();
     ej.hash_duration = lib->hash_duration;
     ej.num_segments = world;
-    ej.header_bytes = (uint32_t)NeedleHipLibrary::kSlabHeader;
+    auto segment = [&](int k, const uint8_t *slab) {  // a slab: 32-byte header (word 0 = runs found), then the runs
+      ej.segment_count[k] = reinterpret_cast<const uint32_t *>(slab);
+      ej.segment_runs[k] = reinterpret_cast<const NeedleHipRun *>(slab + NeedleHipLibrary::kSlabHeader);
+    };
     if (world > 1) {
-      for (int r = 0; r < world; r++) ej.segment_base[r] = j.d_heads.ptr + (size_t)r * j.head_bytes();
+      for (int r = 0; r < world && r < 64; r++) segment(r, j.d_heads.ptr + (size_t)r * j.head_bytes());
       ej.segment_capacity = j.head_runs;
     } else {
-      ej.segment_base[0] = mine;
+      segment(0, mine);
       ej.segment_capacity = j.slab_runs;
     }
     ej.max_runs = (uint64_t)ej.segment_capacity * (uint64_t)world;

@@ -143,6 +143,10 @@ class Comparator {
   Status best_matches(size_t num_videos, const PairEntries &pair_entries, bool display, bool use_skip_files,
                       bool write_skip_files, std::vector<VideoResult> *per_video, size_t v0 = 0,
                       size_t v1 = ~(size_t)0) const;
+  // :593-626, the walk with side effects over results that are already there (any[v]: video v has a candidate at all)
+  Status walk_results(size_t num_videos, const std::vector<uint8_t> &any, const std::vector<Status> &status, bool display,
+                      bool use_skip_files, bool write_skip_files, std::vector<VideoResult> *per_video, size_t v0,
+                      size_t v1) const;
 
  private:
   std::vector<std::string> videos_;

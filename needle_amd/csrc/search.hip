@@ -10,6 +10,7 @@
 // the host's lower bound on the run length that can pass it, so the output list stays short.
 //
 // Integer-only (xor, popcount, compare, add): results are exact by construction.
+#include "epilogue.h"
 #include "hipctx.h"
 
 #include <algorithm>
@@ -807,6 +808,81 @@ Status gpu_scan_issued_evaluations(uint64_t *lane_evaluations, bool reset, uint6
   return Status::Ok();
 }
 
+namespace {
+// grow-only device buffers kept per device (guarded by gpu_mutex()): a search-only call over a library pays for its
+// copies and kernels, not for hipMalloc / hipFree
+struct HostCallBuffers {
+  DeviceBuffer<uint32_t> d_hashes, d_count;
+  DeviceBuffer<NeedleHipRun> d_runs;
+  void *pinned = nullptr;  // results of the device epilogue + its failure count
+  size_t pinned_bytes = 0;
+};
+HostCallBuffers *host_call_buffers() {
+  static std::map<int, HostCallBuffers *> all;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  HostCallBuffers *&hb = all[dev];
+  if (!hb) hb = new HostCallBuffers();
+  return hb;
+}
+}  // namespace
+
+Status gpu_search_results_host(const uint32_t *hashes, size_t num_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
+                               const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold, EpilogueJob job,
+                               std::vector<NeedleHipSearchResult> *results, uint32_t *failed, std::vector<NeedleHipRun> *runs,
+                               size_t *num_runs) {
+  std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
+  Status s = ensure_device();
+  if (!s.ok()) return s;
+  for (size_t i = 0; i < num_seqs; i++)
+    if ((uint64_t)seqs[i].offset + seqs[i].len > num_hashes)
+      return Status::Make(NeedleError_InvalidArgument, "hamming_runs: sequence outside the hash arena");
+  hipStream_t stream = library_stream();
+  HostCallBuffers *hb = host_call_buffers();
+  if (!(s = hb->d_hashes.reserve(std::max<size_t>(num_hashes, 1))).ok() || !(s = hb->d_count.reserve(1)).ok()) return s;
+  const size_t want = ((size_t)job.n + 1) * sizeof(NeedleHipSearchResult);
+  if (want > hb->pinned_bytes) {
+    if (hb->pinned) (void)hipHostFree(hb->pinned);
+    hb->pinned = nullptr;
+    hb->pinned_bytes = 0;
+    NEEDLE_HIP_TRY(hipHostMalloc(&hb->pinned, want, hipHostMallocDefault));
+    hb->pinned_bytes = want;
+  }
+  NeedleHipSearchResult *pinned = static_cast<NeedleHipSearchResult *>(hb->pinned);
+  uint32_t *pinned_failed = reinterpret_cast<uint32_t *>(pinned + job.n);
+  NEEDLE_HIP_TRY(hipMemcpyAsync(hb->d_hashes.ptr, hashes, num_hashes * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  uint32_t capacity = (uint32_t)std::min<uint64_t>(
+      0x7fffffffu, std::max<uint64_t>({(uint64_t)1 << 16, (uint64_t)hb->d_runs.count, 3 * (uint64_t)num_problems}));
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (!(s = hb->d_runs.reserve(capacity)).ok()) return s;
+    s = gpu_hamming_runs_device(hb->d_hashes.ptr, seqs, num_seqs, problems, num_problems, threshold, hb->d_runs.ptr, capacity,
+                                hb->d_count.ptr, false);
+    if (!s.ok()) return s;
+    job.num_segments = 1;
+    job.segment_count[0] = hb->d_count.ptr;
+    job.segment_runs[0] = hb->d_runs.ptr;
+    job.segment_capacity = capacity;
+    job.max_runs = capacity;
+    if (!(s = gpu_epilogue_enqueue(job, stream, pinned, pinned_failed)).ok()) return s;
+    uint32_t found = 0;
+    NEEDLE_HIP_TRY(hipMemcpyAsync(&found, hb->d_count.ptr, sizeof(found), hipMemcpyDeviceToHost, stream));
+    NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+    if (found <= capacity) {
+      *num_runs = found;
+      *failed = *pinned_failed;
+      results->assign(pinned, pinned + job.n);
+      runs->clear();
+      if (*failed && found) {  // the host epilogue names the failing video in the reference's order: it needs the list
+        runs->resize(found);
+        NEEDLE_HIP_TRY(hipMemcpy(runs->data(), hb->d_runs.ptr, found * sizeof(NeedleHipRun), hipMemcpyDeviceToHost));
+      }
+      return Status::Ok();
+    }
+    capacity = found;  // the scan is deterministic: a second pass with the exact size fits
+  }
+  return Status::Make(NeedleError_Unknown, "hamming_runs: run list did not fit after resize");
+}
+
 Status gpu_hamming_runs_host(const uint32_t *hashes, size_t num_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
                              const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
                              std::vector<NeedleHipRun> *runs) {
@@ -817,17 +893,7 @@ Status gpu_hamming_runs_host(const uint32_t *hashes, size_t num_hashes, const Ne
     if ((uint64_t)seqs[i].offset + seqs[i].len > num_hashes)
       return Status::Make(NeedleError_InvalidArgument, "hamming_runs: sequence outside the hash arena");
   hipStream_t stream = library_stream();
-  // grow-only device buffers kept per device (guarded by gpu_mutex()): a search-only call over a library pays for
-  // its copies and kernels, not for hipMalloc / hipFree
-  struct HostCallBuffers {
-    DeviceBuffer<uint32_t> d_hashes, d_count;
-    DeviceBuffer<NeedleHipRun> d_runs;
-  };
-  static std::map<int, HostCallBuffers *> all;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  HostCallBuffers *&hb = all[dev];
-  if (!hb) hb = new HostCallBuffers();
+  HostCallBuffers *hb = host_call_buffers();
   DeviceBuffer<uint32_t> &d_hashes = hb->d_hashes, &d_count = hb->d_count;
   DeviceBuffer<NeedleHipRun> &d_runs = hb->d_runs;
   if (!(s = d_hashes.reserve(std::max<size_t>(num_hashes, 1))).ok()) return s;
