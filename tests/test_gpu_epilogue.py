@@ -1,9 +1,11 @@
 """-m gpu: the per-video epilogue ON THE DEVICE (needle_amd/csrc/epilogue.hip) against the host form (comparator.cpp)
 and the oracle (comparator.rs:191-249,405-515,583-626 restated in oracle/ora_needle.c).  The device form is what a
-library-scale job uses (>= 65 536 sequence pairs, or NEEDLE_HIP_DEVICE_EPILOGUE=1); both forms see the same run list.
+library-scale job or search call uses (>= 16 384 sequence pairs, or NEEDLE_HIP_DEVICE_EPILOGUE=1); both forms see the same run list.
 What can go wrong is ORDER: the reverse table walk, BinaryHeap's backing-array order, the candidate numbering that
 breaks ties between equal (f32) scores -- so the inputs here are built to tie: the same segment planted bit-identically
 in many videos, competing segments of equal length, several runs per pair, endings, padding."""
+import os
+
 import numpy as np
 import pytest
 
@@ -126,3 +128,28 @@ def test_padding_larger_than_the_match_fails_like_the_host_form(monkeypatch):
         lib.job_begin(cmp, 0)
         with pytest.raises(capi.NeedleError, match="overflow when subtracting durations"):
             lib.job_end(cmp, 0)
+
+
+def test_comparator_objects_use_the_device_epilogue_with_display_and_skip_files(tmp_path, capfd, monkeypatch):
+    """needle_audio_comparator_run (analyze=false) through the device epilogue: what it prints and the skip files it writes
+    equal the host form's, video by video in the reference's order (comparator.rs:593-626), endings and padding included."""
+    eps = [synth.make_episode(k, 95.0 + 5.0 * (k % 3), 21.0, 19.0) for k in range(9)]
+    paths = [str(tmp_path / f"ep{k}.wav") for k in range(9)]
+    for p, e in zip(paths, eps):
+        synth.write_wav(p, e.pcm)
+    capi.Analyzer.from_files(paths).with_include_endings(True).run(0.3, persist=True)
+    outs = {}
+    for device in ("0", "1"):
+        monkeypatch.setenv("NEEDLE_HIP_DEVICE_EPILOGUE", device)
+        for p in paths:
+            skip = p[:-4] + ".needle.skip.json"
+            if os.path.exists(skip):
+                os.unlink(skip)
+        capfd.readouterr()
+        cmp = capi.Comparator(paths, include_endings=True, min_opening_duration=10, min_ending_duration=10, time_padding=0.5)
+        cmp.run(analyze=False, display=True, write_skip_files=True)
+        text = capfd.readouterr().out
+        skips = {p: open(p[:-4] + ".needle.skip.json").read() for p in paths if os.path.exists(p[:-4] + ".needle.skip.json")}
+        outs[device] = (text, skips)
+    assert outs["0"] == outs["1"]
+    assert outs["1"][0].count('* Opening - "') == 9 and len(outs["1"][1]) == 9
