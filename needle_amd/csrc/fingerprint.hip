@@ -126,6 +126,16 @@ Status get_tables(FpTables *out) {
   return Status::Ok();
 }
 
+// NEEDLE_HIP_STFT_SHARE (hipctx.hip stft_stream): 2 = default, the next job's first pass beside this job's tail; 1 = behind
+// this job's recomputation (round-4 measurement); 0 = one stream
+int share_mode() {
+  static const int mode = [] {
+    const char *e = getenv("NEEDLE_HIP_STFT_SHARE");
+    return e ? atoi(e) : 2;
+  }();
+  return mode;
+}
+
 using stft::FpStream;
 using stft::find_stream;
 using stft::stft_chroma_kernel;
@@ -585,10 +595,12 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       if (!(s = desc.upload.put(&desc.streams, &desc.stage, meta, stream, &uploaded)).ok()) return s;
       const int n = (int)meta.size();
       if (!ws->lds_attr_set) {
-        const void *variants[4] = {reinterpret_cast<const void *>(stft_chroma_kernel<1, 0, false>),
+        const void *variants[6] = {reinterpret_cast<const void *>(stft_chroma_kernel<1, 0, false>),
                                    reinterpret_cast<const void *>(stft_chroma_kernel<2, 0, false>),
                                    reinterpret_cast<const void *>(stft_chroma_kernel<1, 0, true>),
-                                   reinterpret_cast<const void *>(stft_chroma_kernel<2, 0, true>)};
+                                   reinterpret_cast<const void *>(stft_chroma_kernel<2, 0, true>),
+                                   reinterpret_cast<const void *>(stft_chroma_kernel<1, 0, true, 3>),
+                                   reinterpret_cast<const void *>(stft_chroma_kernel<2, 0, true, 3>)};
         for (const void *fn : variants)
           NEEDLE_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)(core::kLds2Slots * sizeof(cd))));
@@ -646,7 +658,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
           // (35 KB, 163 VGPRs): started beside a first pass it waits for all of it (kernel trace, profiles/NOTES.md round 4);
           // the kernels behind it (fix-up, scan, simhash) and the certification kernel do fit and run beside it.
           const FpWorkspace::Pipe &other = ws->pipes[pipe ^ 1];
-          static const bool share = getenv("NEEDLE_HIP_STFT_SHARE") && atoi(getenv("NEEDLE_HIP_STFT_SHARE")) != 0;
+          const bool share = share_mode() == 1;  // (default, 2: behind the first pass only)
           if (share && other.recomputed && other.stft_recorded)
             NEEDLE_HIP_TRY(hipStreamWaitEvent(stft, other.recomputed, 0));
           else if (other.stft_done && other.stft_recorded)
@@ -686,14 +698,23 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
         }
         {
           KernelTimer timer("stft_fallback");
-          const uint32_t grid = (uint32_t)std::min<uint64_t>(2ull * (uint64_t)cus, nchunks);
+          // A pipelined call runs BESIDE the next call's first pass (shared-CU overlap): then the 168-VGPR form, whose
+          // workgroup fits the hole one retiring first-pass workgroup leaves (the 229-VGPR form needs two and waited a whole
+          // first pass for them), on a quarter of the workgroups (each holds its slot for its whole, latency-bound life).
+          const bool beside = pp != nullptr && share_mode() == 2 && stft_stream() != nullptr;
+          uint32_t grid = (uint32_t)std::min<uint64_t>((beside ? 1ull : 4ull) * (uint64_t)cus / 2, nchunks);
+          if (const char *e = getenv("NEEDLE_HIP_FALLBACK_GRID")) grid = (uint32_t)std::min<uint64_t>((uint64_t)std::max(1, atoi(e)), nchunks);  // tuning
           const stft::ChunkList list{chunk_buf.ptr, &work->chunk_count};
           auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm, desc.streams.ptr, n,
                                tab.tw, tab.wcos, tab.wconst, tab.bin_slot, tab.fold_tab, chroma_buf.ptr, (uint32_t)pairs,
                                kChunkPairs, list);
           };
-          if (channels == 1) launch(stft_chroma_kernel<1, 0, true>); else launch(stft_chroma_kernel<2, 0, true>);
+          if (beside) {
+            if (channels == 1) launch(stft_chroma_kernel<1, 0, true, 3>); else launch(stft_chroma_kernel<2, 0, true, 3>);
+          } else {
+            if (channels == 1) launch(stft_chroma_kernel<1, 0, true>); else launch(stft_chroma_kernel<2, 0, true>);
+          }
         }
         if (pp) NEEDLE_HIP_TRY(hipEventRecord(pp->recomputed, stream));
         {

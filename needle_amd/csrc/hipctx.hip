@@ -67,8 +67,10 @@ hipStream_t library_stream() {
   hipStream_t s = nullptr;
   // NEEDLE_HIP_LIBRARY_PRIORITY=1 (experiment, with NEEDLE_HIP_STFT_SHARE): the library stream at the highest priority, so
   // that the tail kernels of job k are dispatched into the slots the next job's retiring STFT workgroups free
+  // ... the default whenever that second stream exists (NEEDLE_HIP_STFT_SHARE not 0); NEEDLE_HIP_LIBRARY_PRIORITY=0 / 1 forces
   const char *prio = getenv("NEEDLE_HIP_LIBRARY_PRIORITY");
-  if (prio && atoi(prio) != 0) {
+  const char *share = getenv("NEEDLE_HIP_STFT_SHARE");
+  if (prio ? atoi(prio) != 0 : (share ? atoi(share) != 0 : true)) {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest) != hipSuccess) {
@@ -164,20 +166,23 @@ hipStream_t stft_stream() {
   // being the default; kept for measurements.
   int cus = 0, reserve = 0;
   if (const char *e = getenv("NEEDLE_HIP_STFT_RESERVE_CUS")) reserve = atoi(e);
-  // NEEDLE_HIP_STFT_SHARE=1 (round 4 experiment): a plain second stream, no CU mask -- the next job's STFT shares every CU
-  // with the previous job's tail kernels, and room for those is made by capping the STFT's workgroups per CU through its
-  // dynamic LDS size instead (NEEDLE_HIP_STFT_LDS_BYTES, fingerprint32.hip)
-  if (const char *e = getenv("NEEDLE_HIP_STFT_SHARE"))
-    if (atoi(e) != 0 && reserve == 0) {
-      int least = 0, greatest = 0;
-      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-      if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) {
-        (void)hipGetLastError();
-        s = nullptr;
-      }
-      streams[dev] = s;
-      return s;
+  // Default (round 4): a plain second stream, no CU mask, lowest priority -- the next job's first pass shares every CU
+  // with the previous job's tail kernels, which are dispatched into the holes its retiring workgroups leave (they are all
+  // built to fit one: the f64 recomputation in its 168-VGPR form).  A job then takes its first pass (stretched by what the
+  // tail takes beside it: 0.46 -> 0.52 ms at 28 x 24 min) instead of first pass + tail (0.57): 0.54 ms.
+  // NEEDLE_HIP_STFT_SHARE=0: one stream, as before; =1: the first pass waits for the other pipe's recomputation (the
+  // ordering needed while that kernel took two holes).
+  const char *share_env = getenv("NEEDLE_HIP_STFT_SHARE");
+  if ((share_env ? atoi(share_env) != 0 : true) && reserve == 0) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) != hipSuccess) {
+      (void)hipGetLastError();
+      s = nullptr;
     }
+    streams[dev] = s;
+    return s;
+  }
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (reserve > 0 && cus >= 4 * reserve) {
     // Bit i of the mask is CU i / 8 of XCD i % 8 on this part (tools/cu_mask_probe.hip: a one-bit mask confines one

@@ -95,8 +95,11 @@ struct ChunkList {
   const uint32_t *count;
 };
 
-template <int CH, int LAB = 0, bool LISTED = false>
-__global__ __launch_bounds__(256, 2) void stft_chroma_kernel(const int16_t *__restrict__ pcm,
+// WAVES: minimum waves per SIMD the kernel is compiled for (2: 226-229 VGPRs, the form that runs alone; 3: the LISTED
+// recomputation held to 168 VGPRs -- 63 of them spilled, twice as slow alone -- so that its workgroup fits the hole ONE
+// retiring first-pass workgroup leaves when it runs BESIDE the next job's first pass: fingerprint.hip, "shared-CU overlap")
+template <int CH, int LAB = 0, bool LISTED = false, int WAVES = 2>
+__global__ __launch_bounds__(256, WAVES) void stft_chroma_kernel(const int16_t *__restrict__ pcm,
                                                              const FpStream *__restrict__ streams, int num_streams,
                                                              const cd *__restrict__ tw,
                                                              const double *__restrict__ wcos, core::WindowConst wconst,

@@ -3,7 +3,7 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/r04_share_trace
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-NEEDLE_HIP_STFT_SHARE=1 NEEDLE_HIP_LIBRARY_PRIORITY=1 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -- python3 "$REPO/bench.py" --steps 30 --warmup 5 --preheat 0 --no-extras --no-cpu-baseline > "$OUT/run.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$OUT" -- python3 "$REPO/bench.py" --steps 30 --warmup 5 --preheat 0 --no-extras --no-cpu-baseline > "$OUT/run.log" 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
 rows=[]
