@@ -619,9 +619,9 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       // long launches keep kPairsPerBlock.  A SHORT launch -- one rank's share of a sharded job, a single file --
       // is cut so that every slot gets one workgroup: 4 episodes x 24 min = 11 626 pairs run as 506 workgroups of
       // 23 pairs (0.153 ms) instead of 727 of 16 (0.162 ms); one episode as 485 workgroups of 6 instead of 182 of 16.
-      auto pairs_per_block = [&](uint64_t slots) {
-        uint32_t ppb = kPairsPerBlock;
-        if ((pairs + kPairsPerBlock - 1) / kPairsPerBlock < 2 * slots)
+      auto pairs_per_block = [&](uint64_t slots, uint32_t long_launch = kPairsPerBlock) {
+        uint32_t ppb = long_launch;
+        if (pairs < (long_launch > (uint32_t)kPairsPerBlock ? 40 : 2 * kPairsPerBlock) * slots)
           ppb = (uint32_t)std::min<uint64_t>(40, std::max<uint64_t>(4, (pairs + slots - 1) / slots));
         if (const char *e = getenv("NEEDLE_STFT_PAIRS")) ppb = (uint32_t)std::max(1, atoi(e));
         return ppb;
@@ -677,10 +677,15 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
         {
           hipStream_t on = pp ? stft : stream;
           KernelTimer timer("stft_chroma32", on);
-          const uint32_t ppb = pairs_per_block((uint64_t)kStft32WavesPerSimd * (uint64_t)cus);
-          const uint32_t grid = (uint32_t)(((pairs + ppb - 1) / ppb + 7) / 8 * 8);  // multiple of 8: see the XCD mapping
-          if (!(s = launch_stft_chroma32(channels, grid, on, d_pcm, desc.streams.ptr, n, tab.tw32, tab.win32, tab.bin_slot,
-                                         tab.fold_tab, chroma_buf.ptr, energy_buf.ptr, (uint32_t)pairs, ppb, ctl_buf.ptr,
+          const uint64_t slots = (uint64_t)kStft32WavesPerSimd * (uint64_t)cus;
+          // Long launches: 24 pairs per workgroup and, over the last half round of every XCD's part, 12, 6 and 3
+          // (stft32_schedule.h): fewer workgroup prologues in the bulk, a short ramp at the end; 0.463 -> 0.453 ms alone at
+          // 28 x 24 min against 16 throughout (profiles/NOTES.md).  NEEDLE_STFT_GUIDED: tenths of a round, 0 = off.
+          static const int guided = getenv("NEEDLE_STFT_GUIDED") ? atoi(getenv("NEEDLE_STFT_GUIDED")) : 5;
+          const uint32_t ppb = pairs_per_block(slots, guided > 0 ? 24u : (uint32_t)kPairsPerBlock);
+          const Stft32Schedule schedule = stft32_schedule(pairs, ppb, (slots + 7) / 8, guided > 0, (uint32_t)std::max(guided, 1));
+          if (!(s = launch_stft_chroma32(channels, schedule, on, d_pcm, desc.streams.ptr, n, tab.tw32, tab.win32, tab.bin_slot,
+                                         tab.fold_tab, chroma_buf.ptr, energy_buf.ptr, (uint32_t)pairs, ctl_buf.ptr,
                                          (uint32_t)ctl_words)).ok())
             return s;
         }
@@ -877,8 +882,9 @@ Status gpu_fingerprint_audit_device(const int16_t *d_pcm, const std::vector<Stre
       NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
       const int n = (int)meta.size();
       const uint32_t grid = (uint32_t)(((pairs + kPairsPerBlock - 1) / kPairsPerBlock + 7) / 8 * 8);
-      if (!(s = launch_stft_chroma32(channels, grid, stream, d_pcm, d_streams.ptr, n, tab.tw32, tab.win32, tab.bin_slot, tab.fold_tab,
-                                     chroma32.ptr, energy.ptr, (uint32_t)pairs, kPairsPerBlock, ctl.ptr, 4)).ok())
+      if (!(s = launch_stft_chroma32(channels, stft32_schedule(pairs, kPairsPerBlock, 0, false), stream, d_pcm, d_streams.ptr, n,
+                                     tab.tw32, tab.win32, tab.bin_slot, tab.fold_tab, chroma32.ptr, energy.ptr, (uint32_t)pairs,
+                                     ctl.ptr, 4)).ok())
         return s;
       auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), core::kLds2Slots * sizeof(cd), stream, d_pcm, d_streams.ptr, n, tab.tw,

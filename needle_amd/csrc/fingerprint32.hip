@@ -12,10 +12,12 @@
 
 namespace needle {
 
-Status launch_stft_chroma32(int channels, uint32_t grid, hipStream_t stream, const int16_t *d_pcm,
+Status launch_stft_chroma32(int channels, const Stft32Schedule &schedule, hipStream_t stream, const int16_t *d_pcm,
                             const stft::FpStream *streams, int num_streams, const core::cf *tw32, const float *win32,
                             const uint16_t *bin_slot, const uint32_t *fold_tab, double *chroma, float *energy,
-                            uint32_t total_pairs, uint32_t pairs_per_block, uint32_t *zero_words, uint32_t num_zero_words) {
+                            uint32_t total_pairs, uint32_t *zero_words, uint32_t num_zero_words) {
+  const uint32_t grid = 8u * schedule.blocks_per_xcd;
+  if (grid == 0) return Status::Ok();
   size_t lds_bytes = core::kLds2Slots * sizeof(core::cf);  // 34 832 B: under the 64 KiB that needs no opt-in
   // experiment (NEEDLE_HIP_STFT_SHARE): a larger request caps the workgroups per CU (160 KiB of LDS) and leaves registers
   // and LDS for the previous job's tail kernels running beside this launch; <= 64 KiB so that no opt-in is needed
@@ -26,11 +28,11 @@ Status launch_stft_chroma32(int channels, uint32_t grid, hipStream_t stream, con
   lds_bytes = std::max(lds_bytes, lds_request);
   if (channels == 1)
     hipLaunchKernelGGL((stft::stft_chroma32_kernel<1, kStft32WavesPerSimd>), dim3(grid), dim3(256), lds_bytes, stream, d_pcm,
-                       streams, num_streams, tw32, win32, bin_slot, fold_tab, chroma, energy, total_pairs, pairs_per_block, zero_words,
+                       streams, num_streams, tw32, win32, bin_slot, fold_tab, chroma, energy, total_pairs, schedule, zero_words,
                        num_zero_words);
   else
     hipLaunchKernelGGL((stft::stft_chroma32_kernel<2, kStft32WavesPerSimd>), dim3(grid), dim3(256), lds_bytes, stream, d_pcm,
-                       streams, num_streams, tw32, win32, bin_slot, fold_tab, chroma, energy, total_pairs, pairs_per_block, zero_words,
+                       streams, num_streams, tw32, win32, bin_slot, fold_tab, chroma, energy, total_pairs, schedule, zero_words,
                        num_zero_words);
   NEEDLE_HIP_TRY(hipGetLastError());
   return Status::Ok();

@@ -17,6 +17,7 @@
 // which owns no pitch class -- folds the 256 partials like a class (fp_core.h energy_slot / energy_fold_entry).
 #pragma once
 
+#include "stft32_schedule.h"
 #include "stft_kernel.h"
 
 namespace needle {
@@ -78,16 +79,14 @@ template <int CH, int WAVES_PER_SIMD = 3, int LAB = 0>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
     const int16_t *__restrict__ pcm, const FpStream *__restrict__ streams, int num_streams, const cf *__restrict__ tw32,
     const float *__restrict__ win32, const uint16_t *__restrict__ bin_slot, const uint32_t *__restrict__ fold_tab,
-    double *__restrict__ chroma, float *__restrict__ energy, uint32_t total_pairs, uint32_t pairs_per_block,
+    double *__restrict__ chroma, float *__restrict__ energy, uint32_t total_pairs, const Stft32Schedule sched,
     uint32_t *__restrict__ zero_words = nullptr, uint32_t num_zero_words = 0) {
   extern __shared__ cf lds32[];  // core::kLds2Slots complex slots of 8 bytes
   cf *const lds = lds32;
   using raw_t = typename std::conditional<CH == 1, int16_t, int>::type;
   const int t = threadIdx.x;
-  const uint32_t per_xcd = gridDim.x >> 3;  // one contiguous eighth of the timeline per XCD (stft_kernel.h)
-  const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  const uint32_t first = logical * pairs_per_block;
-  const uint32_t last = min(total_pairs, first + pairs_per_block);
+  uint32_t first, last;  // one contiguous eighth of the timeline per XCD, smaller workgroups at its end (stft32_schedule.h)
+  stft32_block_range(sched, blockIdx.x, total_pairs, &first, &last);
   // the certification control block (counters + chunk bitmap) of the kernels BEHIND this one starts at zero: cleared
   // here by one workgroup instead of by a memset dispatch of its own in front of them (6 us on a 600 us job)
   if (blockIdx.x == 0)
@@ -372,7 +371,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
   }
   if (LAB & kLab32Clock) {  // the stamps replace the energy output of this diagnostic build
     if (t == 0) {
-      uint64_t *o = reinterpret_cast<uint64_t *>(energy) + 2 * (size_t)logical;
+      uint64_t *o = reinterpret_cast<uint64_t *>(energy) + 2 * (size_t)blockIdx.x;
       o[0] = __builtin_amdgcn_s_memtime() - stamp_core;
       o[1] = __builtin_amdgcn_s_memrealtime() - stamp_real;
     }

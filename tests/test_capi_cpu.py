@@ -384,6 +384,17 @@ def test_pair_index_map_matches_the_enumeration(tmp_path):
     assert out.returncode == 0 and "pair_at ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_first_pass_schedule_covers_every_frame_pair_once(tmp_path):
+    """needle_amd/csrc/stft32_schedule.h: the first pass's workgroups get smaller towards the end of each XCD's part of the
+    timeline.  tests/cpp/schedule_check.cpp runs the kernel's own range arithmetic on the host for launches from 0 to
+    5.9 M pairs: every pair exactly once, each XCD front to back, nothing beyond the launch."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "schedule_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "schedule_check.cpp")], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
 def test_rust_ffi_signatures_and_struct_layouts_match_the_headers(tmp_path):
     """The first `cargo build` of rust/needle-hip on a machine with a toolchain should be a formality: every extern
     declaration of ffi.rs has the argument and return types of the C prototype (needle-capi/src/lib.rs:346-637 is the

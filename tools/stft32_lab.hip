@@ -103,16 +103,19 @@ struct Variant {
   double diff = -1.0;
 };
 
+static needle::Stft32Schedule g_schedule;  // set by time_once from the variant's pairs per workgroup and LAB_GUIDED
 static size_t g_lds_bytes = (core::kLds2Slots + 240) * sizeof(cf);  // LAB_LDS_BYTES: more, to cap the workgroups per CU
 template <int WAVES, int LAB>
 static void launch_variant(Lab &L, uint32_t grid, uint32_t ppb) {
   hipLaunchKernelGGL((stft::stft_chroma32_kernel<1, WAVES, LAB>), dim3(grid), dim3(256), g_lds_bytes, L.stream, L.d_pcm,
-                     L.d_streams, L.eps, L.d_tw, L.d_win, L.d_bin_slot, L.d_fold_tab, L.d_chroma, L.d_energy, L.total_pairs, ppb,
-                     (uint32_t *)nullptr, 0u);
+                     L.d_streams, L.eps, L.d_tw, L.d_win, L.d_bin_slot, L.d_fold_tab, L.d_chroma, L.d_energy, L.total_pairs,
+                     g_schedule, (uint32_t *)nullptr, 0u);
 }
 
 static void time_once(Lab &L, Variant &v, bool record) {
-  const uint32_t grid = (uint32_t)(((L.total_pairs + v.ppb - 1) / v.ppb + 7) / 8 * 8);
+  static const bool guided = getenv("LAB_GUIDED") && atoi(getenv("LAB_GUIDED")) != 0;
+  g_schedule = needle::stft32_schedule(L.total_pairs, v.ppb, 96, guided);
+  const uint32_t grid = 8u * g_schedule.blocks_per_xcd;
   CK(hipEventRecord(L.a, L.stream));
   v.launch(L, grid, v.ppb);
   CK(hipEventRecord(L.b, L.stream));
