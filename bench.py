@@ -483,6 +483,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / search_only / roofline_search")
     ap.add_argument("--search-only-episodes", type=int, default=280)
+    ap.add_argument("--no-live-events", action="store_true",
+                    help="diagnostic: no HIP events around the dominant kernel inside the timed region (what they cost)")
     ap.add_argument("--force-comm", action="store_true", help="create a 1-rank communicator even at N=1")
     ap.add_argument("--launch-timeout", type=float, default=120.0,
                     help="N > 1: seconds the ranks of one attempt get before they are killed and restarted over the "
@@ -650,7 +652,7 @@ def main() -> None:
     if world > 1:                                            # every rank times the same kernel: rank 0 decides
         dominant = kernel_names[int(capi.comm_all_gather(np.array([kernel_names.index(dominant)], dtype=np.int32))[0, 0])]
     timed[0], acc[0] = [dominant], kernel_ms
-    capi.set_kernel_timing(dominant)
+    capi.set_kernel_timing(None if args.no_live_events else dominant)
     barrier()
     telemetry = DeviceTelemetry(capi) if rank == 0 else None
     if telemetry:

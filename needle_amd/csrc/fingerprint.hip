@@ -239,7 +239,10 @@ constexpr float kEnergyScale = 16384.0f;            // N * 4: the kernel's sampl
 
 // feature_row + the row's error scale sigma = u sqrt(E_row / n_row); +inf if the row sits within k sigma (relative) of
 // the 0.01 cut, 0 if it is safely under it (features exactly zero in both pipelines) or silent.
-__device__ __forceinline__ float feature_row_cert(const double *__restrict__ in, const float *__restrict__ en, float k,
+// (T = float: a tile staged in LDS by features_classify_cert_kernel -- the first pass's chroma IS f32, kept as doubles in
+// the buffer the f64 recomputation overwrites; the conversion back is exact and the row is the same bit for bit.)
+template <typename T>
+__device__ __forceinline__ float feature_row_cert(const T *__restrict__ in, const float *__restrict__ en, float k,
                                                   double *out) {
   const double coef[5] = {0.25, 0.75, 1.0, 0.75, 0.25};
   double v[kBands];
@@ -248,7 +251,7 @@ __device__ __forceinline__ float feature_row_cert(const double *__restrict__ in,
   for (int c = 0; c < kBands; c++) {
     double acc = 0.0;
 #pragma unroll
-    for (int j = 0; j < 5; j++) acc += in[j * kBands + c] * coef[j];
+    for (int j = 0; j < 5; j++) acc += (double)in[j * kBands + c] * coef[j];
     v[c] = acc;
     squares += acc * acc;
   }
@@ -315,9 +318,17 @@ __global__ __launch_bounds__(64 * kCertWaves) void features_classify_cert_kernel
     uint32_t *__restrict__ chunk_list, CertItem *__restrict__ item_list) {
   __shared__ double tiles[kCertWaves][kTileRowsMax * kFeatPitch];
   __shared__ float sigmas[kCertWaves][kTileRowsMax];
+  // The tile's input -- rows + 4 chroma rows and their energy partials, one contiguous span each -- is staged first, with
+  // coalesced 16-byte loads: every lane building its feature rows straight from global memory is 60 loads of 8 bytes at a
+  // lane stride of 96 bytes, 48 cache lines per instruction, and the wave spent half its life waiting for them (SQ_WAIT_ANY
+  // 49 % of SQ_WAVE_CYCLES, profiles/r04_final_summary.md).  The chroma is staged as the f32 it is (feature_row_cert).
+  __shared__ __attribute__((aligned(16))) float stage[kCertWaves][(kTileRowsMax + 4) * kBands];
+  __shared__ __attribute__((aligned(16))) float stage_en[kCertWaves][(kTileRowsMax + 4) * stft::kEnergyParts];
+  static_assert(((kTileRowsMax + 4) * kBands) % 2 == 0 && stft::kEnergyParts == 4, "the staging loops move double2 / float4");
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t g = blockIdx.x * kCertWaves + wave;
   if (g >= total_tiles) return;  // wave-uniform; the waves of a workgroup never wait for each other
+  __builtin_amdgcn_s_setprio(3);  // a tail kernel beside the next job's first pass: its waves issue first (fingerprint.hip, shared-CU overlap)
   const int si = find_stream<&FpStream::tile_base>(streams, num_streams, g);
   const FpStream st = streams[si];
   const uint32_t k0 = (g - st.tile_base) * items_per_tile;
@@ -328,10 +339,52 @@ __global__ __launch_bounds__(64 * kCertWaves) void features_classify_cert_kernel
   float *sig = sigmas[wave];
   const double *in = chroma + ((uint64_t)st.frame_base + x0) * kBands;
   const float *en = energy + ((uint64_t)st.frame_base + x0) * stft::kEnergyParts;
-  for (uint32_t r = lane; r < rows; r += 64)
-    sig[r] = feature_row_cert(in + (uint64_t)r * kBands, en + (uint64_t)r * stft::kEnergyParts, cert_k,
-                              mine + (SPLIT ? (r >> 1) + (r & 1u) * kHalfRows : r) * kFeatPitch);
+#ifdef NEEDLE_CERT_STAMPS
+  const uint64_t t0 = __builtin_amdgcn_s_memtime();
+  uint64_t t1 = 0, t2 = 0, t3 = 0;
+#endif
+  {
+    float *sc = stage[wave], *se = stage_en[wave];
+    const double2 *in2 = reinterpret_cast<const double2 *>(in);  // 96-byte rows: 16-byte aligned
+    const float4 *en4 = reinterpret_cast<const float4 *>(en);
+    const uint32_t n2 = (rows + 4) * kBands / 2, n4 = rows + 4;
+    // every load of the tile in flight before the first is used (a rolled loop is one memory round trip per 1 KB:
+    // 13 000 of the wave's 30 000 cycles when this was measured)
+    constexpr int kLoads2 = ((kTileRowsMax + 4) * kBands / 2 + 63) / 64, kLoads4 = (kTileRowsMax + 4 + 63) / 64;
+    double2 v2[kLoads2];
+    float4 v4[kLoads4];
+#pragma unroll
+    for (int u = 0; u < kLoads2; u++) {
+      const uint32_t i = lane + 64u * u;
+      v2[u] = i < n2 ? in2[i] : double2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int u = 0; u < kLoads4; u++) {
+      const uint32_t i = lane + 64u * u;
+      v4[u] = i < n4 ? en4[i] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int u = 0; u < kLoads2; u++) {
+      const uint32_t i = lane + 64u * u;
+      if (i < n2) *reinterpret_cast<float2 *>(sc + 2 * i) = float2{(float)v2[u].x, (float)v2[u].y};
+    }
+#pragma unroll
+    for (int u = 0; u < kLoads4; u++) {
+      const uint32_t i = lane + 64u * u;
+      if (i < n4) *reinterpret_cast<float4 *>(se + 4 * i) = v4[u];
+    }
+    wave_lds_fence();
+#ifdef NEEDLE_CERT_STAMPS
+    t1 = __builtin_amdgcn_s_memtime();
+#endif
+    for (uint32_t r = lane; r < rows; r += 64)
+      sig[r] = feature_row_cert(sc + r * kBands, se + r * stft::kEnergyParts, cert_k,
+                                mine + (SPLIT ? (r >> 1) + (r & 1u) * kHalfRows : r) * kFeatPitch);
+  }
   wave_lds_fence();
+#ifdef NEEDLE_CERT_STAMPS
+  t2 = __builtin_amdgcn_s_memtime();
+#endif
   if (lane < count) {
     float s_max = 0.0f;
 #pragma unroll
@@ -343,6 +396,12 @@ __global__ __launch_bounds__(64 * kCertWaves) void features_classify_cert_kernel
     unc = unc || !(r < 0.25);                           // out of the calibrated regime: recompute
     const uint64_t out = st.item_off + k0 + lane;
     items[out] = bits;
+#ifdef NEEDLE_CERT_STAMPS
+    t3 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && (g % 251) == 0)
+      printf("cert tile %u rows %u: stage %llu, rows %llu, classify %llu cycles\n", g, rows, (unsigned long long)(t1 - t0),
+             (unsigned long long)(t2 - t1), (unsigned long long)(t3 - t2));
+#endif
     if (unc) {
       const uint32_t x = x0 + lane * step;              // raw item = first frame of the 20 it covers
       item_list[atomicAdd(&work->item_count, 1u)] = CertItem{st.frame_base + x, 0u, out};
@@ -363,6 +422,7 @@ __global__ __launch_bounds__(256) void fixup_items_kernel(const double *__restri
                                                           uint32_t *__restrict__ items, CertStats *__restrict__ stats,
                                                           uint32_t *__restrict__ zero_word) {
   __shared__ double tiles[4][16 * kFeatPitch];
+  __builtin_amdgcn_s_setprio(3);  // a tail kernel beside the next job's first pass: its waves issue first (fingerprint.hip, shared-CU overlap)
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t n = work->item_count;
   double *mine = tiles[wave];
@@ -491,7 +551,7 @@ struct FpWorkspace {
     DeviceBuffer<float> energy;
     DeviceBuffer<uint32_t> cert_ctl, chunk_list;
     DeviceBuffer<CertItem> item_list;
-    hipEvent_t stft_done = nullptr;   // recorded on the STFT stream behind the first pass
+    hipEvent_t stft_begin = nullptr, stft_done = nullptr;  // bound to the first pass's own dispatch (no marker packets)
     hipEvent_t recomputed = nullptr;  // recorded on the library stream behind the f64 recomputation of the listed chunks
     hipEvent_t consumed = nullptr;    // recorded on the library stream behind the last reader of this set
     hipEvent_t descriptors = nullptr; // recorded on the library stream behind a descriptor upload the STFT must see
@@ -644,8 +704,10 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
             !(s = chunk_buf.reserve(nchunks)).ok() || !(s = item_buf.reserve(std::max<uint64_t>(kept, 1))).ok())
           return s;
         if (pp) {
-          for (hipEvent_t *e : {&pp->stft_done, &pp->consumed, &pp->descriptors, &pp->recomputed})
+          for (hipEvent_t *e : {&pp->consumed, &pp->descriptors, &pp->recomputed})
             if (!*e) NEEDLE_HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+          for (hipEvent_t *e : {&pp->stft_begin, &pp->stft_done})  // these two also time the kernel (KernelTimer's role)
+            if (!*e) NEEDLE_HIP_TRY(hipEventCreate(e));
           // the STFT may start once the previous user of this workspace has read it to the end, and -- only if the
           // descriptor table was uploaded just now -- once that copy has executed (an unconditional wait on the library
           // stream would put the STFT behind the whole previous job, which is the one thing this is here to avoid)
@@ -675,8 +737,12 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
         CertWork *work = reinterpret_cast<CertWork *>(ctl_buf.ptr);
         uint32_t *bitmap = ctl_buf.ptr + sizeof(CertWork) / 4;
         {
+          // A pipelined call's first pass carries its events in its own dispatch packet (hipExtLaunchKernelGGL): the
+          // completion signal of the kernel is `stft_done`, what the library stream waits for, and nothing but the kernel
+          // sits between two first passes on their stream (event records around it were 13 us per job).
           hipStream_t on = pp ? stft : stream;
-          KernelTimer timer("stft_chroma32", on);
+          const bool bound_timing = pp != nullptr && kernel_timing_on("stft_chroma32");
+          KernelTimer timer(pp ? "" : "stft_chroma32", on);  // (the unnamed timer is never selected)
           const uint64_t slots = (uint64_t)kStft32WavesPerSimd * (uint64_t)cus;
           // Long launches: 24 pairs per workgroup and, over the last half round of every XCD's part, 12, 6 and 3
           // (stft32_schedule.h): fewer workgroup prologues in the bulk, a short ramp at the end; 0.463 -> 0.453 ms alone at
@@ -686,11 +752,12 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
           const Stft32Schedule schedule = stft32_schedule(pairs, ppb, (slots + 7) / 8, guided > 0, (uint32_t)std::max(guided, 1));
           if (!(s = launch_stft_chroma32(channels, schedule, on, d_pcm, desc.streams.ptr, n, tab.tw32, tab.win32, tab.bin_slot,
                                          tab.fold_tab, chroma_buf.ptr, energy_buf.ptr, (uint32_t)pairs, ctl_buf.ptr,
-                                         (uint32_t)ctl_words)).ok())
+                                         (uint32_t)ctl_words, bound_timing ? pp->stft_begin : nullptr,
+                                         pp ? pp->stft_done : nullptr)).ok())
             return s;
+          if (bound_timing) bind_kernel_events("stft_chroma32", pp->stft_begin, pp->stft_done);
         }
         if (pp) {  // everything behind the first pass stays on the library stream, behind the STFT's event
-          NEEDLE_HIP_TRY(hipEventRecord(pp->stft_done, stft));
           pp->stft_recorded = true;
           NEEDLE_HIP_TRY(hipStreamWaitEvent(stream, pp->stft_done, 0));
         }

@@ -18,6 +18,8 @@ constexpr int kStft32WavesPerSimd = 3;  // = workgroups per CU (a workgroup puts
 Status launch_stft_chroma32(int channels, const Stft32Schedule &schedule, hipStream_t stream, const int16_t *d_pcm,
                             const stft::FpStream *streams, int num_streams, const core::cf *tw32, const float *win32,
                             const uint16_t *bin_slot, const uint32_t *fold_tab, double *chroma, float *energy,
-                            uint32_t total_pairs, uint32_t *zero_words, uint32_t num_zero_words);
+                            uint32_t total_pairs, uint32_t *zero_words, uint32_t num_zero_words,
+                            hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// (start / stop: events bound to the dispatch itself -- hipExtLaunchKernelGGL -- instead of marker packets around it)
 
 }  // namespace needle

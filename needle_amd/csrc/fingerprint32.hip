@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "hipctx.h"
 #include "stft32_kernel.h"
 
@@ -15,7 +17,8 @@ namespace needle {
 Status launch_stft_chroma32(int channels, const Stft32Schedule &schedule, hipStream_t stream, const int16_t *d_pcm,
                             const stft::FpStream *streams, int num_streams, const core::cf *tw32, const float *win32,
                             const uint16_t *bin_slot, const uint32_t *fold_tab, double *chroma, float *energy,
-                            uint32_t total_pairs, uint32_t *zero_words, uint32_t num_zero_words) {
+                            uint32_t total_pairs, uint32_t *zero_words, uint32_t num_zero_words, hipEvent_t start,
+                            hipEvent_t stop) {
   const uint32_t grid = 8u * schedule.blocks_per_xcd;
   if (grid == 0) return Status::Ok();
   size_t lds_bytes = core::kLds2Slots * sizeof(core::cf);  // 34 832 B: under the 64 KiB that needs no opt-in
@@ -27,13 +30,13 @@ Status launch_stft_chroma32(int channels, const Stft32Schedule &schedule, hipStr
   }();
   lds_bytes = std::max(lds_bytes, lds_request);
   if (channels == 1)
-    hipLaunchKernelGGL((stft::stft_chroma32_kernel<1, kStft32WavesPerSimd>), dim3(grid), dim3(256), lds_bytes, stream, d_pcm,
-                       streams, num_streams, tw32, win32, bin_slot, fold_tab, chroma, energy, total_pairs, schedule, zero_words,
-                       num_zero_words);
+    hipExtLaunchKernelGGL((stft::stft_chroma32_kernel<1, kStft32WavesPerSimd>), dim3(grid), dim3(256), lds_bytes, stream, start, stop, 0,
+                          d_pcm, streams, num_streams, tw32, win32, bin_slot, fold_tab, chroma, energy, total_pairs, schedule,
+                          zero_words, num_zero_words);
   else
-    hipLaunchKernelGGL((stft::stft_chroma32_kernel<2, kStft32WavesPerSimd>), dim3(grid), dim3(256), lds_bytes, stream, d_pcm,
-                       streams, num_streams, tw32, win32, bin_slot, fold_tab, chroma, energy, total_pairs, schedule, zero_words,
-                       num_zero_words);
+    hipExtLaunchKernelGGL((stft::stft_chroma32_kernel<2, kStft32WavesPerSimd>), dim3(grid), dim3(256), lds_bytes, stream, start, stop, 0,
+                          d_pcm, streams, num_streams, tw32, win32, bin_slot, fold_tab, chroma, energy, total_pairs, schedule,
+                          zero_words, num_zero_words);
   NEEDLE_HIP_TRY(hipGetLastError());
   return Status::Ok();
 }

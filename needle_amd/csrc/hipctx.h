@@ -124,6 +124,11 @@ struct KernelTimer {
   bool active = false;
 };
 double kernel_ms(const std::string &name);
+// A launch that carries its own events (hipExtLaunchKernelGGL: the dispatch packet's completion signal IS the stop
+// event -- no marker packets around the kernel): is `name` being timed, and if so, these are its newest start / stop events
+// (not owned; they must outlive the next two launches of that name).
+bool kernel_timing_on(const char *name);
+void bind_kernel_events(const char *name, hipEvent_t start, hipEvent_t stop);
 // "all", a comma-separated list of kernel names, or NULL / "" / "none" (the default, unless the environment
 // variable NEEDLE_HIP_KERNEL_TIMING says otherwise)
 void set_kernel_timing(const char *kernels);

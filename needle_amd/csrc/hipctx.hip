@@ -217,7 +217,7 @@ hipStream_t upload_stream() {
 KernelTimer::KernelTimer(const char *n, hipStream_t on) : name(n), stream(on ? on : library_stream()) {
   hipStream_t s = stream;
   std::lock_guard<std::mutex> lock(g_mu);
-  active = timing_selection().on(name);
+  active = name[0] != '\0' && timing_selection().on(name);
   if (!active) return;
   TimerEvents &t = g_timers[timer_key(name)];
   t.cur ^= 1;
@@ -235,6 +235,20 @@ KernelTimer::~KernelTimer() {
   std::lock_guard<std::mutex> lock(g_mu);
   TimerEvents &t = g_timers[timer_key(name)];
   (void)hipEventRecord(t.stop[t.cur], s);
+  t.recorded[t.cur] = true;
+}
+
+bool kernel_timing_on(const char *name) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  return timing_selection().on(name);
+}
+
+void bind_kernel_events(const char *name, hipEvent_t start, hipEvent_t stop) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  TimerEvents &t = g_timers[timer_key(name)];
+  t.cur ^= 1;
+  t.start[t.cur] = start;
+  t.stop[t.cur] = stop;
   t.recorded[t.cur] = true;
 }
 

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
   constexpr int B = 64 * R;
   unsigned long long groups = 0, survived = 0;  // COUNT only
   extern __shared__ uint32_t lds[];
+  __builtin_amdgcn_s_setprio(3);  // a tail kernel beside the next job's first pass: its waves issue first (fingerprint.hip, shared-CU overlap)
   int lo = 0, hi = num_problems - 1;
   while (lo < hi) {
     int mid = (lo + hi + 1) >> 1;
@@ -523,6 +524,7 @@ __global__ __launch_bounds__(256) void simhash_runs_kernel(const uint32_t *__res
   const uint32_t total = min(*count, capacity);
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t lane = threadIdx.x & 63;
+  __builtin_amdgcn_s_setprio(3);  // a tail kernel beside the next job's first pass: its waves issue first (fingerprint.hip, shared-CU overlap)
   for (uint32_t k = wave; k < total; k += waves) {
     const NeedleHipRun r = runs[k];
     const SearchProblem pr = problems[r.problem];

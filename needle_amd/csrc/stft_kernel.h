@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256, WAVES) void stft_chroma_kernel(const int16_t *
   extern __shared__ cd lds[];  // core::kLds2Slots complex slots
   using raw_t = typename std::conditional<CH == 1, int16_t, int>::type;  // one sample, or one packed L|R pair
   const int t = threadIdx.x;
+  if (LISTED) __builtin_amdgcn_s_setprio(3);  // the recomputation runs beside the next job's first pass: its waves issue first
   // Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x & 7) and each XCD has its own L2.  Neighbouring
   // stretches of the timeline share 2731 of their samples (the frame overlap), so each XCD gets one contiguous
   // eighth of the timeline: the workgroups that run side by side on an XCD are then neighbours in time and the
