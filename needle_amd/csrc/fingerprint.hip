@@ -711,7 +711,14 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
           // the STFT may start once the previous user of this workspace has read it to the end, and -- only if the
           // descriptor table was uploaded just now -- once that copy has executed (an unconditional wait on the library
           // stream would put the STFT behind the whole previous job, which is the one thing this is here to avoid)
-          if (pp->consumed_valid) NEEDLE_HIP_TRY(hipStreamWaitEvent(stft, pp->consumed, 0));
+          // (an event that has completed by now needs no packet in the STFT's queue: nothing but the previous first pass
+          // should sit in front of this one)
+          if (pp->consumed_valid) {
+            if (hipEventQuery(pp->consumed) != hipSuccess) {
+              (void)hipGetLastError();
+              NEEDLE_HIP_TRY(hipStreamWaitEvent(stft, pp->consumed, 0));
+            }
+          }
           // ... and once the OTHER pipe's first pass is through: two STFTs side by side only slow each other down and
           // leave both tails to run alone afterwards (seen in a kernel trace: pairs of 0.67 / 0.76 ms STFTs, then 0.2 ms
           // of tail kernels on an idle chip); what is wanted beside an STFT is the previous call's TAIL
@@ -723,7 +730,7 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
           const bool share = share_mode() == 1;  // (default, 2: behind the first pass only)
           if (share && other.recomputed && other.stft_recorded)
             NEEDLE_HIP_TRY(hipStreamWaitEvent(stft, other.recomputed, 0));
-          else if (other.stft_done && other.stft_recorded)
+          else if (share_mode() != 2 && other.stft_done && other.stft_recorded)  // (2: both on one stream, in order anyway)
             NEEDLE_HIP_TRY(hipStreamWaitEvent(stft, other.stft_done, 0));
           if (uploaded) {
             NEEDLE_HIP_TRY(hipEventRecord(pp->descriptors, stream));
