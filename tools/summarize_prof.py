@@ -19,7 +19,7 @@ KERNELS = {"stft_chroma32": "stft_chroma32_kernel", "features_cert": "features_c
 def short(name):
     for k, v in KERNELS.items():
         if v in name:
-            if k == "stft_chroma" and (", true>" in name or "Lb1E" in name):
+            if k == "stft_chroma" and (", true" in name or "Lb1E" in name):
                 return "stft_fallback"                            # the LISTED instantiation: f64 recomputation of listed chunks
             return k
     return None
