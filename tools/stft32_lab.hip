@@ -185,10 +185,17 @@ int main(int argc, char **argv) {
   };
   if (const char *only = getenv("LAB_ONLY")) {  // "0,2,18": run these variants only (counter passes)
     std::vector<Variant> keep;
-    for (const char *p = only; *p;) {
-      const size_t i = (size_t)std::strtoul(p, const_cast<char **>(&p), 10);
-      if (i < vs.size()) keep.push_back(vs[i]);
+    for (const char *p = only; *p;) {  // indices only; anything else ends the list (a name here once looped forever)
+      char *end = nullptr;
+      const size_t i = (size_t)std::strtoul(p, &end, 10);
+      if (end == p) break;
+      if (i < vs.size() && keep.size() < vs.size()) keep.push_back(vs[i]);
+      p = end;
       while (*p == ',') p++;
+    }
+    if (keep.empty()) {
+      std::fprintf(stderr, "LAB_ONLY takes variant indices (\"0,2,18\")\n");
+      return 2;
     }
     vs = keep;
   }
