@@ -62,7 +62,7 @@ enum : int {
   kLab32NoB1 = 4, kLab32NoB2 = 8, kLab32NoB3 = 16,  // a workgroup barrier replaced by a wave fence
   kLab32NoFold = 32,    // no fold reads / tree / chroma store
   kLab32NoPower = 64,   // no partner reads, powers, power stores
-  kLab32AsmReads = 512, // the 2 x 16 stage inputs as single ds_read_b64 (lds_read16_single) instead of the compiler's ds_read2_b64
+  kLab32CompilerReads = 512, // the 2 x 16 stage inputs through the compiler's own loads (ds_read2_b64) instead of lds_read16_single
   kLab32NoConflict = 1024,  // power stores and fold reads on a trivially conflict-free (and wrong) slot pattern: the
                             // upper bound of what a conflict-free power image could buy
   kLab32ConsumerTw = 2048,  // twiddles on the consumer side in tan form + the window folded into stage 0's first layer
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
     const float *__restrict__ win32, const uint16_t *__restrict__ bin_slot, const uint32_t *__restrict__ fold_tab,
     double *__restrict__ chroma, float *__restrict__ energy, uint32_t total_pairs, const Stft32Schedule sched,
     uint32_t *__restrict__ zero_words = nullptr, uint32_t num_zero_words = 0) {
+  constexpr bool kAsmReads = !(LAB & (kLab32CompilerReads | kLab32ConsumerTw | kLab32Tw1Lds));
   extern __shared__ cf lds32[];  // core::kLds2Slots complex slots of 8 bytes
   cf *const lds = lds32;
   using raw_t = typename std::conditional<CH == 1, int16_t, int>::type;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
       core::dif1_consumer(tt, row1, lds, r);
       wave_lds_fence();
       core::dif2_consumer(tt, row2, lds, r);
-    } else if (LAB & kLab32AsmReads) {
+    } else if (kAsmReads) {  // the product: single ds_read_b64 (0.4549 against 0.4621 ms in tools/stft32_lab, same bits)
       lds_read16_single<17>(lds, core::dif1_base(tt), r);
       core::fft16_head(r);
       core::dif_tails_store<0>(core::dif1_base(tt), 17, pw1, lds, r);
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
     } else {
       core::dif1_streamed_pw<0>(tt, pw1, lds, r);
     }
-    if (!(LAB & (kLab32AsmReads | kLab32ConsumerTw))) {
+    if (!kAsmReads && !(LAB & kLab32ConsumerTw)) {
       wave_lds_fence();  // stage 1 -> 2 stays inside 16 consecutive lanes
       core::dif2_streamed<0>(tt, lds, r);
     }

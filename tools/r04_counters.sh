@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > "$OUT/avail.txt" 2>&1
 grep -o "SQ[C]*_[A-Z0-9_]*\|TCP_[A-Z0-9_]*\|TA_[A-Z0-9_]*" "$OUT/avail.txt" | sort -u > "$OUT/avail_names.txt"
 wc -l "$OUT/avail_names.txt"
-export LAB_ONLY="0,2,19"
+export LAB_ONLY="0,2,17"   # product, 2 waves per SIMD, no workgroup barrier at all (indices into stft32_lab's list)
 pass() { n=$1; shift; timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/p$n" -- "$REPO/tools/stft32_lab" 4 > "$OUT/p$n.log" 2>&1; echo "pass $n rc=$?"; }
 pass 1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD
 pass 2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_EXP_GDS

@@ -162,12 +162,10 @@ int main(int argc, char **argv) {
       {"2 waves/SIMD", launch_variant<2, 0>, true, 16},
       {"window re-read per pair, 3 waves/SIMD", launch_variant<3, kLab32WinLoad>, true, 16},
       {"window re-read per pair, 4 waves/SIMD", launch_variant<4, kLab32WinLoad>, true, 16},
-      {"stage inputs as single ds_read_b64 (asm)", launch_variant<3, kLab32AsmReads>, true, 16},
+      {"stage inputs through the compiler's ds_read2_b64 (round 3's product)", launch_variant<3, kLab32CompilerReads>, true, 16},
       {"samples converted in the load (tbuffer format load)", launch_variant<3, kLab32FormatLoad>, true, 16},
-      {"format loads + single ds_read_b64 (asm)", launch_variant<3, kLab32FormatLoad | kLab32AsmReads>, true, 16},
       {"consumer-side twiddles (tan form) + window folded in", launch_variant<3, kLab32ConsumerTw>, true, 16},
       {"power stores / fold reads conflict-free (wrong slots)", launch_variant<3, kLab32NoConflict>, false, 16},
-      {"conflict-free power image + single reads", launch_variant<3, kLab32NoConflict | kLab32AsmReads>, false, 16},
       {"stage-1 twiddles from LDS [j][n0], 3 waves/SIMD", launch_variant<3, kLab32Tw1Lds>, true, 16},
       {"stage-1 twiddles from LDS, 4 waves/SIMD", launch_variant<4, kLab32Tw1Lds>, true, 16},
       {"stage-1 twiddles from LDS + window re-read, 4 waves", launch_variant<4, kLab32Tw1Lds | kLab32WinLoad>, true, 16},
@@ -181,6 +179,7 @@ int main(int argc, char **argv) {
       {"no partner reads / powers / power stores", launch_variant<3, kLab32NoPower>, false, 16},
       {"no fold, no powers, no energy (transform only)", launch_variant<3, kLab32NoFold | kLab32NoPower | kLab32NoEnergy>, false, 16},
       {"product, 8 pairs per workgroup", launch_variant<3, 0>, true, 8},
+      {"product, 24 pairs per workgroup", launch_variant<3, 0>, true, 24},
       {"product, 32 pairs per workgroup", launch_variant<3, 0>, true, 32},
   };
   if (const char *only = getenv("LAB_ONLY")) {  // "0,2,18": run these variants only (counter passes)
