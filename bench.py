@@ -638,6 +638,7 @@ def main() -> None:
                 "what": f"the same {args.warmup} + {args.steps} steps run first, two untimed jobs after set-up and nothing else "
                         "in front (the --preheat 0 figure); `value` is the steady state reached after the preheat jobs"}
         preheat_jobs = max(0, args.preheat - args.warmup - args.steps)
+    telemetry = DeviceTelemetry(capi) if rank == 0 else None      # (sysfs probing takes milliseconds: not between warm-up and t0)
     for i in range(preheat_jobs):
         step(False)
     barrier()
@@ -654,7 +655,6 @@ def main() -> None:
     timed[0], acc[0] = [dominant], kernel_ms
     capi.set_kernel_timing(None if args.no_live_events else dominant)
     barrier()
-    telemetry = DeviceTelemetry(capi) if rank == 0 else None
     if telemetry:
         telemetry.start()
     t0 = time.perf_counter()
