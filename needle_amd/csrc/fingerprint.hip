@@ -749,7 +749,8 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
           // sits between two first passes on their stream (event records around it were 13 us per job).
           hipStream_t on = pp ? stft : stream;
           const bool bound_timing = pp != nullptr && kernel_timing_on("stft_chroma32");
-          KernelTimer timer(pp ? "" : "stft_chroma32", on);  // (the unnamed timer is never selected)
+          std::unique_ptr<KernelTimer> timer;  // event records around the launch: only where there is no pipe
+          if (!pp) timer.reset(new KernelTimer("stft_chroma32", on));
           const uint64_t slots = (uint64_t)kStft32WavesPerSimd * (uint64_t)cus;
           // Long launches: 24 pairs per workgroup and, over the last half round of every XCD's part, 12, 6 and 3
           // (stft32_schedule.h): fewer workgroup prologues in the bulk, a short ramp at the end; 0.463 -> 0.453 ms alone at

@@ -217,7 +217,7 @@ hipStream_t upload_stream() {
 KernelTimer::KernelTimer(const char *n, hipStream_t on) : name(n), stream(on ? on : library_stream()) {
   hipStream_t s = stream;
   std::lock_guard<std::mutex> lock(g_mu);
-  active = name[0] != '\0' && timing_selection().on(name);
+  active = timing_selection().on(name);
   if (!active) return;
   TimerEvents &t = g_timers[timer_key(name)];
   t.cur ^= 1;
