@@ -237,6 +237,14 @@ __global__ __launch_bounds__(256) void hamming_runs_band_kernel(const uint32_t *
   }
 }
 
+// LDS written by a wave and read back by other lanes of the SAME wave: the stores have to be complete (and the compiler
+// must not move the loads above them); no other wave is involved.
+__device__ __forceinline__ void wave_lds_fence_search() {  // (stft_kernel.h wave_lds_fence: the hardware runs one wave's LDS operations in order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- sampled path: aligned-window candidates + exact cooperative resolution ------------------------------------
 // A maximal run of L >= min_len cells on a diagonal covers at least one ALIGNED window of W rows out of every
 // P = min_len - W + 1 rows (windows at rows [1 + kP, 1 + kP + W)): any W + P - 1 = min_len consecutive rows
@@ -495,6 +503,232 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
   }
 }
 
+// ---- sampled path on the matrix pipe (opt-in: NEEDLE_HIP_SCAN_MFMA=1) ----------------------------------------------
+// The same aligned windows, the same head test and the same candidates as hamming_runs_sampled_kernel, computed
+// differently: the Hamming distances of a window's head rows against every destination position are integer matrix
+// products.  A hash as 32 bytes of +-1 (bit set: +1): dot(a, b) = 32 - 2 d(a, b).  A tile is 32 windows x 32 destination
+// positions; for each of the H head rows s one v_mfma_i32_32x32x32_i8 (K = 32): A row = the window's hash src[w0 + s],
+// B column j = dst[j + s] (j = destination index of the window's FIRST row, i.e. diagonal d = j - w0), accumulator preset
+// to -(32 - 2 t): the result's sign bit is clear exactly where that cell matches.  The OR of the H results is
+// non-negative exactly where ALL head cells match -- the vector form's exact head test at two bitwise instructions per
+// window-diagonal instead of ~8 -- and one AND over a lane's 16 results + one compare tells whether the tile holds any
+// survivor at all (it mostly does not: ~0.05 % of the window-diagonals pass on audio, tools/mfma_filter_model.py).
+// Survivors are queued in LDS and their remaining rows tested 64 windows at a time, one per lane; a window that matches
+// whole is resolved by the wave like in the vector form (same function of the same cells: the emitted runs are
+// identical).  Rows and columns outside the table carry all-zero fragments (product 0: negative).  Operand maps:
+// tools/mfma_i8_layout.hip (profiles/r04_mfma_i8_layout.log).  Needs 32 - 2 t > 0 (t <= 15).
+constexpr int kMfmaHeads = 4;
+constexpr int kMfmaQueue = 128;                   // survivors per wave waiting for the test of their remaining rows (< 64 + 64)
+constexpr int kMfmaFixedWords = 512 + 4 * kMfmaQueue;  // behind the staged destination: byte table (256 x 2 words), 4 queues
+// ... and behind those the A image: every aligned window's H head hashes as 32 bytes of +-1 each, rows padded to 32 windows;
+// a window's row is 4 words longer than its 8 H (36 words: lanes 32 words apart would all meet in two groups of LDS banks)
+constexpr int kMfmaPitch = kMfmaHeads * 8 + 4;
+__host__ __device__ constexpr int mfma_windows(int n, int min_len, int W) {
+  return (n - 1 - W) >= 0 && min_len - W + 1 > 0 ? (n - 1 - W) / (min_len - W + 1) + 1 : 0;  // w0 = 1 + k P, w0 + W - 1 <= n - 1
+}
+__host__ __device__ constexpr size_t mfma_extra_words(int n, int min_len, int W) {
+  return (size_t)kMfmaFixedWords + 4 /* alignment */ + (size_t)((mfma_windows(n, min_len, W) + 31) / 32 * 32) * kMfmaPitch;
+}
+typedef int mfma_v4i __attribute__((ext_vector_type(4)));
+typedef int mfma_v16i __attribute__((ext_vector_type(16)));
+
+template <int W>
+__global__ __launch_bounds__(256, 4) void hamming_runs_mfma_kernel(const uint32_t *__restrict__ hashes,
+                                                                   const SearchProblem *__restrict__ problems,
+                                                                   int num_problems, uint32_t threshold,
+                                                                   NeedleHipRun *__restrict__ runs, uint32_t capacity,
+                                                                   uint32_t *__restrict__ count, int bands_per_wave, int,
+                                                                   unsigned long long *__restrict__) {
+  constexpr int R = kBandR, B = 64 * R, H = kMfmaHeads;
+  extern __shared__ uint32_t lds[];
+  __builtin_amdgcn_s_setprio(3);
+  int lo = 0, hi = num_problems - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (problems[mid].block_base <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SearchProblem pr = problems[lo];
+  const int n = (int)pr.n, m = (int)pr.m;
+  const uint32_t *__restrict__ src = hashes + pr.src_off;
+  const uint32_t *__restrict__ dst = hashes + pr.dst_off;
+  const int min_len = (int)pr.min_len;
+  const int P = min_len - W + 1;
+  const int nW = mfma_windows(n, min_len, W);
+  const int row_tiles = (nW + 31) / 32;
+  uint32_t *ldst = lds;                                   // ldst[B + j] = dst[j], B zero slots on both sides
+  uint32_t *table = lds + (2 * B + m);                    // table[2 b], table[2 b + 1]: the 8 bytes of +-1 for byte value b
+  uint32_t *aimg = table + kMfmaFixedWords;               // 8 words per (window, head row), 16-byte aligned
+  aimg += (4 - ((2 * B + m + kMfmaFixedWords) & 3)) & 3;
+  for (int k = threadIdx.x; k < B; k += blockDim.x) {
+    ldst[k] = 0u;
+    ldst[B + m + k] = 0u;
+  }
+  for (int k = threadIdx.x; k < m; k += blockDim.x) ldst[B + k] = dst[k];
+  for (int b = threadIdx.x; b < 256; b += blockDim.x) {
+    uint32_t w0 = 0, w1 = 0;
+    for (int i = 0; i < 4; i++) {
+      w0 |= (((b >> i) & 1) ? 0x01u : 0xFFu) << (8 * i);
+      w1 |= (((b >> (4 + i)) & 1) ? 0x01u : 0xFFu) << (8 * i);
+    }
+    table[2 * b] = w0;
+    table[2 * b + 1] = w1;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < row_tiles * 32 * H; idx += blockDim.x) {  // rows beyond the last window: zeros (product 0)
+    const int k = idx / H, kb = idx % H;
+    uint32_t *o = aimg + k * kMfmaPitch + 8 * kb;
+    if (k < nW) {
+      const uint32_t hsh = src[1 + k * P + head_row(kb, W, H)];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t byte = (hsh >> (8 * q)) & 0xFFu;
+        o[2 * q] = table[2 * byte];
+        o[2 * q + 1] = table[2 * byte + 1];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; q++) o[q] = 0u;
+    }
+  }
+  __syncthreads();
+
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  uint32_t *queue = table + 512 + wave * kMfmaQueue;
+  const int last_j = m - W;                                     // valid destination positions: 1 .. m - W
+  if (nW <= 0 || last_j < 1) return;
+  const int r = lane & 31, h = lane >> 5;
+  const int t = (int)min(threshold, 15u);
+  const int preset = -(32 - 2 * t);      // per head row: dot = 32 - 2 d, so dot + preset >= 0 <=> d <= t (and < 0 for all-zero fragments)
+  // this wave's share of the pair's column blocks: the workgroups of a pair are laid out as for the vector form
+  const int slots = 4 * bands_per_wave;
+  const int total_bands = (n + m - 3 + B - 1) / B;
+  const int nb = (total_bands + slots - 1) / slots;             // workgroups of this pair
+  const int b_in_pair = (int)(blockIdx.x - pr.block_base);
+  const int col_blocks = last_j / 32 + 1;                        // positions 0 .. last_j
+  const int first_cb = b_in_pair * 4 + wave, stride_cb = nb * 4;
+
+  // exact resolution of one window whose W cells all match on diagonal d, by the whole wave (the vector form's resolve())
+  auto resolve = [&](const int w0, const int d) {
+    const int ilo = d < 0 ? 1 - d : 1;
+    const int ihi = min(n - 1, m - 1 - d);
+    if (w0 < ilo || w0 + W - 1 > ihi) return;
+    int e = w0 + W;
+    bool ended = false;
+    const int fwd_limit = min(ihi, w0 + P + W - 1);
+    while (e <= fwd_limit) {
+      const int row = e + lane;
+      const bool bad = row <= fwd_limit && (uint32_t)__popc(src[row] ^ ldst[B + row + d]) > threshold;
+      const unsigned long long mm = __ballot(bad);
+      if (mm) {
+        e += __ffsll((long long)mm) - 1;
+        ended = true;
+        break;
+      }
+      e += 64;
+    }
+    if (!ended) {
+      if (fwd_limit == w0 + P + W - 1) return;  // the run also covers the next window: it reports the run
+      e = ihi + 1;
+    }
+    const int b = e - 1;
+    int a = ilo;
+    int q = w0 - 1;
+    while (q >= ilo) {
+      const int row = q - lane;
+      const bool bad = row >= ilo && (uint32_t)__popc(src[row] ^ ldst[B + row + d]) > threshold;
+      const unsigned long long mm = __ballot(bad);
+      if (mm) {
+        a = q - (__ffsll((long long)mm) - 1) + 1;
+        break;
+      }
+      q -= 64;
+    }
+    const int len = b - a + 1;
+    if (len >= min_len && lane == 0) {
+      const uint32_t slot = atomicAdd(count, 1u);
+      if (slot < capacity) runs[slot] = NeedleHipRun{(uint32_t)lo, (uint32_t)b, (uint32_t)(b + d), (uint32_t)len, 0u, 0u};
+    }
+  };
+  // the test of every row of up to 64 queued survivors, one per lane, then the resolution of those that match whole
+  auto verify = [&](const int first, const int cnt) {
+    wave_lds_fence_search();
+    bool whole = false;
+    int w0 = 0, d = 0;
+    if (lane < cnt) {
+      const uint32_t e = queue[first + lane];
+      const int k = (int)(e >> 16), j = (int)(e & 0xFFFFu);
+      w0 = 1 + k * P;
+      d = j - w0;
+      uint32_t miss = 0u;
+#pragma unroll
+      for (int s = 0; s < W; s++) miss |= (uint32_t)((uint32_t)__popc(src[w0 + s] ^ ldst[B + j + s]) > threshold);
+      whole = miss == 0u;
+    }
+    unsigned long long cand = __ballot(whole);
+    while (cand) {
+      const int src_lane = __ffsll((long long)cand) - 1;
+      cand &= cand - 1;
+      resolve(__shfl(w0, src_lane), __shfl(d, src_lane));
+    }
+  };
+
+  mfma_v16i presets;
+#pragma unroll
+  for (int q = 0; q < 16; q++) presets[q] = preset;
+  int qn = 0;  // wave-uniform: survivors waiting in this wave's queue (< 64 whenever a register's survivors are added)
+  for (int cb = first_cb; cb < col_blocks; cb += stride_cb) {
+    const int j = 32 * cb + r;                   // this lane's column = destination position
+    const bool col_ok = j >= 1 && j <= last_j;
+    mfma_v4i fb[H];                              // lane (r, h): half h of dst[j + s] for the H head rows s, as +-1 bytes
+#pragma unroll
+    for (int kb = 0; kb < H; kb++) {
+      const uint32_t half = (ldst[B + j + head_row(kb, W, H)] >> (16 * h)) & 0xFFFFu;
+      const uint32_t lo8 = half & 0xFFu, hi8 = half >> 8;
+      fb[kb][0] = (int)table[2 * lo8];
+      fb[kb][1] = (int)table[2 * lo8 + 1];
+      fb[kb][2] = (int)table[2 * hi8];
+      fb[kb][3] = (int)table[2 * hi8 + 1];
+    }
+#pragma unroll 1
+    for (int rt = 0; rt < row_tiles; rt++) {
+      // one product per head row (K = 32 each, independent accumulators), each preset to -(32 - 2 t): its sign bit is
+      // clear exactly where that row's cell matches; a window-diagonal survives iff the OR of the H results is non-negative
+      mfma_v16i u;
+      {
+        const mfma_v4i *fa = reinterpret_cast<const mfma_v4i *>(aimg + (size_t)(32 * rt + r) * kMfmaPitch + 4 * h);
+        mfma_v16i acc[H];
+#pragma unroll
+        for (int kb = 0; kb < H; kb++) acc[kb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[2 * kb], fb[kb], presets, 0, 0, 0);
+        u = acc[0];
+#pragma unroll
+        for (int kb = 1; kb < H; kb++) u |= acc[kb];
+      }
+      int all = -1;
+#pragma unroll
+      for (int q = 0; q < 16; q++) all &= u[q];
+      if (__ballot(all >= 0 && col_ok) == 0ull) continue;  // (wave-uniform) no survivor in this tile: the usual case
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const bool pass = u[q] >= 0 && col_ok;
+        const unsigned long long mask = __ballot(pass);
+        if (mask == 0ull) continue;              // wave-uniform
+        if (pass) {
+          const int k = 32 * rt + (q & 3) + 8 * (q >> 2) + 4 * h;
+          const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+          queue[qn + (int)before] = ((uint32_t)k << 16) | (uint32_t)j;
+        }
+        qn += (int)__popcll(mask);
+        if (qn >= 64) {                          // the newest 64 leave; what stays is below them
+          verify(qn - 64, 64);
+          qn -= 64;
+        }
+      }
+    }
+  }
+  if (qn > 0) verify(0, qn);
+}
+
 // ---- simhash of every emitted run (comparator.rs:149-153,226-229) -----------------------------------------------
 // The scan kernels leave NeedleHipRun.problem = index of the problem descriptor; this pass computes
 // chromaprint's simhash32 over the L+1 hashes [end-len ..= end] of both sequences and replaces the index by
@@ -571,13 +805,14 @@ SampledKernel sampled_kernel(ScanShape sh) {
 struct SearchPlan {
   std::vector<NeedleHipSeq> seqs;          // inputs ...
   std::vector<NeedleHipProblem> problems;
-  int mode[4] = {0, 0, 0, 0};              // ... and the switches that steer the choice ([3]: threshold beyond the sampled kernel's bit trick)
+  int mode[5] = {0, 0, 0, 0, 0};           // ... and the switches that steer the choice ([3]: threshold beyond the sampled kernel's bit trick,
+                                           // [4]: the sampled path's first stage on the matrix pipe)
   std::vector<SearchProblem> meta;         // derived: the pairs the chosen kernel can stage, then the oversize ones
   size_t staged = 0;                       // how many of meta go to the chosen kernel
   uint64_t oversize_blocks = 0;            // grid of the unstaged kernel over meta[staged..]
   uint64_t blocks = 0;
   size_t lds_bytes = 0;
-  bool sampled = false, fast = false;
+  bool sampled = false, fast = false, mfma = false;
   int bands_per_wave = 1;
   bool valid = false;
   bool matches(const NeedleHipSeq *s, size_t ns, const NeedleHipProblem *p, size_t np, const int *m) const {
@@ -627,8 +862,10 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     // video must not fail the search of the whole library (the reference has no bound).
     size_t lds_limit = 160 * 1024;
     if (const char *e = getenv("NEEDLE_HIP_SEARCH_LDS_LIMIT")) lds_limit = (size_t)std::max(1, atoi(e));  // tests
+    const bool mfma = sampled && mode[4] != 0;
     auto lds_need = [&](const SearchProblem &m) {
-      return ((fast || sampled) ? (size_t)m.m + 2 * kBandB : (size_t)m.n + m.m) * sizeof(uint32_t);
+      return ((fast || sampled) ? (size_t)m.m + 2 * kBandB + (mfma ? mfma_extra_words((int)m.n, (int)m.min_len, kSampleW) : 0) : (size_t)m.n + m.m) *
+             sizeof(uint32_t);
     };
     std::stable_partition(meta.begin(), meta.end(), [&](const SearchProblem &m) { return lds_need(m) <= lds_limit; });
     size_t staged = 0;
@@ -671,6 +908,7 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     plan->staged = staged;
     plan->oversize_blocks = ob;
     plan->sampled = sampled;
+    plan->mfma = mfma;
     plan->fast = fast;
     plan->bands_per_wave = bands_per_wave;
     plan->lds_bytes = lds_bytes;
@@ -716,9 +954,10 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
   if (!s.ok()) return s;
   hipStream_t stream = library_stream();
   if (!count_is_zero) NEEDLE_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
-  const int mode[4] = {getenv("NEEDLE_HIP_GENERIC_SEARCH") != nullptr, getenv("NEEDLE_HIP_BAND_SEARCH") != nullptr,
+  const int mode[5] = {getenv("NEEDLE_HIP_GENERIC_SEARCH") != nullptr, getenv("NEEDLE_HIP_BAND_SEARCH") != nullptr,
                        getenv("NEEDLE_HIP_BANDS_PER_WAVE") ? std::max(1, atoi(getenv("NEEDLE_HIP_BANDS_PER_WAVE"))) : 0,
-                       threshold > 31u};  // every cell matches at 32: the band / generic kernels take such a launch
+                       threshold > 31u,   // every cell matches at 32: the band / generic kernels take such a launch
+                       getenv("NEEDLE_HIP_SCAN_MFMA") != nullptr && threshold <= 15u && scan_shape().w == kSampleW};
   SearchWorkspace *ws = workspace();
   SearchPlan &plan = ws->plan;
   const bool reuse = plan.matches(seqs, num_seqs, problems, num_problems, mode);
@@ -737,6 +976,8 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_kernel<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_band_kernel<kBandR, kBandU>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_mfma_kernel<kSampleW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       for (int w : {4, 8, 16})
         for (int h : {2, 3, 4}) {
@@ -762,6 +1003,10 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
           hipLaunchKernelGGL(sampled_kernel<true>(scan_shape()), dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
                              ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,
                              ws->eval_groups);
+        } else if (plan.mfma) {
+          hipLaunchKernelGGL(hamming_runs_mfma_kernel<kSampleW>, dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
+                             ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,
+                             (unsigned long long *)nullptr);
         } else {
           hipLaunchKernelGGL(sampled_kernel<false>(scan_shape()), dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
                              ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,

@@ -124,14 +124,16 @@ def test_hamming_runs_equal_reference_dp(n, m):
     assert got == _oracle_runs(src, dst, thr, min_len)
 
 
-@pytest.fixture(params=["sampled", "sampled-rows", "sampled-sparse", "band", "generic"])
+@pytest.fixture(params=["sampled", "sampled-rows", "sampled-sparse", "sampled-mfma", "band", "generic"])
 def search_mode(request):
     """The launcher picks the aligned-window kernel for min_len >= 23, the band kernel for >= 21 and the
     one-lane-per-diagonal kernel otherwise; the environment switches force the slower ones so every kernel is
     checked on the same inputs -- and the aligned-window kernel with the survivors of a window's head rows always
     walked row by row (NEEDLE_HIP_SPARSE_MAX=0) or always finished one diagonal at a time (1000)."""
-    keys = ("NEEDLE_HIP_BAND_SEARCH", "NEEDLE_HIP_GENERIC_SEARCH", "NEEDLE_HIP_SPARSE_MAX")
+    keys = ("NEEDLE_HIP_BAND_SEARCH", "NEEDLE_HIP_GENERIC_SEARCH", "NEEDLE_HIP_SPARSE_MAX", "NEEDLE_HIP_SCAN_MFMA")
     old = {k: os.environ.pop(k, None) for k in keys}
+    if request.param == "sampled-mfma":          # the aligned-window kernel's first stage on the matrix pipe (opt-in)
+        os.environ["NEEDLE_HIP_SCAN_MFMA"] = "1"
     if request.param == "band":
         os.environ["NEEDLE_HIP_BAND_SEARCH"] = "1"
     elif request.param == "generic":
