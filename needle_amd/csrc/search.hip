@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
 // identical).  Rows and columns outside the table carry all-zero fragments (product 0: negative).  Operand maps:
 // tools/mfma_i8_layout.hip (profiles/r04_mfma_i8_layout.log).  Needs 32 - 2 t > 0 (t <= 15).
 constexpr int kMfmaHeads = 4;
-constexpr int kMfmaQueue = 128;                   // survivors per wave waiting for the test of their remaining rows (< 64 + 64)
+constexpr int kMfmaQueue = 64 + 4 * 64;           // survivors per wave waiting for the test of their remaining rows
 constexpr int kMfmaFixedWords = 512 + 4 * kMfmaQueue;  // behind the staged destination: byte table (256 x 2 words), 4 queues
 // ... and behind those the A image: every aligned window's H head hashes as 32 bytes of +-1 each, rows padded to 32 windows;
 // a window's row is 4 words longer than its 8 H (36 words: lanes 32 words apart would all meet in two groups of LDS banks)
@@ -676,51 +676,68 @@ __global__ __launch_bounds__(256, 4) void hamming_runs_mfma_kernel(const uint32_
   mfma_v16i presets;
 #pragma unroll
   for (int q = 0; q < 16; q++) presets[q] = preset;
-  int qn = 0;  // wave-uniform: survivors waiting in this wave's queue (< 64 whenever a register's survivors are added)
+  int qn = 0;  // wave-uniform: survivors waiting in this wave's queue (< 64 at the start of a tile)
+  auto load_a = [&](const int rt, mfma_v4i (&fa)[H]) {
+    const mfma_v4i *img = reinterpret_cast<const mfma_v4i *>(aimg + (size_t)(32 * rt + r) * kMfmaPitch + 4 * h);
+#pragma unroll
+    for (int kb = 0; kb < H; kb++) fa[kb] = img[2 * kb];
+  };
   for (int cb = first_cb; cb < col_blocks; cb += stride_cb) {
     const int j = 32 * cb + r;                   // this lane's column = destination position
     const bool col_ok = j >= 1 && j <= last_j;
-    mfma_v4i fb[H];                              // lane (r, h): half h of dst[j + s] for the H head rows s, as +-1 bytes
+    // lane (r, h): half h of dst[j + s] for the H head rows s, as +-1 bytes.  On the vector ALU (four bits -> four
+    // selector bytes of 0 / 1 -> v_perm_b32 picks 0xFF / 0x01): random 8-byte reads of the byte table cost three LDS
+    // cycles in four to bank conflicts (SQ_LDS_BANK_CONFLICT, tools/scan_mfma_counters.sh)
+    mfma_v4i fb[H];
 #pragma unroll
     for (int kb = 0; kb < H; kb++) {
-      const uint32_t half = (ldst[B + j + head_row(kb, W, H)] >> (16 * h)) & 0xFFFFu;
-      const uint32_t lo8 = half & 0xFFu, hi8 = half >> 8;
-      fb[kb][0] = (int)table[2 * lo8];
-      fb[kb][1] = (int)table[2 * lo8 + 1];
-      fb[kb][2] = (int)table[2 * hi8];
-      fb[kb][3] = (int)table[2 * hi8 + 1];
+      const uint32_t half = ldst[B + j + head_row(kb, W, H)] >> (16 * h);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t sel = (((half >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u;
+        fb[kb][q] = (int)__builtin_amdgcn_perm(0u, 0x000001FFu, sel);
+      }
     }
+    // ONE tile body (the loop over row tiles is not unrolled: the survivors' path below holds the whole resolution code);
+    // the A fragments of the next row tile are read while this one is multiplied
+    mfma_v4i fa[H];
+    load_a(0, fa);
 #pragma unroll 1
     for (int rt = 0; rt < row_tiles; rt++) {
-      // one product per head row (K = 32 each, independent accumulators), each preset to -(32 - 2 t): its sign bit is
-      // clear exactly where that row's cell matches; a window-diagonal survives iff the OR of the H results is non-negative
-      mfma_v16i u;
-      {
-        const mfma_v4i *fa = reinterpret_cast<const mfma_v4i *>(aimg + (size_t)(32 * rt + r) * kMfmaPitch + 4 * h);
-        mfma_v16i acc[H];
+      mfma_v4i fn[H];
+      load_a(min(rt + 1, row_tiles - 1), fn);
+      // a product per head row (K = 32 each), each preset to -(32 - 2 t): its sign bit is clear exactly where that row's
+      // cell matches; a window-diagonal survives iff the OR of the H results is non-negative
+      mfma_v16i u = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0], fb[0], presets, 0, 0, 0);
 #pragma unroll
-        for (int kb = 0; kb < H; kb++) acc[kb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[2 * kb], fb[kb], presets, 0, 0, 0);
-        u = acc[0];
+      for (int kb = 1; kb < H; kb++) u |= __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[kb], fb[kb], presets, 0, 0, 0);
 #pragma unroll
-        for (int kb = 1; kb < H; kb++) u |= acc[kb];
-      }
-      int all = -1;
+      for (int kb = 0; kb < H; kb++) fa[kb] = fn[kb];
+      // survivors are rare (~0.05 % of the results): the registers are ANDed in four groups of four (a group's AND is
+      // non-negative iff one of its registers is), the groups into one word, and only a group that holds one is looked at
+      int grp[4];
 #pragma unroll
-      for (int q = 0; q < 16; q++) all &= u[q];
+      for (int g = 0; g < 4; g++) grp[g] = (u[4 * g] & u[4 * g + 1]) & (u[4 * g + 2] & u[4 * g + 3]);
+      const int all = (grp[0] & grp[1]) & (grp[2] & grp[3]);
       if (__ballot(all >= 0 && col_ok) == 0ull) continue;  // (wave-uniform) no survivor in this tile: the usual case
 #pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const bool pass = u[q] >= 0 && col_ok;
-        const unsigned long long mask = __ballot(pass);
-        if (mask == 0ull) continue;              // wave-uniform
-        if (pass) {
-          const int k = 32 * rt + (q & 3) + 8 * (q >> 2) + 4 * h;
-          const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-          queue[qn + (int)before] = ((uint32_t)k << 16) | (uint32_t)j;
+      for (int g = 0; g < 4; g++) {
+        if (__ballot(grp[g] >= 0 && col_ok) == 0ull) continue;  // wave-uniform
+#pragma unroll
+        for (int q = 4 * g; q < 4 * g + 4; q++) {
+          const bool pass = u[q] >= 0 && col_ok;
+          const unsigned long long mask = __ballot(pass);
+          if (mask != 0ull) {                    // wave-uniform
+            if (pass) {
+              const int k = 32 * rt + (q & 3) + 8 * (q >> 2) + 4 * h;
+              const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+              queue[qn + (int)before] = ((uint32_t)k << 16) | (uint32_t)j;
+            }
+            qn += (int)__popcll(mask);
+          }
         }
-        qn += (int)__popcll(mask);
-        if (qn >= 64) {                          // the newest 64 leave; what stays is below them
-          verify(qn - 64, 64);
+        while (qn >= 64) {                       // (a group adds at most 256 to the < 64 that were waiting) the newest 64
+          verify(qn - 64, 64);                   // leave; what stays is below them
           qn -= 64;
         }
       }

@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 #define CK(x)                                                                              \
@@ -142,7 +143,55 @@ static void find_maps(const char *name) {
   }
 }
 
+// issue cadence: cycles (s_memtime) per v_mfma_i32_32x32x32_i8 of one wave, four independent accumulators, 256 in a row;
+// several waves per SIMD (the workgroups are 256 threads = one wave per SIMD, `wgs` of them per CU are resident together)
+__global__ __launch_bounds__(256) void mfma_rate(const v4i *a, const v4i *b, int *sink, unsigned long long *cycles) {
+  const int l = threadIdx.x & 63;
+  v4i fa = a[l], fb = b[l];
+  v16i c0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+  __builtin_amdgcn_s_barrier();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < 64; i++) {
+    c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, c3, 0, 0, 0);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  int x = 0;
+  for (int r = 0; r < 16; r++) x += c0[r] + c1[r] + c2[r] + c3[r];
+  sink[blockIdx.x * 256 + threadIdx.x] = x;
+  if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+static void rate(const int blocks) {
+  int8_t *da, *db;
+  int *sink;
+  unsigned long long *cyc;
+  CK(hipMalloc(&da, 1024));
+  CK(hipMalloc(&db, 1024));
+  CK(hipMemset(da, 1, 1024));
+  CK(hipMemset(db, 1, 1024));
+  CK(hipMalloc(&sink, (size_t)blocks * 256 * 4));
+  CK(hipMalloc(&cyc, (size_t)blocks * 8));
+  for (int rep = 0; rep < 2; rep++) {
+    hipLaunchKernelGGL(mfma_rate, dim3(blocks), dim3(256), 0, 0, (const v4i *)da, (const v4i *)db, sink, cyc);
+    CK(hipDeviceSynchronize());
+  }
+  std::vector<unsigned long long> h(blocks);
+  CK(hipMemcpy(h.data(), cyc, (size_t)blocks * 8, hipMemcpyDeviceToHost));
+  std::sort(h.begin(), h.end());
+  std::printf("v_mfma_i32_32x32x32_i8 issue cadence, 256 per wave, %d workgroups of 4 waves on the device: min %.1f  median %.1f  max %.1f cycles per instruction of one wave\n",
+              blocks, h.front() / 256.0, h[h.size() / 2] / 256.0, h.back() / 256.0);
+  CK(hipFree(da));
+  CK(hipFree(db));
+  CK(hipFree(sink));
+  CK(hipFree(cyc));
+}
+
 int main() {
+  rate(256);
+  rate(1024);
   const int bad32 = check("v_mfma_i32_32x32x32_i8", 32, 32, 32, true);
   const int bad16 = check("v_mfma_i32_16x16x64_i8", 16, 16, 64, false);
   if (bad32) find_maps<16>("v_mfma_i32_32x32x32_i8");
