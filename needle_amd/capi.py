@@ -95,7 +95,7 @@ NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_host_alloc_free", "needle_hip_int_valu_ceiling",
     "needle_hip_comparator_results_from_runs", "needle_hip_library_job_runs", "needle_hip_library_job_comm_bytes",
     "needle_hip_host_threads", "needle_hip_fingerprint_audit_device", "needle_hip_library_audit",
-    "needle_hip_scan_counts"]
+    "needle_hip_scan_counts", "needle_hip_scan_last_launch"]
 
 _LIB = None
 
@@ -273,6 +273,15 @@ def scan_counts(reset: bool = False) -> Tuple[int, int]:
     lib().needle_hip_scan_counts.argtypes = [C.POINTER(C.c_uint64), C.c_bool]
     check(lib().needle_hip_scan_counts(c, reset))
     return int(c[0]), int(c[1])
+
+
+def scan_last_launch() -> Tuple[int, int]:
+    """(form, matrix products) of this process's last scan launch: form 3 = aligned windows on the vector ALU, 4 = with the
+    head rows on the matrix pipe (then the second value counts its v_mfma_i32_32x32x32_i8 instructions)."""
+    form, products = C.c_int32(0), C.c_uint64(0)
+    lib().needle_hip_scan_last_launch.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+    check(lib().needle_hip_scan_last_launch(C.byref(form), C.byref(products)))
+    return int(form.value), int(products.value)
 
 
 def host_threads() -> int:

@@ -440,6 +440,12 @@ enum NeedleError needle_hip_scan_counts(uint64_t counts[2], bool reset) {
   });
 }
 
+enum NeedleError needle_hip_scan_last_launch(int32_t *form, uint64_t *matrix_products) {
+  if (!form || !matrix_products) return NeedleError_NullArgument;
+  gpu_scan_last_launch(form, matrix_products);
+  return NeedleError_Ok;
+}
+
 enum NeedleError needle_hip_int_valu_ceiling(double *cells_per_second) {
   if (!cells_per_second) return NeedleError_NullArgument;
   return guarded([&]() -> NeedleError {

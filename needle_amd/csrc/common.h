@@ -176,6 +176,7 @@ constexpr uint64_t kDeviceEpiloguePairs = 1u << 14;
 // Diagnostic (search.hip): cells/s of the band scan's 4-instruction cell on registers only, measured on this device.
 Status gpu_int_valu_ceiling(double *cells_per_second);
 Status gpu_scan_issued_evaluations(uint64_t *lane_evaluations, bool reset, uint64_t *head_survivors = nullptr);
+void gpu_scan_last_launch(int32_t *form, uint64_t *matrix_products);  // needle_hip_scan_last_launch
 // certified f32 first pass of the fingerprinter: {items, items recomputed in f64, chunks of frame pairs, chunks recomputed}
 Status gpu_fingerprint_cert_stats(uint64_t out[4], bool reset);
 // audit of that first pass: both transforms over the same PCM, every kept item compared on the device (fingerprint.hip)

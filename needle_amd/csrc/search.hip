@@ -14,6 +14,7 @@
 #include "hipctx.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -533,7 +534,7 @@ typedef int mfma_v4i __attribute__((ext_vector_type(4)));
 typedef int mfma_v16i __attribute__((ext_vector_type(16)));
 
 template <int W>
-__global__ __launch_bounds__(256, 4) void hamming_runs_mfma_kernel(const uint32_t *__restrict__ hashes,
+__global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_t *__restrict__ hashes,
                                                                    const SearchProblem *__restrict__ problems,
                                                                    int num_problems, uint32_t threshold,
                                                                    NeedleHipRun *__restrict__ runs, uint32_t capacity,
@@ -830,6 +831,7 @@ struct SearchPlan {
   uint64_t blocks = 0;
   size_t lds_bytes = 0;
   bool sampled = false, fast = false, mfma = false;
+  uint64_t mfma_products = 0;                 // v_mfma instructions a launch of the matrix-pipe form issues
   int bands_per_wave = 1;
   bool valid = false;
   bool matches(const NeedleHipSeq *s, size_t ns, const NeedleHipProblem *p, size_t np, const int *m) const {
@@ -879,7 +881,19 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     // video must not fail the search of the whole library (the reference has no bound).
     size_t lds_limit = 160 * 1024;
     if (const char *e = getenv("NEEDLE_HIP_SEARCH_LDS_LIMIT")) lds_limit = (size_t)std::max(1, atoi(e));  // tests
-    const bool mfma = sampled && mode[4] != 0;
+    // The matrix-pipe form of the sampled scan pays on large launches whose windows fill their row tiles of 32: measured
+    // 1.14 / 1.19 / 1.22 x the vector form at 19 900 / 79 800 / 499 500 pairs of 45-minute windows (73 windows in 96 rows),
+    // 0.9 x at 39 060 pairs of 24-minute ones (39 in 64) and at the 378 pairs of the headline job.
+    bool mfma = sampled && mode[4] == 1;
+    if (sampled && mode[4] == 2 && meta.size() >= (size_t)kDeviceEpiloguePairs) {
+      uint64_t windows = 0, rows = 0;
+      for (const SearchProblem &m : meta) {
+        const uint64_t w = (uint64_t)mfma_windows((int)m.n, (int)m.min_len, kSampleW);
+        windows += w;
+        rows += (w + 31) / 32 * 32;
+      }
+      mfma = rows > 0 && 10 * windows >= 7 * rows;
+    }
     auto lds_need = [&](const SearchProblem &m) {
       return ((fast || sampled) ? (size_t)m.m + 2 * kBandB + (mfma ? mfma_extra_words((int)m.n, (int)m.min_len, kSampleW) : 0) : (size_t)m.n + m.m) *
              sizeof(uint32_t);
@@ -926,6 +940,13 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     plan->oversize_blocks = ob;
     plan->sampled = sampled;
     plan->mfma = mfma;
+    plan->mfma_products = 0;
+    if (mfma)
+      for (size_t i = 0; i < staged; i++) {
+        const SearchProblem &m = meta[i];
+        const uint64_t w = (uint64_t)mfma_windows((int)m.n, (int)m.min_len, kSampleW);
+        if (w > 0 && m.m >= (uint32_t)kSampleW + 1) plan->mfma_products += (w + 31) / 32 * (((uint64_t)m.m - kSampleW) / 32 + 1) * kMfmaHeads;
+      }
     plan->fast = fast;
     plan->bands_per_wave = bands_per_wave;
     plan->lds_bytes = lds_bytes;
@@ -937,6 +958,18 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
   plan->valid = true;
   return Status::Ok();
 }
+
+// NEEDLE_HIP_SCAN_MFMA: 1 = the matrix-pipe form of the sampled scan wherever it applies, 0 = never, unset = where it pays
+// (build_plan).  It applies to thresholds <= 15 and the default window shape.  -> mode[4]: 0 off, 1 forced, 2 automatic
+int mfma_request(uint32_t threshold) {
+  if (threshold > 15u || scan_shape().w != kSampleW) return 0;
+  const char *e = getenv("NEEDLE_HIP_SCAN_MFMA");
+  if (!e) return 2;
+  return atoi(e) != 0 ? 1 : 0;
+}
+
+std::atomic<int32_t> g_last_form{0};
+std::atomic<uint64_t> g_last_products{0};
 
 struct SearchWorkspace {
   DeviceBuffer<SearchProblem> problems;
@@ -963,6 +996,11 @@ SearchWorkspace *workspace() {
 
 }  // namespace
 
+void gpu_scan_last_launch(int32_t *form, uint64_t *matrix_products) {
+  *form = g_last_form.load();
+  *matrix_products = g_last_products.load();
+}
+
 Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
                                const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
                                NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync, bool count_is_zero) {
@@ -974,7 +1012,7 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
   const int mode[5] = {getenv("NEEDLE_HIP_GENERIC_SEARCH") != nullptr, getenv("NEEDLE_HIP_BAND_SEARCH") != nullptr,
                        getenv("NEEDLE_HIP_BANDS_PER_WAVE") ? std::max(1, atoi(getenv("NEEDLE_HIP_BANDS_PER_WAVE"))) : 0,
                        threshold > 31u,   // every cell matches at 32: the band / generic kernels take such a launch
-                       getenv("NEEDLE_HIP_SCAN_MFMA") != nullptr && threshold <= 15u && scan_shape().w == kSampleW};
+                       mfma_request(threshold)};
   SearchWorkspace *ws = workspace();
   SearchPlan &plan = ws->plan;
   const bool reuse = plan.matches(seqs, num_seqs, problems, num_problems, mode);
@@ -1007,6 +1045,8 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
       ws->lds_attr_set = true;
     }
     const int staged = (int)plan.staged, oversize = (int)(meta.size() - plan.staged);
+    g_last_form.store(staged > 0 ? (sampled ? (plan.mfma ? 4 : 3) : fast ? 2 : 1) : 1);
+    g_last_products.store(staged > 0 && plan.mfma ? plan.mfma_products : 0);
     if (staged > 0) {
       KernelTimer timer("hamming_runs");
       if (sampled) {

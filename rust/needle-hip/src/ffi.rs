@@ -133,6 +133,9 @@ extern "C" {
     pub fn needle_hip_fingerprint_cert_stats(counts: *mut u64, reset: bool) -> NeedleError;
     /// Cell evaluations issued by the counting instantiation of the scan (NEEDLE_HIP_SCAN_COUNT=1).
     pub fn needle_hip_scan_issued_evaluations(lane_evaluations: *mut u64, reset: bool) -> NeedleError;
+    /// Form of this process's last scan launch (3: aligned windows on the vector ALU, 4: head rows on the matrix pipe)
+    /// and, for form 4, the matrix instructions it issued.
+    pub fn needle_hip_scan_last_launch(form: *mut i32, matrix_products: *mut u64) -> NeedleError;
     /// The library's `hipStream_t` on the current device (NULL without one).
     pub fn needle_hip_stream() -> *mut c_void;
     pub fn needle_hip_analyzer_run_pcm(
