@@ -699,28 +699,20 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
         fb[kb][q] = (int)__builtin_amdgcn_perm(0u, 0x000001FFu, sel);
       }
     }
-    // ONE tile body (the loop over row tiles is not unrolled: the survivors' path below holds the whole resolution code);
-    // the A fragments of the next row tile are read while this one is multiplied
-    mfma_v4i fa[H];
-    load_a(0, fa);
-#pragma unroll 1
-    for (int rt = 0; rt < row_tiles; rt++) {
-      mfma_v4i fn[H];
-      load_a(min(rt + 1, row_tiles - 1), fn);
-      // a product per head row (K = 32 each), each preset to -(32 - 2 t): its sign bit is clear exactly where that row's
-      // cell matches; a window-diagonal survives iff the OR of the H results is non-negative
+    // a tile: a product per head row (K = 32 each), each preset to -(32 - 2 t) -- its sign bit is clear exactly where that
+    // row's cell matches; a window-diagonal survives iff the OR of the H results is non-negative
+    auto tile = [&](const mfma_v4i (&fa)[H], const int rt) {
+      asm volatile("" : "+v"(presets));          // stays in its 16 registers (otherwise re-built from scalars for every tile)
       mfma_v16i u = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0], fb[0], presets, 0, 0, 0);
 #pragma unroll
       for (int kb = 1; kb < H; kb++) u |= __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[kb], fb[kb], presets, 0, 0, 0);
-#pragma unroll
-      for (int kb = 0; kb < H; kb++) fa[kb] = fn[kb];
       // survivors are rare (~0.05 % of the results): the registers are ANDed in four groups of four (a group's AND is
       // non-negative iff one of its registers is), the groups into one word, and only a group that holds one is looked at
       int grp[4];
 #pragma unroll
       for (int g = 0; g < 4; g++) grp[g] = (u[4 * g] & u[4 * g + 1]) & (u[4 * g + 2] & u[4 * g + 3]);
       const int all = (grp[0] & grp[1]) & (grp[2] & grp[3]);
-      if (__ballot(all >= 0 && col_ok) == 0ull) continue;  // (wave-uniform) no survivor in this tile: the usual case
+      if (__ballot(all >= 0 && col_ok) == 0ull) return;  // (wave-uniform) no survivor in this tile: the usual case
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         if (__ballot(grp[g] >= 0 && col_ok) == 0ull) continue;  // wave-uniform
@@ -742,7 +734,19 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
           qn -= 64;
         }
       }
+    };
+    // two row tiles per turn, their A fragments in two register sets: one is read from the image while the other is multiplied
+    mfma_v4i fa0[H], fa1[H];
+    load_a(0, fa0);
+    int rt = 0;
+#pragma unroll 1
+    for (; rt + 1 < row_tiles; rt += 2) {
+      load_a(rt + 1, fa1);
+      tile(fa0, rt);
+      load_a(min(rt + 2, row_tiles - 1), fa0);
+      tile(fa1, rt + 1);
     }
+    if (rt < row_tiles) tile(fa0, rt);
   }
   if (qn > 0) verify(0, qn);
 }
