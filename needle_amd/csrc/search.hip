@@ -596,6 +596,13 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
   uint32_t *queue = table + 512 + wave * kMfmaQueue;
+  uint32_t *ntab = table + 16 * wave;           // (the byte table has served the A image: its first words are reused)
+  if (lane < 16) {
+    uint32_t w = 0;
+    for (int i = 0; i < 4; i++) w |= (((lane >> i) & 1) ? 0x01u : 0xFFu) << (8 * i);
+    ntab[lane] = w;
+  }
+  wave_lds_fence_search();
   const int last_j = m - W;                                     // valid destination positions: 1 .. m - W
   if (nW <= 0 || last_j < 1) return;
   const int r = lane & 31, h = lane >> 5;
@@ -686,18 +693,16 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
   for (int cb = first_cb; cb < col_blocks; cb += stride_cb) {
     const int j = 32 * cb + r;                   // this lane's column = destination position
     const bool col_ok = j >= 1 && j <= last_j;
-    // lane (r, h): half h of dst[j + s] for the H head rows s, as +-1 bytes.  On the vector ALU (four bits -> four
-    // selector bytes of 0 / 1 -> v_perm_b32 picks 0xFF / 0x01): random 8-byte reads of the byte table cost three LDS
-    // cycles in four to bank conflicts (SQ_LDS_BANK_CONFLICT, tools/scan_mfma_counters.sh)
+    // lane (r, h): half h of dst[j + s] for the H head rows s, as +-1 bytes, four bits at a time through a table of 16
+    // words (16 banks: lanes that ask for different entries never collide, equal ones are one broadcast; the 256-entry
+    // byte table's 8-byte reads lost three LDS cycles in four to bank conflicts -- tools/scan_mfma_counters.sh -- and the
+    // same expansion on the vector ALU, v_perm_b32 on spread selector bits, costs four instructions a word instead of two)
     mfma_v4i fb[H];
 #pragma unroll
     for (int kb = 0; kb < H; kb++) {
       const uint32_t half = ldst[B + j + head_row(kb, W, H)] >> (16 * h);
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const uint32_t sel = (((half >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u;
-        fb[kb][q] = (int)__builtin_amdgcn_perm(0u, 0x000001FFu, sel);
-      }
+      for (int q = 0; q < 4; q++) fb[kb][q] = (int)ntab[(half >> (4 * q)) & 0xFu];
     }
     // a tile: a product per head row (K = 32 each), each preset to -(32 - 2 t) -- its sign bit is clear exactly where that
     // row's cell matches; a window-diagonal survives iff the OR of the H results is non-negative
