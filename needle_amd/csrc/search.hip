@@ -624,7 +624,29 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
     int e = w0 + W;
     bool ended = false;
     const int fwd_limit = min(ihi, w0 + P + W - 1);
-    while (e <= fwd_limit) {
+    // The first 64 rows of BOTH directions are read together: most candidates are chance matches of one window on
+    // self-similar audio and end within them, and two dependent trips to the source sequence (global memory) per candidate
+    // were a third of a wave's time.  `a_first`: first row of the run if the backward scan ends inside these rows.
+    int a_first = -1;
+    bool back_open = false;                      // the 64 rows in front of the window all match: the scan goes on below
+    {
+      const int frow = e + lane, brow = w0 - 1 - lane;
+      const bool f_in = frow <= fwd_limit, b_in = brow >= ilo;
+      const uint32_t fs = f_in ? src[frow] : 0u, bs = b_in ? src[brow] : 0u;
+      const bool bad_f = f_in && (uint32_t)__popc(fs ^ ldst[B + frow + d]) > threshold;
+      const bool bad_b = b_in && (uint32_t)__popc(bs ^ ldst[B + brow + d]) > threshold;
+      const unsigned long long mf = __ballot(bad_f), mb = __ballot(bad_b);
+      if (mf) {
+        e += __ffsll((long long)mf) - 1;
+        ended = true;
+      } else {
+        e += 64;
+      }
+      if (mb) a_first = (w0 - 1) - (__ffsll((long long)mb) - 1) + 1;
+      else back_open = w0 - 1 - 63 > ilo;        // rows below w0 - 64 are still to be looked at
+      if (!mb && !back_open) a_first = ilo;      // the run reaches the first row of the diagonal
+    }
+    while (!ended && e <= fwd_limit) {
       const int row = e + lane;
       const bool bad = row <= fwd_limit && (uint32_t)__popc(src[row] ^ ldst[B + row + d]) > threshold;
       const unsigned long long mm = __ballot(bad);
@@ -640,8 +662,8 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
       e = ihi + 1;
     }
     const int b = e - 1;
-    int a = ilo;
-    int q = w0 - 1;
+    int a = a_first >= 0 ? a_first : ilo;
+    int q = back_open ? w0 - 1 - 64 : ilo - 1;   // (nothing left to scan unless the first block was all matches)
     while (q >= ilo) {
       const int row = q - lane;
       const bool bad = row >= ilo && (uint32_t)__popc(src[row] ^ ldst[B + row + d]) > threshold;
