@@ -124,6 +124,9 @@ def test_config4_full_size_on_one_gpu():
     lib.job_begin(cmp, 1)
     results2, found2 = lib.job_end(cmp, 1)
     assert found == found2 and found >= n * (n - 1) // 2
+    if "NEEDLE_HIP_SCAN_MFMA" not in os.environ:                 # a launch of this size takes the scan's matrix-pipe form by itself
+        form, products = capi.scan_last_launch()
+        assert form == 4 and products > 0
     got_all = [None if r is None else (r.opening, r.ending) for r in results]
     assert got_all == [None if r is None else (r.opening, r.ending) for r in results2]
     assert sum(1 for r in results if r is not None and r.opening is not None) == n      # detected: 2000

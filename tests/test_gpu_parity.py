@@ -175,6 +175,9 @@ def test_fast_kernels_equal_reference_dp(n, m, min_len, search_mode):
     assert got == want
     if n > 400 and m > 400:
         assert len(want) >= 2
+    if min(n, m) >= 2:                                           # which kernel really ran (needle_hip_scan_last_launch)
+        form = capi.scan_last_launch()[0]
+        assert form == {"sampled-mfma": 4, "band": 2, "generic": 1}.get(search_mode, 3), (form, search_mode, n, m, min_len)
 
 
 def test_fast_kernels_all_cells_match_and_many_problems(search_mode):
