@@ -664,6 +664,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     device_state = telemetry.stop() if telemetry else None
+    scan_form, scan_products = capi.scan_last_launch()           # of the timed jobs (a counting launch below is the vector form's)
     extra_steps = min(args.steps, 10)
     timed[0], acc[0] = list(kernel_names), extra_ms
     capi.set_kernel_timing("all")
@@ -792,7 +793,7 @@ def main() -> None:
             try:
                 out["roofline_search"] = search_roofline(capi.int_valu_ceiling(), issued_evals, float(pcount) * kept[0] * kept[0],
                                                          avg["hamming_runs"])
-                form, products = capi.scan_last_launch()
+                form, products = scan_form, scan_products
                 if form == 4:                                    # the job's scan took the matrix-pipe form (large launches)
                     sec = avg["hamming_runs"] * 1e-3
                     tops = products * 65536.0 / sec / 1e12 if sec > 0 else 0.0

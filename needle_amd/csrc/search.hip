@@ -520,15 +520,21 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
 // tools/mfma_i8_layout.hip (profiles/r04_mfma_i8_layout.log).  Needs 32 - 2 t > 0 (t <= 15).
 constexpr int kMfmaHeads = 4;
 constexpr int kMfmaQueue = 64 + 4 * 64;           // survivors per wave waiting for the test of their remaining rows
-constexpr int kMfmaFixedWords = 512 + 4 * kMfmaQueue;  // behind the staged destination: byte table (256 x 2 words), 4 queues
-// ... and behind those the A image: every aligned window's H head hashes as 32 bytes of +-1 each, rows padded to 32 windows;
+constexpr int kMfmaFixedWords = 4 * kMfmaQueue + 4 * 16;  // behind the staged destination: 4 queues + 4 tables of 16 words; the byte table
+                                                       // (256 x 2 words) that builds the A image lies over the queues, which are not in use yet
+static_assert(kMfmaFixedWords >= 512, "the byte table has to fit");
+// ... and behind those the A image: every aligned window's H head hashes as 32 bytes of +-1 each, then ONE row of zeros for
+// the rows of the last tile that lie beyond the last window (product 0: negative);
 // a window's row is 4 words longer than its 8 H (36 words: lanes 32 words apart would all meet in two groups of LDS banks)
 constexpr int kMfmaPitch = kMfmaHeads * 8 + 4;
 __host__ __device__ constexpr int mfma_windows(int n, int min_len, int W) {
   return (n - 1 - W) >= 0 && min_len - W + 1 > 0 ? (n - 1 - W) / (min_len - W + 1) + 1 : 0;  // w0 = 1 + k P, w0 + W - 1 <= n - 1
 }
+__host__ __device__ constexpr size_t mfma_extra_words_for(uint64_t windows) {  // windows of ALL the sources a workgroup takes
+  return (size_t)kMfmaFixedWords + 4 /* alignment */ + (size_t)(windows + 1) * kMfmaPitch;  // + one row of zeros
+}
 __host__ __device__ constexpr size_t mfma_extra_words(int n, int min_len, int W) {
-  return (size_t)kMfmaFixedWords + 4 /* alignment */ + (size_t)((mfma_windows(n, min_len, W) + 31) / 32 * 32) * kMfmaPitch;
+  return mfma_extra_words_for((uint64_t)mfma_windows(n, min_len, W));
 }
 typedef int mfma_v4i __attribute__((ext_vector_type(4)));
 typedef int mfma_v16i __attribute__((ext_vector_type(16)));
@@ -548,13 +554,21 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
     int mid = (lo + hi + 1) >> 1;
     if (problems[mid].block_base <= blockIdx.x) lo = mid; else hi = mid - 1;
   }
+  // A workgroup takes ONE destination sequence and up to two sources (SearchProblem::pad: 1 = the next entry of the table
+  // has the same destination and minimum length and belongs to this workgroup, build_plan): their windows share the row
+  // tiles -- 73 + 73 windows fill 4.6 of 5 tiles instead of 2.3 of 3 each --, the destination's staging and expansion.
   const SearchProblem pr = problems[lo];
+  const bool two = pr.pad == 1u;
+  const SearchProblem pr2 = problems[two ? lo + 1 : lo];
   const int n = (int)pr.n, m = (int)pr.m;
+  const int n2 = two ? (int)pr2.n : 0;
   const uint32_t *__restrict__ src = hashes + pr.src_off;
+  const uint32_t *__restrict__ src2 = hashes + pr2.src_off;
   const uint32_t *__restrict__ dst = hashes + pr.dst_off;
   const int min_len = (int)pr.min_len;
   const int P = min_len - W + 1;
-  const int nW = mfma_windows(n, min_len, W);
+  const int nW1 = mfma_windows(n, min_len, W);
+  const int nW = nW1 + (two ? mfma_windows(n2, min_len, W) : 0);   // rows of the tiles: windows of both sources
   const int row_tiles = (nW + 31) / 32;
   uint32_t *ldst = lds;                                   // ldst[B + j] = dst[j], B zero slots on both sides
   uint32_t *table = lds + (2 * B + m);                    // table[2 b], table[2 b + 1]: the 8 bytes of +-1 for byte value b
@@ -575,11 +589,11 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
     table[2 * b + 1] = w1;
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < row_tiles * 32 * H; idx += blockDim.x) {  // rows beyond the last window: zeros (product 0)
+  for (int idx = threadIdx.x; idx < (nW + 1) * H; idx += blockDim.x) {  // row nW: zeros
     const int k = idx / H, kb = idx % H;
     uint32_t *o = aimg + k * kMfmaPitch + 8 * kb;
     if (k < nW) {
-      const uint32_t hsh = src[1 + k * P + head_row(kb, W, H)];
+      const uint32_t hsh = k < nW1 ? src[1 + k * P + head_row(kb, W, H)] : src2[1 + (k - nW1) * P + head_row(kb, W, H)];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const uint32_t byte = (hsh >> (8 * q)) & 0xFFu;
@@ -595,8 +609,8 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
 
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
-  uint32_t *queue = table + 512 + wave * kMfmaQueue;
-  uint32_t *ntab = table + 16 * wave;           // (the byte table has served the A image: its first words are reused)
+  uint32_t *queue = table + wave * kMfmaQueue;  // (the byte table has served the A image: the queues take its place)
+  uint32_t *ntab = table + 4 * kMfmaQueue + 16 * wave;
   if (lane < 16) {
     uint32_t w = 0;
     for (int i = 0; i < 4; i++) w |= (((lane >> i) & 1) ? 0x01u : 0xFFu) << (8 * i);
@@ -617,9 +631,11 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
   const int first_cb = b_in_pair * 4 + wave, stride_cb = nb * 4;
 
   // exact resolution of one window whose W cells all match on diagonal d, by the whole wave (the vector form's resolve())
-  auto resolve = [&](const int w0, const int d) {
+  auto resolve = [&](const int w0, const int d, const bool second) {  // (`second`: wave-uniform)
+    const uint32_t *__restrict__ sp = second ? src2 : src;
+    const int ns = second ? n2 : n;
     const int ilo = d < 0 ? 1 - d : 1;
-    const int ihi = min(n - 1, m - 1 - d);
+    const int ihi = min(ns - 1, m - 1 - d);
     if (w0 < ilo || w0 + W - 1 > ihi) return;
     int e = w0 + W;
     bool ended = false;
@@ -632,7 +648,7 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
     {
       const int frow = e + lane, brow = w0 - 1 - lane;
       const bool f_in = frow <= fwd_limit, b_in = brow >= ilo;
-      const uint32_t fs = f_in ? src[frow] : 0u, bs = b_in ? src[brow] : 0u;
+      const uint32_t fs = f_in ? sp[frow] : 0u, bs = b_in ? sp[brow] : 0u;
       const bool bad_f = f_in && (uint32_t)__popc(fs ^ ldst[B + frow + d]) > threshold;
       const bool bad_b = b_in && (uint32_t)__popc(bs ^ ldst[B + brow + d]) > threshold;
       const unsigned long long mf = __ballot(bad_f), mb = __ballot(bad_b);
@@ -648,7 +664,7 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
     }
     while (!ended && e <= fwd_limit) {
       const int row = e + lane;
-      const bool bad = row <= fwd_limit && (uint32_t)__popc(src[row] ^ ldst[B + row + d]) > threshold;
+      const bool bad = row <= fwd_limit && (uint32_t)__popc(sp[row] ^ ldst[B + row + d]) > threshold;
       const unsigned long long mm = __ballot(bad);
       if (mm) {
         e += __ffsll((long long)mm) - 1;
@@ -666,7 +682,7 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
     int q = back_open ? w0 - 1 - 64 : ilo - 1;   // (nothing left to scan unless the first block was all matches)
     while (q >= ilo) {
       const int row = q - lane;
-      const bool bad = row >= ilo && (uint32_t)__popc(src[row] ^ ldst[B + row + d]) > threshold;
+      const bool bad = row >= ilo && (uint32_t)__popc(sp[row] ^ ldst[B + row + d]) > threshold;
       const unsigned long long mm = __ballot(bad);
       if (mm) {
         a = q - (__ffsll((long long)mm) - 1) + 1;
@@ -677,29 +693,34 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
     const int len = b - a + 1;
     if (len >= min_len && lane == 0) {
       const uint32_t slot = atomicAdd(count, 1u);
-      if (slot < capacity) runs[slot] = NeedleHipRun{(uint32_t)lo, (uint32_t)b, (uint32_t)(b + d), (uint32_t)len, 0u, 0u};
+      if (slot < capacity)
+        runs[slot] = NeedleHipRun{(uint32_t)(second ? lo + 1 : lo), (uint32_t)b, (uint32_t)(b + d), (uint32_t)len, 0u, 0u};
     }
   };
   // the test of every row of up to 64 queued survivors, one per lane, then the resolution of those that match whole
   auto verify = [&](const int first, const int cnt) {
     wave_lds_fence_search();
     bool whole = false;
-    int w0 = 0, d = 0;
+    int w0 = 0, d = 0, second = 0;
     if (lane < cnt) {
       const uint32_t e = queue[first + lane];
-      const int k = (int)(e >> 16), j = (int)(e & 0xFFFFu);
+      int k = (int)(e >> 16);
+      const int j = (int)(e & 0xFFFFu);
+      second = k >= nW1 ? 1 : 0;
+      k -= second ? nW1 : 0;
+      const uint32_t *__restrict__ sp = second ? src2 : src;
       w0 = 1 + k * P;
       d = j - w0;
       uint32_t miss = 0u;
 #pragma unroll
-      for (int s = 0; s < W; s++) miss |= (uint32_t)((uint32_t)__popc(src[w0 + s] ^ ldst[B + j + s]) > threshold);
+      for (int s = 0; s < W; s++) miss |= (uint32_t)((uint32_t)__popc(sp[w0 + s] ^ ldst[B + j + s]) > threshold);
       whole = miss == 0u;
     }
     unsigned long long cand = __ballot(whole);
     while (cand) {
       const int src_lane = __ffsll((long long)cand) - 1;
       cand &= cand - 1;
-      resolve(__shfl(w0, src_lane), __shfl(d, src_lane));
+      resolve(__shfl(w0, src_lane), __shfl(d, src_lane), __shfl(second, src_lane) != 0);
     }
   };
 
@@ -708,7 +729,7 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
   for (int q = 0; q < 16; q++) presets[q] = preset;
   int qn = 0;  // wave-uniform: survivors waiting in this wave's queue (< 64 at the start of a tile)
   auto load_a = [&](const int rt, mfma_v4i (&fa)[H]) {
-    const mfma_v4i *img = reinterpret_cast<const mfma_v4i *>(aimg + (size_t)(32 * rt + r) * kMfmaPitch + 4 * h);
+    const mfma_v4i *img = reinterpret_cast<const mfma_v4i *>(aimg + (size_t)min(32 * rt + r, nW) * kMfmaPitch + 4 * h);
 #pragma unroll
     for (int kb = 0; kb < H; kb++) fa[kb] = img[2 * kb];
   };
@@ -934,6 +955,33 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     while (staged < meta.size() && lds_need(meta[staged]) <= lds_limit) staged++;
     size_t lds_bytes = 0;
     int bands_per_wave = 1;
+    // Matrix-pipe form: the staged problems sorted by destination, and two neighbours that share destination and minimum
+    // length given to ONE workgroup (pad 1 = "the next entry is mine too", pad 2 = that entry: it owns no workgroups).
+    // The runs carry the index of their own entry either way, so the order of the table is free.
+    auto windows_of = [&](const SearchProblem &m) { return (uint64_t)mfma_windows((int)m.n, (int)m.min_len, kSampleW); };
+    auto group_need = [&](const SearchProblem &a, const SearchProblem &b) {
+      return ((size_t)a.m + 2 * kBandB + mfma_extra_words_for(windows_of(a) + windows_of(b))) * sizeof(uint32_t);
+    };
+    if (mfma) {
+      std::stable_sort(meta.begin(), meta.begin() + (ptrdiff_t)staged, [](const SearchProblem &a, const SearchProblem &b) {
+        if (a.dst_off != b.dst_off) return a.dst_off < b.dst_off;
+        if (a.m != b.m) return a.m < b.m;
+        return a.min_len < b.min_len;
+      });
+      for (size_t i = 0; i < staged; i++) {
+        SearchProblem &a = meta[i];
+        a.pad = 0;
+        if (i + 1 < staged) {
+          const SearchProblem &b = meta[i + 1];
+          if (a.dst_off == b.dst_off && a.m == b.m && a.min_len == b.min_len && windows_of(a) + windows_of(b) < 65536 &&
+              group_need(a, b) <= lds_limit && !getenv("NEEDLE_HIP_MFMA_SINGLE")) {
+            a.pad = 1;
+            meta[i + 1].pad = 2;
+            i++;
+          }
+        }
+      }
+    }
     if (fast || sampled) {
       uint64_t fb = 0, total_bands = 0;
       for (size_t i = 0; i < staged; i++) total_bands += ((uint64_t)meta[i].n + meta[i].m - 3 + kBandB - 1) / kBandB;
@@ -945,11 +993,12 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
       for (size_t i = 0; i < staged; i++) {
         SearchProblem &m = meta[i];
         m.block_base = (uint32_t)fb;
+        if (mfma && m.pad == 2) continue;        // its workgroups are its neighbour's (same base as the entry after it)
         const uint64_t diags = (uint64_t)m.n + m.m - 3;
         const uint64_t bands = (diags + kBandB - 1) / kBandB;
         const uint64_t per_block = 4 * (uint64_t)(sampled ? bands_per_wave : 1);
         fb += (bands + per_block - 1) / per_block;
-        lds_bytes = std::max(lds_bytes, lds_need(m));
+        lds_bytes = std::max(lds_bytes, mfma && m.pad == 1 ? group_need(m, meta[i + 1]) : lds_need(m));
       }
       blocks = fb;
     } else {
@@ -975,7 +1024,8 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     if (mfma)
       for (size_t i = 0; i < staged; i++) {
         const SearchProblem &m = meta[i];
-        const uint64_t w = (uint64_t)mfma_windows((int)m.n, (int)m.min_len, kSampleW);
+        if (m.pad == 2) continue;
+        const uint64_t w = windows_of(m) + (m.pad == 1 ? windows_of(meta[i + 1]) : 0);
         if (w > 0 && m.m >= (uint32_t)kSampleW + 1) plan->mfma_products += (w + 31) / 32 * (((uint64_t)m.m - kSampleW) / 32 + 1) * kMfmaHeads;
       }
     plan->fast = fast;
@@ -993,7 +1043,8 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
 // NEEDLE_HIP_SCAN_MFMA: 1 = the matrix-pipe form of the sampled scan wherever it applies, 0 = never, unset = where it pays
 // (build_plan).  It applies to thresholds <= 15 and the default window shape.  -> mode[4]: 0 off, 1 forced, 2 automatic
 int mfma_request(uint32_t threshold) {
-  if (threshold > 15u || scan_shape().w != kSampleW) return 0;
+  if (threshold > 15u || scan_shape().w != kSampleW || getenv("NEEDLE_HIP_SCAN_SHAPE") || getenv("NEEDLE_HIP_SCAN_COUNT")) return 0;
+  // (a counting launch and a launch of another window shape are the vector form's by definition)
   const char *e = getenv("NEEDLE_HIP_SCAN_MFMA");
   if (!e) return 2;
   return atoi(e) != 0 ? 1 : 0;
