@@ -324,6 +324,7 @@ def search_only(capi, synth, episodes, minutes, reps=5):
             scan.append(capi.last_kernel_ms("hamming_runs"))
             simh.append(capi.last_kernel_ms("simhash_runs"))
     capi.set_kernel_timing(None)
+    scan_form, scan_products = capi.scan_last_launch()           # of the timed calls (the counting launch is the vector form's)
     os.environ["NEEDLE_HIP_SCAN_COUNT"] = "1"                   # one more call through the counting scan (untimed)
     try:
         cmp.run(analyze=False, display=False)
@@ -348,6 +349,7 @@ def search_only(capi, synth, episodes, minutes, reps=5):
             "wall_ms": round(1e3 * wall, 3), "pairs_per_s": round(pairs / wall, 1),
             "scan_kernel_ms": round(sum(scan) / len(scan), 4), "simhash_kernel_ms": round(sum(simh) / len(simh), 4),
             "table_cells": float(pairs) * n_h * n_h, "prepare_s": round(prep_s, 2), "issued_evals": issued,
+            "scan_form": scan_form, "matrix_instructions": scan_products,
             "what": "needle_audio_comparator_run(analyze=false) over .needle.dat files in the page cache: read + parse, "
                     "H2D of hashes, scan, simhash, per-video epilogue on the device (from 16 384 sequence pairs up; the run "
                     "list stays in HBM), D2H of the results; wall clock per call"}
@@ -837,6 +839,11 @@ def main() -> None:
             if "ceiling_cells_per_s" in vec:
                 so["roofline"] = search_roofline(vec["ceiling_cells_per_s"], so.pop("issued_evals"),
                                                  so["table_cells"], so["scan_kernel_ms"])
+            if so.get("scan_form") == 4 and so["scan_kernel_ms"] > 0:  # the call's scan took the matrix-pipe form
+                tops = so["matrix_instructions"] * 65536.0 / (so["scan_kernel_ms"] * 1e-3) / 1e12
+                so["roofline"] = {"bound": "mfma", "kernel": "hamming_runs (aligned windows, head rows on the matrix pipe)",
+                                  "unit": "TOP/s", "achieved": round(tops, 1), "peak": I8_DENSE_PEAK_TOPS,
+                                  "frac": round(tops / I8_DENSE_PEAK_TOPS, 4), "vector_form": so.get("roofline")}
             out["search_only"] = so
         if world == 1 and not args.no_cpu_baseline:
             if eps is not None:

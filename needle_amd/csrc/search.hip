@@ -933,18 +933,32 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     // video must not fail the search of the whole library (the reference has no bound).
     size_t lds_limit = 160 * 1024;
     if (const char *e = getenv("NEEDLE_HIP_SEARCH_LDS_LIMIT")) lds_limit = (size_t)std::max(1, atoi(e));  // tests
-    // The matrix-pipe form of the sampled scan pays on large launches whose windows fill their row tiles of 32: measured
-    // 1.14 / 1.19 / 1.22 x the vector form at 19 900 / 79 800 / 499 500 pairs of 45-minute windows (73 windows in 96 rows),
-    // 0.9 x at 39 060 pairs of 24-minute ones (39 in 64) and at the 378 pairs of the headline job.
+    // The matrix-pipe form of the sampled scan pays on large launches whose windows fill their row tiles of 32 (two sources
+    // of one destination share a workgroup's tiles): measured against the vector form, scan kernel, 1.41 x at 39 060 pairs of
+    // 24-minute windows (2 x 39 windows in 3 tiles), 1.66 x at 499 500 pairs of 45-minute ones (2 x 73 in 5); 0.97 x on the
+    // headline's 378 pairs, where the scan hides beside the next job's first pass anyway.
+    auto windows_of = [&](const SearchProblem &m) { return (uint64_t)mfma_windows((int)m.n, (int)m.min_len, kSampleW); };
+    auto same_group = [](const SearchProblem &a, const SearchProblem &b) {
+      return a.dst_off == b.dst_off && a.m == b.m && a.min_len == b.min_len;
+    };
     bool mfma = sampled && mode[4] == 1;
-    if (sampled && mode[4] == 2 && meta.size() >= (size_t)kDeviceEpiloguePairs) {
-      uint64_t windows = 0, rows = 0;
-      for (const SearchProblem &m : meta) {
-        const uint64_t w = (uint64_t)mfma_windows((int)m.n, (int)m.min_len, kSampleW);
-        windows += w;
-        rows += (w + 31) / 32 * 32;
+    const bool candidate = sampled && (mode[4] == 1 || (mode[4] == 2 && meta.size() >= (size_t)kDeviceEpiloguePairs));
+    if (candidate) {  // the table sorted by destination (the runs carry the index of their own entry: its order is free)
+      std::stable_sort(meta.begin(), meta.end(), [](const SearchProblem &a, const SearchProblem &b) {
+        if (a.dst_off != b.dst_off) return a.dst_off < b.dst_off;
+        if (a.m != b.m) return a.m < b.m;
+        return a.min_len < b.min_len;
+      });
+      if (!mfma) {
+        uint64_t windows = 0, rows = 0;
+        for (size_t i = 0; i < meta.size(); i++) {
+          uint64_t w = windows_of(meta[i]);
+          if (i + 1 < meta.size() && same_group(meta[i], meta[i + 1])) w += windows_of(meta[++i]);
+          windows += w;
+          rows += (w + 31) / 32 * 32;
+        }
+        mfma = rows > 0 && 10 * windows >= 7 * rows;
       }
-      mfma = rows > 0 && 10 * windows >= 7 * rows;
     }
     auto lds_need = [&](const SearchProblem &m) {
       return ((fast || sampled) ? (size_t)m.m + 2 * kBandB + (mfma ? mfma_extra_words((int)m.n, (int)m.min_len, kSampleW) : 0) : (size_t)m.n + m.m) *
@@ -955,25 +969,18 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     while (staged < meta.size() && lds_need(meta[staged]) <= lds_limit) staged++;
     size_t lds_bytes = 0;
     int bands_per_wave = 1;
-    // Matrix-pipe form: the staged problems sorted by destination, and two neighbours that share destination and minimum
-    // length given to ONE workgroup (pad 1 = "the next entry is mine too", pad 2 = that entry: it owns no workgroups).
-    // The runs carry the index of their own entry either way, so the order of the table is free.
-    auto windows_of = [&](const SearchProblem &m) { return (uint64_t)mfma_windows((int)m.n, (int)m.min_len, kSampleW); };
+    // Matrix-pipe form: two neighbours of the (sorted) table that share destination and minimum length are given to ONE
+    // workgroup (pad 1 = "the next entry is mine too", pad 2 = that entry: it owns no workgroups).
     auto group_need = [&](const SearchProblem &a, const SearchProblem &b) {
       return ((size_t)a.m + 2 * kBandB + mfma_extra_words_for(windows_of(a) + windows_of(b))) * sizeof(uint32_t);
     };
     if (mfma) {
-      std::stable_sort(meta.begin(), meta.begin() + (ptrdiff_t)staged, [](const SearchProblem &a, const SearchProblem &b) {
-        if (a.dst_off != b.dst_off) return a.dst_off < b.dst_off;
-        if (a.m != b.m) return a.m < b.m;
-        return a.min_len < b.min_len;
-      });
       for (size_t i = 0; i < staged; i++) {
         SearchProblem &a = meta[i];
         a.pad = 0;
         if (i + 1 < staged) {
           const SearchProblem &b = meta[i + 1];
-          if (a.dst_off == b.dst_off && a.m == b.m && a.min_len == b.min_len && windows_of(a) + windows_of(b) < 65536 &&
+          if (same_group(a, b) && windows_of(a) + windows_of(b) < 65536 &&
               group_need(a, b) <= lds_limit && !getenv("NEEDLE_HIP_MFMA_SINGLE")) {
             a.pad = 1;
             meta[i + 1].pad = 2;
