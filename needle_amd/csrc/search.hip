@@ -519,6 +519,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
 // identical).  Rows and columns outside the table carry all-zero fragments (product 0: negative).  Operand maps:
 // tools/mfma_i8_layout.hip (profiles/r04_mfma_i8_layout.log).  Needs 32 - 2 t > 0 (t <= 15).
 constexpr int kMfmaHeads = 4;
+constexpr int kMfmaMembers = 4;                   // sources a workgroup takes at most (of one destination)
 constexpr int kMfmaQueue = 64 + 4 * 64;           // survivors per wave waiting for the test of their remaining rows
 constexpr int kMfmaFixedWords = 4 * kMfmaQueue + 4 * 16;  // behind the staged destination: 4 queues + 4 tables of 16 words; the byte table
                                                        // (256 x 2 words) that builds the A image lies over the queues, which are not in use yet
@@ -554,22 +555,32 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
     int mid = (lo + hi + 1) >> 1;
     if (problems[mid].block_base <= blockIdx.x) lo = mid; else hi = mid - 1;
   }
-  // A workgroup takes ONE destination sequence and up to two sources (SearchProblem::pad: 1 = the next entry of the table
-  // has the same destination and minimum length and belongs to this workgroup, build_plan): their windows share the row
-  // tiles -- 73 + 73 windows fill 4.6 of 5 tiles instead of 2.3 of 3 each --, the destination's staging and expansion.
+  // A workgroup takes ONE destination sequence and up to four sources (SearchProblem::pad of its first entry: how many of
+  // the following entries of the table -- same destination, same minimum length -- belong to it too, build_plan): their
+  // windows share the row tiles (73 + 73 windows fill 4.6 of 5 tiles instead of 2.3 of 3 each; 4 x 39 fill 4.9 of 5), the
+  // destination's staging and its expansion.  Members are told apart with selects, not indexed (no register arrays).
   const SearchProblem pr = problems[lo];
-  const bool two = pr.pad == 1u;
-  const SearchProblem pr2 = problems[two ? lo + 1 : lo];
-  const int n = (int)pr.n, m = (int)pr.m;
-  const int n2 = two ? (int)pr2.n : 0;
+  const int followers = min((int)(pr.pad & 0xFFu), kMfmaMembers - 1);
+  const SearchProblem pr1 = problems[followers > 0 ? lo + 1 : lo], pr2 = problems[followers > 1 ? lo + 2 : lo],
+                      pr3 = problems[followers > 2 ? lo + 3 : lo];
+  const int n = (int)pr.n, m = (int)pr.m;     // (n: the first member's -- it also fixes the workgroups of the group)
+  const int n1 = (int)pr1.n, n2 = (int)pr2.n, n3 = (int)pr3.n;
   const uint32_t *__restrict__ src = hashes + pr.src_off;
+  const uint32_t *__restrict__ src1 = hashes + pr1.src_off;
   const uint32_t *__restrict__ src2 = hashes + pr2.src_off;
+  const uint32_t *__restrict__ src3 = hashes + pr3.src_off;
   const uint32_t *__restrict__ dst = hashes + pr.dst_off;
   const int min_len = (int)pr.min_len;
   const int P = min_len - W + 1;
-  const int nW1 = mfma_windows(n, min_len, W);
-  const int nW = nW1 + (two ? mfma_windows(n2, min_len, W) : 0);   // rows of the tiles: windows of both sources
+  const int w1 = mfma_windows(n, min_len, W);                                   // first row of member 1, 2, 3 (= all rows when
+  const int w2 = w1 + (followers > 0 ? mfma_windows(n1, min_len, W) : 0);       // there is no such member)
+  const int w3 = w2 + (followers > 1 ? mfma_windows(n2, min_len, W) : 0);
+  const int nW = w3 + (followers > 2 ? mfma_windows(n3, min_len, W) : 0);       // rows of the tiles: windows of all members
   const int row_tiles = (nW + 31) / 32;
+  auto member_of = [&](const int row) { return (row >= w1 ? 1 : 0) + (row >= w2 ? 1 : 0) + (row >= w3 ? 1 : 0); };
+  auto first_row = [&](const int g) { return g == 0 ? 0 : g == 1 ? w1 : g == 2 ? w2 : w3; };
+  auto source_of = [&](const int g) { return g == 0 ? src : g == 1 ? src1 : g == 2 ? src2 : src3; };
+  auto length_of = [&](const int g) { return g == 0 ? n : g == 1 ? n1 : g == 2 ? n2 : n3; };
   uint32_t *ldst = lds;                                   // ldst[B + j] = dst[j], B zero slots on both sides
   uint32_t *table = lds + (2 * B + m);                    // table[2 b], table[2 b + 1]: the 8 bytes of +-1 for byte value b
   uint32_t *aimg = table + kMfmaFixedWords;               // 8 words per (window, head row), 16-byte aligned
@@ -593,7 +604,8 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
     const int k = idx / H, kb = idx % H;
     uint32_t *o = aimg + k * kMfmaPitch + 8 * kb;
     if (k < nW) {
-      const uint32_t hsh = k < nW1 ? src[1 + k * P + head_row(kb, W, H)] : src2[1 + (k - nW1) * P + head_row(kb, W, H)];
+      const int g = member_of(k);
+      const uint32_t hsh = source_of(g)[1 + (k - first_row(g)) * P + head_row(kb, W, H)];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const uint32_t byte = (hsh >> (8 * q)) & 0xFFu;
@@ -631,9 +643,9 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
   const int first_cb = b_in_pair * 4 + wave, stride_cb = nb * 4;
 
   // exact resolution of one window whose W cells all match on diagonal d, by the whole wave (the vector form's resolve())
-  auto resolve = [&](const int w0, const int d, const bool second) {  // (`second`: wave-uniform)
-    const uint32_t *__restrict__ sp = second ? src2 : src;
-    const int ns = second ? n2 : n;
+  auto resolve = [&](const int w0, const int d, const int g) {  // (g, the member: wave-uniform)
+    const uint32_t *__restrict__ sp = source_of(g);
+    const int ns = length_of(g);
     const int ilo = d < 0 ? 1 - d : 1;
     const int ihi = min(ns - 1, m - 1 - d);
     if (w0 < ilo || w0 + W - 1 > ihi) return;
@@ -694,21 +706,21 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
     if (len >= min_len && lane == 0) {
       const uint32_t slot = atomicAdd(count, 1u);
       if (slot < capacity)
-        runs[slot] = NeedleHipRun{(uint32_t)(second ? lo + 1 : lo), (uint32_t)b, (uint32_t)(b + d), (uint32_t)len, 0u, 0u};
+        runs[slot] = NeedleHipRun{(uint32_t)(lo + g), (uint32_t)b, (uint32_t)(b + d), (uint32_t)len, 0u, 0u};
     }
   };
   // the test of every row of up to 64 queued survivors, one per lane, then the resolution of those that match whole
   auto verify = [&](const int first, const int cnt) {
     wave_lds_fence_search();
     bool whole = false;
-    int w0 = 0, d = 0, second = 0;
+    int w0 = 0, d = 0, g = 0;
     if (lane < cnt) {
       const uint32_t e = queue[first + lane];
       int k = (int)(e >> 16);
       const int j = (int)(e & 0xFFFFu);
-      second = k >= nW1 ? 1 : 0;
-      k -= second ? nW1 : 0;
-      const uint32_t *__restrict__ sp = second ? src2 : src;
+      g = member_of(k);
+      k -= first_row(g);
+      const uint32_t *__restrict__ sp = source_of(g);
       w0 = 1 + k * P;
       d = j - w0;
       uint32_t miss = 0u;
@@ -720,7 +732,7 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
     while (cand) {
       const int src_lane = __ffsll((long long)cand) - 1;
       cand &= cand - 1;
-      resolve(__shfl(w0, src_lane), __shfl(d, src_lane), __shfl(second, src_lane) != 0);
+      resolve(__shfl(w0, src_lane), __shfl(d, src_lane), __builtin_amdgcn_readfirstlane(__shfl(g, src_lane)));
     }
   };
 
@@ -953,7 +965,9 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
         uint64_t windows = 0, rows = 0;
         for (size_t i = 0; i < meta.size(); i++) {
           uint64_t w = windows_of(meta[i]);
-          if (i + 1 < meta.size() && same_group(meta[i], meta[i + 1])) w += windows_of(meta[++i]);
+          for (int k = 1; k < kMfmaMembers && i + 1 < meta.size() && same_group(meta[i], meta[i + 1]) &&
+                          ((size_t)meta[i].m + 2 * kBandB + mfma_extra_words_for(w + windows_of(meta[i + 1]))) * sizeof(uint32_t) <= 53760; k++)
+            w += windows_of(meta[++i]);
           windows += w;
           rows += (w + 31) / 32 * 32;
         }
@@ -969,24 +983,29 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     while (staged < meta.size() && lds_need(meta[staged]) <= lds_limit) staged++;
     size_t lds_bytes = 0;
     int bands_per_wave = 1;
-    // Matrix-pipe form: two neighbours of the (sorted) table that share destination and minimum length are given to ONE
-    // workgroup (pad 1 = "the next entry is mine too", pad 2 = that entry: it owns no workgroups).
-    auto group_need = [&](const SearchProblem &a, const SearchProblem &b) {
-      return ((size_t)a.m + 2 * kBandB + mfma_extra_words_for(windows_of(a) + windows_of(b))) * sizeof(uint32_t);
+    // Matrix-pipe form: up to kMfmaMembers neighbours of the (sorted) table that share destination and minimum length are
+    // given to ONE workgroup while it still fits a CU three times (53 760 bytes: 42 LDS granules of 1280; a workgroup of
+    // 53 776 bytes ran two to a CU and a fifth slower).  pad of the first = how many followers; a follower (pad bit 31) owns
+    // no workgroups.
+    constexpr size_t kThreePerCu = 53760;
+    auto group_need = [&](const SearchProblem &a, uint64_t windows) {
+      return ((size_t)a.m + 2 * kBandB + mfma_extra_words_for(windows)) * sizeof(uint32_t);
     };
     if (mfma) {
-      for (size_t i = 0; i < staged; i++) {
+      const bool single = getenv("NEEDLE_HIP_MFMA_SINGLE") != nullptr;  // tests, measurements: one source per workgroup
+      for (size_t i = 0; i < staged;) {
         SearchProblem &a = meta[i];
         a.pad = 0;
-        if (i + 1 < staged) {
-          const SearchProblem &b = meta[i + 1];
-          if (same_group(a, b) && windows_of(a) + windows_of(b) < 65536 &&
-              group_need(a, b) <= lds_limit && !getenv("NEEDLE_HIP_MFMA_SINGLE")) {
-            a.pad = 1;
-            meta[i + 1].pad = 2;
-            i++;
-          }
+        uint64_t windows = windows_of(a);
+        size_t k = 1;
+        while (!single && k < (size_t)kMfmaMembers && i + k < staged && same_group(a, meta[i + k]) &&
+               windows + windows_of(meta[i + k]) < 65536 && group_need(a, windows + windows_of(meta[i + k])) <= kThreePerCu) {
+          windows += windows_of(meta[i + k]);
+          meta[i + k].pad = 0x80000000u;
+          k++;
         }
+        a.pad = (uint32_t)(k - 1);
+        i += k;
       }
     }
     if (fast || sampled) {
@@ -1000,12 +1019,18 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
       for (size_t i = 0; i < staged; i++) {
         SearchProblem &m = meta[i];
         m.block_base = (uint32_t)fb;
-        if (mfma && m.pad == 2) continue;        // its workgroups are its neighbour's (same base as the entry after it)
+        if (mfma && (m.pad & 0x80000000u)) continue;  // its workgroups are its group's (same base as the entry after it)
         const uint64_t diags = (uint64_t)m.n + m.m - 3;
         const uint64_t bands = (diags + kBandB - 1) / kBandB;
         const uint64_t per_block = 4 * (uint64_t)(sampled ? bands_per_wave : 1);
         fb += (bands + per_block - 1) / per_block;
-        lds_bytes = std::max(lds_bytes, mfma && m.pad == 1 ? group_need(m, meta[i + 1]) : lds_need(m));
+        if (mfma) {
+          uint64_t windows = windows_of(m);
+          for (uint32_t f = 1; f <= m.pad; f++) windows += windows_of(meta[i + f]);
+          lds_bytes = std::max(lds_bytes, group_need(m, windows));
+        } else {
+          lds_bytes = std::max(lds_bytes, lds_need(m));
+        }
       }
       blocks = fb;
     } else {
@@ -1031,8 +1056,9 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     if (mfma)
       for (size_t i = 0; i < staged; i++) {
         const SearchProblem &m = meta[i];
-        if (m.pad == 2) continue;
-        const uint64_t w = windows_of(m) + (m.pad == 1 ? windows_of(meta[i + 1]) : 0);
+        if (m.pad & 0x80000000u) continue;
+        uint64_t w = windows_of(m);
+        for (uint32_t f = 1; f <= m.pad; f++) w += windows_of(meta[i + f]);
         if (w > 0 && m.m >= (uint32_t)kSampleW + 1) plan->mfma_products += (w + 31) / 32 * (((uint64_t)m.m - kSampleW) / 32 + 1) * kMfmaHeads;
       }
     plan->fast = fast;
