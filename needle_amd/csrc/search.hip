@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
   }
 }
 
-// ---- sampled path on the matrix pipe (opt-in: NEEDLE_HIP_SCAN_MFMA=1) ----------------------------------------------
+// ---- sampled path on the matrix pipe (large launches by themselves, build_plan; NEEDLE_HIP_SCAN_MFMA=0 / 1 forces) ------
 // The same aligned windows, the same head test and the same candidates as hamming_runs_sampled_kernel, computed
 // differently: the Hamming distances of a window's head rows against every destination position are integer matrix
 // products.  A hash as 32 bytes of +-1 (bit set: +1): dot(a, b) = 32 - 2 d(a, b).  A tile is 32 windows x 32 destination
@@ -516,8 +516,9 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
 // survivor at all (it mostly does not: ~0.05 % of the window-diagonals pass on audio, tools/mfma_filter_model.py).
 // Survivors are queued in LDS and their remaining rows tested 64 windows at a time, one per lane; a window that matches
 // whole is resolved by the wave like in the vector form (same function of the same cells: the emitted runs are
-// identical).  Rows and columns outside the table carry all-zero fragments (product 0: negative).  Operand maps:
-// tools/mfma_i8_layout.hip (profiles/r04_mfma_i8_layout.log).  Needs 32 - 2 t > 0 (t <= 15).
+// identical).  Rows beyond the last window read a row of zeros (product 0: negative), columns outside the table are masked
+// when survivors are collected.  Operand maps: tools/mfma_i8_layout.hip (profiles/r04_mfma_i8_layout.log).  Needs
+// 32 - 2 t > 0 (t <= 15).  History and measurements: profiles/NOTES.md, "The scan's head rows on the matrix pipe".
 constexpr int kMfmaHeads = 4;
 constexpr int kMfmaMembers = 4;                   // sources a workgroup takes at most (of one destination)
 constexpr int kMfmaQueue = 64 + 4 * 64;           // survivors per wave waiting for the test of their remaining rows
