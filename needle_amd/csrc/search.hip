@@ -812,6 +812,8 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
   if (qn > 0) verify(0, qn);
 }
 
+#include "scan_mfma_kernel.h"
+
 // ---- simhash of every emitted run (comparator.rs:149-153,226-229) -----------------------------------------------
 // The scan kernels leave NeedleHipRun.problem = index of the problem descriptor; this pass computes
 // chromaprint's simhash32 over the L+1 hashes [end-len ..= end] of both sequences and replaces the index by
@@ -888,14 +890,15 @@ SampledKernel sampled_kernel(ScanShape sh) {
 struct SearchPlan {
   std::vector<NeedleHipSeq> seqs;          // inputs ...
   std::vector<NeedleHipProblem> problems;
-  int mode[5] = {0, 0, 0, 0, 0};           // ... and the switches that steer the choice ([3]: threshold beyond the sampled kernel's bit trick,
-                                           // [4]: the sampled path's first stage on the matrix pipe)
+  int mode[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ... and the switches that steer the choice ([3]: threshold beyond the sampled kernel's bit trick,
+                                           // [4]: the sampled path's first stage on the matrix pipe, [5..7]: its form, waves per workgroup, chain)
   std::vector<SearchProblem> meta;         // derived: the pairs the chosen kernel can stage, then the oversize ones
   size_t staged = 0;                       // how many of meta go to the chosen kernel
   uint64_t oversize_blocks = 0;            // grid of the unstaged kernel over meta[staged..]
   uint64_t blocks = 0;
   size_t lds_bytes = 0;
   bool sampled = false, fast = false, mfma = false;
+  int mfma_form = 0, mfma_waves = 0, mfma_chain = 0, mfma_splits = 1;  // form 2 (scan_mfma_kernel.h): workgroup shape, accumulator chains, workgroups per group
   uint64_t mfma_products = 0;                 // v_mfma instructions a launch of the matrix-pipe form issues
   int bands_per_wave = 1;
   bool valid = false;
@@ -905,6 +908,12 @@ struct SearchPlan {
            std::memcmp(problems.data(), p, np * sizeof(NeedleHipProblem)) == 0;
   }
 };
+
+int device_cus() {  // compute units of the current device (256 on MI355X)
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  return cus > 0 ? cus : 256;
+}
 
 Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProblem *problems, size_t num_problems,
                   const int *mode, SearchPlan *plan) {
@@ -954,6 +963,17 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     auto same_group = [](const SearchProblem &a, const SearchProblem &b) {
       return a.dst_off == b.dst_off && a.m == b.m && a.min_len == b.min_len;
     };
+    // The matrix-pipe forms give neighbours of the (sorted) table that share destination and minimum length to ONE workgroup
+    // while its LDS still lets the intended number of workgroups share a CU.  Form 1 (round 4): up to four sources, three
+    // workgroups of four waves per CU (53 760 bytes: 42 LDS granules of 1280; a workgroup of 53 776 bytes ran two to a CU
+    // and a fifth slower).  Form 2 (scan_mfma_kernel.h): up to eight sources, 12 / waves workgroups per CU.
+    const int form = mode[5], waves = mode[6];
+    const size_t group_budget = form == 2 ? (waves == 4 ? 53760 : waves == 8 ? 81920 : 163840) : 53760;
+    const size_t max_members = form == 2 ? (size_t)kM2Members : (size_t)kMfmaMembers;
+    auto group_need = [&](const SearchProblem &a, uint64_t windows) {
+      return form == 2 ? m2_lds_words(a.m, windows, waves) * sizeof(uint32_t)
+                       : ((size_t)a.m + 2 * kBandB + mfma_extra_words_for(windows)) * sizeof(uint32_t);
+    };
     bool mfma = sampled && mode[4] == 1;
     const bool candidate = sampled && (mode[4] == 1 || (mode[4] == 2 && meta.size() >= (size_t)kDeviceEpiloguePairs));
     if (candidate) {  // the table sorted by destination (the runs carry the index of their own entry: its order is free)
@@ -962,12 +982,12 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
         if (a.m != b.m) return a.m < b.m;
         return a.min_len < b.min_len;
       });
-      if (!mfma) {
+      if (!mfma) {  // automatic: where the windows of a group fill at least 70 % of its row tiles of 32
         uint64_t windows = 0, rows = 0;
         for (size_t i = 0; i < meta.size(); i++) {
           uint64_t w = windows_of(meta[i]);
-          for (int k = 1; k < kMfmaMembers && i + 1 < meta.size() && same_group(meta[i], meta[i + 1]) &&
-                          ((size_t)meta[i].m + 2 * kBandB + mfma_extra_words_for(w + windows_of(meta[i + 1]))) * sizeof(uint32_t) <= 53760; k++)
+          for (size_t k = 1; k < max_members && i + 1 < meta.size() && same_group(meta[i], meta[i + 1]) &&
+                             group_need(meta[i], w + windows_of(meta[i + 1])) <= group_budget; k++)
             w += windows_of(meta[++i]);
           windows += w;
           rows += (w + 31) / 32 * 32;
@@ -976,22 +996,16 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
       }
     }
     auto lds_need = [&](const SearchProblem &m) {
-      return ((fast || sampled) ? (size_t)m.m + 2 * kBandB + (mfma ? mfma_extra_words((int)m.n, (int)m.min_len, kSampleW) : 0) : (size_t)m.n + m.m) *
-             sizeof(uint32_t);
+      if (mfma) return group_need(m, windows_of(m));
+      return ((fast || sampled) ? (size_t)m.m + 2 * kBandB : (size_t)m.n + m.m) * sizeof(uint32_t);
     };
     std::stable_partition(meta.begin(), meta.end(), [&](const SearchProblem &m) { return lds_need(m) <= lds_limit; });
     size_t staged = 0;
     while (staged < meta.size() && lds_need(meta[staged]) <= lds_limit) staged++;
     size_t lds_bytes = 0;
     int bands_per_wave = 1;
-    // Matrix-pipe form: up to kMfmaMembers neighbours of the (sorted) table that share destination and minimum length are
-    // given to ONE workgroup while it still fits a CU three times (53 760 bytes: 42 LDS granules of 1280; a workgroup of
-    // 53 776 bytes ran two to a CU and a fifth slower).  pad of the first = how many followers; a follower (pad bit 31) owns
-    // no workgroups.
-    constexpr size_t kThreePerCu = 53760;
-    auto group_need = [&](const SearchProblem &a, uint64_t windows) {
-      return ((size_t)a.m + 2 * kBandB + mfma_extra_words_for(windows)) * sizeof(uint32_t);
-    };
+    // pad of a group's first entry = how many followers; a follower (pad bit 31) owns no workgroups
+    size_t groups = 0;
     if (mfma) {
       const bool single = getenv("NEEDLE_HIP_MFMA_SINGLE") != nullptr;  // tests, measurements: one source per workgroup
       for (size_t i = 0; i < staged;) {
@@ -999,15 +1013,31 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
         a.pad = 0;
         uint64_t windows = windows_of(a);
         size_t k = 1;
-        while (!single && k < (size_t)kMfmaMembers && i + k < staged && same_group(a, meta[i + k]) &&
-               windows + windows_of(meta[i + k]) < 65536 && group_need(a, windows + windows_of(meta[i + k])) <= kThreePerCu) {
+        while (!single && k < max_members && i + k < staged && same_group(a, meta[i + k]) &&
+               windows + windows_of(meta[i + k]) < 65536 && group_need(a, windows + windows_of(meta[i + k])) <= group_budget) {
           windows += windows_of(meta[i + k]);
           meta[i + k].pad = 0x80000000u;
           k++;
         }
         a.pad = (uint32_t)(k - 1);
         i += k;
+        groups++;
       }
+    }
+    // form 2: the index of group G's first entry rides in the pad field of the table's G-th entry (bits 8 .. 30), so a
+    // workgroup finds its group with one load
+    if (mfma && form == 2) {
+      if (staged >= ((size_t)1 << 23)) return Status::Make(NeedleError_InvalidArgument, "hamming_runs: too many problems for one launch");
+      size_t g = 0;
+      for (size_t i = 0; i < staged; i++)
+        if (!(meta[i].pad & 0x80000000u)) meta[g++].pad |= (uint32_t)i << 8;
+    }
+    // form 2: one workgroup per group; a launch of few groups splits each over several workgroups (column units strided)
+    int splits = 1;
+    if (mfma && form == 2 && groups > 0) {
+      const uint64_t slots = (uint64_t)device_cus() * (uint64_t)(waves == 4 ? 3 : waves == 8 ? 2 : 1);
+      splits = (int)std::min<uint64_t>(8, std::max<uint64_t>(1, (2 * slots + groups - 1) / groups));
+      if (const char *e = getenv("NEEDLE_HIP_MFMA_SPLITS")) splits = std::max(1, std::min(64, atoi(e)));  // tests, tuning
     }
     if (fast || sampled) {
       uint64_t fb = 0, total_bands = 0;
@@ -1024,10 +1054,10 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
         const uint64_t diags = (uint64_t)m.n + m.m - 3;
         const uint64_t bands = (diags + kBandB - 1) / kBandB;
         const uint64_t per_block = 4 * (uint64_t)(sampled ? bands_per_wave : 1);
-        fb += (bands + per_block - 1) / per_block;
+        fb += mfma && form == 2 ? (uint64_t)splits : (bands + per_block - 1) / per_block;
         if (mfma) {
           uint64_t windows = windows_of(m);
-          for (uint32_t f = 1; f <= m.pad; f++) windows += windows_of(meta[i + f]);
+          for (uint32_t f = 1; f <= (m.pad & 0xFFu); f++) windows += windows_of(meta[i + f]);
           lds_bytes = std::max(lds_bytes, group_need(m, windows));
         } else {
           lds_bytes = std::max(lds_bytes, lds_need(m));
@@ -1059,10 +1089,18 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
         const SearchProblem &m = meta[i];
         if (m.pad & 0x80000000u) continue;
         uint64_t w = windows_of(m);
-        for (uint32_t f = 1; f <= m.pad; f++) w += windows_of(meta[i + f]);
-        if (w > 0 && m.m >= (uint32_t)kSampleW + 1) plan->mfma_products += (w + 31) / 32 * (((uint64_t)m.m - kSampleW) / 32 + 1) * kMfmaHeads;
+        for (uint32_t f = 1; f <= (m.pad & 0xFFu); f++) w += windows_of(meta[i + f]);
+        if (w > 0 && m.m >= (uint32_t)kSampleW + 1) {
+          uint64_t col_blocks = ((uint64_t)m.m - kSampleW) / 32 + 1;
+          if (form == 2) col_blocks = (col_blocks + kM2ColBlocks - 1) / kM2ColBlocks * kM2ColBlocks;  // whole units are multiplied
+          plan->mfma_products += (w + 31) / 32 * col_blocks * kMfmaHeads;
+        }
       }
     plan->fast = fast;
+    plan->mfma_form = mfma ? form : 0;
+    plan->mfma_waves = waves;
+    plan->mfma_chain = mode[7];
+    plan->mfma_splits = splits;
     plan->bands_per_wave = bands_per_wave;
     plan->lds_bytes = lds_bytes;
   }
@@ -1082,6 +1120,27 @@ int mfma_request(uint32_t threshold) {
   const char *e = getenv("NEEDLE_HIP_SCAN_MFMA");
   if (!e) return 2;
   return atoi(e) != 0 ? 1 : 0;
+}
+
+// Which matrix-pipe form and in which shape (measurements; the defaults are what won, profiles/NOTES.md round 5):
+// NEEDLE_HIP_MFMA_FORM 1 = round 4's kernel, 2 = scan_mfma_kernel.h; NEEDLE_HIP_MFMA_WAVES 4 / 8 / 12 / 16 waves per
+// workgroup (3 / 2 / 1 / 1 workgroups per CU; 8 and 16: four waves per SIMD, one accumulator pair).
+struct MfmaShape {
+  int form = 2, waves = 8, chain = 2;
+};
+MfmaShape mfma_shape() {
+  MfmaShape sh;
+  if (const char *e = getenv("NEEDLE_HIP_MFMA_FORM")) sh.form = atoi(e) == 1 ? 1 : 2;
+  if (const char *e = getenv("NEEDLE_HIP_MFMA_WAVES")) {
+    const int w = atoi(e);
+    if (w == 4 || w == 8 || w == 12 || w == 16) sh.waves = w;
+  }
+  return sh;
+}
+using Mfma2Kernel = void (*)(const uint32_t *, const SearchProblem *, int, uint32_t, NeedleHipRun *, uint32_t, uint32_t *, int);
+Mfma2Kernel mfma2_kernel(int waves) {
+  return waves == 4 ? hamming_runs_mfma2_kernel<kSampleW, 4, 3> : waves == 16 ? hamming_runs_mfma2_kernel<kSampleW, 16, 4>
+       : waves == 12 ? hamming_runs_mfma2_kernel<kSampleW, 12, 3> : hamming_runs_mfma2_kernel<kSampleW, 8, 4>;
 }
 
 std::atomic<int32_t> g_last_form{0};
@@ -1125,10 +1184,11 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
   if (!s.ok()) return s;
   hipStream_t stream = library_stream();
   if (!count_is_zero) NEEDLE_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
-  const int mode[5] = {getenv("NEEDLE_HIP_GENERIC_SEARCH") != nullptr, getenv("NEEDLE_HIP_BAND_SEARCH") != nullptr,
+  const MfmaShape shape = mfma_shape();
+  const int mode[8] = {getenv("NEEDLE_HIP_GENERIC_SEARCH") != nullptr, getenv("NEEDLE_HIP_BAND_SEARCH") != nullptr,
                        getenv("NEEDLE_HIP_BANDS_PER_WAVE") ? std::max(1, atoi(getenv("NEEDLE_HIP_BANDS_PER_WAVE"))) : 0,
                        threshold > 31u,   // every cell matches at 32: the band / generic kernels take such a launch
-                       mfma_request(threshold)};
+                       mfma_request(threshold), shape.form, shape.waves, shape.chain};
   SearchWorkspace *ws = workspace();
   SearchPlan &plan = ws->plan;
   const bool reuse = plan.matches(seqs, num_seqs, problems, num_problems, mode);
@@ -1150,6 +1210,9 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_mfma_kernel<kSampleW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      for (int w : {4, 8, 12, 16})
+        NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mfma2_kernel(w)),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       for (int w : {4, 8, 16})
         for (int h : {2, 3, 4}) {
           if (h >= w) continue;
@@ -1176,6 +1239,10 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
           hipLaunchKernelGGL(sampled_kernel<true>(scan_shape()), dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
                              ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,
                              ws->eval_groups);
+        } else if (plan.mfma && plan.mfma_form == 2) {
+          hipLaunchKernelGGL(mfma2_kernel(plan.mfma_waves), dim3((uint32_t)blocks), dim3(64 * plan.mfma_waves),
+                             lds_bytes, stream, d_hashes, ws->problems.ptr, staged, threshold, d_runs, capacity, d_count,
+                             plan.mfma_splits);
         } else if (plan.mfma) {
           hipLaunchKernelGGL(hamming_runs_mfma_kernel<kSampleW>, dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
                              ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,

@@ -76,14 +76,17 @@ def main():
     flush()
     pipelined_ms = 1e3 * (time.perf_counter() - t0) / jobs
     cs = capi.cert_stats(reset=True)
-    os.environ["NEEDLE_HIP_SCAN_COUNT"] = "1"
-    step(False)
-    flush()
-    capi.scan_counts(reset=True)
-    step(False)
-    flush()
-    issued, survivors = capi.scan_counts(reset=True)
-    del os.environ["NEEDLE_HIP_SCAN_COUNT"]
+    scan_form, scan_products = capi.scan_last_launch()           # of the timed jobs (the counting launches below are the vector form's)
+    issued, survivors = 0, 0
+    if not os.environ.get("NEEDLE_LIBRARY_DEVICE_NO_COUNT"):
+        os.environ["NEEDLE_HIP_SCAN_COUNT"] = "1"
+        step(False)
+        flush()
+        capi.scan_counts(reset=True)
+        step(False)
+        flush()
+        issued, survivors = capi.scan_counts(reset=True)
+        del os.environ["NEEDLE_HIP_SCAN_COUNT"]
     import hashlib
     runs_arr = lib.job_runs((seq[0] - 1) & 1)
     keys = np.stack([runs_arr[f].astype(np.uint32) for f in ("problem", "src_end", "dst_end", "len", "src_match_hash", "dst_match_hash")], axis=1)
@@ -99,7 +102,8 @@ def main():
            "kernel_ms": {k: round(v / jobs, 4) for k, v in acc.items()},
            "host_ms_per_job": {k: round(1e3 * v / (2 * jobs), 3) for k, v in host.items()},
            "runs": int(state["runs"]), "run_list_digest": digest, "scan_shape": os.environ.get("NEEDLE_HIP_SCAN_SHAPE", "8,3"),
-           "head_survivors": survivors,
+           "head_survivors": survivors, "scan_form": scan_form, "scan_matrix_products": scan_products,
+           "scan_int8_ops_per_s": round(scan_products * 65536.0 / max(scan_ms * 1e-3, 1e-12), 1),
            "detected": sum(1 for r in state["res"] if r is not None and r.opening is not None),
            "fallback": {"items": cs["items_recomputed"] / max(cs["items"], 1), "chunks": cs["chunks_recomputed"] / max(cs["chunks"], 1)},
            "scan_roofline": {"issued_cell_evaluations": issued, "lane_instructions_per_s": round(3.0 * issued / (scan_ms * 1e-3), 1),
