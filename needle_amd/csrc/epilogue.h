@@ -32,6 +32,16 @@ struct EpilogueJob {
   const std::vector<uint64_t> *row_seek = nullptr, *ts = nullptr;
 };
 
+// The device form gives a pair's runs to ONE lane (insertion order + heap): a pair with more runs than this (silence against
+// silence, one sustained tone against itself) would keep that lane busy for seconds.  Then bit 31 of the failure word is
+// set and the caller computes the results with the host form (threaded, n log n) from the run list -- same results.
+// NEEDLE_HIP_EPILOGUE_BUCKET_LIMIT is not a switch: tests lower the constant by building with -D.
+#ifndef NEEDLE_EPILOGUE_BUCKET_LIMIT
+#define NEEDLE_EPILOGUE_BUCKET_LIMIT 256
+#endif
+constexpr uint32_t kEpilogueBucketLimit = NEEDLE_EPILOGUE_BUCKET_LIMIT;
+constexpr uint32_t kEpilogueBucketTooLarge = 0x80000000u;
+
 // Enqueues the epilogue kernels on `stream` behind whatever fills the segments, then the copies of results[n] and of the
 // failure count (videos whose padding / hash duration exceed the match end: the reference panics) into HOST memory
 // (pinned: the copies are asynchronous).  Counts beyond a segment's capacity are clamped: the host redoes such a job.
@@ -39,8 +49,9 @@ Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHi
 
 // Comparator::run_with_frame_hashes with both halves on the device (search.hip): host hash arena in, scan + simhash, the
 // epilogue above on the run list where it lies, the n per-video results out; the run list itself never crosses PCIe.
-// `job` carries everything but the segments.  *failed > 0: the caller falls back to the host epilogue (which reports the
-// video that fails, in the reference's order) -- `runs` then holds the downloaded list.
+// `job` carries everything but the segments.  *failed != 0 (a failing video, or kEpilogueBucketTooLarge): the caller falls
+// back to the host epilogue (which reports the video that fails, in the reference's order) -- `runs` then holds the
+// downloaded list.
 Status gpu_search_results_host(const uint32_t *hashes, size_t num_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
                                const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold, EpilogueJob job,
                                std::vector<NeedleHipSearchResult> *results, uint32_t *failed, std::vector<NeedleHipRun> *runs,

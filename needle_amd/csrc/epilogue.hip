@@ -193,12 +193,17 @@ __global__ __launch_bounds__(64) void pair_entries_kernel(EpilogueParams pr, con
                                                           NeedleHipRun *__restrict__ sorted, const uint32_t *__restrict__ row_len,
                                                           const uint32_t *__restrict__ row_ts, const uint64_t *__restrict__ row_seek,
                                                           const uint64_t *__restrict__ ts, DeviceEntry *__restrict__ entries,
-                                                          uint32_t *__restrict__ valid) {
+                                                          uint32_t *__restrict__ valid, uint32_t *__restrict__ failed) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= pr.buckets) return;
   const uint32_t lo = start[b], hi = start[b + 1];
   uint32_t out = 0;
-  if (hi > lo) {
+  if (hi - lo > kEpilogueBucketLimit) {
+    // One lane orders a bucket by insertion (quadratic) and builds its heap alone: right for the handful of runs a pair of
+    // episodes has, not for the thousands two stretches of silence or of one sustained tone produce (an S x S block of equal
+    // hashes is ~2 S runs).  Such a library is handed back to the host form (threaded, n log n): bit 31 of `failed`.
+    atomicOr(failed, kEpilogueBucketTooLarge);
+  } else if (hi > lo) {
     // the reference walks its table backwards: i = n-1..1 and, inside, j = m-1..1 (:191-192)
     for (uint32_t a = lo + 1; a < hi; a++) {
       const NeedleHipRun x = sorted[a];
@@ -529,7 +534,7 @@ Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHi
   {
     KernelTimer timer("epilogue_entries", stream);
     hipLaunchKernelGGL(pair_entries_kernel, dim3((pr.buckets + 63) / 64), dim3(64), 0, stream, pr, ws->start.ptr, ws->sorted.ptr,
-                       ws->row_len.ptr, ws->row_ts.ptr, ws->row_seek.ptr, ws->ts.ptr, ws->entries.ptr, ws->valid.ptr);
+                       ws->row_len.ptr, ws->row_ts.ptr, ws->row_seek.ptr, ws->ts.ptr, ws->entries.ptr, ws->valid.ptr, ws->ctl.ptr + 2);
   }
   if (pr.v1 > pr.v0) {
     KernelTimer timer("epilogue_best_match", stream);

@@ -18,7 +18,8 @@ std::mutex g_mu;
 std::map<int, hipStream_t> g_streams;
 
 struct TimerEvents {  // two alternating event pairs, so the newest COMPLETED launch can be read without blocking
-  hipEvent_t start[2] = {nullptr, nullptr}, stop[2] = {nullptr, nullptr};
+  hipEvent_t start[2] = {nullptr, nullptr}, stop[2] = {nullptr, nullptr};   // what kernel_ms reads: own[] or a caller's events
+  hipEvent_t own_start[2] = {nullptr, nullptr}, own_stop[2] = {nullptr, nullptr};  // created by KernelTimer, recorded only by it
   bool recorded[2] = {false, false};
   int cur = 1;
 };
@@ -221,10 +222,13 @@ KernelTimer::KernelTimer(const char *n, hipStream_t on) : name(n), stream(on ? o
   if (!active) return;
   TimerEvents &t = g_timers[timer_key(name)];
   t.cur ^= 1;
-  if (!t.start[t.cur]) {
-    (void)hipEventCreate(&t.start[t.cur]);
-    (void)hipEventCreate(&t.stop[t.cur]);
+  if (!t.own_start[t.cur]) {
+    (void)hipEventCreate(&t.own_start[t.cur]);
+    (void)hipEventCreate(&t.own_stop[t.cur]);
   }
+  // (a slot may hold events bound by bind_kernel_events: a pipelined job's synchronisation points, never recorded from here)
+  t.start[t.cur] = t.own_start[t.cur];
+  t.stop[t.cur] = t.own_stop[t.cur];
   t.recorded[t.cur] = false;
   (void)hipEventRecord(t.start[t.cur], s);
 }

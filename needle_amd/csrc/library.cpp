@@ -97,6 +97,8 @@ struct NeedleHipLibrary {
     void *host_results = nullptr;
     size_t host_results_bytes = 0;
     bool device_epilogue = false, sharded = false;
+    bool shape_fixed = false;  // `sharded` was decided when the job was enqueued (device epilogue requested): job_end keeps it even if the
+                               // device form then failed on THIS rank alone -- the other ranks enter the collective that decision implies
     const NeedleHipRun *last_runs = nullptr;  // the complete run list of the job that finished last in this slot
     size_t last_total = 0;
     uint64_t comm_bytes[4] = {0, 0, 0, 0};  // received per rank in this job: hash rows, run heads, results; scans repeated
@@ -732,11 +734,14 @@ NeedleError job_search_and_gather(NeedleHipLibrary *lib, const NeedleAudioCompar
   const Comparator &cmp = comparator_of(comparator);
   const size_t Rc = cmp.include_endings() ? 2 : 1;
   j.device_epilogue = device_epilogue_wanted(lib, Rc) && lib->n >= 2;
+  j.shape_fixed = j.device_epilogue;
   if (j.device_epilogue) {
     // every rank for all videos, or -- more than one rank and a library large enough to pay for one more collective -- each
     // for its own block of videos (the decision cannot wait for the run count: the pairs stand in for it)
+    uint64_t shard_from = 1u << 16;
+    if (const char *e = getenv("NEEDLE_HIP_SHARD_EPILOGUE_PAIRS")) shard_from = (uint64_t)std::max(1, atoi(e));  // tests
     j.sharded = world > 1 && (getenv("NEEDLE_HIP_SHARD_EPILOGUE") ? atoi(getenv("NEEDLE_HIP_SHARD_EPILOGUE")) != 0
-                                                                   : (uint64_t)pair_count(lib->n) * Rc >= (1u << 16));
+                                                                   : (uint64_t)pair_count(lib->n) * Rc >= shard_from);
     const size_t want = (lib->n + 1) * sizeof(NeedleHipSearchResult);
     if (want > j.host_results_bytes) {
       if (j.host_results) (void)hipHostFree(j.host_results);
@@ -782,9 +787,11 @@ NeedleError job_search_and_gather(NeedleHipLibrary *lib, const NeedleAudioCompar
     NeedleHipSearchResult *hr = static_cast<NeedleHipSearchResult *>(j.host_results);
     Status s = world <= 64 ? gpu_epilogue_enqueue(ej, down, hr, reinterpret_cast<uint32_t *>(hr + lib->n))
                            : Status::Make(NeedleError_InvalidArgument, "device epilogue: more than 64 ranks");
-    if (!s.ok()) {  // (workspaces that do not fit: the host form computes the same results from the downloaded run list)
-      j.device_epilogue = false;
-      (void)hipGetLastError();
+    if (const char *e = getenv("NEEDLE_HIP_TEST_EPILOGUE_FAIL_RANK"))  // tests: the device form "fails" on one rank alone
+      if (atoi(e) == rank) s = Status::Make(NeedleError_Unknown, "device epilogue: failure injected by the test");
+    if (!s.ok()) {  // (workspaces that do not fit: the host form computes the same results from the downloaded run list --
+      j.device_epilogue = false;  // for the same block of videos, j.sharded stands: a rank that fell back alone must still
+      (void)hipGetLastError();    // meet the others in the collective they enter, or not enter one they skip)
     }
   }
   if (hipEventRecord(j.done, down) != hipSuccess)
@@ -1003,7 +1010,7 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
     // 5. the order-sensitive per-video epilogue (comparator.rs:583-626): every rank for all videos while that is
     // cheaper than another collective, otherwise each rank for its own block of videos + one all-gather of results
     std::vector<VideoResult> res;
-    const bool sharded = j.device_epilogue ? j.sharded : (world > 1 && shard_epilogue(total));
+    const bool sharded = j.shape_fixed ? j.sharded : (world > 1 && shard_epilogue(total));
     size_t v0 = 0, vcount = lib->n;
     if (sharded) shard_range(lib->n, world, rank, &v0, &vcount);
     const auto t0 = std::chrono::steady_clock::now();
@@ -1014,9 +1021,13 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
     const NeedleHipSearchResult *device_results = nullptr;
     if (j.device_epilogue) {  // computed on the device behind the gather (epilogue.hip); j.done covers its copies
       device_results = static_cast<const NeedleHipSearchResult *>(j.host_results);
-      if (*reinterpret_cast<const uint32_t *>(device_results + lib->n) != 0)
+      const uint32_t fail = *reinterpret_cast<const uint32_t *>(device_results + lib->n);
+      if (fail & kEpilogueBucketTooLarge)
+        device_results = nullptr;  // a pair with more runs than one lane should order: the host form below, same block of videos
+      else if (fail != 0)
         s = Status::Make(NeedleError_Unknown, "overflow when subtracting durations (time_padding / hash_duration exceed the match end)");
-    } else {
+    }
+    if (!device_results) {
       const std::vector<const FrameHashesData *> fh = lib->shell_pointers();
       s = cmp.results_from_runs(fh, run_list, total, false, false, false, &res, v0, v0 + vcount);
     }

@@ -817,23 +817,68 @@ __global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_
 // ---- simhash of every emitted run (comparator.rs:149-153,226-229) -----------------------------------------------
 // The scan kernels leave NeedleHipRun.problem = index of the problem descriptor; this pass computes
 // chromaprint's simhash32 over the L+1 hashes [end-len ..= end] of both sequences and replaces the index by
-// the caller's tag.  One wave per run.  The slice is read 64 hashes at a time (one coalesced load); bit b of the
-// 64 hashes is counted with one ballot + scalar popcount, so the 32 counters are wave-uniform (scalar registers)
-// and a hash costs about two instructions instead of a dependent load per hash and bit-plane lane.
-__device__ __forceinline__ uint32_t wave_simhash32(const uint32_t *__restrict__ slice, uint32_t count, uint32_t lane) {
-  uint32_t ones[32];
+// the caller's tag.  One wave per run.
+//
+// simhash32 needs, per bit position, how many of the slice's hashes have it set: the column sums of a (hashes x 32) bit
+// matrix.  Round 3 counted a column with one ballot + scalar popcount per bit and 64 hashes: 4 instructions x 32 bits per
+// block, 1500 per run of 370 hashes on both sides -- at library scale (4 M runs) the kernel was bound by exactly that
+// instruction count (10.9 ms of a 221 ms job).  Now a block of 64 hashes is TRANSPOSED in registers: lanes 0-31 and 32-63
+// each hold a 32 x 32 bit matrix, one row (hash) per lane; five exchange steps (partner lane ^ 16, 8, 4, 2, 1 through
+// ds_swizzle, a rotate and a bit-field insert with per-lane constants: three instructions a step) leave lane i with
+// COLUMN 31 - i, and one v_bcnt adds that column's ones to the lane's counter: 16 instructions per 64 hashes instead of
+// 128.  The slice's blocks are loaded together (eight in flight per side), so a run costs one trip to memory per side.
+struct TransposeLane {  // per-lane constants of the five steps
+  uint32_t rot[5], mask[5];
+};
+__device__ __forceinline__ TransposeLane transpose_lane(uint32_t lane) {
+  TransposeLane t;
+  uint32_t m = 0x0000FFFFu;
 #pragma unroll
-  for (int b = 0; b < 32; b++) ones[b] = 0;
-  for (uint32_t q0 = 0; q0 < count; q0 += 64) {
-    const uint32_t q = q0 + lane;
-    const uint32_t h = q < count ? slice[q] : 0u;  // beyond the slice: no ones
-#pragma unroll
-    for (int b = 0; b < 32; b++) ones[b] += (uint32_t)__popcll(__ballot((h >> b) & 1u));
+  for (int k = 0; k < 5; k++) {
+    const uint32_t j = 16u >> k;
+    const bool hi = (lane & j) != 0u;
+    t.rot[k] = hi ? 32u - j : j;          // rotate right: low lanes take the partner's bits from j places up, high lanes from j down
+    t.mask[k] = hi ? m << j : m;
+    m ^= m << (j >> 1);
   }
-  uint32_t out = 0;
+  return t;
+}
+template <int PATTERN>
+__device__ __forceinline__ uint32_t swizzle_xor(uint32_t x) {  // lane ^ (PATTERN >> 10) within 32 lanes: LDS crossbar, no memory
+  return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, PATTERN);
+}
+// x: one hash per lane -> lane i (of each half of the wave): bit column 31 - i of its half's 32 hashes
+__device__ __forceinline__ uint32_t transpose32(uint32_t x, const TransposeLane &t) {
+#define NEEDLE_TSTEP(K, J)                                                              \
+  {                                                                                     \
+    const uint32_t y = swizzle_xor<((J) << 10) | 0x1F>(x);                              \
+    const uint32_t r = __builtin_amdgcn_alignbit(y, y, t.rot[K]);                      \
+    x = (r & t.mask[K]) | (x & ~t.mask[K]);                                             \
+  }
+  NEEDLE_TSTEP(0, 16) NEEDLE_TSTEP(1, 8) NEEDLE_TSTEP(2, 4) NEEDLE_TSTEP(3, 2) NEEDLE_TSTEP(4, 1)
+#undef NEEDLE_TSTEP
+  return x;
+}
+__device__ __forceinline__ uint32_t wave_simhash32(const uint32_t *__restrict__ slice, uint32_t count, uint32_t lane, const TransposeLane &t) {
+  constexpr int kBlocks = 8;                       // 512 hashes per turn
+  uint32_t ones = 0;                               // lane i: hashes of its half (so far) with bit 31 - (i & 31) set
+  for (uint32_t q0 = 0; q0 < count; q0 += 64 * kBlocks) {
+    uint32_t h[kBlocks];
 #pragma unroll
-  for (int b = 0; b < 32; b++) out |= (2u * ones[b] > count ? 1u : 0u) << b;  // set iff ones > zeros; a tie leaves it clear
-  return out;
+    for (int u = 0; u < kBlocks; u++) {
+      const uint32_t q = q0 + 64 * u + lane;
+      h[u] = q < count ? slice[q] : 0u;            // beyond the slice: no ones
+    }
+#pragma unroll
+    for (int u = 0; u < kBlocks; u++) {
+      if (q0 + 64 * u >= count) break;             // (wave-uniform)
+      ones += (uint32_t)__popc(transpose32(h[u], t));
+    }
+  }
+  ones += (uint32_t)__shfl_xor((int)ones, 32);     // both halves' hashes
+  // bit 31 - i set iff ones > zeros (a tie leaves it clear): lanes 0 .. 31 give the word, bit-reversed
+  const unsigned long long set = __builtin_amdgcn_ballot_w64(2u * ones > count);
+  return __brev((uint32_t)set);
 }
 
 __global__ __launch_bounds__(256) void simhash_runs_kernel(const uint32_t *__restrict__ hashes,
@@ -844,11 +889,12 @@ __global__ __launch_bounds__(256) void simhash_runs_kernel(const uint32_t *__res
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t lane = threadIdx.x & 63;
   __builtin_amdgcn_s_setprio(3);  // a tail kernel beside the next job's first pass: its waves issue first (fingerprint.hip, shared-CU overlap)
+  const TransposeLane t = transpose_lane(lane);
   for (uint32_t k = wave; k < total; k += waves) {
     const NeedleHipRun r = runs[k];
     const SearchProblem pr = problems[r.problem];
-    const uint32_t src_hash = wave_simhash32(hashes + pr.src_off + (r.src_end - r.len), r.len + 1u, lane);
-    const uint32_t dst_hash = wave_simhash32(hashes + pr.dst_off + (r.dst_end - r.len), r.len + 1u, lane);
+    const uint32_t src_hash = wave_simhash32(hashes + pr.src_off + (r.src_end - r.len), r.len + 1u, lane, t);
+    const uint32_t dst_hash = wave_simhash32(hashes + pr.dst_off + (r.dst_end - r.len), r.len + 1u, lane, t);
     if (lane == 0) {
       runs[k].problem = pr.tag;
       runs[k].src_match_hash = src_hash;
@@ -1345,16 +1391,20 @@ Status gpu_search_results_host(const uint32_t *hashes, size_t num_hashes, const 
     s = gpu_hamming_runs_device(hb->d_hashes.ptr, seqs, num_seqs, problems, num_problems, threshold, hb->d_runs.ptr, capacity,
                                 hb->d_count.ptr, false);
     if (!s.ok()) return s;
-    job.num_segments = 1;
-    job.segment_count[0] = hb->d_count.ptr;
-    job.segment_runs[0] = hb->d_runs.ptr;
-    job.segment_capacity = capacity;
-    job.max_runs = capacity;
-    if (!(s = gpu_epilogue_enqueue(job, stream, pinned, pinned_failed)).ok()) return s;
+    // the run count first (one small copy behind the scan): an attempt whose list overflowed is repeated without its
+    // epilogue ever running, and the epilogue's workspaces (144 bytes per run, kept for the life of the process) are sized
+    // by the runs there ARE, not by the capacity of the list (3 runs per pair of room: 770 MB at 2000 videos)
     uint32_t found = 0;
     NEEDLE_HIP_TRY(hipMemcpyAsync(&found, hb->d_count.ptr, sizeof(found), hipMemcpyDeviceToHost, stream));
     NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
     if (found <= capacity) {
+      job.num_segments = 1;
+      job.segment_count[0] = hb->d_count.ptr;
+      job.segment_runs[0] = hb->d_runs.ptr;
+      job.segment_capacity = capacity;
+      job.max_runs = (uint64_t)found + (found >> 3) + 1024;   // (grow-only workspaces: a margin so that the next call's few more runs fit)
+      if (!(s = gpu_epilogue_enqueue(job, stream, pinned, pinned_failed)).ok()) return s;
+      NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
       *num_runs = found;
       *failed = *pinned_failed;
       results->assign(pinned, pinned + job.n);

@@ -7,7 +7,7 @@
 // rate.  Its chroma is NOT the contract's; it is a first pass whose every consumer is certified:
 // features_classify_cert_kernel (fingerprint.hip) accepts an item only if all 48 threshold comparisons clear a
 // data-dependent radius, and every other item is recomputed from f64 chroma (stft_chroma_kernel over the listed
-// chunks of frame pairs + fixup_items_kernel).  What the radius needs from here is the frame's total energy
+// chunks of frame pairs + fixup_items_kernel).  What the radius needs from here is the total energy of the frame PAIR (one transform)
 // E = sum |x|^2 next to its 12 pitch-class sums: with a strong component outside chromaprint's band (a 5 kHz tone, a
 // DC offset) the f32 transform's noise floor is set by E, not by the in-band energy the features are normalised by.
 //
@@ -240,9 +240,14 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void stft_chroma32_kernel(
         out[c] = (double)acc.x;
         if (p.has_b) out[kBands + c] = (double)acc.y;
       } else if (!(LAB & kLab32Clock)) {  // the fourth wave: rows 12..15 hold the four partial sums of the frames' energy
+        // BOTH frames get the energy of the PAIR: they went through one complex transform, and what separates them
+        // afterwards (X_a = (Z_k + conj Z_{N-k}) / 2, X_b = (Z_k - conj Z_{N-k}) / 2i) leaves an error of u |Z| in each --
+        // a frame of three samples of an onset beside a full-scale partner carries the PARTNER's noise floor.  Found by
+        // tools/fuzz_cert_adversarial.py (round 5): with the frame's own energy such an item was accepted at 75 S.
         float *out = energy + p.row * kEnergyParts;
-        out[c - kBands] = acc.x;
-        if (p.has_b) out[kEnergyParts + c - kBands] = acc.y;
+        const float e = p.has_b ? acc.x + acc.y : acc.x;
+        out[c - kBands] = e;
+        if (p.has_b) out[kEnergyParts + c - kBands] = e;
       }
     }
   };

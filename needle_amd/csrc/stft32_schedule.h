@@ -30,7 +30,8 @@ inline Stft32Schedule stft32_schedule(uint64_t total_pairs, uint32_t pairs_per_b
   s.count[0] = s.blocks_per_xcd = (uint32_t)blocks;
   if (!guided || ppb < 8 || 4 * blocks < 5 * slots_per_xcd || tail_tenths < 1 || tail_tenths > 20) return s;  // short launches: every slot gets one workgroup anyway
   const uint64_t part = (total_pairs + 7) / 8;
-  const uint64_t tail = slots_per_xcd * ppb * tail_tenths / 10;     // one round's worth of pairs (tail_tenths: tuning)
+  uint64_t tail = slots_per_xcd * ppb * tail_tenths / 10;           // one round's worth of pairs (tail_tenths: tuning)
+  if (tail > part) tail = part;                                     // (tenths > 12: the guard above only promises 1.25 rounds)
   s.pairs_per_xcd = (uint32_t)part;
   s.count[0] = (uint32_t)((part - tail) / ppb);
   const uint64_t rest = part - (uint64_t)s.count[0] * ppb;

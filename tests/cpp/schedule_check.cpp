@@ -8,8 +8,8 @@
 
 using needle::Stft32Schedule;
 
-static int check(uint64_t total, uint32_t ppb, uint64_t slots, bool guided) {
-  const Stft32Schedule s = needle::stft32_schedule(total, ppb, slots, guided);
+static int check(uint64_t total, uint32_t ppb, uint64_t slots, bool guided, uint32_t tenths = 10) {
+  const Stft32Schedule s = needle::stft32_schedule(total, ppb, slots, guided, tenths);
   std::vector<uint8_t> seen(total, 0);
   std::vector<uint32_t> prev_last(8, 0);
   uint64_t smaller = 0;
@@ -29,7 +29,7 @@ static int check(uint64_t total, uint32_t ppb, uint64_t slots, bool guided) {
   for (uint64_t g = 0; g < total; g++)
     if (!seen[g]) return std::printf("pair %llu missing (total %llu ppb %u slots %llu guided %d)\n", (unsigned long long)g,
                                      (unsigned long long)total, ppb, (unsigned long long)slots, (int)guided), 1;
-  if (guided && ppb >= 8 && (total + ppb - 1) / ppb >= 8 * 3 * slots + 64 && smaller < slots)
+  if (guided && tenths == 10 && ppb >= 8 && (total + ppb - 1) / ppb >= 8 * 3 * slots + 64 && smaller < slots)
     return std::printf("guided schedule without a fine tail (total %llu)\n", (unsigned long long)total), 1;
   return 0;
 }
@@ -41,6 +41,11 @@ int main() {
       for (uint64_t slots : {0ull, 1ull, 12ull, 96ull})
         for (bool guided : {false, true}) bad += check(total, ppb, slots, guided);
   for (uint64_t total = 20000; total < 60000; total += 997) bad += check(total, 24, 96, true);
+  // every tail the tuning switch accepts (NEEDLE_HIP_STFT_GUIDED: tenths of a round, 1 .. 20), on launches barely past the
+  // guard of 1.25 rounds: a tail longer than an XCD's part used to wrap around
+  for (uint32_t tenths = 1; tenths <= 20; tenths++)
+    for (uint64_t total : {8ull * 24 * 96 * 5 / 4, 8ull * 24 * 96 * 5 / 4 + 191, 8ull * 24 * 96 * 3 / 2, 8ull * 24 * 96 * 2, 500001ull})
+      bad += check(total, 24, 96, true, tenths);
   std::printf("%s\n", bad ? "FAILED" : "ok");
   return bad ? 1 : 0;
 }

@@ -197,8 +197,10 @@ static void emu_pair(const int16_t *fa, const int16_t *fb, int channels, double 
       chroma_a[c] = (double)lane[0].x;
       if (chroma_b) chroma_b[c] = (double)lane[0].y;
     } else {
-      if (energy_a) energy_a[c - 12] = (float)lane[0].x;
-      if (energy_b) energy_b[c - 12] = (float)lane[0].y;
+      // both frames carry the energy of the PAIR (stft32_kernel.h: one transform, one noise floor)
+      const float e = fb ? (float)lane[0].x + (float)lane[0].y : (float)lane[0].x;
+      if (energy_a) energy_a[c - 12] = e;
+      if (energy_b) energy_b[c - 12] = fb ? e : 0.0f;
     }
   }
 }

@@ -83,7 +83,7 @@ def test_diagonal_scan_loop_matches_oracle_dp(emu):
 def test_f32_first_pass_schedule_chroma_and_energy(emu):
     """stft_chroma32_kernel's per-thread code stepped on the CPU (same schedule, f32 arithmetic, table window and
     twiddles): its chroma is the oracle's within f32 round-off, and the four energy partials the fourth wave folds
-    add up to the sum of squares of the windowed frame (times the kernel's 1/2 input scale, squared)."""
+    add up to the sum of squares of the two windowed frames of the pair (times the kernel's 1/2 input scale, squared)."""
     emu.emu_stft_chroma_pair_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     e = synth.make_episode(2, 40.0, 10.0)
     pcm = e.pcm[: 20 * 11025]
@@ -98,8 +98,9 @@ def test_f32_first_pass_schedule_chroma_and_energy(emu):
         assert a[0] >= 0, f"layout check failed with code {a[0]}"
         assert np.max(np.abs(a - chroma[f])) / chroma[f].max() < 2e-6
         assert np.max(np.abs(b - chroma[f + 1])) / chroma[f + 1].max() < 2e-6
-        assert abs(float(ea.sum()) / float(((fa * window) ** 2).sum()) - 1.0) < 1e-5
-        assert abs(float(eb.sum()) / float(((fb * window) ** 2).sum()) - 1.0) < 1e-5
+        pair = float(((fa * window) ** 2).sum()) + float(((fb * window) ** 2).sum())   # both frames carry the PAIR's energy
+        assert abs(float(ea.sum()) / pair - 1.0) < 1e-5
+        assert abs(float(eb.sum()) / pair - 1.0) < 1e-5
     # odd frame count: frame B absent -> its energy is exactly zero
     emu.emu_stft_chroma_pair_f32(fa.ctypes.data, None, 1, a.ctypes.data, None, ea.ctypes.data, eb.ctypes.data)
     assert float(eb.sum()) == 0.0 and np.max(np.abs(a - chroma[len(chroma) - 2])) / chroma[len(chroma) - 2].max() < 2e-6

@@ -259,3 +259,32 @@ def test_audit_on_audio_and_hostile_signals(monkeypatch):
     z = lib.audit()
     print("audit audio:", a, "zoo:", z)
     assert z["mismatches"] == 0 and z["accepted_mismatches"] == 0 and z["max_error_over_s"] <= 16.0, z
+
+def test_adversarial_corpus_stays_inside_the_radius(monkeypatch):
+    """tools/fuzz_cert_adversarial.py SEARCHES for inputs that maximise the audit's |log v32 - log v64| / S over accepted
+    items (round 5: 295 488 candidates after the fix below).  Its first half minute found one at 75 S -- above K = 64: an
+    onset three samples into a frame whose partner in the packed two-for-one transform is at full scale.  The frame's error is
+    set by the PAIR's energy (what separates the two spectra leaves u |Z| in each), so S is now built from that; the same input
+    measures < 1 S, and the best the search reached afterwards is 2.05.  The corpus (parameter vectors; the PCM is regenerated)
+    is audited here: no accepted item may differ from the f64 pipeline's, and the largest ratio stays below 8."""
+    import importlib.util
+    import json
+    _mode(monkeypatch)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_cert_adversarial", os.path.join(root, "tools", "fuzz_cert_adversarial.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    corpus = json.load(open(os.path.join(root, "tests", "golden", "cert_adversarial.json")))
+    thetas = [corpus["before_pair_energy"]["theta"]] + [v["theta"] for v in corpus["after_pair_energy"]["families"].values()]
+    pcms = [fz.synth(np.array(th)) for th in thetas]
+    aud = fz.Auditor(len(pcms))
+    first = aud.audit(pcms[:1])
+    assert first["accepted_mismatches"] == 0 and first["mismatches"] == 0
+    assert first["max_error_over_s"] < 8.0, first                   # 75.5 with each frame's own energy
+    a = aud.audit(pcms)
+    assert a["items"] == len(pcms) * fz.ITEMS and a["accepted"] > 0
+    assert a["accepted_mismatches"] == 0 and a["mismatches"] == 0, a
+    assert a["max_error_over_s"] < 8.0, a
+    got = capi.fingerprint(pcms, step=1)                             # and the product's items are the oracle's
+    for g, p in zip(got, pcms):
+        assert g.tolist() == O.fingerprint(p).tolist()

@@ -97,6 +97,41 @@ def test_device_epilogue_on_planted_hashes_equals_host_and_oracle(monkeypatch, n
     assert sum(1 for r in dev if r is not None and r[0] is not None) >= n // 2
 
 
+def test_pairs_with_hundreds_of_runs_go_back_to_the_host_form(monkeypatch):
+    """two stretches of one repeated hash (silence, a sustained tone) give a pair ~2 S runs -- every diagonal of an
+    S x S block is one.  The device form orders a pair's runs in ONE lane, quadratically; beyond 256 runs per pair it sets a
+    flag instead and the job's results come from the host form.  Same results either way, and equal to the oracle's."""
+    rng = np.random.default_rng(77)
+    n, S = 5, 230
+    lens = [int(round(400.0 * synth.RATE))] * n                         # ~800 kept hashes in the opening half
+    lib = capi.Library(n)
+    lib.stream_pcm([np.zeros(v, dtype=np.int16) for v in lens], lens)
+    kept = len(lib.frame_hashes(0).opening_data()[0])
+    assert kept > 500
+    d_arena, stride = lib.hash_arena()
+    rows = []
+    for v in range(n):
+        h = rng.integers(0, 2 ** 32, kept, dtype=np.uint64).astype(np.uint32)
+        if v < 3:
+            h[40 + 5 * v: 40 + 5 * v + S] = np.uint32(0x5A5A1234)          # one hash, S times: "silence"
+        seg = np.arange(90, dtype=np.uint32) * np.uint32(2654435761)
+        h[350: 350 + len(seg)] = seg                                        # and an ordinary shared segment behind it
+        rows.append(h)
+        capi.check(capi.lib().needle_hip_memcpy_h2d(d_arena + 4 * v * stride, h.ctypes.data, h.nbytes))
+    cmp = capi.Comparator([f"v{v}.wav" for v in range(n)], min_opening_duration=15)
+    host, runs_h = _job(lib, cmp, monkeypatch, device=False)
+    dev, runs_d = _job(lib, cmp, monkeypatch, device=True)
+    assert runs_h == runs_d > 3 * 2 * (S - 70)                              # the silent pairs alone: > 256 runs each
+    assert dev == host
+    hd = O.duration_from_secs_f32(0.3)
+    ofh = []
+    for v in range(n):
+        f = lib.frame_hashes(v)
+        ofh.append(O.FrameHashes(list(zip(f.opening_data()[0].tolist(), f.opening_data()[1].tolist())), [], hd, ""))
+    want = O.run_with_frame_hashes(O.Comparator(min_opening_duration=15 * NS), ofh, threads=8)
+    assert dev == _as(want)
+
+
 def test_device_epilogue_on_audio_with_two_jobs_in_flight(monkeypatch):
     eps = [synth.make_episode(k, 100.0 + 7.0 * k, 22.0, 21.0) for k in range(6)]
     lens = [len(e.pcm) for e in eps]
