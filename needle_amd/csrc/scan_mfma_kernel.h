@@ -8,30 +8,35 @@
 //
 // Round 4's form kept the matrix pipe 27 % busy: beside its 4 products a tile cost 88 vector and 16 scalar instructions, a
 // wave runs its instructions in order at 5 - 8 cycles each, and three waves per SIMD (166 registers) cannot cover that.
-// Measured on the way to this form (profiles/NOTES.md, round 5): with the vector work of a tile taken out altogether the
-// kernel still takes 51 % of its time -- the matrix pipe's own floor at the clock the chip holds under this load -- so
-// everything else has to shrink towards "hidden", and what costs most is not arithmetic but BRANCHES per tile (every
-// tile with a survivor took a scalar detour of ~100 instructions).  Hence:
+// What was measured on the way to this form (profiles/NOTES.md, round 5): what costs most is not arithmetic but BRANCHES
+// per tile (every tile with a survivor took a scalar detour of ~100 instructions) and trips to global memory inside the
+// tile loop.  Hence:
 //  * The products only FLAG.  The four products of a tile accumulate into two register sets -- rows (0 + 2) and rows
 //    (4 + 7), each preset so that its sign bit is SET where the SUM of two rows' distances is <= 2 t, a necessary
-//    condition of "both <= t".  16 + 16 result registers are folded into four words (one per group of four
-//    windows: 16 three-input bitwise instructions) and the four sign bits are shifted into a per-lane mask (v_alignbit).
-//    No compare, no branch: eight tiles are multiplied and folded in a straight line, software-pipelined (the next tile's
-//    products are issued before this tile's fold).
-//  * Every eight tiles a lane looks at its own mask.  A set bit = (tile, group of four windows) with a possible survivor
-//    at this lane's destination position: the lane tests those four windows' head rows EXACTLY with popcounts out of LDS
-//    (the vector form's test), then the tail rows of what passes, then kM2Probe rows on either side (a whole window whose
-//    run ends inside them is shorter than any min_len this path takes: dropped) -- all per lane, all from LDS.  No queue,
-//    no second pass.  What remains (a few windows per pair: real runs) is resolved by the wave against the source sequence
-//    in global memory, two rows per lane and direction in one trip.
-//  * One workgroup = one destination x up to EIGHT sources (as many as the CU's LDS holds): staging and the expansion of
-//    the destination's hashes into B fragments are shared by 10 - 19 row tiles instead of 5; an A fragment read serves both
-//    column blocks of a unit; waves take units from a counter in LDS, so none idles while another still has units.
+//    condition of "both <= t" (0.20 % of the window-diagonals pass on synthetic audio, 0.05 % the exact head test).
+//    16 + 16 result registers are folded into four words (one per group of four windows) and the four sign bits are
+//    shifted into a per-lane flag word (v_alignbit): 24 vector instructions, no compare, no branch, eight tiles in a
+//    straight line.
+//  * Every eight tiles the flag words become ITEMS = (group of four windows, destination position), handed out one per
+//    lane, 64 at a time, whatever lane flagged them (a position that looks like many windows -- a sustained sound --
+//    flags the same lane again and again: left to that lane, the wave waits for it).  A lane tests its item's four
+//    windows' head rows EXACTLY with popcounts (the vector form's test), then the tail rows of what passes, then
+//    kM2Probe rows on either side (a whole window whose run ends inside them is shorter than any min_len this path
+//    takes: dropped) -- all from LDS.  What remains (a few windows per pair: real runs) is resolved by the wave against
+//    the source sequence in global memory, two rows per lane and direction in one trip.
+//  * One workgroup = one destination x up to EIGHT sources (as many as its share of the CU's LDS holds): staging and the
+//    expansion of the destination's hashes into B fragments are shared by 7 - 19 row tiles instead of 5; an A fragment
+//    read serves both column blocks of a unit; waves take units from a counter in LDS, so none idles while another still
+//    has units; a workgroup finds its group with one load (round 4: a binary search of the table, 17 dependent loads).
+//  * Default shape (mfma_waves(), search.hip): workgroups of 8 waves, two per CU, four waves per SIMD (128 registers: one
+//    accumulator pair, a tile folded before the next is multiplied).  Measured against it: 16 waves x 1 (same), 12 waves
+//    x 1 with two accumulator pairs and the next tile's products issued before the fold (5 % slower), 4 waves x 3 (45 %).
 //  * Columns outside the table get all-zero B fragments and rows beyond the last window read a row of zeros
 //    (product 0 + preset > 0: never flagged).
 // Operand maps of the instruction: tools/mfma_i8_layout.hip.  Needs t <= 15.
 #ifndef NEEDLE_M2_LAB
-#define NEEDLE_M2_LAB 0                       // timing laboratory (tools/build_variant.sh): bits switch parts off -- WRONG results
+#define NEEDLE_M2_LAB 0                       // timing laboratory (tools/build_variant.sh), WRONG results: 1 flags ignored (the tile loop
+                                              // alone), 2 head survivors dropped, 64 a workgroup's setup alone
 #endif
 constexpr int kM2Heads = 4;
 constexpr int kM2Members = 8;                 // sources a workgroup takes at most (of one destination)
@@ -62,12 +67,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   static_assert(W == 8, "head rows {0, 2, 4, 7} and tail rows {1, 3, 5, 6} of a window of 8");
   constexpr int H = kM2Heads, PITCH = kM2Pitch, CB = kM2ColBlocks, E = kM2Probe, NR = kM2Rows;
   extern __shared__ uint32_t lds[];
-#if NEEDLE_M2_LAB & 32   // laboratory: phase stamps of every 400th workgroup, printed
-  const unsigned long long lab_t0 = __builtin_amdgcn_s_memtime();
-#endif
-#if !(NEEDLE_M2_LAB & 4)   // laboratory: wave priority left at 0
   __builtin_amdgcn_s_setprio(3);
-#endif
   // Which group: workgroup / splits.  Its first entry's index lies in the pad field (bits 8 .. 30) of the table entry whose
   // POSITION is the group's number (build_plan) -- one load, not a binary search of the table (17 dependent trips to
   // global memory at 80 000 pairs: half the life of a workgroup of 24-minute windows).
@@ -156,9 +156,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   for (int q = threadIdx.x; q < PITCH; q += 64 * WAVES) aimg[nW * PITCH + q] = 0u;  // the row the last tile reads beyond the last window
   __syncthreads();
 
-#if NEEDLE_M2_LAB & 32
-  const unsigned long long lab_t1 = __builtin_amdgcn_s_memtime();
-#endif
   const int lane = (int)(threadIdx.x & 63);
   uint32_t *queue = queues + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kM2Queue;
   const int last_j = m - W;                      // valid destination positions of a window's first row: 1 .. m - W
@@ -374,10 +371,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   };
   // a group's word is negative iff one of its four windows passes both sums; its sign goes into the flags
   auto fold = [&](const mfma_v16i &ua, const mfma_v16i &ub, uint32_t &flags) {
-#if NEEDLE_M2_LAB & 8   // laboratory: one instruction instead of the fold -- the products and the loop alone
-    flags = __builtin_amdgcn_alignbit(flags, (uint32_t)(ua[0] & ub[15]) & 0x7FFFFFFFu, 31);
-    return;
-#endif
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       int a = ua[4 * g] & ub[4 * g];
@@ -427,12 +420,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     uint32_t flags = 0u;                                             // sign bits of the groups' words: set = look here
     load_a(0, fa);
     if constexpr (PER_SIMD <= 3) {
-      // Software-pipelined AND interleaved.  A wave issues in order, and a product blocks it until the pipe takes it
-      // (32 cycles after the one before): four products written back to back are ~128 cycles in which the wave folds
-      // nothing.  So each product is followed by a quarter of the PREVIOUS tile's fold (6 of its 24 vector instructions:
-      // what a product's 32 cycles hide, MI355X_MICROARCH.md) -- __builtin_amdgcn_sched_group_barrier pins that order --
-      // and a wave alone keeps its SIMD's pipe fed.  Two accumulator pairs; ONE set of A fragments: each fragment of the
-      // next row tile is read right behind the last product that takes the current one, three products ahead of its use.
+      // Software-pipelined: a tile's four products are issued before the tile in front of it is folded (two accumulator
+      // pairs), and the next row tile's A fragments are asked for behind the last product that reads this row tile's.
+      // (Measured and dropped: pinning "one product, six instructions of the fold" with __builtin_amdgcn_sched_group_barrier
+      // -- 4.69 against 4.48 ms at 79 800 pairs; the compiler copied fragments to make room for the early reads.)
       mfma_v16i a0, b0, a1, b1;
       products(fa, fb[0], a0, b0);                                   // tile (row 0, block 0)
 #pragma unroll 1
@@ -440,23 +431,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         products(fa, fb[1], a1, b1);                                 // the loop is conditional (a conditional product made the  (rt, 1)
         load_a(rt + 1, fa);                                          // compiler copy both accumulator pairs twice per turn)
         fold(a0, b0, flags);                                         // (rt, 0)
-#if !(NEEDLE_M2_LAB & 16)   // laboratory: the order left to the compiler
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one matrix instruction,
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // the read that replaces its A fragment,
-          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);        // six vector instructions of the fold
-        }
-#endif
         products(fa, fb[0], a0, b0);                                 // (rt + 1, 0)
         fold(a1, b1, flags);                                         // (rt, 1)
-#if !(NEEDLE_M2_LAB & 16)
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-        }
-#endif
         if ((rt & (kM2Batch - 1)) == kM2Batch - 1) {
 #if !(NEEDLE_M2_LAB & 1)   // laboratory: flags ignored -- the tile loop alone
           enqueue(flags, rt - (kM2Batch - 1), 2 * kM2Batch, j0);
@@ -499,11 +475,4 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
 #endif
   }
   if (qn > 0) process(0, qn);
-#if NEEDLE_M2_LAB & 32
-  if (blockIdx.x % 400 == 7 && lane == 0) {
-    const unsigned long long lab_t2 = __builtin_amdgcn_s_memtime();
-    printf("wg %u wave %u members %d nW %d row_tiles %d units %d: setup %llu loop %llu cycles\n", blockIdx.x, threadIdx.x >> 6, members, nW,
-           row_tiles, units, lab_t1 - lab_t0, lab_t2 - lab_t1);
-  }
-#endif
 }

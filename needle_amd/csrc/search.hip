@@ -505,312 +505,14 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
 }
 
 // ---- sampled path on the matrix pipe (large launches by themselves, build_plan; NEEDLE_HIP_SCAN_MFMA=0 / 1 forces) ------
-// The same aligned windows, the same head test and the same candidates as hamming_runs_sampled_kernel, computed
-// differently: the Hamming distances of a window's head rows against every destination position are integer matrix
-// products.  A hash as 32 bytes of +-1 (bit set: +1): dot(a, b) = 32 - 2 d(a, b).  A tile is 32 windows x 32 destination
-// positions; for each of the H head rows s one v_mfma_i32_32x32x32_i8 (K = 32): A row = the window's hash src[w0 + s],
-// B column j = dst[j + s] (j = destination index of the window's FIRST row, i.e. diagonal d = j - w0), accumulator preset
-// to -(32 - 2 t): the result's sign bit is clear exactly where that cell matches.  The OR of the H results is
-// non-negative exactly where ALL head cells match -- the vector form's exact head test at two bitwise instructions per
-// window-diagonal instead of ~8 -- and one AND over a lane's 16 results + one compare tells whether the tile holds any
-// survivor at all (it mostly does not: ~0.05 % of the window-diagonals pass on audio, tools/mfma_filter_model.py).
-// Survivors are queued in LDS and their remaining rows tested 64 windows at a time, one per lane; a window that matches
-// whole is resolved by the wave like in the vector form (same function of the same cells: the emitted runs are
-// identical).  Rows beyond the last window read a row of zeros (product 0: negative), columns outside the table are masked
-// when survivors are collected.  Operand maps: tools/mfma_i8_layout.hip (profiles/r04_mfma_i8_layout.log).  Needs
-// 32 - 2 t > 0 (t <= 15).  History and measurements: profiles/NOTES.md, "The scan's head rows on the matrix pipe".
-constexpr int kMfmaHeads = 4;
-constexpr int kMfmaMembers = 4;                   // sources a workgroup takes at most (of one destination)
-constexpr int kMfmaQueue = 64 + 4 * 64;           // survivors per wave waiting for the test of their remaining rows
-constexpr int kMfmaFixedWords = 4 * kMfmaQueue + 4 * 16;  // behind the staged destination: 4 queues + 4 tables of 16 words; the byte table
-                                                       // (256 x 2 words) that builds the A image lies over the queues, which are not in use yet
-static_assert(kMfmaFixedWords >= 512, "the byte table has to fit");
-// ... and behind those the A image: every aligned window's H head hashes as 32 bytes of +-1 each, then ONE row of zeros for
-// the rows of the last tile that lie beyond the last window (product 0: negative);
-// a window's row is 4 words longer than its 8 H (36 words: lanes 32 words apart would all meet in two groups of LDS banks)
-constexpr int kMfmaPitch = kMfmaHeads * 8 + 4;
+// The same aligned windows, the same head test and the same candidates as hamming_runs_sampled_kernel, with the first stage
+// as int8 matrix products: scan_mfma_kernel.h (round 5; round 4's form -- one product per head row, OR of the four results,
+// survivors queued -- is in the history: commit 76713c3, and what was measured on the way in profiles/NOTES.md).
 __host__ __device__ constexpr int mfma_windows(int n, int min_len, int W) {
   return (n - 1 - W) >= 0 && min_len - W + 1 > 0 ? (n - 1 - W) / (min_len - W + 1) + 1 : 0;  // w0 = 1 + k P, w0 + W - 1 <= n - 1
 }
-__host__ __device__ constexpr size_t mfma_extra_words_for(uint64_t windows) {  // windows of ALL the sources a workgroup takes
-  return (size_t)kMfmaFixedWords + 4 /* alignment */ + (size_t)(windows + 1) * kMfmaPitch;  // + one row of zeros
-}
-__host__ __device__ constexpr size_t mfma_extra_words(int n, int min_len, int W) {
-  return mfma_extra_words_for((uint64_t)mfma_windows(n, min_len, W));
-}
 typedef int mfma_v4i __attribute__((ext_vector_type(4)));
 typedef int mfma_v16i __attribute__((ext_vector_type(16)));
-
-template <int W>
-__global__ __launch_bounds__(256, 3) void hamming_runs_mfma_kernel(const uint32_t *__restrict__ hashes,
-                                                                   const SearchProblem *__restrict__ problems,
-                                                                   int num_problems, uint32_t threshold,
-                                                                   NeedleHipRun *__restrict__ runs, uint32_t capacity,
-                                                                   uint32_t *__restrict__ count, int bands_per_wave, int,
-                                                                   unsigned long long *__restrict__) {
-  constexpr int R = kBandR, B = 64 * R, H = kMfmaHeads;
-  extern __shared__ uint32_t lds[];
-  __builtin_amdgcn_s_setprio(3);
-  int lo = 0, hi = num_problems - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (problems[mid].block_base <= blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  // A workgroup takes ONE destination sequence and up to four sources (SearchProblem::pad of its first entry: how many of
-  // the following entries of the table -- same destination, same minimum length -- belong to it too, build_plan): their
-  // windows share the row tiles (73 + 73 windows fill 4.6 of 5 tiles instead of 2.3 of 3 each; 4 x 39 fill 4.9 of 5), the
-  // destination's staging and its expansion.  Members are told apart with selects, not indexed (no register arrays).
-  const SearchProblem pr = problems[lo];
-  const int followers = min((int)(pr.pad & 0xFFu), kMfmaMembers - 1);
-  const SearchProblem pr1 = problems[followers > 0 ? lo + 1 : lo], pr2 = problems[followers > 1 ? lo + 2 : lo],
-                      pr3 = problems[followers > 2 ? lo + 3 : lo];
-  const int n = (int)pr.n, m = (int)pr.m;     // (n: the first member's -- it also fixes the workgroups of the group)
-  const int n1 = (int)pr1.n, n2 = (int)pr2.n, n3 = (int)pr3.n;
-  const uint32_t *__restrict__ src = hashes + pr.src_off;
-  const uint32_t *__restrict__ src1 = hashes + pr1.src_off;
-  const uint32_t *__restrict__ src2 = hashes + pr2.src_off;
-  const uint32_t *__restrict__ src3 = hashes + pr3.src_off;
-  const uint32_t *__restrict__ dst = hashes + pr.dst_off;
-  const int min_len = (int)pr.min_len;
-  const int P = min_len - W + 1;
-  const int w1 = mfma_windows(n, min_len, W);                                   // first row of member 1, 2, 3 (= all rows when
-  const int w2 = w1 + (followers > 0 ? mfma_windows(n1, min_len, W) : 0);       // there is no such member)
-  const int w3 = w2 + (followers > 1 ? mfma_windows(n2, min_len, W) : 0);
-  const int nW = w3 + (followers > 2 ? mfma_windows(n3, min_len, W) : 0);       // rows of the tiles: windows of all members
-  const int row_tiles = (nW + 31) / 32;
-  auto member_of = [&](const int row) { return (row >= w1 ? 1 : 0) + (row >= w2 ? 1 : 0) + (row >= w3 ? 1 : 0); };
-  auto first_row = [&](const int g) { return g == 0 ? 0 : g == 1 ? w1 : g == 2 ? w2 : w3; };
-  auto source_of = [&](const int g) { return g == 0 ? src : g == 1 ? src1 : g == 2 ? src2 : src3; };
-  auto length_of = [&](const int g) { return g == 0 ? n : g == 1 ? n1 : g == 2 ? n2 : n3; };
-  uint32_t *ldst = lds;                                   // ldst[B + j] = dst[j], B zero slots on both sides
-  uint32_t *table = lds + (2 * B + m);                    // table[2 b], table[2 b + 1]: the 8 bytes of +-1 for byte value b
-  uint32_t *aimg = table + kMfmaFixedWords;               // 8 words per (window, head row), 16-byte aligned
-  aimg += (4 - ((2 * B + m + kMfmaFixedWords) & 3)) & 3;
-  for (int k = threadIdx.x; k < B; k += blockDim.x) {
-    ldst[k] = 0u;
-    ldst[B + m + k] = 0u;
-  }
-  for (int k = threadIdx.x; k < m; k += blockDim.x) ldst[B + k] = dst[k];
-  for (int b = threadIdx.x; b < 256; b += blockDim.x) {
-    uint32_t w0 = 0, w1 = 0;
-    for (int i = 0; i < 4; i++) {
-      w0 |= (((b >> i) & 1) ? 0x01u : 0xFFu) << (8 * i);
-      w1 |= (((b >> (4 + i)) & 1) ? 0x01u : 0xFFu) << (8 * i);
-    }
-    table[2 * b] = w0;
-    table[2 * b + 1] = w1;
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < (nW + 1) * H; idx += blockDim.x) {  // row nW: zeros
-    const int k = idx / H, kb = idx % H;
-    uint32_t *o = aimg + k * kMfmaPitch + 8 * kb;
-    if (k < nW) {
-      const int g = member_of(k);
-      const uint32_t hsh = source_of(g)[1 + (k - first_row(g)) * P + head_row(kb, W, H)];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const uint32_t byte = (hsh >> (8 * q)) & 0xFFu;
-        o[2 * q] = table[2 * byte];
-        o[2 * q + 1] = table[2 * byte + 1];
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 8; q++) o[q] = 0u;
-    }
-  }
-  __syncthreads();
-
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = (int)(threadIdx.x & 63);
-  uint32_t *queue = table + wave * kMfmaQueue;  // (the byte table has served the A image: the queues take its place)
-  uint32_t *ntab = table + 4 * kMfmaQueue + 16 * wave;
-  if (lane < 16) {
-    uint32_t w = 0;
-    for (int i = 0; i < 4; i++) w |= (((lane >> i) & 1) ? 0x01u : 0xFFu) << (8 * i);
-    ntab[lane] = w;
-  }
-  wave_lds_fence_search();
-  const int last_j = m - W;                                     // valid destination positions: 1 .. m - W
-  if (nW <= 0 || last_j < 1) return;
-  const int r = lane & 31, h = lane >> 5;
-  const int t = (int)min(threshold, 15u);
-  const int preset = -(32 - 2 * t);      // per head row: dot = 32 - 2 d, so dot + preset >= 0 <=> d <= t (and < 0 for all-zero fragments)
-  // this wave's share of the pair's column blocks: the workgroups of a pair are laid out as for the vector form
-  const int slots = 4 * bands_per_wave;
-  const int total_bands = (n + m - 3 + B - 1) / B;
-  const int nb = (total_bands + slots - 1) / slots;             // workgroups of this pair
-  const int b_in_pair = (int)(blockIdx.x - pr.block_base);
-  const int col_blocks = last_j / 32 + 1;                        // positions 0 .. last_j
-  const int first_cb = b_in_pair * 4 + wave, stride_cb = nb * 4;
-
-  // exact resolution of one window whose W cells all match on diagonal d, by the whole wave (the vector form's resolve())
-  auto resolve = [&](const int w0, const int d, const int g) {  // (g, the member: wave-uniform)
-    const uint32_t *__restrict__ sp = source_of(g);
-    const int ns = length_of(g);
-    const int ilo = d < 0 ? 1 - d : 1;
-    const int ihi = min(ns - 1, m - 1 - d);
-    if (w0 < ilo || w0 + W - 1 > ihi) return;
-    int e = w0 + W;
-    bool ended = false;
-    const int fwd_limit = min(ihi, w0 + P + W - 1);
-    // The first 64 rows of BOTH directions are read together: most candidates are chance matches of one window on
-    // self-similar audio and end within them, and two dependent trips to the source sequence (global memory) per candidate
-    // were a third of a wave's time.  `a_first`: first row of the run if the backward scan ends inside these rows.
-    int a_first = -1;
-    bool back_open = false;                      // the 64 rows in front of the window all match: the scan goes on below
-    {
-      const int frow = e + lane, brow = w0 - 1 - lane;
-      const bool f_in = frow <= fwd_limit, b_in = brow >= ilo;
-      const uint32_t fs = f_in ? sp[frow] : 0u, bs = b_in ? sp[brow] : 0u;
-      const bool bad_f = f_in && (uint32_t)__popc(fs ^ ldst[B + frow + d]) > threshold;
-      const bool bad_b = b_in && (uint32_t)__popc(bs ^ ldst[B + brow + d]) > threshold;
-      const unsigned long long mf = __ballot(bad_f), mb = __ballot(bad_b);
-      if (mf) {
-        e += __ffsll((long long)mf) - 1;
-        ended = true;
-      } else {
-        e += 64;
-      }
-      if (mb) a_first = (w0 - 1) - (__ffsll((long long)mb) - 1) + 1;
-      else back_open = w0 - 1 - 63 > ilo;        // rows below w0 - 64 are still to be looked at
-      if (!mb && !back_open) a_first = ilo;      // the run reaches the first row of the diagonal
-    }
-    while (!ended && e <= fwd_limit) {
-      const int row = e + lane;
-      const bool bad = row <= fwd_limit && (uint32_t)__popc(sp[row] ^ ldst[B + row + d]) > threshold;
-      const unsigned long long mm = __ballot(bad);
-      if (mm) {
-        e += __ffsll((long long)mm) - 1;
-        ended = true;
-        break;
-      }
-      e += 64;
-    }
-    if (!ended) {
-      if (fwd_limit == w0 + P + W - 1) return;  // the run also covers the next window: it reports the run
-      e = ihi + 1;
-    }
-    const int b = e - 1;
-    int a = a_first >= 0 ? a_first : ilo;
-    int q = back_open ? w0 - 1 - 64 : ilo - 1;   // (nothing left to scan unless the first block was all matches)
-    while (q >= ilo) {
-      const int row = q - lane;
-      const bool bad = row >= ilo && (uint32_t)__popc(sp[row] ^ ldst[B + row + d]) > threshold;
-      const unsigned long long mm = __ballot(bad);
-      if (mm) {
-        a = q - (__ffsll((long long)mm) - 1) + 1;
-        break;
-      }
-      q -= 64;
-    }
-    const int len = b - a + 1;
-    if (len >= min_len && lane == 0) {
-      const uint32_t slot = atomicAdd(count, 1u);
-      if (slot < capacity)
-        runs[slot] = NeedleHipRun{(uint32_t)(lo + g), (uint32_t)b, (uint32_t)(b + d), (uint32_t)len, 0u, 0u};
-    }
-  };
-  // the test of every row of up to 64 queued survivors, one per lane, then the resolution of those that match whole
-  auto verify = [&](const int first, const int cnt) {
-    wave_lds_fence_search();
-    bool whole = false;
-    int w0 = 0, d = 0, g = 0;
-    if (lane < cnt) {
-      const uint32_t e = queue[first + lane];
-      int k = (int)(e >> 16);
-      const int j = (int)(e & 0xFFFFu);
-      g = member_of(k);
-      k -= first_row(g);
-      const uint32_t *__restrict__ sp = source_of(g);
-      w0 = 1 + k * P;
-      d = j - w0;
-      uint32_t miss = 0u;
-#pragma unroll
-      for (int s = 0; s < W; s++) miss |= (uint32_t)((uint32_t)__popc(sp[w0 + s] ^ ldst[B + j + s]) > threshold);
-      whole = miss == 0u;
-    }
-    unsigned long long cand = __ballot(whole);
-    while (cand) {
-      const int src_lane = __ffsll((long long)cand) - 1;
-      cand &= cand - 1;
-      resolve(__shfl(w0, src_lane), __shfl(d, src_lane), __builtin_amdgcn_readfirstlane(__shfl(g, src_lane)));
-    }
-  };
-
-  mfma_v16i presets;
-#pragma unroll
-  for (int q = 0; q < 16; q++) presets[q] = preset;
-  int qn = 0;  // wave-uniform: survivors waiting in this wave's queue (< 64 at the start of a tile)
-  auto load_a = [&](const int rt, mfma_v4i (&fa)[H]) {
-    const mfma_v4i *img = reinterpret_cast<const mfma_v4i *>(aimg + (size_t)min(32 * rt + r, nW) * kMfmaPitch + 4 * h);
-#pragma unroll
-    for (int kb = 0; kb < H; kb++) fa[kb] = img[2 * kb];
-  };
-  for (int cb = first_cb; cb < col_blocks; cb += stride_cb) {
-    const int j = 32 * cb + r;                   // this lane's column = destination position
-    const bool col_ok = j >= 1 && j <= last_j;
-    // lane (r, h): half h of dst[j + s] for the H head rows s, as +-1 bytes, four bits at a time through a table of 16
-    // words (16 banks: lanes that ask for different entries never collide, equal ones are one broadcast; the 256-entry
-    // byte table's 8-byte reads lost three LDS cycles in four to bank conflicts -- tools/scan_mfma_counters.sh -- and the
-    // same expansion on the vector ALU, v_perm_b32 on spread selector bits, costs four instructions a word instead of two)
-    mfma_v4i fb[H];
-#pragma unroll
-    for (int kb = 0; kb < H; kb++) {
-      const uint32_t half = ldst[B + j + head_row(kb, W, H)] >> (16 * h);
-#pragma unroll
-      for (int q = 0; q < 4; q++) fb[kb][q] = (int)ntab[(half >> (4 * q)) & 0xFu];
-    }
-    // a tile: a product per head row (K = 32 each), each preset to -(32 - 2 t) -- its sign bit is clear exactly where that
-    // row's cell matches; a window-diagonal survives iff the OR of the H results is non-negative
-    auto tile = [&](const mfma_v4i (&fa)[H], const int rt) {
-      asm volatile("" : "+v"(presets));          // stays in its 16 registers (otherwise re-built from scalars for every tile)
-      mfma_v16i u = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0], fb[0], presets, 0, 0, 0);
-#pragma unroll
-      for (int kb = 1; kb < H; kb++) u |= __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[kb], fb[kb], presets, 0, 0, 0);
-      // survivors are rare (~0.05 % of the results): the registers are ANDed in four groups of four (a group's AND is
-      // non-negative iff one of its registers is), the groups into one word, and only a group that holds one is looked at
-      int grp[4];
-#pragma unroll
-      for (int g = 0; g < 4; g++) grp[g] = (u[4 * g] & u[4 * g + 1]) & (u[4 * g + 2] & u[4 * g + 3]);
-      const int all = (grp[0] & grp[1]) & (grp[2] & grp[3]);
-      if (__ballot(all >= 0 && col_ok) == 0ull) return;  // (wave-uniform) no survivor in this tile: the usual case
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        if (__ballot(grp[g] >= 0 && col_ok) == 0ull) continue;  // wave-uniform
-#pragma unroll
-        for (int q = 4 * g; q < 4 * g + 4; q++) {
-          const bool pass = u[q] >= 0 && col_ok;
-          const unsigned long long mask = __ballot(pass);
-          if (mask != 0ull) {                    // wave-uniform
-            if (pass) {
-              const int k = 32 * rt + (q & 3) + 8 * (q >> 2) + 4 * h;
-              const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-              queue[qn + (int)before] = ((uint32_t)k << 16) | (uint32_t)j;
-            }
-            qn += (int)__popcll(mask);
-          }
-        }
-        while (qn >= 64) {                       // (a group adds at most 256 to the < 64 that were waiting) the newest 64
-          verify(qn - 64, 64);                   // leave; what stays is below them
-          qn -= 64;
-        }
-      }
-    };
-    // two row tiles per turn, their A fragments in two register sets: one is read from the image while the other is multiplied
-    mfma_v4i fa0[H], fa1[H];
-    load_a(0, fa0);
-    int rt = 0;
-#pragma unroll 1
-    for (; rt + 1 < row_tiles; rt += 2) {
-      load_a(rt + 1, fa1);
-      tile(fa0, rt);
-      load_a(min(rt + 2, row_tiles - 1), fa0);
-      tile(fa1, rt + 1);
-    }
-    if (rt < row_tiles) tile(fa0, rt);
-  }
-  if (qn > 0) verify(0, qn);
-}
 
 #include "scan_mfma_kernel.h"
 
@@ -944,7 +646,7 @@ struct SearchPlan {
   uint64_t blocks = 0;
   size_t lds_bytes = 0;
   bool sampled = false, fast = false, mfma = false;
-  int mfma_form = 0, mfma_waves = 0, mfma_chain = 0, mfma_splits = 1;  // form 2 (scan_mfma_kernel.h): workgroup shape, accumulator chains, workgroups per group
+  int mfma_waves = 0, mfma_splits = 1;      // scan_mfma_kernel.h: waves per workgroup, workgroups per group
   uint64_t mfma_products = 0;                 // v_mfma instructions a launch of the matrix-pipe form issues
   int bands_per_wave = 1;
   bool valid = false;
@@ -1009,19 +711,21 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     auto same_group = [](const SearchProblem &a, const SearchProblem &b) {
       return a.dst_off == b.dst_off && a.m == b.m && a.min_len == b.min_len;
     };
-    // The matrix-pipe forms give neighbours of the (sorted) table that share destination and minimum length to ONE workgroup
-    // while its LDS still lets the intended number of workgroups share a CU.  Form 1 (round 4): up to four sources, three
-    // workgroups of four waves per CU (53 760 bytes: 42 LDS granules of 1280; a workgroup of 53 776 bytes ran two to a CU
-    // and a fifth slower).  Form 2 (scan_mfma_kernel.h): up to eight sources, 12 / waves workgroups per CU.
-    const int form = mode[5], waves = mode[6];
-    const size_t group_budget = form == 2 ? (waves == 4 ? 53760 : waves == 8 ? 81920 : 163840) : 53760;
-    const size_t max_members = form == 2 ? (size_t)kM2Members : (size_t)kMfmaMembers;
-    auto group_need = [&](const SearchProblem &a, uint64_t windows) {
-      return form == 2 ? m2_lds_words(a.m, windows, waves) * sizeof(uint32_t)
-                       : ((size_t)a.m + 2 * kBandB + mfma_extra_words_for(windows)) * sizeof(uint32_t);
-    };
+    // The matrix-pipe form gives neighbours of the (sorted) table that share destination and minimum length to ONE
+    // workgroup -- up to eight sources -- while its LDS still lets the intended number of workgroups share a CU (LDS comes
+    // in granules of 1280 bytes: 53 760 is a third of a CU's, 81 920 half).
+    const int waves = mode[6];
+    const size_t group_budget = waves == 4 ? 53760 : waves == 8 ? 81920 : 163840;
+    const size_t max_members = (size_t)kM2Members;
+    auto group_need = [&](const SearchProblem &a, uint64_t windows) { return m2_lds_words(a.m, windows, waves) * sizeof(uint32_t); };
     bool mfma = sampled && mode[4] == 1;
-    const bool candidate = sampled && (mode[4] == 1 || (mode[4] == 2 && meta.size() >= (size_t)kDeviceEpiloguePairs));
+    // From how many sequence pairs: the matrix-pipe kernel is the faster KERNEL from ~2000 pairs of 24-minute windows up
+    // (0.13 against 0.14 ms at 2016, 0.19 / 0.32 at 4950, 0.31 / 0.62 at 9730, 0.46 / 0.84 at 16 290), but inside a pipelined
+    // job the scan runs beside the next job's first pass, where the vector form's small workgroups fit the holes better:
+    // jobs of 9730 pairs take 3.8 (vector) against 4.2 ms, of 16 290 pairs 5.9 against 5.0.  So: a call with nothing beside
+    // it (mode[5]) from 2048 pairs, a job from 16 384.
+    const size_t mfma_from = mode[5] ? 2048 : (size_t)kDeviceEpiloguePairs;
+    const bool candidate = sampled && (mode[4] == 1 || (mode[4] == 2 && meta.size() >= mfma_from));
     if (candidate) {  // the table sorted by destination (the runs carry the index of their own entry: its order is free)
       std::stable_sort(meta.begin(), meta.end(), [](const SearchProblem &a, const SearchProblem &b) {
         if (a.dst_off != b.dst_off) return a.dst_off < b.dst_off;
@@ -1070,17 +774,17 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
         groups++;
       }
     }
-    // form 2: the index of group G's first entry rides in the pad field of the table's G-th entry (bits 8 .. 30), so a
-    // workgroup finds its group with one load
-    if (mfma && form == 2) {
+    // the index of group G's first entry rides in the pad field of the table's G-th entry (bits 8 .. 30), so a workgroup
+    // finds its group with one load
+    if (mfma) {
       if (staged >= ((size_t)1 << 23)) return Status::Make(NeedleError_InvalidArgument, "hamming_runs: too many problems for one launch");
       size_t g = 0;
       for (size_t i = 0; i < staged; i++)
         if (!(meta[i].pad & 0x80000000u)) meta[g++].pad |= (uint32_t)i << 8;
     }
-    // form 2: one workgroup per group; a launch of few groups splits each over several workgroups (column units strided)
+    // one workgroup per group; a launch of few groups splits each over several workgroups (column units strided)
     int splits = 1;
-    if (mfma && form == 2 && groups > 0) {
+    if (mfma && groups > 0) {
       const uint64_t slots = (uint64_t)device_cus() * (uint64_t)(waves == 4 ? 3 : waves == 8 ? 2 : 1);
       splits = (int)std::min<uint64_t>(8, std::max<uint64_t>(1, (2 * slots + groups - 1) / groups));
       if (const char *e = getenv("NEEDLE_HIP_MFMA_SPLITS")) splits = std::max(1, std::min(64, atoi(e)));  // tests, tuning
@@ -1100,7 +804,7 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
         const uint64_t diags = (uint64_t)m.n + m.m - 3;
         const uint64_t bands = (diags + kBandB - 1) / kBandB;
         const uint64_t per_block = 4 * (uint64_t)(sampled ? bands_per_wave : 1);
-        fb += mfma && form == 2 ? (uint64_t)splits : (bands + per_block - 1) / per_block;
+        fb += mfma ? (uint64_t)splits : (bands + per_block - 1) / per_block;
         if (mfma) {
           uint64_t windows = windows_of(m);
           for (uint32_t f = 1; f <= (m.pad & 0xFFu); f++) windows += windows_of(meta[i + f]);
@@ -1138,14 +842,12 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
         for (uint32_t f = 1; f <= (m.pad & 0xFFu); f++) w += windows_of(meta[i + f]);
         if (w > 0 && m.m >= (uint32_t)kSampleW + 1) {
           uint64_t col_blocks = ((uint64_t)m.m - kSampleW) / 32 + 1;
-          if (form == 2) col_blocks = (col_blocks + kM2ColBlocks - 1) / kM2ColBlocks * kM2ColBlocks;  // whole units are multiplied
-          plan->mfma_products += (w + 31) / 32 * col_blocks * kMfmaHeads;
+          col_blocks = (col_blocks + kM2ColBlocks - 1) / kM2ColBlocks * kM2ColBlocks;  // whole units are multiplied
+          plan->mfma_products += (w + 31) / 32 * col_blocks * kM2Heads;
         }
       }
     plan->fast = fast;
-    plan->mfma_form = mfma ? form : 0;
     plan->mfma_waves = waves;
-    plan->mfma_chain = mode[7];
     plan->mfma_splits = splits;
     plan->bands_per_wave = bands_per_wave;
     plan->lds_bytes = lds_bytes;
@@ -1168,20 +870,16 @@ int mfma_request(uint32_t threshold) {
   return atoi(e) != 0 ? 1 : 0;
 }
 
-// Which matrix-pipe form and in which shape (measurements; the defaults are what won, profiles/NOTES.md round 5):
-// NEEDLE_HIP_MFMA_FORM 1 = round 4's kernel, 2 = scan_mfma_kernel.h; NEEDLE_HIP_MFMA_WAVES 4 / 8 / 12 / 16 waves per
-// workgroup (3 / 2 / 1 / 1 workgroups per CU; 8 and 16: four waves per SIMD, one accumulator pair).
-struct MfmaShape {
-  int form = 2, waves = 8, chain = 2;
-};
-MfmaShape mfma_shape() {
-  MfmaShape sh;
-  if (const char *e = getenv("NEEDLE_HIP_MFMA_FORM")) sh.form = atoi(e) == 1 ? 1 : 2;
+// The matrix-pipe form's workgroup shape (measurements; the default is what won, profiles/NOTES.md round 5):
+// NEEDLE_HIP_MFMA_WAVES 4 / 8 / 12 / 16 waves per workgroup (3 / 2 / 1 / 1 workgroups per CU; 8 and 16: four waves per
+// SIMD, one accumulator pair).
+int mfma_waves() {
+  int waves = 8;
   if (const char *e = getenv("NEEDLE_HIP_MFMA_WAVES")) {
     const int w = atoi(e);
-    if (w == 4 || w == 8 || w == 12 || w == 16) sh.waves = w;
+    if (w == 4 || w == 8 || w == 12 || w == 16) waves = w;
   }
-  return sh;
+  return waves;
 }
 using Mfma2Kernel = void (*)(const uint32_t *, const SearchProblem *, int, uint32_t, NeedleHipRun *, uint32_t, uint32_t *, int);
 Mfma2Kernel mfma2_kernel(int waves) {
@@ -1224,17 +922,17 @@ void gpu_scan_last_launch(int32_t *form, uint64_t *matrix_products) {
 
 Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
                                const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
-                               NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync, bool count_is_zero) {
+                               NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync, bool count_is_zero,
+                               bool standalone) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   Status s = ensure_device();
   if (!s.ok()) return s;
   hipStream_t stream = library_stream();
   if (!count_is_zero) NEEDLE_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
-  const MfmaShape shape = mfma_shape();
   const int mode[8] = {getenv("NEEDLE_HIP_GENERIC_SEARCH") != nullptr, getenv("NEEDLE_HIP_BAND_SEARCH") != nullptr,
                        getenv("NEEDLE_HIP_BANDS_PER_WAVE") ? std::max(1, atoi(getenv("NEEDLE_HIP_BANDS_PER_WAVE"))) : 0,
                        threshold > 31u,   // every cell matches at 32: the band / generic kernels take such a launch
-                       mfma_request(threshold), shape.form, shape.waves, shape.chain};
+                       mfma_request(threshold), standalone || sync ? 1 : 0, mfma_waves(), 0};
   SearchWorkspace *ws = workspace();
   SearchPlan &plan = ws->plan;
   const bool reuse = plan.matches(seqs, num_seqs, problems, num_problems, mode);
@@ -1253,8 +951,6 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_kernel<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_band_kernel<kBandR, kBandU>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(hamming_runs_mfma_kernel<kSampleW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       for (int w : {4, 8, 12, 16})
         NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mfma2_kernel(w)),
@@ -1285,14 +981,10 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
           hipLaunchKernelGGL(sampled_kernel<true>(scan_shape()), dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
                              ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,
                              ws->eval_groups);
-        } else if (plan.mfma && plan.mfma_form == 2) {
+        } else if (plan.mfma) {
           hipLaunchKernelGGL(mfma2_kernel(plan.mfma_waves), dim3((uint32_t)blocks), dim3(64 * plan.mfma_waves),
                              lds_bytes, stream, d_hashes, ws->problems.ptr, staged, threshold, d_runs, capacity, d_count,
                              plan.mfma_splits);
-        } else if (plan.mfma) {
-          hipLaunchKernelGGL(hamming_runs_mfma_kernel<kSampleW>, dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
-                             ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,
-                             (unsigned long long *)nullptr);
         } else {
           hipLaunchKernelGGL(sampled_kernel<false>(scan_shape()), dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
                              ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,
@@ -1389,7 +1081,7 @@ Status gpu_search_results_host(const uint32_t *hashes, size_t num_hashes, const 
   for (int attempt = 0; attempt < 2; attempt++) {
     if (!(s = hb->d_runs.reserve(capacity)).ok()) return s;
     s = gpu_hamming_runs_device(hb->d_hashes.ptr, seqs, num_seqs, problems, num_problems, threshold, hb->d_runs.ptr, capacity,
-                                hb->d_count.ptr, false);
+                                hb->d_count.ptr, false, false, true);
     if (!s.ok()) return s;
     // the run count first (one small copy behind the scan): an attempt whose list overflowed is repeated without its
     // epilogue ever running, and the epilogue's workspaces (144 bytes per run, kept for the life of the process) are sized
@@ -1443,7 +1135,7 @@ Status gpu_hamming_runs_host(const uint32_t *hashes, size_t num_hashes, const Ne
   for (int attempt = 0; attempt < 2; attempt++) {
     if (!(s = d_runs.reserve(capacity)).ok()) return s;
     s = gpu_hamming_runs_device(d_hashes.ptr, seqs, num_seqs, problems, num_problems, threshold, d_runs.ptr,
-                                capacity, d_count.ptr, false);
+                                capacity, d_count.ptr, false, false, true);
     if (!s.ok()) return s;
     uint32_t found = 0;
     NEEDLE_HIP_TRY(hipMemcpyAsync(&found, d_count.ptr, sizeof(found), hipMemcpyDeviceToHost, stream));

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Round 5: the scan's matrix-pipe forms against each other at LIBRARY scale on audio-like hashes (tools/library_device.py:
 episodes x minutes generated in HBM, full O(N^2) search), one process per variant.  A variant is a set of environment
-switches (NEEDLE_HIP_MFMA_FORM / _WAVES / _CHAIN, NEEDLE_HIP_SCAN_MFMA=0 for the vector form).  Per variant: scan kernel
+switches (NEEDLE_HIP_MFMA_WAVES, NEEDLE_HIP_SCAN_MFMA=0 for the vector form).  Per variant: scan kernel
 ms (HIP events), job ms, runs and the digest of the complete sorted run list -- which must be the same for all.
 
 usage: python tools/scan_mfma_sweep.py [episodes=600] [minutes=45] [variants=all]
@@ -15,12 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 VARIANTS = {
     "vector": {"NEEDLE_HIP_SCAN_MFMA": "0"},
-    "form1": {"NEEDLE_HIP_MFMA_FORM": "1"},
     "w4": {"NEEDLE_HIP_MFMA_WAVES": "4"},
     "w12": {"NEEDLE_HIP_MFMA_WAVES": "12"},
-    "w6": {"NEEDLE_HIP_MFMA_WAVES": "6"},
     "w8": {"NEEDLE_HIP_MFMA_WAVES": "8"},
     "w16": {"NEEDLE_HIP_MFMA_WAVES": "16"},
+    "w8forced": {"NEEDLE_HIP_MFMA_WAVES": "8", "NEEDLE_HIP_SCAN_MFMA": "1"},    # below the size the automatic choice takes it from
 }
 # laboratory builds (tools/build_variant.sh, wrong results, timing only): <lab>@<variant>, e.g. m2lab1@w12c2
 LAB_DIR = os.path.join(ROOT, "needle_amd", "lib", "ab")

@@ -12,8 +12,8 @@ from collections import defaultdict
 KERNELS = {"stft_chroma32": "stft_chroma32_kernel", "features_cert": "features_classify_cert_kernel", "fixup_items": "fixup_items_kernel",
            "stft_chroma": "stft_chroma_kernel", "fir_norm": "fir_norm_kernel", "features_classify": "features_classify_kernel",
            "classify": "classify_kernel",
-           "hamming_runs_sampled": "hamming_runs_sampled_kernel", "hamming_runs_band": "hamming_runs_band_kernel", "hamming_runs": "hamming_runs_kernel",
-           "simhash_runs": "simhash_runs_kernel"}
+           "hamming_runs_mfma": "hamming_runs_mfma2_kernel", "hamming_runs_sampled": "hamming_runs_sampled_kernel", "hamming_runs_band": "hamming_runs_band_kernel", "hamming_runs": "hamming_runs_kernel",
+           "simhash_runs": "simhash_runs_kernel", "epilogue_entries": "pair_entries_kernel", "epilogue_best_match": "best_match_kernel"}
 
 
 def short(name):
