@@ -15,7 +15,7 @@
 //    (4 + 7), each preset so that its sign bit is SET where the SUM of two rows' distances is <= 2 t, a necessary
 //    condition of "both <= t" (0.20 % of the window-diagonals pass on synthetic audio, 0.05 % the exact head test).
 //    16 + 16 result registers are folded into four words (one per group of four windows) and the four sign bits are
-//    shifted into a per-lane flag word (v_alignbit): 24 vector instructions, no compare, no branch, eight tiles in a
+//    shifted into a per-lane flag word (v_alignbit): 20 vector instructions, no compare, no branch, eight tiles in a
 //    straight line.
 //  * Every eight tiles the flag words become ITEMS = (group of four windows, destination position), handed out one per
 //    lane, 64 at a time, whatever lane flagged them (a position that looks like many windows -- a sustained sound --
@@ -375,8 +375,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     for (int g = 0; g < 4; g++) {
       int a = ua[4 * g] & ub[4 * g];
 #pragma unroll
-      for (int q = 4 * g + 1; q < 4 * g + 4; q++) a = (ua[q] & ub[q]) | a;
-      flags = __builtin_amdgcn_alignbit(flags, (uint32_t)a, 31);
+      for (int q = 4 * g + 1; q < 4 * g + 4; q++) a = __builtin_amdgcn_bitop3_b32(ua[q], ub[q], a, 0xEA);   // (ua & ub) | a: one instruction
+      flags = __builtin_amdgcn_alignbit(flags, (uint32_t)a, 31);  // (written as C the compiler makes it and, and, and, and_or, or3)
     }
   };
 
@@ -446,14 +446,18 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
       fold(a0, b0, flags);
       fold(a1, b1, flags);
     } else {
+      // One accumulator pair, and the compiler held to it: left alone it issues the second tile's products inside the first
+      // tile's fold on a SECOND pair, and at 128 registers that costs B fragments copied and spilled in every turn.
       mfma_v16i a0, b0;
 #pragma unroll 1
       for (int rt = 0; rt + 1 < row_tiles; rt++) {
         products(fa, fb[0], a0, b0);
         fold(a0, b0, flags);
+        __builtin_amdgcn_sched_barrier(0);
         products(fa, fb[1], a0, b0);
         load_a(rt + 1, fa);
         fold(a0, b0, flags);
+        __builtin_amdgcn_sched_barrier(0);
         if ((rt & (kM2Batch - 1)) == kM2Batch - 1) {
 #if !(NEEDLE_M2_LAB & 1)
           enqueue(flags, rt - (kM2Batch - 1), 2 * kM2Batch, j0);
