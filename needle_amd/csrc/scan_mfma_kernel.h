@@ -47,23 +47,78 @@ constexpr int kM2Rows = kSampleW + 2 * kM2Probe;  // source hashes kept per wind
 constexpr int kM2ColBlocks = 2;               // column blocks of 32 positions a wave takes per unit
 constexpr int kM2Batch = 4;                   // row tiles (x 2 column blocks = 8 tiles = 32 flag bits) between two looks at the flags
 constexpr int kM2Queue = 128;                 // items a wave can hold: < 64 waiting + the <= 64 one turn adds
-constexpr int kM2CtlWords = 32;               // [0] unit counter, [1 + g] first row of member g (g = members: all rows), [10 + g] source offset, [18 + g] source length
+constexpr int kM2CtlWords = 48;               // [0] unit counter, [1 + g] first row of member g (g = members: all rows), [10 + g] source offset, [18 + g] source length, [26 + g] first window of its image, [36 + g] (SRC) row 0 of its sequence in LDS
 static_assert((kM2Batch & (kM2Batch - 1)) == 0 && 8 * kM2Batch <= 32, "a batch's flags fill at most one word");
 static_assert(kM2Probe == 4 && kM2Rows == 16, "a window's sixteen source hashes are read as 16-byte words");
 static_assert(kSampleW + 2 * kM2Probe - 2 < 2 * kSampleW - 1 + 8, "a run that ends inside the probed rows must be shorter than any min_len the sampled path takes");
 
 // LDS words of a workgroup: staged destination (+ 64 zeros), tables, per-window source hashes, A image
 __host__ __device__ constexpr size_t m2_round4(size_t x) { return (x + 3) & ~(size_t)3; }
-__host__ __device__ constexpr size_t m2_lds_words(uint64_t m, uint64_t windows, int waves) {
-  return m2_round4(m + 64) + kM2CtlWords + 16 + (size_t)waves * kM2Queue + (size_t)kM2Rows * windows + (size_t)(windows + 1) * kM2Pitch;
+// src_words: 0, or (SRC form) the members' WHOLE sequences in LDS: the sum of m2_src_words(n) -- then no per-window rows
+__host__ __device__ constexpr size_t m2_src_words(uint64_t n) { return m2_round4(n + 8); }   // 4 words in front of the rows, >= 4 behind
+__host__ __device__ constexpr size_t m2_lds_words(uint64_t m, uint64_t windows, int waves, uint64_t src_words = 0) {
+  return m2_round4(m + 64) + kM2CtlWords + 16 + (size_t)waves * kM2Queue + (src_words ? (size_t)src_words : (size_t)kM2Rows * windows) +
+         (size_t)(windows + 1) * kM2Pitch;
+}
+
+// A source sequence's windows as a workgroup wants them in LDS -- per window kM2Pitch words of the A image (its four head
+// hashes as 32 negated +-1 bytes each, then w0) and kM2Rows source hashes around it -- built ONCE per launch in global
+// memory (m2_window_images_kernel) instead of by every workgroup that takes the sequence as a source: at 2000 videos a
+// sequence is a source 1999 times, and gathering + expanding its windows was a tenth of the scan (a workgroup's setup
+// alone: 0.44 of 4.0 ms at 79 800 pairs).  A workgroup copies its members' images with 16-byte loads.
+constexpr int kM2ImageWords = kM2Pitch + kM2Rows;   // per window
+struct M2ImageSeq {
+  uint32_t src_off, n;     // the sequence in the hash arena
+  uint32_t first_window;   // of its image, in windows
+  uint32_t windows;
+};
+template <int W>
+__global__ __launch_bounds__(256) void m2_window_images_kernel(const uint32_t *__restrict__ hashes, const M2ImageSeq *__restrict__ seqs,
+                                                               int num_seqs, uint32_t total_windows, uint32_t min_len,
+                                                               uint32_t *__restrict__ images) {
+  constexpr int H = kM2Heads, PITCH = kM2Pitch, E = kM2Probe, NR = kM2Rows;
+  const uint32_t P = min_len - W + 1;
+  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total_windows * NR; idx += gridDim.x * blockDim.x) {
+    const uint32_t k = idx / NR;
+    const int s = (int)(idx % NR) - E;             // row w0 + s
+    int lo = 0, hi = num_seqs - 1;                 // the sequence whose image holds window k
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (seqs[mid].first_window <= k) lo = mid; else hi = mid - 1;
+    }
+    const M2ImageSeq q = seqs[lo];
+    const uint32_t w0 = 1u + (k - q.first_window) * P;
+    const int row = (int)w0 + s;
+    const uint32_t hsh = row >= 0 && row < (int)q.n ? hashes[q.src_off + (uint32_t)row] : 0u;
+    uint32_t *img = images + (size_t)k * kM2ImageWords;
+    img[PITCH + s + E] = hsh;
+    if (s == 0) img[8 * H] = w0;
+    if (s == 1 || s == 3 || s == 5) img[8 * H + (s + 1) / 2] = 0u;   // (the row's three spare words)
+    if (s == 0 || s == 2 || s == 4 || s == 7) {
+      uint32_t *o = img + 8 * (s == 7 ? 3 : s >> 1);
+#pragma unroll
+      for (int b = 0; b < 8; b++) {
+        const uint32_t nib = (~hsh >> (4 * b)) & 0xFu;   // negated: a set bit becomes -1
+        uint32_t w = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) w |= (((nib >> i) & 1u) ? 0x01u : 0xFFu) << (8 * i);
+        o[b] = w;
+      }
+    }
+  }
 }
 
 // WAVES per workgroup; PER_SIMD waves the registers have to allow on a SIMD (3: up to 168 registers, the tiles software-
 // pipelined over two accumulator pairs; 4: up to 128, one pair, a tile folded before the next is multiplied).
-template <int W, int WAVES, int PER_SIMD>
+// SRC: the members' whole source sequences are staged in LDS beside the destination (a 16-wave workgroup with all of a CU's
+// LDS: 4 sources of 45-minute windows, 8 of 24-minute ones).  The items' exact tests read their rows there, and so does the
+// resolution of real runs -- which otherwise costs its wave a trip to global memory per aligned window the run covers
+// (a sixth of the scan at 79 800 pairs of 45-minute windows, a third at 39 060 pairs of 24-minute ones).
+template <int W, int WAVES, int PER_SIMD, bool SRC>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_SIMD, PER_SIMD))) void hamming_runs_mfma2_kernel(
     const uint32_t *__restrict__ hashes, const SearchProblem *__restrict__ problems, int num_problems, uint32_t threshold,
-    NeedleHipRun *__restrict__ runs, uint32_t capacity, uint32_t *__restrict__ count, int splits) {
+    NeedleHipRun *__restrict__ runs, uint32_t capacity, uint32_t *__restrict__ count, int splits,
+    const uint32_t *__restrict__ images) {
   static_assert(W == 8, "head rows {0, 2, 4, 7} and tail rows {1, 3, 5, 6} of a window of 8");
   constexpr int H = kM2Heads, PITCH = kM2Pitch, CB = kM2ColBlocks, E = kM2Probe, NR = kM2Rows;
   extern __shared__ uint32_t lds[];
@@ -87,16 +142,25 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   uint32_t *ctl = lds + dst_words;
   uint32_t *ntab = ctl + kM2CtlWords;            // 4 bits -> 4 bytes of +-1
   uint32_t *queues = ntab + 16;                  // per wave: items waiting for their exact test
-  uint32_t *wsrc = queues + WAVES * kM2Queue;    // per window: the source hashes of rows w0 - E .. w0 + W + E - 1 (zero where there is none)
-  uint32_t *aimg = wsrc + NR * nW;               // 16-byte aligned: every size above is a multiple of 4 words
+  // per window the source hashes of rows w0 - E .. w0 + W + E - 1 (zero where there is none) -- or, SRC, every member's
+  // whole sequence (4 words of room in front of row 0 and at least 4 behind the last: the probed rows of a window at
+  // either end read there, and what they read is not looked at)
+  uint32_t *wsrc = queues + WAVES * kM2Queue;
+  int src_words = 0;
+  if (SRC)
+    for (int g = 0; g < members; g++) src_words += (int)m2_src_words(problems[lo + g].n);
+  uint32_t *aimg = wsrc + (SRC ? src_words : NR * nW);   // 16-byte aligned: every size above is a multiple of 4 words
 
   if (threadIdx.x == 0) {
     ctl[0] = 0u;
-    int rows = 0;
+    int rows = 0, at = 0;
     for (int g = 0; g < members; g++) {
       ctl[1 + g] = (uint32_t)rows;
       ctl[10 + g] = problems[lo + g].src_off;
       ctl[18 + g] = problems[lo + g].n;
+      ctl[26 + g] = problems[lo + g].block_base;
+      ctl[36 + g] = (uint32_t)at + 4u;            // (SRC) row 0 of member g in wsrc
+      at += (int)m2_src_words(problems[lo + g].n);
       rows += mfma_windows((int)problems[lo + g].n, min_len, W);
     }
     ctl[1 + members] = (uint32_t)rows;
@@ -119,7 +183,42 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     }
     for (; k < dst_words; k += nt) ldst[k] = k < m ? dst[k] : 0u;
   }
+  if (SRC) {                                       // the members' sequences, one after the other
+    int at = 0;
+    for (int g = 0; g < members; g++) {
+      const SearchProblem pg = problems[lo + g];
+      const uint32_t *__restrict__ sp = hashes + pg.src_off;
+      const int n = (int)pg.n, words = (int)m2_src_words(pg.n);
+      for (int k = threadIdx.x; k < words; k += 64 * WAVES) wsrc[at + k] = k >= 4 && k - 4 < n ? sp[k - 4] : 0u;
+      at += words;
+    }
+  }
   __syncthreads();
+  if (images != nullptr) {
+    // the members' window images, built once per launch (m2_window_images_kernel): SearchProblem::block_base of an entry =
+    // first window of its source's image.  16-byte pieces: 9 of a window's A-image row, 4 of its source hashes.
+    constexpr int kPieces = SRC ? PITCH / 4 : kM2ImageWords / 4;   // (SRC: the rows come from the staged sequences)
+    static_assert(kM2ImageWords % 4 == 0 && PITCH % 4 == 0, "");
+    constexpr int kU = 4;                         // pieces in flight per thread
+    for (int base = threadIdx.x; base < nW * kPieces; base += kU * 64 * WAVES) {
+      mfma_v4i v[kU];
+      uint32_t *to[kU];
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        const int idx = min(base + u * 64 * WAVES, nW * kPieces - 1);
+        const int k = idx / kPieces, piece = idx % kPieces;
+        int g = 0;
+        for (int i = 1; i < members; i++) g += (uint32_t)k >= ctl[1 + i] ? 1 : 0;
+        const uint32_t from = ctl[26 + g] + ((uint32_t)k - ctl[1 + g]);
+        v[u] = *reinterpret_cast<const mfma_v4i *>(images + (size_t)from * kM2ImageWords + 4 * piece);
+        if (piece == PITCH / 4 - 1) v[u][0] |= (int)((uint32_t)g << 28);   // w0 -> member << 28 | w0
+        to[u] = piece < PITCH / 4 ? aimg + k * PITCH + 4 * piece : wsrc + NR * k + 4 * (piece - PITCH / 4);
+      }
+#pragma unroll
+      for (int u = 0; u < kU; u++)
+        if (base + u * 64 * WAVES < nW * kPieces) *reinterpret_cast<mfma_v4i *>(to[u]) = v[u];
+    }
+  } else {
   // The windows' source hashes and the A image: one thread per (window, one of its NR rows), four windows per turn with
   // their four loads in flight together (a workgroup of 24-minute windows spent as long here, one dependent trip to
   // global memory per window, as on its tiles).  64 WAVES is a multiple of NR: a thread keeps its row s.
@@ -143,7 +242,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
       for (int u = 0; u < kU; u++) {
         const int k = k0 + u * kStep;
         if (k >= nW) break;
-        wsrc[NR * k + s + E] = hv[u];
+        if (!SRC) wsrc[NR * k + s + E] = hv[u];
         if (s == 0) aimg[k * PITCH + 8 * H] = wm[u];
         if (s == 0 || s == 2 || s == 4 || s == 7) {                  // head rows 0 .. 3
           uint32_t *o = aimg + k * PITCH + 8 * (s == 7 ? 3 : s >> 1);
@@ -152,6 +251,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         }
       }
     }
+  }
   }
   for (int q = threadIdx.x; q < PITCH; q += 64 * WAVES) aimg[nW * PITCH + q] = 0u;  // the row the last tile reads beyond the last window
   __syncthreads();
@@ -181,7 +281,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   // goes further back is followed 256 rows per trip.  (Measured and dropped: collecting such windows and resolving four
   // per trip -- the arrays of the four went to scratch memory and the kernel took 1.4 x as long.)
   auto resolve = [&](const int w0, const int d, const int g) {  // (wave-uniform arguments)
-    const uint32_t *__restrict__ sp = hashes + __builtin_amdgcn_readfirstlane(ctl[10 + g]);
+    const uint32_t *__restrict__ sp = hashes + __builtin_amdgcn_readfirstlane(ctl[10 + g]);   // (!SRC)
+    const uint32_t *lrow = wsrc + __builtin_amdgcn_readfirstlane(ctl[36 + g]);                 // (SRC) the member's rows in LDS
     const int ns = (int)__builtin_amdgcn_readfirstlane(ctl[18 + g]);
     const int ilo = d < 0 ? 1 - d : 1;
     const int ihi = min(ns - 1, m - 1 - d);
@@ -189,7 +290,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     const int fwd_limit = min(ihi, w0 + P + W - 1);  // last row of the NEXT aligned window
     auto bad_at = [&](const int row, const bool in) {  // does row `row` of the diagonal mismatch?  (false outside `in`)
       const int rr = in ? row : w0;
-      return in && (uint32_t)__popc(sp[rr] ^ ldst[rr + d]) > threshold;
+      return in && (uint32_t)__popc((SRC ? lrow[rr] : sp[rr]) ^ ldst[rr + d]) > threshold;
     };
     int e = w0 + W;
     bool ended = false;
@@ -272,10 +373,18 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int k = min(kbase + i, nW - 1);
-        const mfma_v4i lo4 = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E);       // rows 0 .. 3 of the window
-        const mfma_v4i hi4 = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E + 4);   // rows 4 .. 7
-        const uint32_t miss = ((uint32_t)__popc((uint32_t)lo4[0] ^ d0) + bias) | ((uint32_t)__popc((uint32_t)lo4[2] ^ d2) + bias) |
-                              ((uint32_t)__popc((uint32_t)hi4[0] ^ d4) + bias) | ((uint32_t)__popc((uint32_t)hi4[3] ^ d7) + bias);
+        uint32_t s0, s2, s4, s7;                  // the window's head rows
+        if (SRC) {
+          const uint32_t wm = aimg[k * PITCH + 8 * H];
+          const uint32_t *row = wsrc + ctl[36 + (wm >> 28)] + (wm & 0x0FFFFFFFu);
+          s0 = row[0], s2 = row[2], s4 = row[4], s7 = row[7];
+        } else {
+          const mfma_v4i lo4 = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E);       // rows 0 .. 3 of the window
+          const mfma_v4i hi4 = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E + 4);   // rows 4 .. 7
+          s0 = (uint32_t)lo4[0], s2 = (uint32_t)lo4[2], s4 = (uint32_t)hi4[0], s7 = (uint32_t)hi4[3];
+        }
+        const uint32_t miss = ((uint32_t)__popc(s0 ^ d0) + bias) | ((uint32_t)__popc(s2 ^ d2) + bias) |
+                              ((uint32_t)__popc(s4 ^ d4) + bias) | ((uint32_t)__popc(s7 ^ d7) + bias);
         passm |= (miss < 32u && kbase + i < nW) ? 1u << i : 0u;
       }
     }
@@ -290,27 +399,25 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
       int w0 = 0, d = 0, g = 0;
       if ((passm >> i) & 1u) {
         const int k = kbase + i;
-        const mfma_v4i lo4 = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E);
-        const mfma_v4i hi4 = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E + 4);
-        const uint32_t miss = ((uint32_t)__popc((uint32_t)lo4[1] ^ ldst[j + 1]) + bias) | ((uint32_t)__popc((uint32_t)lo4[3] ^ ldst[j + 3]) + bias) |
-                              ((uint32_t)__popc((uint32_t)hi4[1] ^ ldst[j + 5]) + bias) | ((uint32_t)__popc((uint32_t)hi4[2] ^ ldst[j + 6]) + bias);
+        const uint32_t wm = aimg[k * PITCH + 8 * H];
+        g = (int)(wm >> 28);
+        w0 = (int)(wm & 0x0FFFFFFFu);
+        d = j - w0;
+        // the window's 16 rows w0 - E .. w0 + W + E - 1: a copy per window, or (SRC) where they lie in the member's sequence
+        const uint32_t *rows = SRC ? wsrc + ctl[36 + g] + w0 - E : wsrc + NR * k;
+        const uint32_t miss = ((uint32_t)__popc(rows[E + 1] ^ ldst[j + 1]) + bias) | ((uint32_t)__popc(rows[E + 3] ^ ldst[j + 3]) + bias) |
+                              ((uint32_t)__popc(rows[E + 5] ^ ldst[j + 5]) + bias) | ((uint32_t)__popc(rows[E + 6] ^ ldst[j + 6]) + bias);
         if (miss < 32u) {
-          const uint32_t wm = aimg[k * PITCH + 8 * H];
-          g = (int)(wm >> 28);
-          w0 = (int)(wm & 0x0FFFFFFFu);
-          d = j - w0;
           const int ns = (int)ctl[18 + g];
           const int ilo = d < 0 ? 1 - d : 1;
           const int ihi = min(ns - 1, m - 1 - d);
           if (w0 >= ilo && w0 + W - 1 <= ihi) {   // window inside the table on this diagonal (resolve()'s first test)
-            const mfma_v4i before = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k);            // rows w0 - E .. w0 - 1
-            const mfma_v4i after = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E + W);     // rows w0 + W .. w0 + W + E - 1
             bool f_end = false, b_end = false;    // the run ends inside the probed rows: a mismatch there, or the table's edge
 #pragma unroll
             for (int e = 0; e < E; e++) {
               const int fr = w0 + W + e, br = w0 - E + e;
-              f_end |= fr > ihi || (uint32_t)__popc((uint32_t)after[e] ^ ldst[min(fr, ihi) + d]) > threshold;
-              b_end |= br < ilo || (uint32_t)__popc((uint32_t)before[e] ^ ldst[max(br, ilo) + d]) > threshold;
+              f_end |= fr > ihi || (uint32_t)__popc(rows[E + W + e] ^ ldst[min(fr, ihi) + d]) > threshold;
+              b_end |= br < ilo || (uint32_t)__popc(rows[e] ^ ldst[max(br, ilo) + d]) > threshold;
             }
             whole = !(f_end && b_end);            // ended on both sides: at most W + 2 E - 2 rows, below every min_len of this path
           }

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 
 namespace needle {
 
@@ -647,6 +648,8 @@ struct SearchPlan {
   size_t lds_bytes = 0;
   bool sampled = false, fast = false, mfma = false;
   int mfma_waves = 0, mfma_splits = 1;      // scan_mfma_kernel.h: waves per workgroup, workgroups per group
+  std::vector<M2ImageSeq> image_seqs;       // ... and the source sequences whose window images a pre-pass builds (empty: workgroups build their own)
+  uint32_t image_windows = 0, image_min_len = 0;
   uint64_t mfma_products = 0;                 // v_mfma instructions a launch of the matrix-pipe form issues
   int bands_per_wave = 1;
   bool valid = false;
@@ -717,7 +720,11 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     const int waves = mode[6];
     const size_t group_budget = waves == 4 ? 53760 : waves == 8 ? 81920 : 163840;
     const size_t max_members = (size_t)kM2Members;
-    auto group_need = [&](const SearchProblem &a, uint64_t windows) { return m2_lds_words(a.m, windows, waves) * sizeof(uint32_t); };
+    const bool src_in_lds = waves == 16 && !(getenv("NEEDLE_HIP_MFMA_SRC") && atoi(getenv("NEEDLE_HIP_MFMA_SRC")) == 0);  // the SRC form: the members' whole sequences staged beside the destination
+    auto group_need = [&](const SearchProblem &a, uint64_t windows, uint64_t src_words) {
+      return m2_lds_words(a.m, windows, waves, src_in_lds ? src_words : 0) * sizeof(uint32_t);
+    };
+    auto src_words_of = [&](const SearchProblem &m) { return src_in_lds ? (uint64_t)m2_src_words(m.n) : (uint64_t)0; };
     bool mfma = sampled && mode[4] == 1;
     // From how many sequence pairs: the matrix-pipe kernel is the faster KERNEL from ~2000 pairs of 24-minute windows up
     // (0.13 against 0.14 ms at 2016, 0.19 / 0.32 at 4950, 0.31 / 0.62 at 9730, 0.46 / 0.84 at 16 290), but inside a pipelined
@@ -735,10 +742,12 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
       if (!mfma) {  // automatic: where the windows of a group fill at least 70 % of its row tiles of 32
         uint64_t windows = 0, rows = 0;
         for (size_t i = 0; i < meta.size(); i++) {
-          uint64_t w = windows_of(meta[i]);
+          uint64_t w = windows_of(meta[i]), sw = src_words_of(meta[i]);
           for (size_t k = 1; k < max_members && i + 1 < meta.size() && same_group(meta[i], meta[i + 1]) &&
-                             group_need(meta[i], w + windows_of(meta[i + 1])) <= group_budget; k++)
+                             group_need(meta[i], w + windows_of(meta[i + 1]), sw + src_words_of(meta[i + 1])) <= group_budget; k++) {
             w += windows_of(meta[++i]);
+            sw += src_words_of(meta[i]);
+          }
           windows += w;
           rows += (w + 31) / 32 * 32;
         }
@@ -746,7 +755,7 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
       }
     }
     auto lds_need = [&](const SearchProblem &m) {
-      if (mfma) return group_need(m, windows_of(m));
+      if (mfma) return group_need(m, windows_of(m), src_words_of(m));
       return ((fast || sampled) ? (size_t)m.m + 2 * kBandB : (size_t)m.n + m.m) * sizeof(uint32_t);
     };
     std::stable_partition(meta.begin(), meta.end(), [&](const SearchProblem &m) { return lds_need(m) <= lds_limit; });
@@ -761,11 +770,13 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
       for (size_t i = 0; i < staged;) {
         SearchProblem &a = meta[i];
         a.pad = 0;
-        uint64_t windows = windows_of(a);
+        uint64_t windows = windows_of(a), sw = src_words_of(a);
         size_t k = 1;
         while (!single && k < max_members && i + k < staged && same_group(a, meta[i + k]) &&
-               windows + windows_of(meta[i + k]) < 65536 && group_need(a, windows + windows_of(meta[i + k])) <= group_budget) {
+               windows + windows_of(meta[i + k]) < 65536 &&
+               group_need(a, windows + windows_of(meta[i + k]), sw + src_words_of(meta[i + k])) <= group_budget) {
           windows += windows_of(meta[i + k]);
+          sw += src_words_of(meta[i + k]);
           meta[i + k].pad = 0x80000000u;
           k++;
         }
@@ -806,9 +817,12 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
         const uint64_t per_block = 4 * (uint64_t)(sampled ? bands_per_wave : 1);
         fb += mfma ? (uint64_t)splits : (bands + per_block - 1) / per_block;
         if (mfma) {
-          uint64_t windows = windows_of(m);
-          for (uint32_t f = 1; f <= (m.pad & 0xFFu); f++) windows += windows_of(meta[i + f]);
-          lds_bytes = std::max(lds_bytes, group_need(m, windows));
+          uint64_t windows = windows_of(m), sw = src_words_of(m);
+          for (uint32_t f = 1; f <= (m.pad & 0xFFu); f++) {
+            windows += windows_of(meta[i + f]);
+            sw += src_words_of(meta[i + f]);
+          }
+          lds_bytes = std::max(lds_bytes, group_need(m, windows, sw));
         } else {
           lds_bytes = std::max(lds_bytes, lds_need(m));
         }
@@ -846,6 +860,36 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
           plan->mfma_products += (w + 31) / 32 * col_blocks * kM2Heads;
         }
       }
+    // The matrix-pipe form's window images (scan_mfma_kernel.h): one per distinct source sequence, when the launch has ONE
+    // minimum length (a library of equal-length videos; otherwise the window positions differ per pair and workgroups
+    // build their own).  block_base of a staged entry -- not read by that kernel otherwise -- = first window of its source's image.
+    plan->image_seqs.clear();
+    plan->image_windows = plan->image_min_len = 0;
+    if (mfma && staged > 0 && !getenv("NEEDLE_HIP_MFMA_NO_IMAGES")) {
+      bool one = true;
+      for (size_t i = 1; i < staged && one; i++) one = meta[i].min_len == meta[0].min_len;
+      if (one) {
+        std::unordered_map<uint64_t, uint32_t> first_of;   // (src_off, n) -> first window
+        uint64_t total = 0;
+        for (size_t i = 0; i < staged; i++) {
+          const uint64_t key = ((uint64_t)meta[i].src_off << 32) | meta[i].n;
+          auto it = first_of.find(key);
+          if (it == first_of.end()) {
+            const uint32_t w = (uint32_t)windows_of(meta[i]);
+            it = first_of.emplace(key, (uint32_t)total).first;
+            plan->image_seqs.push_back(M2ImageSeq{meta[i].src_off, meta[i].n, (uint32_t)total, w});
+            total += w;
+          }
+          meta[i].block_base = it->second;
+        }
+        if (total == 0 || total * kM2ImageWords * sizeof(uint32_t) > ((uint64_t)1 << 31)) {
+          plan->image_seqs.clear();           // (nothing to build, or more than 2 GB of images: built in place)
+        } else {
+          plan->image_windows = (uint32_t)total;
+          plan->image_min_len = meta[0].min_len;
+        }
+      }
+    }
     plan->fast = fast;
     plan->mfma_waves = waves;
     plan->mfma_splits = splits;
@@ -881,10 +925,11 @@ int mfma_waves() {
   }
   return waves;
 }
-using Mfma2Kernel = void (*)(const uint32_t *, const SearchProblem *, int, uint32_t, NeedleHipRun *, uint32_t, uint32_t *, int);
+using Mfma2Kernel = void (*)(const uint32_t *, const SearchProblem *, int, uint32_t, NeedleHipRun *, uint32_t, uint32_t *, int, const uint32_t *);
 Mfma2Kernel mfma2_kernel(int waves) {
-  return waves == 4 ? hamming_runs_mfma2_kernel<kSampleW, 4, 3> : waves == 16 ? hamming_runs_mfma2_kernel<kSampleW, 16, 4>
-       : waves == 12 ? hamming_runs_mfma2_kernel<kSampleW, 12, 3> : hamming_runs_mfma2_kernel<kSampleW, 8, 4>;
+  if (waves == 16 && getenv("NEEDLE_HIP_MFMA_SRC") && atoi(getenv("NEEDLE_HIP_MFMA_SRC")) == 0) return hamming_runs_mfma2_kernel<kSampleW, 16, 4, false>;
+  return waves == 4 ? hamming_runs_mfma2_kernel<kSampleW, 4, 3, false> : waves == 16 ? hamming_runs_mfma2_kernel<kSampleW, 16, 4, true>
+       : waves == 12 ? hamming_runs_mfma2_kernel<kSampleW, 12, 3, false> : hamming_runs_mfma2_kernel<kSampleW, 8, 4, false>;
 }
 
 std::atomic<int32_t> g_last_form{0};
@@ -895,6 +940,10 @@ struct SearchWorkspace {
   PinnedStage stage;
   DescriptorUpload<SearchProblem> upload;
   SearchPlan plan;            // of the last launch
+  DeviceBuffer<M2ImageSeq> image_seqs;   // matrix-pipe form: the sequences whose window images the pre-pass builds ...
+  PinnedStage image_stage;
+  DescriptorUpload<M2ImageSeq> image_upload;
+  DeviceBuffer<uint32_t> images;         // ... and the images
   bool lds_attr_set = false;  // > 64 KiB of dynamic LDS needs an explicit opt-in, per device
   unsigned long long *eval_groups = nullptr;  // device; NEEDLE_HIP_SCAN_COUNT=1 launches add to it
 };
@@ -982,9 +1031,19 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
                              ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,
                              ws->eval_groups);
         } else if (plan.mfma) {
+          const uint32_t *images = nullptr;
+          if (!plan.image_seqs.empty()) {   // the sources' window images, once per launch (the hashes are this job's)
+            if (!(s = ws->image_upload.put(&ws->image_seqs, &ws->image_stage, plan.image_seqs, stream)).ok() ||
+                !(s = ws->images.reserve((size_t)plan.image_windows * kM2ImageWords)).ok())
+              return s;
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(8192, ((uint64_t)plan.image_windows * kM2Rows + 255) / 256);
+            hipLaunchKernelGGL(m2_window_images_kernel<kSampleW>, dim3(grid), dim3(256), 0, stream, d_hashes, ws->image_seqs.ptr,
+                               (int)plan.image_seqs.size(), plan.image_windows, plan.image_min_len, ws->images.ptr);
+            images = ws->images.ptr;
+          }
           hipLaunchKernelGGL(mfma2_kernel(plan.mfma_waves), dim3((uint32_t)blocks), dim3(64 * plan.mfma_waves),
                              lds_bytes, stream, d_hashes, ws->problems.ptr, staged, threshold, d_runs, capacity, d_count,
-                             plan.mfma_splits);
+                             plan.mfma_splits, images);
         } else {
           hipLaunchKernelGGL(sampled_kernel<false>(scan_shape()), dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
                              ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,
