@@ -47,18 +47,15 @@ constexpr int kM2Rows = kSampleW + 2 * kM2Probe;  // source hashes kept per wind
 constexpr int kM2ColBlocks = 2;               // column blocks of 32 positions a wave takes per unit
 constexpr int kM2Batch = 4;                   // row tiles (x 2 column blocks = 8 tiles = 32 flag bits) between two looks at the flags
 constexpr int kM2Queue = 128;                 // items a wave can hold: < 64 waiting + the <= 64 one turn adds
-constexpr int kM2CtlWords = 48;               // [0] unit counter, [1 + g] first row of member g (g = members: all rows), [10 + g] source offset, [18 + g] source length, [26 + g] first window of its image, [36 + g] (SRC) row 0 of its sequence in LDS
+constexpr int kM2CtlWords = 36;               // [0] unit counter, [1 + g] first row of member g (g = members: all rows), [10 + g] source offset, [18 + g] source length, [26 + g] first window of its image
 static_assert((kM2Batch & (kM2Batch - 1)) == 0 && 8 * kM2Batch <= 32, "a batch's flags fill at most one word");
 static_assert(kM2Probe == 4 && kM2Rows == 16, "a window's sixteen source hashes are read as 16-byte words");
 static_assert(kSampleW + 2 * kM2Probe - 2 < 2 * kSampleW - 1 + 8, "a run that ends inside the probed rows must be shorter than any min_len the sampled path takes");
 
 // LDS words of a workgroup: staged destination (+ 64 zeros), tables, per-window source hashes, A image
 __host__ __device__ constexpr size_t m2_round4(size_t x) { return (x + 3) & ~(size_t)3; }
-// src_words: 0, or (SRC form) the members' WHOLE sequences in LDS: the sum of m2_src_words(n) -- then no per-window rows
-__host__ __device__ constexpr size_t m2_src_words(uint64_t n) { return m2_round4(n + 8); }   // 4 words in front of the rows, >= 4 behind
-__host__ __device__ constexpr size_t m2_lds_words(uint64_t m, uint64_t windows, int waves, uint64_t src_words = 0) {
-  return m2_round4(m + 64) + kM2CtlWords + 16 + (size_t)waves * kM2Queue + (src_words ? (size_t)src_words : (size_t)kM2Rows * windows) +
-         (size_t)(windows + 1) * kM2Pitch;
+__host__ __device__ constexpr size_t m2_lds_words(uint64_t m, uint64_t windows, int waves) {
+  return m2_round4(m + 64) + kM2CtlWords + 16 + (size_t)waves * kM2Queue + (size_t)kM2Rows * windows + (size_t)(windows + 1) * kM2Pitch;
 }
 
 // A source sequence's windows as a workgroup wants them in LDS -- per window kM2Pitch words of the A image (its four head
@@ -110,11 +107,11 @@ __global__ __launch_bounds__(256) void m2_window_images_kernel(const uint32_t *_
 
 // WAVES per workgroup; PER_SIMD waves the registers have to allow on a SIMD (3: up to 168 registers, the tiles software-
 // pipelined over two accumulator pairs; 4: up to 128, one pair, a tile folded before the next is multiplied).
-// SRC: the members' whole source sequences are staged in LDS beside the destination (a 16-wave workgroup with all of a CU's
-// LDS: 4 sources of 45-minute windows, 8 of 24-minute ones).  The items' exact tests read their rows there, and so does the
-// resolution of real runs -- which otherwise costs its wave a trip to global memory per aligned window the run covers
-// (a sixth of the scan at 79 800 pairs of 45-minute windows, a third at 39 060 pairs of 24-minute ones).
-template <int W, int WAVES, int PER_SIMD, bool SRC>
+// (Measured and dropped, commit d27d279: a 16-wave form with the members' WHOLE source sequences staged in LDS, so that the
+// resolution of real runs never leaves the CU -- half as many sources per workgroup and their staging cost more than the
+// trips to global memory it saved: 4.59 against 3.89 ms at 79 800 pairs of 45-minute windows, 1.13 against 0.98 at 39 060
+// pairs of 24-minute ones.)
+template <int W, int WAVES, int PER_SIMD>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_SIMD, PER_SIMD))) void hamming_runs_mfma2_kernel(
     const uint32_t *__restrict__ hashes, const SearchProblem *__restrict__ problems, int num_problems, uint32_t threshold,
     NeedleHipRun *__restrict__ runs, uint32_t capacity, uint32_t *__restrict__ count, int splits,
@@ -142,25 +139,18 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   uint32_t *ctl = lds + dst_words;
   uint32_t *ntab = ctl + kM2CtlWords;            // 4 bits -> 4 bytes of +-1
   uint32_t *queues = ntab + 16;                  // per wave: items waiting for their exact test
-  // per window the source hashes of rows w0 - E .. w0 + W + E - 1 (zero where there is none) -- or, SRC, every member's
-  // whole sequence (4 words of room in front of row 0 and at least 4 behind the last: the probed rows of a window at
-  // either end read there, and what they read is not looked at)
+  // per window the source hashes of rows w0 - E .. w0 + W + E - 1 (zero where there is none)
   uint32_t *wsrc = queues + WAVES * kM2Queue;
-  int src_words = 0;
-  if (SRC)
-    for (int g = 0; g < members; g++) src_words += (int)m2_src_words(problems[lo + g].n);
-  uint32_t *aimg = wsrc + (SRC ? src_words : NR * nW);   // 16-byte aligned: every size above is a multiple of 4 words
+  uint32_t *aimg = wsrc + NR * nW;               // 16-byte aligned: every size above is a multiple of 4 words
 
   if (threadIdx.x == 0) {
     ctl[0] = 0u;
-    int rows = 0, at = 0;
+    int rows = 0;
     for (int g = 0; g < members; g++) {
       ctl[1 + g] = (uint32_t)rows;
       ctl[10 + g] = problems[lo + g].src_off;
       ctl[18 + g] = problems[lo + g].n;
       ctl[26 + g] = problems[lo + g].block_base;
-      ctl[36 + g] = (uint32_t)at + 4u;            // (SRC) row 0 of member g in wsrc
-      at += (int)m2_src_words(problems[lo + g].n);
       rows += mfma_windows((int)problems[lo + g].n, min_len, W);
     }
     ctl[1 + members] = (uint32_t)rows;
@@ -183,21 +173,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     }
     for (; k < dst_words; k += nt) ldst[k] = k < m ? dst[k] : 0u;
   }
-  if (SRC) {                                       // the members' sequences, one after the other
-    int at = 0;
-    for (int g = 0; g < members; g++) {
-      const SearchProblem pg = problems[lo + g];
-      const uint32_t *__restrict__ sp = hashes + pg.src_off;
-      const int n = (int)pg.n, words = (int)m2_src_words(pg.n);
-      for (int k = threadIdx.x; k < words; k += 64 * WAVES) wsrc[at + k] = k >= 4 && k - 4 < n ? sp[k - 4] : 0u;
-      at += words;
-    }
-  }
   __syncthreads();
   if (images != nullptr) {
     // the members' window images, built once per launch (m2_window_images_kernel): SearchProblem::block_base of an entry =
     // first window of its source's image.  16-byte pieces: 9 of a window's A-image row, 4 of its source hashes.
-    constexpr int kPieces = SRC ? PITCH / 4 : kM2ImageWords / 4;   // (SRC: the rows come from the staged sequences)
+    constexpr int kPieces = kM2ImageWords / 4;
     static_assert(kM2ImageWords % 4 == 0 && PITCH % 4 == 0, "");
     constexpr int kU = 4;                         // pieces in flight per thread
     for (int base = threadIdx.x; base < nW * kPieces; base += kU * 64 * WAVES) {
@@ -242,7 +222,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
       for (int u = 0; u < kU; u++) {
         const int k = k0 + u * kStep;
         if (k >= nW) break;
-        if (!SRC) wsrc[NR * k + s + E] = hv[u];
+        wsrc[NR * k + s + E] = hv[u];
         if (s == 0) aimg[k * PITCH + 8 * H] = wm[u];
         if (s == 0 || s == 2 || s == 4 || s == 7) {                  // head rows 0 .. 3
           uint32_t *o = aimg + k * PITCH + 8 * (s == 7 ? 3 : s >> 1);
@@ -281,27 +261,32 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   // goes further back is followed 256 rows per trip.  (Measured and dropped: collecting such windows and resolving four
   // per trip -- the arrays of the four went to scratch memory and the kernel took 1.4 x as long.)
   auto resolve = [&](const int w0, const int d, const int g) {  // (wave-uniform arguments)
-    const uint32_t *__restrict__ sp = hashes + __builtin_amdgcn_readfirstlane(ctl[10 + g]);   // (!SRC)
-    const uint32_t *lrow = wsrc + __builtin_amdgcn_readfirstlane(ctl[36 + g]);                 // (SRC) the member's rows in LDS
+    const uint32_t *__restrict__ sp = hashes + __builtin_amdgcn_readfirstlane(ctl[10 + g]);
     const int ns = (int)__builtin_amdgcn_readfirstlane(ctl[18 + g]);
     const int ilo = d < 0 ? 1 - d : 1;
     const int ihi = min(ns - 1, m - 1 - d);
     if (w0 < ilo || w0 + W - 1 > ihi) return;
     const int fwd_limit = min(ihi, w0 + P + W - 1);  // last row of the NEXT aligned window
-    auto bad_at = [&](const int row, const bool in) {  // does row `row` of the diagonal mismatch?  (false outside `in`)
+    // Does row `row` of the diagonal mismatch?  (false outside `in`)  The load is UNCONDITIONAL (of row w0 outside `in`) and
+    // the result combined without a branch: written as `in && ...` every row's load sat in a branch of its own behind
+    // the wait for the previous one -- four trips to global memory instead of one.
+    auto cell_at = [&](const int row, const bool in) {
       const int rr = in ? row : w0;
-      return in && (uint32_t)__popc((SRC ? lrow[rr] : sp[rr]) ^ ldst[rr + d]) > threshold;
+      return sp[rr] ^ ldst[rr + d];
     };
+    auto bad = [&](const uint32_t x, const bool in) { return (int)in & (int)((uint32_t)__popc(x) > threshold); };
     int e = w0 + W;
     bool ended = false;
     int a = -1;                                   // first row of the run, once known
     int q = w0 - 1;                               // next row to look at going back
     {
       const int f0 = e + lane, f1 = e + 64 + lane, b0 = q - lane, b1 = q - 64 - lane;
-      const bool xf0 = bad_at(f0, f0 <= fwd_limit), xf1 = bad_at(f1, f1 <= fwd_limit);
-      const bool xb0 = bad_at(b0, b0 >= ilo), xb1 = bad_at(b1, b1 >= ilo);
-      const unsigned long long mf0 = __builtin_amdgcn_ballot_w64(xf0), mf1 = __builtin_amdgcn_ballot_w64(xf1);
-      const unsigned long long mb0 = __builtin_amdgcn_ballot_w64(xb0), mb1 = __builtin_amdgcn_ballot_w64(xb1);
+      const uint32_t cf0 = cell_at(f0, f0 <= fwd_limit), cf1 = cell_at(f1, f1 <= fwd_limit);
+      const uint32_t cb0 = cell_at(b0, b0 >= ilo), cb1 = cell_at(b1, b1 >= ilo);
+      const unsigned long long mf0 = __builtin_amdgcn_ballot_w64(bad(cf0, f0 <= fwd_limit) != 0);
+      const unsigned long long mf1 = __builtin_amdgcn_ballot_w64(bad(cf1, f1 <= fwd_limit) != 0);
+      const unsigned long long mb0 = __builtin_amdgcn_ballot_w64(bad(cb0, b0 >= ilo) != 0);
+      const unsigned long long mb1 = __builtin_amdgcn_ballot_w64(bad(cb1, b1 >= ilo) != 0);
       if (mf0) {
         e += __ffsll((long long)mf0) - 1;
         ended = true;
@@ -318,7 +303,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     }
     while (!ended && e <= fwd_limit) {            // (only when P > 120)
       const int row = e + lane;
-      const unsigned long long mm = __builtin_amdgcn_ballot_w64(bad_at(row, row <= fwd_limit));
+      const unsigned long long mm = __builtin_amdgcn_ballot_w64(bad(cell_at(row, row <= fwd_limit), row <= fwd_limit) != 0);
       if (mm) {
         e += __ffsll((long long)mm) - 1;
         ended = true;
@@ -333,8 +318,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     const int b = e - 1;
     while (a < 0) {                               // rows q, q - 1, ... still to be looked at, 256 per trip
       unsigned long long mm[4];
+      uint32_t cell[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) mm[i] = __builtin_amdgcn_ballot_w64(bad_at(q - 64 * i - lane, q - 64 * i - lane >= ilo));
+      for (int i = 0; i < 4; i++) cell[i] = cell_at(q - 64 * i - lane, q - 64 * i - lane >= ilo);
+#pragma unroll
+      for (int i = 0; i < 4; i++) mm[i] = __builtin_amdgcn_ballot_w64(bad(cell[i], q - 64 * i - lane >= ilo) != 0);
       int hit = -1;
 #pragma unroll
       for (int i = 3; i >= 0; i--)
@@ -373,16 +361,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int k = min(kbase + i, nW - 1);
-        uint32_t s0, s2, s4, s7;                  // the window's head rows
-        if (SRC) {
-          const uint32_t wm = aimg[k * PITCH + 8 * H];
-          const uint32_t *row = wsrc + ctl[36 + (wm >> 28)] + (wm & 0x0FFFFFFFu);
-          s0 = row[0], s2 = row[2], s4 = row[4], s7 = row[7];
-        } else {
-          const mfma_v4i lo4 = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E);       // rows 0 .. 3 of the window
-          const mfma_v4i hi4 = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E + 4);   // rows 4 .. 7
-          s0 = (uint32_t)lo4[0], s2 = (uint32_t)lo4[2], s4 = (uint32_t)hi4[0], s7 = (uint32_t)hi4[3];
-        }
+        const mfma_v4i lo4 = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E);       // rows 0 .. 3 of the window
+        const mfma_v4i hi4 = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E + 4);   // rows 4 .. 7
+        const uint32_t s0 = (uint32_t)lo4[0], s2 = (uint32_t)lo4[2], s4 = (uint32_t)hi4[0], s7 = (uint32_t)hi4[3];
         const uint32_t miss = ((uint32_t)__popc(s0 ^ d0) + bias) | ((uint32_t)__popc(s2 ^ d2) + bias) |
                               ((uint32_t)__popc(s4 ^ d4) + bias) | ((uint32_t)__popc(s7 ^ d7) + bias);
         passm |= (miss < 32u && kbase + i < nW) ? 1u << i : 0u;
@@ -403,8 +384,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         g = (int)(wm >> 28);
         w0 = (int)(wm & 0x0FFFFFFFu);
         d = j - w0;
-        // the window's 16 rows w0 - E .. w0 + W + E - 1: a copy per window, or (SRC) where they lie in the member's sequence
-        const uint32_t *rows = SRC ? wsrc + ctl[36 + g] + w0 - E : wsrc + NR * k;
+        const uint32_t *rows = wsrc + NR * k;     // the window's 16 rows w0 - E .. w0 + W + E - 1
         const uint32_t miss = ((uint32_t)__popc(rows[E + 1] ^ ldst[j + 1]) + bias) | ((uint32_t)__popc(rows[E + 3] ^ ldst[j + 3]) + bias) |
                               ((uint32_t)__popc(rows[E + 5] ^ ldst[j + 5]) + bias) | ((uint32_t)__popc(rows[E + 6] ^ ldst[j + 6]) + bias);
         if (miss < 32u) {

@@ -720,11 +720,7 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     const int waves = mode[6];
     const size_t group_budget = waves == 4 ? 53760 : waves == 8 ? 81920 : 163840;
     const size_t max_members = (size_t)kM2Members;
-    const bool src_in_lds = waves == 16 && !(getenv("NEEDLE_HIP_MFMA_SRC") && atoi(getenv("NEEDLE_HIP_MFMA_SRC")) == 0);  // the SRC form: the members' whole sequences staged beside the destination
-    auto group_need = [&](const SearchProblem &a, uint64_t windows, uint64_t src_words) {
-      return m2_lds_words(a.m, windows, waves, src_in_lds ? src_words : 0) * sizeof(uint32_t);
-    };
-    auto src_words_of = [&](const SearchProblem &m) { return src_in_lds ? (uint64_t)m2_src_words(m.n) : (uint64_t)0; };
+    auto group_need = [&](const SearchProblem &a, uint64_t windows) { return m2_lds_words(a.m, windows, waves) * sizeof(uint32_t); };
     bool mfma = sampled && mode[4] == 1;
     // From how many sequence pairs: the matrix-pipe kernel is the faster KERNEL from ~2000 pairs of 24-minute windows up
     // (0.13 against 0.14 ms at 2016, 0.19 / 0.32 at 4950, 0.31 / 0.62 at 9730, 0.46 / 0.84 at 16 290), but inside a pipelined
@@ -742,12 +738,10 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
       if (!mfma) {  // automatic: where the windows of a group fill at least 70 % of its row tiles of 32
         uint64_t windows = 0, rows = 0;
         for (size_t i = 0; i < meta.size(); i++) {
-          uint64_t w = windows_of(meta[i]), sw = src_words_of(meta[i]);
+          uint64_t w = windows_of(meta[i]);
           for (size_t k = 1; k < max_members && i + 1 < meta.size() && same_group(meta[i], meta[i + 1]) &&
-                             group_need(meta[i], w + windows_of(meta[i + 1]), sw + src_words_of(meta[i + 1])) <= group_budget; k++) {
+                             group_need(meta[i], w + windows_of(meta[i + 1])) <= group_budget; k++)
             w += windows_of(meta[++i]);
-            sw += src_words_of(meta[i]);
-          }
           windows += w;
           rows += (w + 31) / 32 * 32;
         }
@@ -755,7 +749,7 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
       }
     }
     auto lds_need = [&](const SearchProblem &m) {
-      if (mfma) return group_need(m, windows_of(m), src_words_of(m));
+      if (mfma) return group_need(m, windows_of(m));
       return ((fast || sampled) ? (size_t)m.m + 2 * kBandB : (size_t)m.n + m.m) * sizeof(uint32_t);
     };
     std::stable_partition(meta.begin(), meta.end(), [&](const SearchProblem &m) { return lds_need(m) <= lds_limit; });
@@ -770,13 +764,12 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
       for (size_t i = 0; i < staged;) {
         SearchProblem &a = meta[i];
         a.pad = 0;
-        uint64_t windows = windows_of(a), sw = src_words_of(a);
+        uint64_t windows = windows_of(a);
         size_t k = 1;
         while (!single && k < max_members && i + k < staged && same_group(a, meta[i + k]) &&
                windows + windows_of(meta[i + k]) < 65536 &&
-               group_need(a, windows + windows_of(meta[i + k]), sw + src_words_of(meta[i + k])) <= group_budget) {
+               group_need(a, windows + windows_of(meta[i + k])) <= group_budget) {
           windows += windows_of(meta[i + k]);
-          sw += src_words_of(meta[i + k]);
           meta[i + k].pad = 0x80000000u;
           k++;
         }
@@ -817,12 +810,9 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
         const uint64_t per_block = 4 * (uint64_t)(sampled ? bands_per_wave : 1);
         fb += mfma ? (uint64_t)splits : (bands + per_block - 1) / per_block;
         if (mfma) {
-          uint64_t windows = windows_of(m), sw = src_words_of(m);
-          for (uint32_t f = 1; f <= (m.pad & 0xFFu); f++) {
-            windows += windows_of(meta[i + f]);
-            sw += src_words_of(meta[i + f]);
-          }
-          lds_bytes = std::max(lds_bytes, group_need(m, windows, sw));
+          uint64_t windows = windows_of(m);
+          for (uint32_t f = 1; f <= (m.pad & 0xFFu); f++) windows += windows_of(meta[i + f]);
+          lds_bytes = std::max(lds_bytes, group_need(m, windows));
         } else {
           lds_bytes = std::max(lds_bytes, lds_need(m));
         }
@@ -927,9 +917,8 @@ int mfma_waves() {
 }
 using Mfma2Kernel = void (*)(const uint32_t *, const SearchProblem *, int, uint32_t, NeedleHipRun *, uint32_t, uint32_t *, int, const uint32_t *);
 Mfma2Kernel mfma2_kernel(int waves) {
-  if (waves == 16 && getenv("NEEDLE_HIP_MFMA_SRC") && atoi(getenv("NEEDLE_HIP_MFMA_SRC")) == 0) return hamming_runs_mfma2_kernel<kSampleW, 16, 4, false>;
-  return waves == 4 ? hamming_runs_mfma2_kernel<kSampleW, 4, 3, false> : waves == 16 ? hamming_runs_mfma2_kernel<kSampleW, 16, 4, true>
-       : waves == 12 ? hamming_runs_mfma2_kernel<kSampleW, 12, 3, false> : hamming_runs_mfma2_kernel<kSampleW, 8, 4, false>;
+  return waves == 4 ? hamming_runs_mfma2_kernel<kSampleW, 4, 3> : waves == 16 ? hamming_runs_mfma2_kernel<kSampleW, 16, 4>
+       : waves == 12 ? hamming_runs_mfma2_kernel<kSampleW, 12, 3> : hamming_runs_mfma2_kernel<kSampleW, 8, 4>;
 }
 
 std::atomic<int32_t> g_last_form{0};
