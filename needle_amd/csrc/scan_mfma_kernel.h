@@ -36,18 +36,28 @@
 // Operand maps of the instruction: tools/mfma_i8_layout.hip.  Needs t <= 15.
 #ifndef NEEDLE_M2_LAB
 #define NEEDLE_M2_LAB 0                       // timing laboratory (tools/build_variant.sh), WRONG results: 1 flags ignored (the tile loop
-                                              // alone), 2 head survivors dropped, 64 a workgroup's setup alone
+                                              // alone), 2 head survivors dropped, 4 whole windows not resolved, 8 event counts, 16 a resolution's trip and no more, 32 a walk ends at its first mismatch, 64 a workgroup's setup alone
+#endif
+#if NEEDLE_M2_LAB & 8   // laboratory: event counts (search.hip prints them after the launch)
+__device__ unsigned long long m2_dbg[8];
+#define M2_COUNT(i) do { if (lane == 0) atomicAdd(&m2_dbg[i], 1ull); } while (0)
+#define M2_COUNT_LANES(i, n) atomicAdd(&m2_dbg[i], (unsigned long long)(n))
+#else
+#define M2_COUNT(i) do { } while (0)
+#define M2_COUNT_LANES(i, n) do { } while (0)
 #endif
 constexpr int kM2Heads = 4;
 constexpr int kM2Members = 8;                 // sources a workgroup takes at most (of one destination)
-constexpr int kM2Pitch = kM2Heads * 8 + 4;    // words of a window's row in the A image: 4 x 32 bytes of +-1, the window's member << 28 | w0, 3 spare
-                                              // (36: lanes 32 words apart would all meet in two groups of LDS banks)
+constexpr int kM2Pitch = kM2Heads * 4 + 4;    // words of a window's row in the A image: 4 x 32 FP4 nibbles of +-1, the window's member << 28 | w0, 3 spare
+                                              // (20: sixteen lanes' 16-byte reads of one instruction fall into sixteen different groups of four banks)
+constexpr int kM2RunBuf = 64;                 // runs a workgroup collects in LDS before it asks for room in the run list (one atomic)
+constexpr int kM2Table = 256;                 // a byte of hash bits -> its eight FP4 nibbles (bit set: +1 = 0x2, clear: -1 = 0xA)
 constexpr int kM2Probe = 4;                   // rows tested per lane on either side of a whole window
 constexpr int kM2Rows = kSampleW + 2 * kM2Probe;  // source hashes kept per window: rows w0 - 4 .. w0 + 11
 constexpr int kM2ColBlocks = 2;               // column blocks of 32 positions a wave takes per unit
 constexpr int kM2Batch = 4;                   // row tiles (x 2 column blocks = 8 tiles = 32 flag bits) between two looks at the flags
 constexpr int kM2Queue = 128;                 // items a wave can hold: < 64 waiting + the <= 64 one turn adds
-constexpr int kM2CtlWords = 36;               // [0] unit counter, [1 + g] first row of member g (g = members: all rows), [10 + g] source offset, [18 + g] source length, [26 + g] first window of its image
+constexpr int kM2CtlWords = 36;               // [0] unit counter, [1 + g] first row of member g (g = members: all rows), [10 + g] source offset, [18 + g] source length, [26 + g] first window of its image, [34] runs collected, [35] their first slot in the run list
 static_assert((kM2Batch & (kM2Batch - 1)) == 0 && 8 * kM2Batch <= 32, "a batch's flags fill at most one word");
 static_assert(kM2Probe == 4 && kM2Rows == 16, "a window's sixteen source hashes are read as 16-byte words");
 static_assert(kSampleW + 2 * kM2Probe - 2 < 2 * kSampleW - 1 + 8, "a run that ends inside the probed rows must be shorter than any min_len the sampled path takes");
@@ -55,7 +65,8 @@ static_assert(kSampleW + 2 * kM2Probe - 2 < 2 * kSampleW - 1 + 8, "a run that en
 // LDS words of a workgroup: staged destination (+ 64 zeros), tables, per-window source hashes, A image
 __host__ __device__ constexpr size_t m2_round4(size_t x) { return (x + 3) & ~(size_t)3; }
 __host__ __device__ constexpr size_t m2_lds_words(uint64_t m, uint64_t windows, int waves) {
-  return m2_round4(m + 64) + kM2CtlWords + 16 + (size_t)waves * kM2Queue + (size_t)kM2Rows * windows + (size_t)(windows + 1) * kM2Pitch;
+  return m2_round4(m + 64) + kM2CtlWords + kM2Table + 4 * kM2RunBuf + (size_t)waves * kM2Queue + (size_t)kM2Rows * windows +
+         (size_t)(windows + 1) * kM2Pitch;
 }
 
 // A source sequence's windows as a workgroup wants them in LDS -- per window kM2Pitch words of the A image (its four head
@@ -64,6 +75,12 @@ __host__ __device__ constexpr size_t m2_lds_words(uint64_t m, uint64_t windows, 
 // sequence is a source 1999 times, and gathering + expanding its windows was a tenth of the scan (a workgroup's setup
 // alone: 0.44 of 4.0 ms at 79 800 pairs).  A workgroup copies its members' images with 16-byte loads.
 constexpr int kM2ImageWords = kM2Pitch + kM2Rows;   // per window
+// the eight low bits of x as FP4 (e2m1) nibbles: bit i set -> +1.0 (0x2), clear -> -1.0 (0xA), in nibble i
+__host__ __device__ constexpr uint32_t m2_nibbles(uint32_t x) {
+  uint32_t w = 0;
+  for (int i = 0; i < 8; i++) w |= (((x >> i) & 1u) ? 0x2u : 0xAu) << (4 * i);
+  return w;
+}
 struct M2ImageSeq {
   uint32_t src_off, n;     // the sequence in the hash arena
   uint32_t first_window;   // of its image, in windows
@@ -89,18 +106,12 @@ __global__ __launch_bounds__(256) void m2_window_images_kernel(const uint32_t *_
     const uint32_t hsh = row >= 0 && row < (int)q.n ? hashes[q.src_off + (uint32_t)row] : 0u;
     uint32_t *img = images + (size_t)k * kM2ImageWords;
     img[PITCH + s + E] = hsh;
-    if (s == 0) img[8 * H] = w0;
-    if (s == 1 || s == 3 || s == 5) img[8 * H + (s + 1) / 2] = 0u;   // (the row's three spare words)
+    if (s == 0) img[4 * H] = w0;
+    if (s == 1 || s == 3 || s == 5) img[4 * H + (s + 1) / 2] = 0u;   // (the row's three spare words)
     if (s == 0 || s == 2 || s == 4 || s == 7) {
-      uint32_t *o = img + 8 * (s == 7 ? 3 : s >> 1);
+      uint32_t *o = img + 4 * (s == 7 ? 3 : s >> 1);
 #pragma unroll
-      for (int b = 0; b < 8; b++) {
-        const uint32_t nib = (~hsh >> (4 * b)) & 0xFu;   // negated: a set bit becomes -1
-        uint32_t w = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) w |= (((nib >> i) & 1u) ? 0x01u : 0xFFu) << (8 * i);
-        o[b] = w;
-      }
+      for (int b = 0; b < 4; b++) o[b] = m2_nibbles(~hsh >> (8 * b));   // negated: a set bit becomes -1
     }
   }
 }
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     NeedleHipRun *__restrict__ runs, uint32_t capacity, uint32_t *__restrict__ count, int splits,
     const uint32_t *__restrict__ images) {
   static_assert(W == 8, "head rows {0, 2, 4, 7} and tail rows {1, 3, 5, 6} of a window of 8");
-  constexpr int H = kM2Heads, PITCH = kM2Pitch, CB = kM2ColBlocks, E = kM2Probe, NR = kM2Rows;
+  constexpr int H = kM2Heads, HP = H / 2, PITCH = kM2Pitch, CB = kM2ColBlocks, E = kM2Probe, NR = kM2Rows;
   extern __shared__ uint32_t lds[];
   __builtin_amdgcn_s_setprio(3);
   // Which group: workgroup / splits.  Its first entry's index lies in the pad field (bits 8 .. 30) of the table entry whose
@@ -137,14 +148,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   const int dst_words = (int)m2_round4((size_t)m + 64);
   uint32_t *ldst = lds;                          // ldst[j] = dst[j], zeros behind
   uint32_t *ctl = lds + dst_words;
-  uint32_t *ntab = ctl + kM2CtlWords;            // 4 bits -> 4 bytes of +-1
-  uint32_t *queues = ntab + 16;                  // per wave: items waiting for their exact test
+  uint32_t *ntab = ctl + kM2CtlWords;            // 8 bits -> 8 nibbles of +-1
+  uint32_t *runbuf = ntab + kM2Table;            // the workgroup's runs: (pair, last row, last column, length)
+  uint32_t *queues = runbuf + 4 * kM2RunBuf;     // per wave: items waiting for their exact test
   // per window the source hashes of rows w0 - E .. w0 + W + E - 1 (zero where there is none)
   uint32_t *wsrc = queues + WAVES * kM2Queue;
   uint32_t *aimg = wsrc + NR * nW;               // 16-byte aligned: every size above is a multiple of 4 words
 
   if (threadIdx.x == 0) {
     ctl[0] = 0u;
+    ctl[34] = 0u;
     int rows = 0;
     for (int g = 0; g < members; g++) {
       ctl[1 + g] = (uint32_t)rows;
@@ -155,11 +168,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     }
     ctl[1 + members] = (uint32_t)rows;
   }
-  if (threadIdx.x < 16) {
-    uint32_t w = 0;
-    for (int i = 0; i < 4; i++) w |= (((threadIdx.x >> i) & 1) ? 0x01u : 0xFFu) << (8 * i);
-    ntab[threadIdx.x] = w;
-  }
+  static_assert(64 * WAVES >= kM2Table, "");
+  if (threadIdx.x < kM2Table) ntab[threadIdx.x] = m2_nibbles(threadIdx.x);
   {
     constexpr int kU = 4;
     const int nt = 64 * WAVES;
@@ -223,11 +233,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         const int k = k0 + u * kStep;
         if (k >= nW) break;
         wsrc[NR * k + s + E] = hv[u];
-        if (s == 0) aimg[k * PITCH + 8 * H] = wm[u];
+        if (s == 0) aimg[k * PITCH + 4 * H] = wm[u];
         if (s == 0 || s == 2 || s == 4 || s == 7) {                  // head rows 0 .. 3
-          uint32_t *o = aimg + k * PITCH + 8 * (s == 7 ? 3 : s >> 1);
+          uint32_t *o = aimg + k * PITCH + 4 * (s == 7 ? 3 : s >> 1);
 #pragma unroll
-          for (int q = 0; q < 8; q++) o[q] = ntab[(~hv[u] >> (4 * q)) & 0xFu];   // negated: a set bit becomes -1
+          for (int q = 0; q < 4; q++) o[q] = ntab[(~hv[u] >> (8 * q)) & 0xFFu];   // negated: a set bit becomes -1
         }
       }
     }
@@ -253,93 +263,155 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   const int units = (col_blocks + CB - 1) / CB;
   const int b_in_group = (int)(blockIdx.x - (uint32_t)group * (uint32_t)splits);
 
-  // Exact resolution of one window whose W cells all match on diagonal d, by the whole wave: the same function of the same
-  // cells as the vector form's resolve(), read differently.  The source sequence lies in global memory and a trip there
-  // costs a wave microseconds, so one trip fetches two rows per lane in EACH direction: the 128 rows behind the window
-  // reach the end of the next aligned window whenever P <= 120 (the usual case: one trip decides whether the run goes on
-  // into the next window, which then reports it), and 128 rows in front of it end most runs that stop here; a run that
-  // goes further back is followed 256 rows per trip.  (Measured and dropped: collecting such windows and resolving four
-  // per trip -- the arrays of the four went to scratch memory and the kernel took 1.4 x as long.)
-  auto resolve = [&](const int w0, const int d, const int g) {  // (wave-uniform arguments)
-    const uint32_t *__restrict__ sp = hashes + __builtin_amdgcn_readfirstlane(ctl[10 + g]);
+  const uint32_t p_magic = (uint32_t)(0xFFFFFFFFull / (uint32_t)P);   // ~ 2^32 / P from below (P >= W: the host takes this path from min_len >= 2 W - 1)
+  const uint32_t bias = 31u - (uint32_t)t;        // popcount + bias has bit 5 set exactly when the cell does NOT match
+  // Is window k (member g, first row w0) WHOLE at destination position j: inside the table on its diagonal, its W cells all
+  // match, and its run does not end inside the kM2Probe rows on BOTH sides (such a run has at most W + 2 E - 2 rows, below
+  // every min_len this path takes)?  All from LDS, asked by the whole wave about ONE window (wave-uniform arguments): lane
+  // s < 16 looks at row w0 - E + s.  One predicate for three askers who must agree: a window about itself, about its
+  // successor, and the walk below about the windows it passes.  (Run per lane by 64 lanes in step it was 0.33 of the scan's
+  // 1.0 ms at 39 060 pairs.)
+  auto window_whole_wave = [&](const int k, const int g, const int w0, const int j) __attribute__((always_inline)) {
+    const int d = j - w0;
     const int ns = (int)__builtin_amdgcn_readfirstlane(ctl[18 + g]);
     const int ilo = d < 0 ? 1 - d : 1;
     const int ihi = min(ns - 1, m - 1 - d);
+    const int row = w0 - E + (lane & (NR - 1));
+    const bool in = row >= ilo && row <= ihi;
+    const bool is_bad = !in || (uint32_t)__popc(wsrc[NR * k + (lane & (NR - 1))] ^ ldst[min(max(row, ilo), ihi) + d]) > threshold;
+    const uint32_t mask = (uint32_t)__builtin_amdgcn_ballot_w64(is_bad) & 0xFFFFu;
+    constexpr uint32_t kWindow = ((1u << W) - 1u) << E, kBelow = (1u << E) - 1u, kAbove = kBelow << (E + W);
+    return (mask & kWindow) == 0u && !((mask & kBelow) != 0u && (mask & kAbove) != 0u);
+  };
+
+  // Exact resolution, by the whole wave, of a CHAIN: consecutive aligned windows of one member, all whole on diagonal d.
+  // Only the chain's LAST window (the one whose successor is not whole) comes here; the others do nothing -- they used to
+  // spend a trip to global memory each on finding out that the run goes on into the next window, and with two runs of
+  // five windows per pair those trips were 0.43 of 0.97 ms at 39 060 pairs of 24-minute windows.  From the last window the
+  // wave follows the diagonal forward to the run's end, then backward: every maximal stretch of matching cells of at
+  // least min_len rows is a run (the same function of the same cells as the table walk, comparator.rs:178-236).  At a
+  // mismatch in row x the walk is over -- unless x lies in the GAP above an aligned window that is whole: that window
+  // has left its run to its successor's chain, that is to this walk, which goes on below x.  (A mismatch INSIDE an aligned
+  // window: the window is not whole, so the one below it is the last of a chain of its own.)
+  // A trip fetches eight rows per lane backward (and the first one two forward): a 90-second run is two trips.
+  auto resolve = [&](const int w0, const int d, const int g) __attribute__((always_inline)) {  // (wave-uniform arguments)
+    const uint32_t *__restrict__ sp = hashes + __builtin_amdgcn_readfirstlane(ctl[10 + g]);
+    const int ns = (int)__builtin_amdgcn_readfirstlane(ctl[18 + g]);
+    const int kg = (int)__builtin_amdgcn_readfirstlane(ctl[1 + g]);   // the member's first window
+    const int ilo = d < 0 ? 1 - d : 1;
+    const int ihi = min(ns - 1, m - 1 - d);
     if (w0 < ilo || w0 + W - 1 > ihi) return;
-    const int fwd_limit = min(ihi, w0 + P + W - 1);  // last row of the NEXT aligned window
-    // Does row `row` of the diagonal mismatch?  (false outside `in`)  The load is UNCONDITIONAL (of row w0 outside `in`) and
-    // the result combined without a branch: written as `in && ...` every row's load sat in a branch of its own behind
-    // the wait for the previous one -- four trips to global memory instead of one.
+    M2_COUNT(0);
+#if NEEDLE_M2_LAB & 4    // laboratory: whole windows found, none resolved
+    if (threshold < (1u << 20)) return;
+#endif
+    // The cell of row `row` (of row w0 outside `in`): the load is UNCONDITIONAL and the result combined without a branch.
+    // Written as `in && ...` every row's load sat in a branch of its own behind the wait for the previous one -- a trip each.
     auto cell_at = [&](const int row, const bool in) {
       const int rr = in ? row : w0;
-      return sp[rr] ^ ldst[rr + d];
+      return sp[(uint32_t)rr] ^ ldst[rr + d];     // (unsigned: one address register per load beside the scalar base)
     };
-    auto bad = [&](const uint32_t x, const bool in) { return (int)in & (int)((uint32_t)__popc(x) > threshold); };
-    int e = w0 + W;
-    bool ended = false;
-    int a = -1;                                   // first row of the run, once known
-    int q = w0 - 1;                               // next row to look at going back
-    {
-      const int f0 = e + lane, f1 = e + 64 + lane, b0 = q - lane, b1 = q - 64 - lane;
-      const uint32_t cf0 = cell_at(f0, f0 <= fwd_limit), cf1 = cell_at(f1, f1 <= fwd_limit);
-      const uint32_t cb0 = cell_at(b0, b0 >= ilo), cb1 = cell_at(b1, b1 >= ilo);
-      const unsigned long long mf0 = __builtin_amdgcn_ballot_w64(bad(cf0, f0 <= fwd_limit) != 0);
-      const unsigned long long mf1 = __builtin_amdgcn_ballot_w64(bad(cf1, f1 <= fwd_limit) != 0);
-      const unsigned long long mb0 = __builtin_amdgcn_ballot_w64(bad(cb0, b0 >= ilo) != 0);
-      const unsigned long long mb1 = __builtin_amdgcn_ballot_w64(bad(cb1, b1 >= ilo) != 0);
-      if (mf0) {
-        e += __ffsll((long long)mf0) - 1;
-        ended = true;
-      } else if (mf1) {
-        e += 64 + __ffsll((long long)mf1) - 1;
-        ended = true;
-      } else {
-        e += 128;
+    auto bad = [&](const uint32_t x, const bool in) { return ((int)in & (int)((uint32_t)__popc(x) > threshold)) != 0; };
+    // A run goes to the workgroup's buffer in LDS; the buffer asks for its slots of the run list with ONE atomic at the end
+    // (returning atomics on one address go one after the other: at 39 060 pairs the 79 027 of them WERE the resolution's
+    // 0.43 ms, whatever the walk did).  A workgroup with more runs than the buffer holds emits the rest directly.
+    auto emit = [&](const int a, const int b) {
+      if (b - a + 1 >= min_len && lane == 0) {
+        const uint32_t at = __hip_atomic_fetch_add(&ctl[34], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (at < (uint32_t)kM2RunBuf) {
+          runbuf[4 * at] = (uint32_t)(lo + g), runbuf[4 * at + 1] = (uint32_t)b, runbuf[4 * at + 2] = (uint32_t)(b + d),
+          runbuf[4 * at + 3] = (uint32_t)(b - a + 1);
+        } else {
+          const uint32_t slot = atomicAdd(count, 1u);
+          if (slot < capacity)
+            runs[slot] = NeedleHipRun{(uint32_t)(lo + g), (uint32_t)b, (uint32_t)(b + d), (uint32_t)(b - a + 1), 0u, 0u};
+        }
       }
-      if (mb0) a = q - (__ffsll((long long)mb0) - 1) + 1;
-      else if (mb1) a = q - 64 - (__ffsll((long long)mb1) - 1) + 1;
-      else if (q - 128 < ilo) a = ilo;            // every row down to the first one of the diagonal matches
-      q -= 128;
-    }
-    while (!ended && e <= fwd_limit) {            // (only when P > 120)
-      const int row = e + lane;
-      const unsigned long long mm = __builtin_amdgcn_ballot_w64(bad(cell_at(row, row <= fwd_limit), row <= fwd_limit) != 0);
-      if (mm) {
-        e += __ffsll((long long)mm) - 1;
+    };
+    constexpr int kBack = 8;                      // rows per lane of a backward trip
+    int e = w0 + W;                               // forward: first row not known to match
+    int q = w0 - 1;                               // backward: next row to look at
+    int b = 0;                                    // last row of the stretch the backward walk is in
+    // Rows q - 64 i - lane, i < kBack, have been looked at (bit i of a lane's badmask: its row of block i mismatches); true
+    // when the walk is over.  Every mismatch of the block is handled from these bits (audio-like runs are ragged: a row over
+    // the threshold every hundred rows or so).  One ballot at a time: eight live masks cost the kernel its scalar registers
+    // (spilled to lanes all over the item path: the head tests took 0.13 instead of 0.08 ms).
+    auto back_step = [&](const uint32_t badmask) __attribute__((always_inline)) {
+      const int q0 = q;
+      int pos = q0;                               // rows above pos are done
+      for (;;) {
+        int x = -1;                               // the mismatch nearest to pos
+#pragma unroll 1
+        for (int i = 0; i < kBack && x < 0; i++) {
+          const unsigned long long mm = __builtin_amdgcn_ballot_w64(((badmask >> i) & 1u) != 0u && q0 - 64 * i - lane <= pos);
+          if (mm) x = q0 - 64 * i - (__ffsll((long long)mm) - 1);
+        }
+        if (x < 0) {
+          if (q0 - 64 * kBack < ilo) {            // every row down to the first one of the diagonal matches
+            emit(ilo, b);
+            return true;
+          }
+          q = q0 - 64 * kBack;
+          return false;
+        }
+        emit(x + 1, b);
+        M2_COUNT(2);
+        int idx = (int)__umulhi((uint32_t)(x - 1), p_magic);   // (x - 1) / P: the aligned window that starts at or below x
+        idx += ((idx + 1) * P <= x - 1) - (idx * P > x - 1);   // (x >= ilo >= 1; the reciprocal is off by one at most)
+        const int ws = 1 + idx * P;
+        if (x <= ws + W - 1) return true;         // x inside it
+#if NEEDLE_M2_LAB & 32   // laboratory: the walk ends at its first mismatch
+        if (threshold < (1u << 20)) return true;
+#endif
+        if (!window_whole_wave(kg + idx, g, ws, ws + d)) return true;
+        b = x - 1;                                // x in the gap above a whole window: its run is this walk's
+        pos = x - 1;
+        M2_COUNT(3);
+      }
+    };
+    // A trip: kBack rows per lane backward -- and on the first one two forward, which end the run unless it goes on for
+    // more than 128 rows behind its chain's last window (min_len > 128, or the member's last window).
+    bool over = false, first = true, ended = false;
+#pragma unroll 1
+    while (!over) {
+      uint32_t cf[2], cb[kBack];
+      M2_COUNT(1);
+#pragma unroll
+      for (int i = 0; i < 2; i++) cf[i] = cell_at(e + 64 * i + lane, first && e + 64 * i + lane <= ihi);
+#pragma unroll
+      for (int i = 0; i < kBack; i++) cb[i] = cell_at(q - 64 * i - lane, q - 64 * i - lane >= ilo);
+      if (first) {
+        const unsigned long long mf0 = __builtin_amdgcn_ballot_w64(bad(cf[0], e + lane <= ihi));
+        const unsigned long long mf1 = __builtin_amdgcn_ballot_w64(bad(cf[1], e + 64 + lane <= ihi));
         ended = true;
-        break;
+        if (mf0) e += __ffsll((long long)mf0) - 1;
+        else if (mf1) e += 64 + __ffsll((long long)mf1) - 1;
+        else e += 128, ended = false;
+#pragma unroll 1
+        while (!ended && e <= ihi) {
+          uint32_t c[4];
+          M2_COUNT(4);
+#pragma unroll
+          for (int i = 0; i < 4; i++) c[i] = cell_at(e + 64 * i + lane, e + 64 * i + lane <= ihi);
+          int step = 256;
+#pragma unroll
+          for (int i = 3; i >= 0; i--) {
+            const unsigned long long mf = __builtin_amdgcn_ballot_w64(bad(c[i], e + 64 * i + lane <= ihi));
+            if (mf) step = 64 * i + __ffsll((long long)mf) - 1, ended = true;
+          }
+          e += step;
+        }
+        if (!ended) e = ihi + 1;                  // the run reaches the table edge (comparator.rs:197)
+        b = e - 1;
+        first = false;
       }
-      e += 64;
-    }
-    if (!ended) {
-      if (fwd_limit == w0 + P + W - 1) return;   // the run also covers the next window: that one reports it
-      e = ihi + 1;                                // the run reaches the table edge (comparator.rs:197)
-    }
-    const int b = e - 1;
-    while (a < 0) {                               // rows q, q - 1, ... still to be looked at, 256 per trip
-      unsigned long long mm[4];
-      uint32_t cell[4];
+      uint32_t badmask = 0u;
 #pragma unroll
-      for (int i = 0; i < 4; i++) cell[i] = cell_at(q - 64 * i - lane, q - 64 * i - lane >= ilo);
-#pragma unroll
-      for (int i = 0; i < 4; i++) mm[i] = __builtin_amdgcn_ballot_w64(bad(cell[i], q - 64 * i - lane >= ilo) != 0);
-      int hit = -1;
-#pragma unroll
-      for (int i = 3; i >= 0; i--)
-        if (mm[i]) hit = i;
-      if (hit >= 0) {
-        const unsigned long long mh = hit == 0 ? mm[0] : hit == 1 ? mm[1] : hit == 2 ? mm[2] : mm[3];
-        a = q - 64 * hit - (__ffsll((long long)mh) - 1) + 1;
-      } else if (q - 256 < ilo) {
-        a = ilo;
-      }
-      q -= 256;
-    }
-    const int len = b - a + 1;
-    if (len >= min_len && lane == 0) {
-      const uint32_t slot = atomicAdd(count, 1u);
-      if (slot < capacity)
-        runs[slot] = NeedleHipRun{(uint32_t)(lo + g), (uint32_t)b, (uint32_t)(b + d), (uint32_t)len, 0u, 0u};
+      for (int i = 0; i < kBack; i++) badmask |= bad(cb[i], q - 64 * i - lane >= ilo) ? 1u << i : 0u;
+#if NEEDLE_M2_LAB & 16   // laboratory: the trip made, nothing done with it
+      if (threshold < (1u << 20)) { if (badmask == 0x12345u) atomicAdd(count, 1u); return; }
+#endif
+      over = back_step(badmask);
     }
   };
 
@@ -348,8 +420,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   // windows -- a sustained sound -- flags the same lane again and again: left to that lane, the wave would wait for it).
   // A lane tests its item's four windows' head rows EXACTLY with popcounts out of LDS (the vector form's test), then the
   // tail rows of what passes, then kM2Probe rows on either side; what remains is resolved by the wave.
-  const uint32_t bias = 31u - (uint32_t)t;        // popcount + bias has bit 5 set exactly when the cell does NOT match
-  auto process = [&](const int first, const int cnt) {
+  auto process = [&](const int first, const int cnt) __attribute__((always_inline)) {
     wave_lds_fence_search();
     uint32_t passm = 0u;                          // windows of the group (bit i) whose four head cells all match
     int kbase = 0, j = 0;
@@ -372,43 +443,34 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
 #if NEEDLE_M2_LAB & 2   // laboratory: head survivors dropped (threshold < 2^20: the mask is zero, but not for the compiler)
     passm &= threshold >> 20;
 #endif
+    M2_COUNT_LANES(6, lane < cnt ? 1 : 0);
+    M2_COUNT_LANES(7, __popc(passm));
     if (__builtin_amdgcn_ballot_w64(passm != 0u) == 0ull) return;
-    // the rest of the window, its neighbourhood, and the resolution of what stays: window by window (rare)
+    // The tail rows of what passed, lane by lane; what passes those as well is rare (a window in fifty of the head
+    // survivors) and is looked at by the WAVE, window by window: whole?  the last of its chain -- no successor (the member's
+    // last window), or one that is not whole on this diagonal?  Then the chain is resolved.
 #pragma unroll 1
     for (int i = 0; i < 4; i++) {
-      bool whole = false;
-      int w0 = 0, d = 0, g = 0;
+      bool tails = false;
+      int k = 0;
       if ((passm >> i) & 1u) {
-        const int k = kbase + i;
-        const uint32_t wm = aimg[k * PITCH + 8 * H];
-        g = (int)(wm >> 28);
-        w0 = (int)(wm & 0x0FFFFFFFu);
-        d = j - w0;
-        const uint32_t *rows = wsrc + NR * k;     // the window's 16 rows w0 - E .. w0 + W + E - 1
+        k = kbase + i;
+        const uint32_t *rows = wsrc + NR * k;
         const uint32_t miss = ((uint32_t)__popc(rows[E + 1] ^ ldst[j + 1]) + bias) | ((uint32_t)__popc(rows[E + 3] ^ ldst[j + 3]) + bias) |
                               ((uint32_t)__popc(rows[E + 5] ^ ldst[j + 5]) + bias) | ((uint32_t)__popc(rows[E + 6] ^ ldst[j + 6]) + bias);
-        if (miss < 32u) {
-          const int ns = (int)ctl[18 + g];
-          const int ilo = d < 0 ? 1 - d : 1;
-          const int ihi = min(ns - 1, m - 1 - d);
-          if (w0 >= ilo && w0 + W - 1 <= ihi) {   // window inside the table on this diagonal (resolve()'s first test)
-            bool f_end = false, b_end = false;    // the run ends inside the probed rows: a mismatch there, or the table's edge
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-              const int fr = w0 + W + e, br = w0 - E + e;
-              f_end |= fr > ihi || (uint32_t)__popc(rows[E + W + e] ^ ldst[min(fr, ihi) + d]) > threshold;
-              b_end |= br < ilo || (uint32_t)__popc(rows[e] ^ ldst[max(br, ilo) + d]) > threshold;
-            }
-            whole = !(f_end && b_end);            // ended on both sides: at most W + 2 E - 2 rows, below every min_len of this path
-          }
-        }
+        tails = miss < 32u;
       }
-      unsigned long long cand = __builtin_amdgcn_ballot_w64(whole);
+      unsigned long long cand = __builtin_amdgcn_ballot_w64(tails);
+      M2_COUNT_LANES(5, tails ? 1 : 0);
       while (cand) {
         const int src_lane = __ffsll((long long)cand) - 1;
         cand &= cand - 1;
-        resolve(__builtin_amdgcn_readfirstlane(__shfl(w0, src_lane)), __builtin_amdgcn_readfirstlane(__shfl(d, src_lane)),
-                __builtin_amdgcn_readfirstlane(__shfl(g, src_lane)));
+        const int ck = __builtin_amdgcn_readlane(k, src_lane), cj = __builtin_amdgcn_readlane(j, src_lane);
+        const uint32_t wm = __builtin_amdgcn_readfirstlane(aimg[ck * PITCH + 4 * H]);
+        const int g = (int)(wm >> 28), w0 = (int)(wm & 0x0FFFFFFFu);
+        if (!window_whole_wave(ck, g, w0, cj)) continue;
+        if (ck + 1 < (int)__builtin_amdgcn_readfirstlane(ctl[2 + g]) && window_whole_wave(ck + 1, g, w0 + P, cj + P)) continue;
+        resolve(w0, cj - w0, g);
       }
     }
   };
@@ -416,11 +478,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   // n slots in all), group g.  One item per lane and turn (turns = the most set bits any lane holds), 64 are processed
   // as soon as they are there.
   int qn = 0;                                     // wave-uniform: items waiting in this wave's queue (< 64 between turns)
-  auto enqueue = [&](uint32_t flags, const int rt0, const int n_slots, const int j0) {
+  // (ONE call site, and one of process() inside: the rare paths' code, inlined at three sites each, had grown to where the
+  // waves waited for instructions -- the same head tests took 0.12 instead of 0.08 ms.  flush: the wave's last call.)
+  auto enqueue = [&](uint32_t flags, const int rt0, const int n_slots, const int j0, const bool flush) __attribute__((always_inline)) {
     for (;;) {
       const bool act = flags != 0u;
       const unsigned long long ball = __builtin_amdgcn_ballot_w64(act);
-      if (ball == 0ull) break;
       if (act) {
         const int idx = 4 * n_slots - 1 - (__ffs((int)flags) - 1);
         flags &= flags - 1u;
@@ -431,139 +494,123 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         queue[qn + (int)before] = (j << 16) | kbase;
       }
       qn += (int)__popcll(ball);
-      if (qn >= 64) {
-        process(qn - 64, 64);
-        qn -= 64;
+      const int cnt = qn >= 64 ? 64 : (ball == 0ull && flush) ? qn : 0;
+      if (cnt > 0) {
+        process(qn - cnt, cnt);
+        qn -= cnt;
       }
+      if (ball == 0ull) break;
     }
   };
 
   const uint32_t *arow = aimg + r * PITCH + 4 * h;                                         // rows of a full tile: + rt 32 PITCH
   const uint32_t *arow_last = aimg + min(32 * (row_tiles - 1) + r, nW) * PITCH + 4 * h;  // the last tile's may lie beyond the last window
-  auto load_a = [&](const int rt, mfma_v4i (&fa)[H]) {
+  auto load_a = [&](const int rt, mfma_v4i (&fa)[HP]) {
     const uint32_t *ap = rt == row_tiles - 1 ? arow_last : arow + rt * 32 * PITCH;
 #pragma unroll
-    for (int kb = 0; kb < H; kb++) fa[kb] = *reinterpret_cast<const mfma_v4i *>(ap + 8 * kb);
+    for (int kb = 0; kb < HP; kb++) fa[kb] = *reinterpret_cast<const mfma_v4i *>(ap + 8 * kb);
   };
-  mfma_v16i presets;
+  mfma_v16f presets;
 #pragma unroll
-  for (int q = 0; q < 16; q++) presets[q] = preset;
-  // rows (0 + 2) accumulate in ua, rows (4 + 7) in ub; the two chains alternate, so a product never waits for its own accumulator
-  auto products = [&](const mfma_v4i (&fa)[H], const mfma_v4i (&fbk)[H], mfma_v16i &ua, mfma_v16i &ub) {
+  for (int q = 0; q < 16; q++) presets[q] = (float)preset;
+  // One product = TWO head rows: lane half h of the A and B fragments holds the 32 nibbles of the first (h = 0) or second
+  // (h = 1) row of the pair, K = 64 sums over both.  Rows (0, 2) -> ua, rows (4, 7) -> ub: independent, no chain.
+  // (Both operands FP4, scale operands 0: the compiler picks the unscaled v_mfma_f32_32x32x64_f8f6f4, whose scale is 2^0 --
+  // tools/mfma_fp4_probe.hip.  The fragments are 4 registers; the builtin's type is 8 wide, the upper half is dropped.)
+  auto product = [&](const mfma_v4i &a, const mfma_v4i &b) {
+    const mfma_v8i a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, presets, 4, 4, 0, 0, 0, 0);
+  };
+  auto products = [&](const mfma_v4i (&fa)[HP], const mfma_v4i (&fbk)[HP], mfma_v16f &ua, mfma_v16f &ub) {
     asm volatile("" : "+v"(presets));            // stays in its 16 registers (otherwise re-built from scalars for every tile)
-    ua = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[0], fbk[0], presets, 0, 0, 0);
-    ub = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[2], fbk[2], presets, 0, 0, 0);
-    ua = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[1], fbk[1], ua, 0, 0, 0);
-    ub = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[3], fbk[3], ub, 0, 0, 0);
+    ua = product(fa[0], fbk[0]);
+    ub = product(fa[1], fbk[1]);
   };
   // a group's word is negative iff one of its four windows passes both sums; its sign goes into the flags
-  auto fold = [&](const mfma_v16i &ua, const mfma_v16i &ub, uint32_t &flags) {
+  auto fold = [&](const mfma_v16f &ua, const mfma_v16f &ub, uint32_t &flags) {
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-      int a = ua[4 * g] & ub[4 * g];
+      uint32_t a = __float_as_uint(ua[4 * g]) & __float_as_uint(ub[4 * g]);
 #pragma unroll
-      for (int q = 4 * g + 1; q < 4 * g + 4; q++) a = __builtin_amdgcn_bitop3_b32(ua[q], ub[q], a, 0xEA);   // (ua & ub) | a: one instruction
-      flags = __builtin_amdgcn_alignbit(flags, (uint32_t)a, 31);  // (written as C the compiler makes it and, and, and, and_or, or3)
+      for (int q = 4 * g + 1; q < 4 * g + 4; q++)                // (ua & ub) | a: one instruction
+        a = (uint32_t)__builtin_amdgcn_bitop3_b32((int)__float_as_uint(ua[q]), (int)__float_as_uint(ub[q]), (int)a, 0xEA);
+      flags = __builtin_amdgcn_alignbit(flags, a, 31);           // (written as C the compiler makes it and, and, and, and_or, or3)
     }
   };
 
 #if NEEDLE_M2_LAB & 64   // laboratory: a workgroup's setup alone
   if (threshold < (1u << 20)) return;
 #endif
-  for (;;) {
+  // One accumulator pair, and the compiler held to it: left alone it issues the second tile's products inside the first
+  // tile's fold on a SECOND pair, and at 128 registers that costs B fragments copied and spilled in every turn.  (Round 5's
+  // int8 form also had a software-pipelined loop over two pairs for the 3-waves-per-SIMD shapes: 5 % slower, gone.)
+  bool done = false;
+  while (!done) {
     int c = 0;
     if (lane == 0) c = (int)__hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     c = __builtin_amdgcn_readfirstlane(c);
     const int unit = b_in_group + splits * c;     // (every wave sees the counter pass `units`: the loop ends for all)
-    if (unit >= units) break;
-    // B fragments: lane (r, h) holds half h of dst[j + s] for the H head rows s as +-1 bytes, four bits at a time through a
-    // table of 16 words (16 banks: different entries never collide, equal ones are one broadcast)
-    mfma_v4i fb[CB][H];
+    done = unit >= units;                         // then one more turn with nothing in it: the queue's last items
+    // B fragments: lane (r, h) holds dst[j + s] for the head rows s = (0 | 2), (4 | 7) of its half h as 32 nibbles of +-1,
+    // eight bits at a time through a table of 256 words
+    mfma_v4i fb[CB][HP], fa[HP];
     const int j0 = 32 * unit * CB + r;            // this lane's position in the unit's first column block; + 32 in the second
+    if (!done) {
 #pragma unroll
-    for (int cbk = 0; cbk < CB; cbk++) {
-      const int jr = min(j0 + 32 * cbk, m);       // (a unit's second block may lie beyond the table: zeros)
-#pragma unroll
-      for (int kb = 0; kb < H; kb++) {
-        const uint32_t half = ldst[jr + (kb * (W - 1)) / (H - 1)] >> (16 * h);   // head rows 0, 2, 4, 7
-#pragma unroll
-        for (int q = 0; q < 4; q++) fb[cbk][kb][q] = (int)ntab[(half >> (4 * q)) & 0xFu];
-      }
-    }
-    if (unit == 0 || unit * CB + CB > last_j / 32) {  // (wave-uniform) a unit with positions outside 1 .. last_j: their columns
-#pragma unroll                                        // become zeros -- product 0 + preset: positive, never flagged
       for (int cbk = 0; cbk < CB; cbk++) {
-        const bool ok = j0 + 32 * cbk >= 1 && j0 + 32 * cbk <= last_j;
+        const int jr = min(j0 + 32 * cbk, m);     // (a unit's second block may lie beyond the table: zeros)
 #pragma unroll
-        for (int kb = 0; kb < H; kb++)
+        for (int kb = 0; kb < HP; kb++) {
+          const uint32_t hv = ldst[jr + (kb == 0 ? 2 * h : 4 + 3 * h)];
 #pragma unroll
-          for (int q = 0; q < 4; q++) fb[cbk][kb][q] = ok ? fb[cbk][kb][q] : 0;
-      }
-    }
-    // The unit's tiles in the order (row tile, column block), software-pipelined: a tile's four products are issued before
-    // the tile in front of it is folded (two accumulator pairs), and the next row tile's A fragments are asked for behind
-    // the last product that reads this row tile's.
-    mfma_v4i fa[H];
-    uint32_t flags = 0u;                                             // sign bits of the groups' words: set = look here
-    load_a(0, fa);
-    if constexpr (PER_SIMD <= 3) {
-      // Software-pipelined: a tile's four products are issued before the tile in front of it is folded (two accumulator
-      // pairs), and the next row tile's A fragments are asked for behind the last product that reads this row tile's.
-      // (Measured and dropped: pinning "one product, six instructions of the fold" with __builtin_amdgcn_sched_group_barrier
-      // -- 4.69 against 4.48 ms at 79 800 pairs; the compiler copied fragments to make room for the early reads.)
-      mfma_v16i a0, b0, a1, b1;
-      products(fa, fb[0], a0, b0);                                   // tile (row 0, block 0)
-#pragma unroll 1
-      for (int rt = 0; rt + 1 < row_tiles; rt++) {                   // every row tile but the last: the next one exists, nothing in
-        products(fa, fb[1], a1, b1);                                 // the loop is conditional (a conditional product made the  (rt, 1)
-        load_a(rt + 1, fa);                                          // compiler copy both accumulator pairs twice per turn)
-        fold(a0, b0, flags);                                         // (rt, 0)
-        products(fa, fb[0], a0, b0);                                 // (rt + 1, 0)
-        fold(a1, b1, flags);                                         // (rt, 1)
-        if ((rt & (kM2Batch - 1)) == kM2Batch - 1) {
-#if !(NEEDLE_M2_LAB & 1)   // laboratory: flags ignored -- the tile loop alone
-          enqueue(flags, rt - (kM2Batch - 1), 2 * kM2Batch, j0);
-#else
-          if (flags == 0x12345u + threshold) atomicAdd(count, 1u);
-#endif
-          flags = 0u;
+          for (int q = 0; q < 4; q++) fb[cbk][kb][q] = (int)ntab[(hv >> (8 * q)) & 0xFFu];
         }
       }
-      products(fa, fb[1], a1, b1);                                   // the last row tile
-      fold(a0, b0, flags);
-      fold(a1, b1, flags);
-    } else {
-      // One accumulator pair, and the compiler held to it: left alone it issues the second tile's products inside the first
-      // tile's fold on a SECOND pair, and at 128 registers that costs B fragments copied and spilled in every turn.
-      mfma_v16i a0, b0;
+      if (unit == 0 || unit * CB + CB > last_j / 32) {  // (wave-uniform) a unit with positions outside 1 .. last_j: their columns
+#pragma unroll                                          // become zeros -- product 0 + preset: positive, never flagged
+        for (int cbk = 0; cbk < CB; cbk++) {
+          const bool ok = j0 + 32 * cbk >= 1 && j0 + 32 * cbk <= last_j;
+#pragma unroll
+          for (int kb = 0; kb < HP; kb++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) fb[cbk][kb][q] = ok ? fb[cbk][kb][q] : 0;
+        }
+      }
+      load_a(0, fa);
+    }
+    // the unit's tiles in the order (row tile, column block), kM2Batch row tiles between two looks at the flags
+    int rt0 = 0;
+    do {
+      uint32_t flags = 0u;                        // sign bits of the groups' words: set = look here
+      const int nb = done ? 0 : min(kM2Batch, row_tiles - rt0);
+      mfma_v16f a0, b0;
 #pragma unroll 1
-      for (int rt = 0; rt + 1 < row_tiles; rt++) {
+      for (int rt = rt0; rt < rt0 + nb; rt++) {
         products(fa, fb[0], a0, b0);
         fold(a0, b0, flags);
         __builtin_amdgcn_sched_barrier(0);
         products(fa, fb[1], a0, b0);
-        load_a(rt + 1, fa);
+        load_a(min(rt + 1, row_tiles - 1), fa);   // (behind the last product that reads this row tile's; the last one's again)
         fold(a0, b0, flags);
         __builtin_amdgcn_sched_barrier(0);
-        if ((rt & (kM2Batch - 1)) == kM2Batch - 1) {
-#if !(NEEDLE_M2_LAB & 1)
-          enqueue(flags, rt - (kM2Batch - 1), 2 * kM2Batch, j0);
-#else
-          if (flags == 0x12345u + threshold) atomicAdd(count, 1u);
-#endif
-          flags = 0u;
-        }
       }
-      products(fa, fb[0], a0, b0);
-      fold(a0, b0, flags);
-      products(fa, fb[1], a0, b0);
-      fold(a0, b0, flags);
-    }
-#if !(NEEDLE_M2_LAB & 1)
-    enqueue(flags, (row_tiles - 1) & ~(kM2Batch - 1), 2 * (((row_tiles - 1) & (kM2Batch - 1)) + 1), j0);
+#if !(NEEDLE_M2_LAB & 1)   // laboratory: flags ignored -- the tile loop alone
+      enqueue(flags, rt0, 2 * nb, j0, done);
 #else
-    if (flags == 0x12345u + threshold) atomicAdd(count, 1u);
+      if (flags == 0x12345u + threshold) atomicAdd(count, 1u);
 #endif
+      rt0 += kM2Batch;
+    } while (!done && rt0 < row_tiles);
   }
-  if (qn > 0) process(0, qn);
+  // the workgroup's runs: one request for room, then the copy
+  __syncthreads();
+  const uint32_t n_runs = min(ctl[34], (uint32_t)kM2RunBuf);
+  if (n_runs == 0u) return;
+  if (threadIdx.x == 0) ctl[35] = atomicAdd(count, n_runs);
+  __syncthreads();
+  if (threadIdx.x < n_runs) {
+    const uint32_t slot = ctl[35] + threadIdx.x;
+    const uint32_t *e = runbuf + 4 * threadIdx.x;
+    if (slot < capacity) runs[slot] = NeedleHipRun{e[0], e[1], e[2], e[3], 0u, 0u};
+  }
 }

@@ -513,7 +513,8 @@ __host__ __device__ constexpr int mfma_windows(int n, int min_len, int W) {
   return (n - 1 - W) >= 0 && min_len - W + 1 > 0 ? (n - 1 - W) / (min_len - W + 1) + 1 : 0;  // w0 = 1 + k P, w0 + W - 1 <= n - 1
 }
 typedef int mfma_v4i __attribute__((ext_vector_type(4)));
-typedef int mfma_v16i __attribute__((ext_vector_type(16)));
+typedef int mfma_v8i __attribute__((ext_vector_type(8)));
+typedef float mfma_v16f __attribute__((ext_vector_type(16)));
 
 #include "scan_mfma_kernel.h"
 
@@ -847,7 +848,7 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
         if (w > 0 && m.m >= (uint32_t)kSampleW + 1) {
           uint64_t col_blocks = ((uint64_t)m.m - kSampleW) / 32 + 1;
           col_blocks = (col_blocks + kM2ColBlocks - 1) / kM2ColBlocks * kM2ColBlocks;  // whole units are multiplied
-          plan->mfma_products += (w + 31) / 32 * col_blocks * kM2Heads;
+          plan->mfma_products += (w + 31) / 32 * col_blocks * (kM2Heads / 2);
         }
       }
     // The matrix-pipe form's window images (scan_mfma_kernel.h): one per distinct source sequence, when the launch has ONE
@@ -1033,6 +1034,16 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
           hipLaunchKernelGGL(mfma2_kernel(plan.mfma_waves), dim3((uint32_t)blocks), dim3(64 * plan.mfma_waves),
                              lds_bytes, stream, d_hashes, ws->problems.ptr, staged, threshold, d_runs, capacity, d_count,
                              plan.mfma_splits, images);
+#if NEEDLE_M2_LAB & 8
+          {
+            unsigned long long c[8], z[8] = {};
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(m2_dbg), sizeof c);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(m2_dbg), z, sizeof z);
+            fprintf(stderr, "m2 counts: resolve calls %llu, trips %llu, mismatches handled %llu, walks continued %llu, extra forward trips %llu, "
+                            "windows past the tail rows %llu, items %llu, windows past the head rows %llu\n", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+          }
+#endif
         } else {
           hipLaunchKernelGGL(sampled_kernel<false>(scan_shape()), dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
                              ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,
