@@ -39,7 +39,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-I8_DENSE_PEAK_TOPS = 5000.0     # MI355X_MICROARCH.md, matrix cores: int8 runs at 2 x the BF16 rate (~2.5 PF dense)
+FP4_DENSE_PEAK_TOPS = 10000.0   # MI355X_MICROARCH.md, matrix cores: FP4 (block-scaled f8f6f4 form) runs at 4 x the BF16 rate (~2.5 PF dense)
+MATRIX_OPS = 131072.0           # one v_mfma_f32_32x32x64_f8f6f4: 32 x 32 x 64 multiply-adds
 F64_VALU_PEAK_TFLOPS = 78.6    # vector f64 = half the 157.3 TFLOP/s f32 vector rate of MI355X_MICROARCH.md (no faster f64 MFMA)
 F32_VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 (vector)
 RATE = 11025
@@ -426,12 +427,12 @@ def library_scale(capi, synth, episodes, minutes, jobs=3, check=4):
                    "--device-synth): PCM generated in HBM, analyze + all-pairs search + per-video epilogue through "
                    "needle_hip_library_job_begin/_end, two jobs in flight; kernel times from one job run alone"}
     if form == 4 and scan_s > 0:
-        tops = products * 65536.0 / scan_s / 1e12
+        tops = products * MATRIX_OPS / scan_s / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": "hamming_runs (aligned windows, first stage on the matrix pipe)", "unit": "TOP/s",
-                           "achieved": round(tops, 1), "peak": I8_DENSE_PEAK_TOPS, "frac": round(tops / I8_DENSE_PEAK_TOPS, 4),
+                           "achieved": round(tops, 1), "peak": FP4_DENSE_PEAK_TOPS, "frac": round(tops / FP4_DENSE_PEAK_TOPS, 4),
                            "matrix_instructions_per_launch": int(products), "avg_launch_ms": kernel_ms["hamming_runs"],
-                           "note": "v_mfma_i32_32x32x32_i8 instructions the launch issues x 65 536 integer operations / kernel time "
-                                   "against the dense int8 peak of MI355X_MICROARCH.md"}
+                           "note": "v_mfma_f32_32x32x64_f8f6f4 (FP4 operands) instructions the launch issues x 131 072 operations / kernel time "
+                                   "against the dense FP4 peak of MI355X_MICROARCH.md"}
     return out
 
 
@@ -879,9 +880,9 @@ def main() -> None:
         }
         mfma_roofline = None
         if scan_form == 4 and avg["hamming_runs"] > 0:          # this rank's scan took the matrix-pipe form (large launches)
-            tops = scan_products * 65536.0 / (avg["hamming_runs"] * 1e-3) / 1e12
-            mfma_roofline = {"bound": "mfma", "achieved": round(tops, 1), "peak": I8_DENSE_PEAK_TOPS, "unit": "TOP/s",
-                             "frac": round(tops / I8_DENSE_PEAK_TOPS, 4)}
+            tops = scan_products * MATRIX_OPS / (avg["hamming_runs"] * 1e-3) / 1e12
+            mfma_roofline = {"bound": "mfma", "achieved": round(tops, 1), "peak": FP4_DENSE_PEAK_TOPS, "unit": "TOP/s",
+                             "frac": round(tops / FP4_DENSE_PEAK_TOPS, 4)}
             if dominant in ("hamming_runs", "simhash_runs"):     # (whatever --no-extras says, and for every world size)
                 out["roofline"].update(mfma_roofline, matrix_instructions_per_launch=int(scan_products),
                                        hbm={"achieved_gbs": round(achieved, 2), "peak_gbs": HBM_PEAK_GBS,
@@ -894,13 +895,15 @@ def main() -> None:
                 form, products = scan_form, scan_products
                 if form == 4:                                    # the job's scan took the matrix-pipe form (large launches)
                     sec = avg["hamming_runs"] * 1e-3
-                    tops = products * 65536.0 / sec / 1e12 if sec > 0 else 0.0
+                    tops = products * MATRIX_OPS / sec / 1e12 if sec > 0 else 0.0
                     out["roofline_search"] = {
                         "bound": "mfma", "kernel": "hamming_runs (aligned windows, head rows on the matrix pipe)", "unit": "TOP/s",
-                        "achieved": round(tops, 1), "peak": I8_DENSE_PEAK_TOPS, "frac": round(tops / I8_DENSE_PEAK_TOPS, 4),
+                        "achieved": round(tops, 1), "peak": FP4_DENSE_PEAK_TOPS, "frac": round(tops / FP4_DENSE_PEAK_TOPS, 4),
                         "matrix_instructions_per_launch": int(products), "avg_launch_ms": round(avg["hamming_runs"], 5),
-                        "note": "achieved = v_mfma_i32_32x32x32_i8 instructions of the launch x 65 536 integer operations / kernel "
-                                "time; peak = the dense int8 figure of MI355X_MICROARCH.md (2 x BF16)"}
+                        "note": "achieved = v_mfma_f32_32x32x64_f8f6f4 (FP4 operands) instructions of the launch x 131 072 operations / "
+                                "kernel time; peak = the dense FP4 figure of MI355X_MICROARCH.md (4 x BF16).  Round 4 / early "
+                                "round 5 multiplied the same bits as int8 (one head row per instruction, 5 POP/s peak): in those "
+                                "units this is achieved / 5000"}
                 if dominant in ("hamming_runs", "simhash_runs") and form == 4:
                     pass                                         # (done above)
                 elif dominant in ("hamming_runs", "simhash_runs"):   # the scan dominates (library scale): it is not HBM-bound
@@ -923,10 +926,10 @@ def main() -> None:
             vec = out.get("roofline_search", {})
             issued = so.pop("issued_evals", None)
             if so.get("scan_form") == 4 and so["scan_kernel_ms"] > 0:  # the call's scan took the matrix-pipe form
-                tops = so["matrix_instructions"] * 65536.0 / (so["scan_kernel_ms"] * 1e-3) / 1e12
+                tops = so["matrix_instructions"] * MATRIX_OPS / (so["scan_kernel_ms"] * 1e-3) / 1e12
                 so["roofline"] = {"bound": "mfma", "kernel": "hamming_runs (aligned windows, first stage on the matrix pipe)",
-                                  "unit": "TOP/s", "achieved": round(tops, 1), "peak": I8_DENSE_PEAK_TOPS,
-                                  "frac": round(tops / I8_DENSE_PEAK_TOPS, 4)}
+                                  "unit": "TOP/s", "achieved": round(tops, 1), "peak": FP4_DENSE_PEAK_TOPS,
+                                  "frac": round(tops / FP4_DENSE_PEAK_TOPS, 4)}
             elif "ceiling_cells_per_s" in vec:
                 so["roofline"] = search_roofline(vec["ceiling_cells_per_s"], issued, so["table_cells"], so["scan_kernel_ms"])
             out["search_only"] = so

@@ -103,7 +103,7 @@ def main():
            "host_ms_per_job": {k: round(1e3 * v / (2 * jobs), 3) for k, v in host.items()},
            "runs": int(state["runs"]), "run_list_digest": digest, "scan_shape": os.environ.get("NEEDLE_HIP_SCAN_SHAPE", "8,3"),
            "head_survivors": survivors, "scan_form": scan_form, "scan_matrix_products": scan_products,
-           "scan_int8_ops_per_s": round(scan_products * 65536.0 / max(scan_ms * 1e-3, 1e-12), 1),
+           "scan_fp4_ops_per_s": round(scan_products * 131072.0 / max(scan_ms * 1e-3, 1e-12), 1),
            "detected": sum(1 for r in state["res"] if r is not None and r.opening is not None),
            "fallback": {"items": cs["items_recomputed"] / max(cs["items"], 1), "chunks": cs["chunks_recomputed"] / max(cs["chunks"], 1)},
            "scan_roofline": {"issued_cell_evaluations": issued, "lane_instructions_per_s": round(3.0 * issued / (scan_ms * 1e-3), 1),
