@@ -422,44 +422,43 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   // tail rows of what passes, then kM2Probe rows on either side; what remains is resolved by the wave.
   auto process = [&](const int first, const int cnt) __attribute__((always_inline)) {
     wave_lds_fence_search();
-    uint32_t passm = 0u;                          // windows of the group (bit i) whose four head cells all match
+    uint32_t passm = 0u;                          // windows of the group (bit i) whose W cells all match
     int kbase = 0, j = 0;
     if (lane < cnt) {
       const uint32_t item = queue[first + lane];
       kbase = (int)(item & 0xFFFFu);
       j = (int)(item >> 16);
-      const uint32_t d0 = ldst[j], d2 = ldst[j + 2], d4 = ldst[j + 4], d7 = ldst[j + 7];
+      // All eight rows at once: the window's rows come as two 16-byte reads anyway, the destination's eight serve the four
+      // windows.  (Head rows first and the tail rows of the survivors in a loop of their own -- one turn per window with
+      // four lanes in a hundred busy -- was a quarter more instructions.)
+      uint32_t dr[W];
+#pragma unroll
+      for (int s = 0; s < W; s++) dr[s] = ldst[j + s];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int k = min(kbase + i, nW - 1);
         const mfma_v4i lo4 = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E);       // rows 0 .. 3 of the window
         const mfma_v4i hi4 = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E + 4);   // rows 4 .. 7
-        const uint32_t s0 = (uint32_t)lo4[0], s2 = (uint32_t)lo4[2], s4 = (uint32_t)hi4[0], s7 = (uint32_t)hi4[3];
-        const uint32_t miss = ((uint32_t)__popc(s0 ^ d0) + bias) | ((uint32_t)__popc(s2 ^ d2) + bias) |
-                              ((uint32_t)__popc(s4 ^ d4) + bias) | ((uint32_t)__popc(s7 ^ d7) + bias);
+        uint32_t miss = 0u;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          miss |= ((uint32_t)__popc((uint32_t)lo4[s] ^ dr[s]) + bias) | ((uint32_t)__popc((uint32_t)hi4[s] ^ dr[4 + s]) + bias);
         passm |= (miss < 32u && kbase + i < nW) ? 1u << i : 0u;
       }
     }
-#if NEEDLE_M2_LAB & 2   // laboratory: head survivors dropped (threshold < 2^20: the mask is zero, but not for the compiler)
+#if NEEDLE_M2_LAB & 2   // laboratory: survivors dropped (threshold < 2^20: the mask is zero, but not for the compiler)
     passm &= threshold >> 20;
 #endif
     M2_COUNT_LANES(6, lane < cnt ? 1 : 0);
     M2_COUNT_LANES(7, __popc(passm));
     if (__builtin_amdgcn_ballot_w64(passm != 0u) == 0ull) return;
-    // The tail rows of what passed, lane by lane; what passes those as well is rare (a window in fifty of the head
-    // survivors) and is looked at by the WAVE, window by window: whole?  the last of its chain -- no successor (the member's
-    // last window), or one that is not whole on this diagonal?  Then the chain is resolved.
+    // What passes is rare (a window in three thousand of the items') and is looked at by the WAVE, window by window:
+    // whole?  the last of its chain -- no successor (the member's last window), or one that is not whole on this diagonal?
+    // Then the chain is resolved.
 #pragma unroll 1
     for (int i = 0; i < 4; i++) {
-      bool tails = false;
-      int k = 0;
-      if ((passm >> i) & 1u) {
-        k = kbase + i;
-        const uint32_t *rows = wsrc + NR * k;
-        const uint32_t miss = ((uint32_t)__popc(rows[E + 1] ^ ldst[j + 1]) + bias) | ((uint32_t)__popc(rows[E + 3] ^ ldst[j + 3]) + bias) |
-                              ((uint32_t)__popc(rows[E + 5] ^ ldst[j + 5]) + bias) | ((uint32_t)__popc(rows[E + 6] ^ ldst[j + 6]) + bias);
-        tails = miss < 32u;
-      }
+      const bool tails = ((passm >> i) & 1u) != 0u;
+      const int k = kbase + i;
       unsigned long long cand = __builtin_amdgcn_ballot_w64(tails);
       M2_COUNT_LANES(5, tails ? 1 : 0);
       while (cand) {
