@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <new>
@@ -293,8 +294,13 @@ enum NeedleError needle_audio_comparator_run(const struct NeedleAudioComparator 
                                              bool threading) {  // lib.rs:612-637
   if (!comparator) return NeedleError_NullArgument;
   return guarded([&]() -> NeedleError {
+    const bool trace = std::getenv("NEEDLE_HIP_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     std::vector<VideoResult> res;
     Status s = comparator->inner.run(analyze, display, use_skip_files, write_skip_files, threading, &res);
+    if (trace)
+      std::fprintf(stderr, "[needle_hip] comparator run, whole call: %.2f ms\n",
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return s.ok() ? NeedleError_Ok : report(s);
   });
 }

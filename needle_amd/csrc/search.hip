@@ -723,12 +723,13 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     const size_t max_members = (size_t)kM2Members;
     auto group_need = [&](const SearchProblem &a, uint64_t windows) { return m2_lds_words(a.m, windows, waves) * sizeof(uint32_t); };
     bool mfma = sampled && mode[4] == 1;
-    // From how many sequence pairs: the matrix-pipe kernel is the faster KERNEL from ~2000 pairs of 24-minute windows up
-    // (0.13 against 0.14 ms at 2016, 0.19 / 0.32 at 4950, 0.31 / 0.62 at 9730, 0.46 / 0.84 at 16 290), but inside a pipelined
-    // job the scan runs beside the next job's first pass, where the vector form's small workgroups fit the holes better:
-    // jobs of 9730 pairs take 3.8 (vector) against 4.2 ms, of 16 290 pairs 5.9 against 5.0.  So: a call with nothing beside
-    // it (mode[5]) from 2048 pairs, a job from 16 384.
-    const size_t mfma_from = mode[5] ? 2048 : (size_t)kDeviceEpiloguePairs;
+    // From how many sequence pairs: with FP4 products the matrix-pipe kernel is the faster kernel from ~2000 pairs of
+    // 24-minute windows up (0.127 against 0.142 ms at 2016, 0.19 / 0.33 at 4950, 0.26 / 0.62 at 9730, 0.38 / 0.83 at 16 110)
+    // and jobs are no slower with it from there on either (two in flight, the scan beside the next job's first pass: 1.56 /
+    // 1.56, 2.65 / 2.71, 4.08 / 4.12, 5.66 / 5.96 ms).  (The int8 form lost inside jobs below 16 384 pairs -- the vector
+    // form's small workgroups fit the holes beside the first pass better -- and a job took it only from there; mode[5], "a
+    // call with nothing beside it", is not looked at any more.)
+    const size_t mfma_from = 2048;
     const bool candidate = sampled && (mode[4] == 1 || (mode[4] == 2 && meta.size() >= mfma_from));
     if (candidate) {  // the table sorted by destination (the runs carry the index of their own entry: its order is free)
       std::stable_sort(meta.begin(), meta.end(), [](const SearchProblem &a, const SearchProblem &b) {
