@@ -1,42 +1,47 @@
-// The sampled scan's first stage on the matrix pipe, second form (round 5).  Included by search.hip inside its anonymous
-// namespace, after SearchProblem, mfma_windows() and the mfma_v4i / mfma_v16i types.
+// The sampled scan's first stage on the matrix pipe (round 5; FP4 products since the second half of that round).  Included
+// by search.hip inside its anonymous namespace, after SearchProblem, mfma_windows() and the mfma_v4i / _v8i / _v16f types.
 //
 // Same aligned windows, same candidates and same runs as hamming_runs_sampled_kernel (comparator.rs:176-200 is what all of
-// them reproduce).  The Hamming distances of a window's head rows against every destination position are int8 matrix
-// products: a hash as 32 bytes of +-1 gives dot(a, b) = 32 - 2 d(a, b).  A tile is 32 aligned windows x 32 destination
-// positions and costs four v_mfma_i32_32x32x32_i8 (head rows 0, 2, 4, 7 of a window of 8).
+// them reproduce).  The Hamming distances of a window's head rows against every destination position are matrix products:
+// a hash as 32 values of +-1 gives dot(a, b) = 32 - 2 d(a, b).  +-1 is exact in FP4 (e2m1: 0x2, 0xA), and gfx950's
+// v_mfma_f32_32x32x64_f8f6f4 with both operands FP4 takes K = 64 -- TWO hash rows -- in the 32 cycles that
+// v_mfma_i32_32x32x32_i8 takes for one (tools/mfma_fp4_probe.hip: exact sums, 33 - 35 ticks either way).  A tile is 32
+// aligned windows x 32 destination positions and costs two instructions (head rows 0 | 2 and 4 | 7 of a window of 8 by lane
+// half); fragments are 16 bytes per lane and operand; the f32 accumulators hold small integers exactly.
 //
-// Round 4's form kept the matrix pipe 27 % busy: beside its 4 products a tile cost 88 vector and 16 scalar instructions, a
-// wave runs its instructions in order at 5 - 8 cycles each, and three waves per SIMD (166 registers) cannot cover that.
-// What was measured on the way to this form (profiles/NOTES.md, round 5): what costs most is not arithmetic but BRANCHES
-// per tile (every tile with a survivor took a scalar detour of ~100 instructions) and trips to global memory inside the
-// tile loop.  Hence:
-//  * The products only FLAG.  The four products of a tile accumulate into two register sets -- rows (0 + 2) and rows
-//    (4 + 7), each preset so that its sign bit is SET where the SUM of two rows' distances is <= 2 t, a necessary
-//    condition of "both <= t" (0.20 % of the window-diagonals pass on synthetic audio, 0.05 % the exact head test).
-//    16 + 16 result registers are folded into four words (one per group of four windows) and the four sign bits are
-//    shifted into a per-lane flag word (v_alignbit): 20 vector instructions, no compare, no branch, eight tiles in a
-//    straight line.
+// Round 4's form (int8, one product per head row) kept the matrix pipe 27 % busy: beside its 4 products a tile cost 88
+// vector and 16 scalar instructions, a wave runs its instructions in order at 5 - 8 cycles each, and three waves per SIMD
+// (166 registers) cannot cover that.  What was measured since (profiles/NOTES.md, round 5): what costs is not arithmetic but
+// BRANCHES per tile, trips to global memory, wave-uniform code run by 64 lanes in step, returning atomics on one address, and
+// rare paths inlined so often that waves wait for instructions.  Hence:
+//  * The products only FLAG.  A tile's two products go into two register sets -- rows (0 + 2) and rows (4 + 7), each
+//    preset so that its sign bit is SET where the SUM of two rows' distances is <= 2 t, a necessary condition of "both
+//    <= t" (0.20 % of the window-diagonals pass on synthetic audio, 0.05 % the exact head test).  16 + 16 result registers
+//    are folded into four words (one per group of four windows) and the four sign bits are shifted into a per-lane flag
+//    word (v_alignbit): 20 vector instructions, no compare, no branch.
 //  * Every eight tiles the flag words become ITEMS = (group of four windows, destination position), handed out one per
 //    lane, 64 at a time, whatever lane flagged them (a position that looks like many windows -- a sustained sound --
 //    flags the same lane again and again: left to that lane, the wave waits for it).  A lane tests its item's four
-//    windows' head rows EXACTLY with popcounts (the vector form's test), then the tail rows of what passes, then
-//    kM2Probe rows on either side (a whole window whose run ends inside them is shorter than any min_len this path
-//    takes: dropped) -- all from LDS.  What remains (a few windows per pair: real runs) is resolved by the wave against
-//    the source sequence in global memory, two rows per lane and direction in one trip.
-//  * One workgroup = one destination x up to EIGHT sources (as many as its share of the CU's LDS holds): staging and the
-//    expansion of the destination's hashes into B fragments are shared by 7 - 19 row tiles instead of 5; an A fragment
-//    read serves both column blocks of a unit; waves take units from a counter in LDS, so none idles while another still
-//    has units; a workgroup finds its group with one load (round 4: a binary search of the table, 17 dependent loads).
-//  * Default shape (mfma_waves(), search.hip): workgroups of 8 waves, two per CU, four waves per SIMD (128 registers: one
-//    accumulator pair, a tile folded before the next is multiplied).  Measured against it: 16 waves x 1 (same), 12 waves
-//    x 1 with two accumulator pairs and the next tile's products issued before the fold (5 % slower), 4 waves x 3 (45 %).
+//    windows on all eight rows with popcounts out of LDS.
+//  * What passes (a window in thousands) is looked at by the WAVE, window by window, sixteen lanes reading its sixteen
+//    rows in LDS (window_whole_wave): whole, and not a run that ends within kM2Probe rows on both sides?  Consecutive whole
+//    windows on a diagonal form a CHAIN; only its last window resolves it -- one trip to global memory fetches 512 rows
+//    backward and 128 forward, every stretch of >= min_len matching rows in it is a run (resolve()).
+//  * Runs go to a buffer in LDS; the workgroup asks for their slots in the run list with one atomic at its end.
+//  * One workgroup = one destination x up to EIGHT sources (as many as its share of the CU's LDS holds); the sources'
+//    windows (A image rows + sixteen hashes each) are built once per launch (m2_window_images_kernel) and copied in; an A
+//    fragment read serves both column blocks of a unit; waves take units from a counter in LDS, so none idles while another
+//    still has units; a workgroup finds its group with one load (round 4: a binary search of the table, 17 dependent loads).
+//  * Default shape (mfma_waves(), search.hip): workgroups of 8 waves, two per CU, four waves per SIMD, ~100 registers, one
+//    accumulator pair, a tile folded before the next is multiplied.  Measured against it: 16 waves x 1 (3.2 against 2.8 ms
+//    at 79 800 pairs of 45-minute windows), 12 x 1 and 4 x 3 (slower still).
 //  * Columns outside the table get all-zero B fragments and rows beyond the last window read a row of zeros
 //    (product 0 + preset > 0: never flagged).
-// Operand maps of the instruction: tools/mfma_i8_layout.hip.  Needs t <= 15.
+// ONE call site of enqueue(), process() and resolve() each (always_inline; at three sites each the kernel was 7500 lines of
+// ISA and every item-path stage 40 - 70 % slower).  Needs t <= 15.
 #ifndef NEEDLE_M2_LAB
 #define NEEDLE_M2_LAB 0                       // timing laboratory (tools/build_variant.sh), WRONG results: 1 flags ignored (the tile loop
-                                              // alone), 2 head survivors dropped, 4 whole windows not resolved, 8 event counts, 16 a resolution's trip and no more, 32 a walk ends at its first mismatch, 64 a workgroup's setup alone
+                                              // alone), 2 the items' survivors dropped, 4 whole windows not resolved, 8 event counts, 16 a resolution's trip and no more, 32 a walk ends at its first mismatch, 64 a workgroup's setup alone
 #endif
 #if NEEDLE_M2_LAB & 8   // laboratory: event counts (search.hip prints them after the launch)
 __device__ unsigned long long m2_dbg[8];
@@ -65,12 +70,11 @@ static_assert(kSampleW + 2 * kM2Probe - 2 < 2 * kSampleW - 1 + 8, "a run that en
 // LDS words of a workgroup: staged destination (+ 64 zeros), tables, per-window source hashes, A image
 __host__ __device__ constexpr size_t m2_round4(size_t x) { return (x + 3) & ~(size_t)3; }
 __host__ __device__ constexpr size_t m2_lds_words(uint64_t m, uint64_t windows, int waves) {
-  return m2_round4(m + 64) + kM2CtlWords + kM2Table + 4 * kM2RunBuf + (size_t)waves * kM2Queue + (size_t)kM2Rows * windows +
-         (size_t)(windows + 1) * kM2Pitch;
+  return m2_round4(m + 64) + kM2CtlWords + kM2Table + 4 * kM2RunBuf + (size_t)waves * kM2Queue + (size_t)(windows + 1) * (kM2Pitch + kM2Rows);
 }
 
 // A source sequence's windows as a workgroup wants them in LDS -- per window kM2Pitch words of the A image (its four head
-// hashes as 32 negated +-1 bytes each, then w0) and kM2Rows source hashes around it -- built ONCE per launch in global
+// hashes as 32 negated +-1 nibbles each, then w0) and kM2Rows source hashes around it -- built ONCE per launch in global
 // memory (m2_window_images_kernel) instead of by every workgroup that takes the sequence as a source: at 2000 videos a
 // sequence is a source 1999 times, and gathering + expanding its windows was a tenth of the scan (a workgroup's setup
 // alone: 0.44 of 4.0 ms at 79 800 pairs).  A workgroup copies its members' images with 16-byte loads.
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     NeedleHipRun *__restrict__ runs, uint32_t capacity, uint32_t *__restrict__ count, int splits,
     const uint32_t *__restrict__ images) {
   static_assert(W == 8, "head rows {0, 2, 4, 7} and tail rows {1, 3, 5, 6} of a window of 8");
-  constexpr int H = kM2Heads, HP = H / 2, PITCH = kM2Pitch, CB = kM2ColBlocks, E = kM2Probe, NR = kM2Rows;
+  constexpr int H = kM2Heads, HP = H / 2, PITCH = kM2Pitch, STRIDE = kM2ImageWords, CB = kM2ColBlocks, E = kM2Probe, NR = kM2Rows;
   extern __shared__ uint32_t lds[];
   __builtin_amdgcn_s_setprio(3);
   // Which group: workgroup / splits.  Its first entry's index lies in the pad field (bits 8 .. 30) of the table entry whose
@@ -152,8 +156,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   uint32_t *runbuf = ntab + kM2Table;            // the workgroup's runs: (pair, last row, last column, length)
   uint32_t *queues = runbuf + 4 * kM2RunBuf;     // per wave: items waiting for their exact test
   // per window the source hashes of rows w0 - E .. w0 + W + E - 1 (zero where there is none)
-  uint32_t *wsrc = queues + WAVES * kM2Queue;
-  uint32_t *aimg = wsrc + NR * nW;               // 16-byte aligned: every size above is a multiple of 4 words
+  // Per window ONE row of kM2ImageWords = 36 words: its A image row (the head hashes' nibbles, then w0), then its sixteen
+  // source hashes.  36 = 4 x 9: sixteen lanes' 16-byte reads of sixteen different windows -- the A fragments of a tile, the
+  // rows of the items' windows -- fall into sixteen different groups of four banks.  (Two arrays, the hashes at a pitch of
+  // 16 words: lanes with different windows met in FOUR groups; SQ_LDS_BANK_CONFLICT was 61 % of SQ_LDS_IDX_ACTIVE.)
+  uint32_t *wimg = queues + WAVES * kM2Queue;    // 16-byte aligned: every size above is a multiple of 4 words
 
   if (threadIdx.x == 0) {
     ctl[0] = 0u;
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         const uint32_t from = ctl[26 + g] + ((uint32_t)k - ctl[1 + g]);
         v[u] = *reinterpret_cast<const mfma_v4i *>(images + (size_t)from * kM2ImageWords + 4 * piece);
         if (piece == PITCH / 4 - 1) v[u][0] |= (int)((uint32_t)g << 28);   // w0 -> member << 28 | w0
-        to[u] = piece < PITCH / 4 ? aimg + k * PITCH + 4 * piece : wsrc + NR * k + 4 * (piece - PITCH / 4);
+        to[u] = wimg + k * STRIDE + 4 * piece;
       }
 #pragma unroll
       for (int u = 0; u < kU; u++)
@@ -232,10 +239,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
       for (int u = 0; u < kU; u++) {
         const int k = k0 + u * kStep;
         if (k >= nW) break;
-        wsrc[NR * k + s + E] = hv[u];
-        if (s == 0) aimg[k * PITCH + 4 * H] = wm[u];
+        wimg[k * STRIDE + PITCH + s + E] = hv[u];
+        if (s == 0) wimg[k * STRIDE + 4 * H] = wm[u];
         if (s == 0 || s == 2 || s == 4 || s == 7) {                  // head rows 0 .. 3
-          uint32_t *o = aimg + k * PITCH + 4 * (s == 7 ? 3 : s >> 1);
+          uint32_t *o = wimg + k * STRIDE + 4 * (s == 7 ? 3 : s >> 1);
 #pragma unroll
           for (int q = 0; q < 4; q++) o[q] = ntab[(~hv[u] >> (8 * q)) & 0xFFu];   // negated: a set bit becomes -1
         }
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     }
   }
   }
-  for (int q = threadIdx.x; q < PITCH; q += 64 * WAVES) aimg[nW * PITCH + q] = 0u;  // the row the last tile reads beyond the last window
+  for (int q = threadIdx.x; q < PITCH; q += 64 * WAVES) wimg[nW * STRIDE + q] = 0u;  // the row the last tile reads beyond the last window
   __syncthreads();
 
   const int lane = (int)(threadIdx.x & 63);
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     const int ihi = min(ns - 1, m - 1 - d);
     const int row = w0 - E + (lane & (NR - 1));
     const bool in = row >= ilo && row <= ihi;
-    const bool is_bad = !in || (uint32_t)__popc(wsrc[NR * k + (lane & (NR - 1))] ^ ldst[min(max(row, ilo), ihi) + d]) > threshold;
+    const bool is_bad = !in || (uint32_t)__popc(wimg[k * STRIDE + PITCH + (lane & (NR - 1))] ^ ldst[min(max(row, ilo), ihi) + d]) > threshold;
     const uint32_t mask = (uint32_t)__builtin_amdgcn_ballot_w64(is_bad) & 0xFFFFu;
     constexpr uint32_t kWindow = ((1u << W) - 1u) << E, kBelow = (1u << E) - 1u, kAbove = kBelow << (E + W);
     return (mask & kWindow) == 0u && !((mask & kBelow) != 0u && (mask & kAbove) != 0u);
@@ -437,8 +444,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int k = min(kbase + i, nW - 1);
-        const mfma_v4i lo4 = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E);       // rows 0 .. 3 of the window
-        const mfma_v4i hi4 = *reinterpret_cast<const mfma_v4i *>(wsrc + NR * k + E + 4);   // rows 4 .. 7
+        const mfma_v4i lo4 = *reinterpret_cast<const mfma_v4i *>(wimg + k * STRIDE + PITCH + E);       // rows 0 .. 3 of the window
+        const mfma_v4i hi4 = *reinterpret_cast<const mfma_v4i *>(wimg + k * STRIDE + PITCH + E + 4);   // rows 4 .. 7
         uint32_t miss = 0u;
 #pragma unroll
         for (int s = 0; s < 4; s++)
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         const int src_lane = __ffsll((long long)cand) - 1;
         cand &= cand - 1;
         const int ck = __builtin_amdgcn_readlane(k, src_lane), cj = __builtin_amdgcn_readlane(j, src_lane);
-        const uint32_t wm = __builtin_amdgcn_readfirstlane(aimg[ck * PITCH + 4 * H]);
+        const uint32_t wm = __builtin_amdgcn_readfirstlane(wimg[ck * STRIDE + 4 * H]);
         const int g = (int)(wm >> 28), w0 = (int)(wm & 0x0FFFFFFFu);
         if (!window_whole_wave(ck, g, w0, cj)) continue;
         if (ck + 1 < (int)__builtin_amdgcn_readfirstlane(ctl[2 + g]) && window_whole_wave(ck + 1, g, w0 + P, cj + P)) continue;
@@ -502,10 +509,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     }
   };
 
-  const uint32_t *arow = aimg + r * PITCH + 4 * h;                                         // rows of a full tile: + rt 32 PITCH
-  const uint32_t *arow_last = aimg + min(32 * (row_tiles - 1) + r, nW) * PITCH + 4 * h;  // the last tile's may lie beyond the last window
+  const uint32_t *arow = wimg + r * STRIDE + 4 * h;                                         // rows of a full tile: + rt 32 STRIDE
+  const uint32_t *arow_last = wimg + min(32 * (row_tiles - 1) + r, nW) * STRIDE + 4 * h;  // the last tile's may lie beyond the last window
   auto load_a = [&](const int rt, mfma_v4i (&fa)[HP]) {
-    const uint32_t *ap = rt == row_tiles - 1 ? arow_last : arow + rt * 32 * PITCH;
+    const uint32_t *ap = rt == row_tiles - 1 ? arow_last : arow + rt * 32 * STRIDE;
 #pragma unroll
     for (int kb = 0; kb < HP; kb++) fa[kb] = *reinterpret_cast<const mfma_v4i *>(ap + 8 * kb);
   };

@@ -180,6 +180,47 @@ def test_fast_kernels_equal_reference_dp(n, m, min_len, search_mode):
         assert form == {"sampled-mfma": 4, "band": 2, "generic": 1}.get(search_mode, 3), (form, search_mode, n, m, min_len)
 
 
+@pytest.mark.parametrize("min_len,seed", [(82, 1), (82, 2), (41, 3), (163, 4), (23, 5)])
+def test_ragged_runs_over_chains_of_windows(min_len, seed, search_mode):
+    """One long common stretch broken by single mismatching rows, the way a shared intro looks in real audio -- what the
+    matrix-pipe form resolves by CHAINS of whole windows (scan_mfma_kernel.h resolve()): mismatches in the gap between two
+    aligned windows (both sides are runs, one walk reports both), inside an aligned window, two in one gap, two next to each
+    other, stretches of exactly min_len and min_len - 1 rows, a window isolated by mismatches two rows off on both sides, a
+    stretch that reaches the table's last row, slowly changing hashes (neighbouring diagonals match as well), and a run
+    that goes on for more than 128 rows behind its chain's last window (min_len 163).  Every kernel form against the DP."""
+    rng = np.random.default_rng(1000 + seed)
+    n, m = 3100, 2950
+    src, dst = _rand_hashes(rng, n), _rand_hashes(rng, m)
+    P = min_len - 8 + 1
+    a, b, L = 140, 87, 2400                                       # src[a + i] ~ dst[b + i]
+    src[a:a + L:2] = src[a + 1:a + L + 1:2]                       # pairs of equal hashes: diagonals d +- 1 match every other row
+    noise = (np.uint32(1) << rng.integers(0, 32, L).astype(np.uint32)) * (rng.random(L) < 0.4)
+    dst[b:b + L] = src[a:a + L] ^ noise
+    tail = min(n, m) - 300                                        # a second stretch up to the last row of both
+    src[n - 300:] = _rand_hashes(rng, 300)
+    dst[m - 300:] = src[n - 300:]
+    del tail
+
+    def first_window_at_or_after(row):                            # aligned windows start at rows 1 + k P
+        return 1 + -(-(row - 1) // P) * P
+    w = first_window_at_or_after(a + 3 * P)
+    breaks = [w + 8 + P // 2,                                     # in a gap
+              w + P + 3,                                          # inside the next aligned window
+              w + 2 * P + 10, w + 2 * P + P - 5,                  # two in one gap
+              w + 4 * P + 20, w + 4 * P + 21,                     # neighbours
+              w + 6 * P - 2, w + 6 * P + 9]                       # two rows off a window on both sides: a 10-row stretch
+    x = w + 8 * P + 11
+    breaks += [x, x + min_len + 1, x + 2 * min_len + 1]           # stretches of exactly min_len and min_len - 1 rows
+    for row in breaks:
+        if a <= row < a + L:
+            dst[b + (row - a)] ^= np.uint32(0xFFFFF000)           # 20 bits: over any threshold used here
+    thr = 10
+    got = _gpu_runs([src, dst], [(0, 1, min_len)], thr).get(0, [])
+    want = _oracle_runs(src, dst, thr, min_len)
+    assert got == want
+    assert len(want) >= 4
+
+
 def test_fast_kernels_all_cells_match_and_many_problems(search_mode):
     rng = np.random.default_rng(77)
     # threshold >= 32: every cell with i, j >= 1 matches; each diagonal is one run as long as the diagonal
