@@ -73,10 +73,10 @@ enum NeedleError needle_hip_scan_issued_evaluations(uint64_t *lane_evaluations, 
  * with NEEDLE_HIP_SCAN_SHAPE="W,H" (W in 4, 8, 16; H in 2..4): every shape emits the same runs (tools/scan_shape_sweep.py). */
 enum NeedleError needle_hip_scan_counts(uint64_t counts[2], bool reset);
 /* Which form of the scan the last launch of this process took: 0 none yet, 1 one lane per diagonal (short minimum runs),
- * 2 bands, 3 aligned windows on the vector ALU, 4 aligned windows with the head rows on the matrix pipe (large launches
- * of thresholds <= 15 whose windows fill their row tiles; NEEDLE_HIP_SCAN_MFMA=0 / 1 forces either) -- and for form 4
- * the v_mfma_i32_32x32x32_i8 instructions that launch issued (65 536 integer operations each): the numerator of ITS
- * roofline.  Every form emits the same runs. */
+ * 2 bands, 3 aligned windows on the vector ALU, 4 aligned windows with the head rows on the matrix pipe (launches of 2048
+ * sequence pairs or more, thresholds <= 15, windows that fill their row tiles; NEEDLE_HIP_SCAN_MFMA=0 / 1 forces either)
+ * -- and for form 4 the v_mfma_f32_32x32x64_f8f6f4 instructions (FP4 operands, two head rows each) that launch issued
+ * (131 072 operations each): the numerator of ITS roofline.  Every form emits the same runs. */
 enum NeedleError needle_hip_scan_last_launch(int32_t *form, uint64_t *matrix_products);
 
 /* ---- fingerprint: the chromaprint Context replacement -------------------------------------------
