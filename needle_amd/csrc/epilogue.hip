@@ -273,9 +273,12 @@ __device__ __forceinline__ float as_secs_f32(uint64_t d) {  // Duration::as_secs
   return secs + frac;
 }
 
-constexpr int kHashTile = 4096;
+constexpr int kImageRows = 512;   // candidates of a stage of the links' b side (best_match_kernel)
+constexpr int kImagePitch = 12;   // words per row of the stage's image: 8 of +-1 bytes + 4 (16-byte reads of sixteen rows: sixteen groups of banks)
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 // One workgroup per wanted video.
-__global__ __launch_bounds__(256) void best_match_kernel(EpilogueParams pr, const uint32_t *__restrict__ start,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void best_match_kernel(EpilogueParams pr, const uint32_t *__restrict__ start,
                                                          const uint32_t *__restrict__ valid, const DeviceEntry *__restrict__ entries,
                                                          Candidate *__restrict__ cand_pool, unsigned long long *__restrict__ cand_cursor,
                                                          uint32_t *__restrict__ links_pool, NeedleHipSearchResult *__restrict__ results,
@@ -283,7 +286,8 @@ __global__ __launch_bounds__(256) void best_match_kernel(EpilogueParams pr, cons
   __shared__ uint32_t scan[256];
   __shared__ uint32_t carry;
   __shared__ unsigned long long pool_base;
-  __shared__ uint32_t tile[kHashTile];
+  __shared__ __attribute__((aligned(16))) uint32_t image[kImageRows * kImagePitch];
+  __shared__ uint32_t ntab[16];
   __shared__ BestKey best[2][256];
   const uint32_t v = pr.v0 + blockIdx.x, t = threadIdx.x;
   const uint64_t n = pr.n;
@@ -357,28 +361,61 @@ __global__ __launch_bounds__(256) void best_match_kernel(EpilogueParams pr, cons
   }
   __threadfence_block();
   __syncthreads();
-  // links[k] = #{b : popcount(h_k ^ h_b) < bound}, k itself included (:434-454): all candidates against all, the b side
-  // staged through LDS a tile at a time
-  for (uint32_t k0 = 0; k0 < c; k0 += 256 * 4) {
-    uint32_t hk[4], acc[4] = {0, 0, 0, 0};
-    for (int u = 0; u < 4; u++) {
-      const uint32_t k = k0 + u * 256 + t;
-      hk[u] = k < c ? cand[k].hash : 0u;
+  // links[k] = #{b : popcount(h_k ^ h_b) < bound}, k itself included (:434-454): all candidates against all -- c x c Hamming
+  // distances, 25 million per video at 2000 videos, and as in the scan a matrix product: with a hash as 32 bytes of +-1,
+  // dot(a, b) = 32 - 2 d(a, b).  One v_mfma_i32_32x32x32_i8 is 32 candidates b (rows, the A side NEGATED) x 32 candidates k
+  // (columns): with the accumulator preset to 32 - 2 bound its sign bit says d < bound.  A lane holds sixteen rows of ITS
+  // column: the sixteen sign bits are shifted into a word, two tiles' words counted with one v_bcnt -- 18 vector
+  // instructions per 1024 pairs (on the vector ALU, one lane per k: xor, popcount, compare, add = 64).  The b side is
+  // staged through LDS as +-1 bytes, kImageRows candidates at a time, built by the workgroup and read by its four waves
+  // as A fragments; a wave owns every fourth block of 32 k and keeps their sums in links[] between the stages.
+  // (Rows beyond c are zero bytes: dot 0, "d = 16" -- counted as a match when bound > 16 and taken out again below.)
+  {
+    const uint32_t lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    if (t < 16) {
+      uint32_t w = 0;
+      for (int i = 0; i < 4; i++) w |= (((t >> i) & 1) ? 0x01u : 0xFFu) << (8 * i);
+      ntab[t] = w;
     }
-    for (uint32_t b0 = 0; b0 < c; b0 += kHashTile) {
-      const uint32_t len = min((uint32_t)kHashTile, c - b0);
-      __syncthreads();
-      for (uint32_t i = t; i < len; i += 256) tile[i] = cand[b0 + i].hash;
-      __syncthreads();
-      for (uint32_t i = 0; i < len; i++) {
-        const uint32_t hb = tile[i];
+    const int preset = 32 - 2 * (int)pr.bound;
+    v16i presets;
 #pragma unroll
-        for (int u = 0; u < 4; u++) acc[u] += (uint32_t)__popc(hk[u] ^ hb) < pr.bound ? 1u : 0u;
+    for (int q = 0; q < 16; q++) presets[q] = preset;
+    const uint32_t k_blocks = (c + 31) / 32;
+    for (uint32_t b0 = 0; b0 < c; b0 += kImageRows) {
+      const uint32_t len = min((uint32_t)kImageRows, c - b0);
+      const uint32_t b_blocks = (len + 31) / 32;
+      __syncthreads();
+      // the stage's image: row i = candidate b0 + i as 32 NEGATED +-1 bytes (a set bit: -1), 8 words at a pitch of 12
+      for (uint32_t i = t; i < b_blocks * 32; i += 256) {
+        const uint32_t hb = i < len ? ~cand[b0 + i].hash : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; q++) image[i * kImagePitch + q] = i < len ? ntab[(hb >> (4 * q)) & 0xFu] : 0u;
       }
-    }
-    for (int u = 0; u < 4; u++) {
-      const uint32_t k = k0 + u * 256 + t;
-      if (k < c) links[k] = acc[u];
+      __syncthreads();
+      const uint32_t pad = b_blocks * 32 - len;   // zero rows of the stage's last block
+      for (uint32_t kb = wave; kb < k_blocks; kb += 4) {
+        const uint32_t k = kb * 32 + r;
+        const uint32_t half = (k < c ? cand[k].hash : 0u) >> (16 * h);
+        v4i fb;                                   // B fragment: column r = candidate k, bits 16 h .. 16 h + 15 as +-1 bytes
+#pragma unroll
+        for (int q = 0; q < 4; q++) fb[q] = (int)ntab[(half >> (4 * q)) & 0xFu];
+        uint32_t cnt = 0, word = 0;
+        for (uint32_t bb = 0; bb < b_blocks; bb++) {
+          const v4i fa = *reinterpret_cast<const v4i *>(image + (bb * 32 + r) * kImagePitch + 4 * h);
+          const v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, presets, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 16; q++) word = __builtin_amdgcn_alignbit(word, (uint32_t)acc[q], 31);
+          if (bb & 1) {
+            cnt += (uint32_t)__popc(word);
+            word = 0;
+          }
+        }
+        cnt += (uint32_t)__popc(word);
+        cnt += (uint32_t)__shfl_xor((int)cnt, 32);   // the column's other sixteen rows of every tile
+        if (preset < 0) cnt -= pad;               // bound > 16: the zero rows counted
+        if (h == 0 && k < c) links[k] = (b0 == 0 ? 0u : links[k]) + cnt;
+      }
     }
   }
   __syncthreads();
