@@ -169,6 +169,11 @@ Status gpu_hamming_runs_host(const uint32_t *hashes, size_t num_hashes, const Ne
                              const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
                              std::vector<NeedleHipRun> *runs);
 
+// the hash arena of a search call in pinned host memory, and its upload enqueued ahead of the call (search.hip)
+uint32_t *gpu_pinned_arena_acquire(size_t words);  // nullptr: none to be had (no device, or one is handed out already)
+void gpu_pinned_arena_release(uint32_t *arena);
+void gpu_prefetch_hashes(const uint32_t *hashes, size_t num_hashes);
+
 // Sequence pairs from which the per-video epilogue runs on the device (epilogue.hip) instead of on host threads
 // (NEEDLE_HIP_DEVICE_EPILOGUE=1 / 0 forces either): the library job and Comparator::run_with_frame_hashes alike.
 constexpr uint64_t kDeviceEpiloguePairs = 1u << 14;

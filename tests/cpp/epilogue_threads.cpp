@@ -22,6 +22,9 @@ Analyzer Analyzer::from_files(std::vector<std::string>, bool, bool) { std::abort
 Status Analyzer::run(ns_t, bool, bool, std::vector<FrameHashesData> *) const { std::abort(); }
 Status gpu_hamming_runs_host(const uint32_t *, size_t, const NeedleHipSeq *, size_t, const NeedleHipProblem *, size_t, uint32_t,
                              std::vector<NeedleHipRun> *) { std::abort(); }
+uint32_t *gpu_pinned_arena_acquire(size_t) { return nullptr; }
+void gpu_pinned_arena_release(uint32_t *) {}
+void gpu_prefetch_hashes(const uint32_t *, size_t) {}
 }  // namespace needle
 struct FrameHashes { needle::FrameHashesData d; };
 struct NeedleAudioComparator { needle::Comparator inner; };
