@@ -180,19 +180,20 @@ def test_fast_kernels_equal_reference_dp(n, m, min_len, search_mode):
         assert form == {"sampled-mfma": 4, "band": 2, "generic": 1}.get(search_mode, 3), (form, search_mode, n, m, min_len)
 
 
-@pytest.mark.parametrize("min_len,seed", [(82, 1), (82, 2), (41, 3), (163, 4), (23, 5)])
+@pytest.mark.parametrize("min_len,seed", [(82, 1), (82, 2), (41, 3), (163, 4), (23, 5), (300, 7), (700, 6)])
 def test_ragged_runs_over_chains_of_windows(min_len, seed, search_mode):
     """One long common stretch broken by single mismatching rows, the way a shared intro looks in real audio -- what the
     matrix-pipe form resolves by CHAINS of whole windows (scan_mfma_kernel.h resolve()): mismatches in the gap between two
     aligned windows (both sides are runs, one walk reports both), inside an aligned window, two in one gap, two next to each
     other, stretches of exactly min_len and min_len - 1 rows, a window isolated by mismatches two rows off on both sides, a
     stretch that reaches the table's last row, slowly changing hashes (neighbouring diagonals match as well), and a run
-    that goes on for more than 128 rows behind its chain's last window (min_len 163).  Every kernel form against the DP."""
+    that goes on for more than 128 rows behind its chain's last window (min_len 163), windows further apart than a walk's
+    block of 512 rows (min_len 700).  Every kernel form against the DP."""
     rng = np.random.default_rng(1000 + seed)
-    n, m = 3100, 2950
-    src, dst = _rand_hashes(rng, n), _rand_hashes(rng, m)
     P = min_len - 8 + 1
-    a, b, L = 140, 87, 2400                                       # src[a + i] ~ dst[b + i]
+    a, b, L = 140, 87, max(2400, 14 * P + 300)                    # src[a + i] ~ dst[b + i]
+    n, m = a + L + 560, b + L + 463                               # (3100 x 2950 for the usual window spacings)
+    src, dst = _rand_hashes(rng, n), _rand_hashes(rng, m)
     src[a:a + L:2] = src[a + 1:a + L + 1:2]                       # pairs of equal hashes: diagonals d +- 1 match every other row
     noise = (np.uint32(1) << rng.integers(0, 32, L).astype(np.uint32)) * (rng.random(L) < 0.4)
     dst[b:b + L] = src[a:a + L] ^ noise
@@ -216,9 +217,14 @@ def test_ragged_runs_over_chains_of_windows(min_len, seed, search_mode):
             dst[b + (row - a)] ^= np.uint32(0xFFFFF000)           # 20 bits: over any threshold used here
     thr = 10
     got = _gpu_runs([src, dst], [(0, 1, min_len)], thr).get(0, [])
-    want = _oracle_runs(src, dst, thr, min_len)
+    if (min_len, seed) not in _RAGGED_WANT:                       # (the DP over 10 000 x 10 000 cells takes the oracle a minute: once)
+        _RAGGED_WANT[(min_len, seed)] = _oracle_runs(src, dst, thr, min_len)
+    want = _RAGGED_WANT[(min_len, seed)]
     assert got == want
     assert len(want) >= 4
+
+
+_RAGGED_WANT = {}
 
 
 def test_fast_kernels_all_cells_match_and_many_problems(search_mode):

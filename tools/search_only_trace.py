@@ -1,13 +1,8 @@
-#!/usr/bin/env python3
-"""bench.py's search_only leg (BASELINE.json configs[2]: 280 x 24 min from .needle.dat files) on its own, with the
-library's phase trace on stderr (NEEDLE_HIP_TRACE=1): where the wall time of needle_audio_comparator_run goes."""
-import json
-import os
-import sys
-
+# phase times (NEEDLE_HIP_TRACE) of bench.py's search_only leg: warm calls of needle_audio_comparator_run(analyze=false)
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402
-from needle_amd import capi, synth  # noqa: E402
-
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 280
-print(json.dumps(bench.search_only(capi, synth, n, 24.0, reps=3)))
+if len(sys.argv) > 1 and sys.argv[1] == "trace":
+    os.environ["NEEDLE_HIP_TRACE"] = "1"
+import bench
+from needle_amd import capi, synth
+print("search_only wall_ms", bench.search_only(capi, synth, 280, 24.0, reps=20)["wall_ms"])
