@@ -292,7 +292,7 @@ def search_roofline(ceiling_cells, issued_evals, covered_cells, scan_ms):
                     "not machine utilisation"}
 
 
-def search_only(capi, synth, episodes, minutes, reps=5):
+def search_only(capi, synth, episodes, minutes, reps=10):
     """BASELINE.json configs[2]: `episodes` x 24-min episodes as real .needle.dat files (written once by this
     analyzer from synthetic audio), then needle_audio_comparator_run(analyze=false) timed from disk: file reads,
     upload of the hashes, scan + simhash + epilogue kernels, download of the results."""
@@ -347,7 +347,7 @@ def search_only(capi, synth, episodes, minutes, reps=5):
     n_h = capi.lib().needle_hip_fingerprint_num_kept(int(round(half * RATE)), 2)
     wall = sum(walls) / len(walls)
     return {"episodes": episodes, "pairs": pairs, "hashes_per_episode": int(n_h),
-            "wall_ms": round(1e3 * wall, 3), "pairs_per_s": round(pairs / wall, 1),
+            "wall_ms": round(1e3 * wall, 3), "wall_ms_each": [round(1e3 * w, 3) for w in walls], "wall_ms_best": round(1e3 * min(walls), 3), "pairs_per_s": round(pairs / wall, 1),
             "scan_kernel_ms": round(sum(scan) / len(scan), 4), "simhash_kernel_ms": round(sum(simh) / len(simh), 4),
             "table_cells": float(pairs) * n_h * n_h, "prepare_s": round(prep_s, 2), "issued_evals": issued,
             "scan_form": scan_form, "matrix_instructions": scan_products,
