@@ -10,7 +10,8 @@
 //                    lexicographic Ord, :22-35) -> the bucket's entries in the heap's backing-array order (:249)
 //   best_match     : one workgroup per video -- its pairs in lexicographic order, openings before endings inside a
 //                    pair (:414-431) = the candidate numbering; links[k] = #{b : popcount(h_k ^ h_b) < bound} over ALL
-//                    its candidates by brute force (:434-454); score = -(links * 0.3f + secs * 0.7f) in unfused f32
+//                    its candidates (:434-454): every pair, as int8 matrix products of the hashes' bits as +-1 whose
+//                    sign bits are counted (exact: a dot product of +-1 bytes IS 32 - 2 popcount); score = -(links * 0.3f + secs * 0.7f) in unfused f32
 //                    (:469); arg-min over (score, index) (:473-475); padding and hash duration (:479-481)
 //
 // Nothing here approximates: ties are broken by the candidate index exactly as the sorted (f32, usize) list of the
