@@ -351,7 +351,11 @@ Status frame_hashes_read(const std::string &path, FrameHashesData *out) {
   if (!r.bad && version != 0) r.bad = true;  // unknown variant index is a bincode error
   const uint32_t tag = r.get<uint32_t>();
   if (!r.bad && tag != 0) r.bad = true;
-  FrameHashesData fh;
+  // parsed INTO *out (whose vectors keep what they had allocated: the comparator hands the same objects in call after call);
+  // on failure *out holds rubbish and the callers drop it
+  FrameHashesData &fh = *out;
+  fh.opening.clear();
+  fh.ending.clear();
   if (!r.bad) r.hashes(&fh.opening);
   if (!r.bad) r.hashes(&fh.ending);
   fh.hash_duration = r.duration();
@@ -363,7 +367,6 @@ Status frame_hashes_read(const std::string &path, FrameHashesData *out) {
   // is_version_valid (data.rs:96-101): with one variant on each side, index 0/0 always agrees;
   // kept as an explicit check for future versions.
   if (version != tag) return Status::Make(NeedleError_FrameHashDataInvalidVersion, "invalid frame hash data version");
-  *out = std::move(fh);
   return Status::Ok();
 }
 
