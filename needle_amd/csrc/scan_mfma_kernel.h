@@ -57,7 +57,7 @@ constexpr int kM2Pitch = kM2Heads * 4 + 4;    // words of a window's row in the 
                                               // (20: sixteen lanes' 16-byte reads of one instruction fall into sixteen different groups of four banks)
 constexpr int kM2RunBuf = 64;                 // runs a workgroup collects in LDS before it asks for room in the run list (one atomic)
 constexpr int kM2Table = 256;                 // a byte of hash bits -> its eight FP4 nibbles (bit set: +1 = 0x2, clear: -1 = 0xA)
-constexpr int kM2Probe = 4;                   // rows tested per lane on either side of a whole window
+constexpr int kM2Probe = 4;                   // rows looked at on either side of a whole window
 constexpr int kM2Rows = kSampleW + 2 * kM2Probe;  // source hashes kept per window: rows w0 - 4 .. w0 + 11
 constexpr int kM2ColBlocks = 2;               // column blocks of 32 positions a wave takes per unit
 constexpr int kM2Batch = 4;                   // row tiles (x 2 column blocks = 8 tiles = 32 flag bits) between two looks at the flags
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     const uint32_t *__restrict__ hashes, const SearchProblem *__restrict__ problems, int num_problems, uint32_t threshold,
     NeedleHipRun *__restrict__ runs, uint32_t capacity, uint32_t *__restrict__ count, int splits,
     const uint32_t *__restrict__ images) {
-  static_assert(W == 8, "head rows {0, 2, 4, 7} and tail rows {1, 3, 5, 6} of a window of 8");
+  static_assert(W == 8, "head rows {0, 2, 4, 7} of a window of 8: two pairs for two products");
   constexpr int H = kM2Heads, HP = H / 2, PITCH = kM2Pitch, STRIDE = kM2ImageWords, CB = kM2ColBlocks, E = kM2Probe, NR = kM2Rows;
   extern __shared__ uint32_t lds[];
   __builtin_amdgcn_s_setprio(3);
@@ -425,8 +425,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   // What the flags point at.  An ITEM = (group of four windows, destination position) that may hold a survivor.  Items
   // are handed out one per lane, 64 at a time, whatever lane flagged them (a destination position that looks like many
   // windows -- a sustained sound -- flags the same lane again and again: left to that lane, the wave would wait for it).
-  // A lane tests its item's four windows' head rows EXACTLY with popcounts out of LDS (the vector form's test), then the
-  // tail rows of what passes, then kM2Probe rows on either side; what remains is resolved by the wave.
+  // A lane tests its item's four windows on all eight rows with popcounts out of LDS; what passes is looked at by the wave
+  // (window_whole_wave, the chain rule) and, if it is the last window of its chain, resolved.
   auto process = [&](const int first, const int cnt) __attribute__((always_inline)) {
     wave_lds_fence_search();
     uint32_t passm = 0u;                          // windows of the group (bit i) whose W cells all match
