@@ -1126,7 +1126,7 @@ uint32_t *gpu_pinned_arena_acquire(size_t words) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   if (!ensure_device().ok()) return nullptr;
   HostCallBuffers *hb = host_call_buffers();
-  if (hb->arena_out) return nullptr;
+  if (hb->arena_out || getenv("NEEDLE_HIP_PAGEABLE_ARENA")) return nullptr;  // (the switch: tests of the pageable path)
   if (words > hb->arena_words) {
     if (hb->arena) (void)hipHostFree(hb->arena);
     hb->arena = nullptr;

@@ -554,6 +554,42 @@ def test_config3_search_only_from_needle_dat_files(tmp_path, capfd):
     # in-memory call returns the same per-video results
     got = cmp.run_with_frame_hashes([capi.FrameHashes.from_path(p[:-4] + ".needle.dat") for p in paths])
     _same_results(got, want)
+    # The search-only call keeps the objects that hold the videos' hashes between calls and fills its hash arena in pinned
+    # memory: the same call again (objects reused), from pageable memory, and -- the objects of the 24 now holding other
+    # videos' hashes -- a library of fewer, shorter videos must print what the first call / the oracle print.
+    cmp.run(analyze=False, display=True)
+    assert capfd.readouterr().out == out
+    os.environ["NEEDLE_HIP_PAGEABLE_ARENA"] = "1"
+    try:
+        cmp.run(analyze=False, display=True)
+    finally:
+        del os.environ["NEEDLE_HIP_PAGEABLE_ARENA"]
+    assert capfd.readouterr().out == out
+    small_fhs, small_paths = [], []
+    for v in range(7):
+        op = _rand_hashes(rng, 900 + 31 * v)
+        if v != 3:
+            op[50 + 11 * v:50 + 11 * v + 300] = intro[:300] ^ ((np.uint32(1) << rng.integers(0, 32, 300).astype(np.uint32)) * (rng.random(300) < 0.5))
+        o = [(int(h), t) for h, (_, t) in zip(op, O.step_and_timestamp(np.repeat(op, 2), hd))]
+        p = tmp_path / f"small-ep{v:02d}.wav"
+        p.write_bytes(bytes(range(256)) * 32 + bytes([100 + v]) * 64)
+        f = O.FrameHashes(o, [], hd, O.header_md5(str(p)))
+        assert O.frame_hashes_write(str(p)[:-4] + ".needle.dat", f) == 0
+        small_fhs.append(f)
+        small_paths.append(str(p))
+    small = capi.Comparator(small_paths, min_opening_duration=30)
+    small.run(analyze=False, display=True)
+    small_out = capfd.readouterr().out
+    small_want = O.run_with_frame_hashes(O.Comparator(min_opening_duration=30 * NS), small_fhs, threads=4)
+    expected = []
+    for p, w in zip(small_paths, small_want):                       # (no endings asked for: comparator.rs:356-381 prints no ending line)
+        expected.append(f"\n{p}\n")
+        if w is None:
+            expected.append("No opening found.")
+        else:
+            expected.append(f'* Opening - "{O.format_time(w.opening[0])}"-"{O.format_time(w.opening[1])}"' if w.opening else "* Opening - N/A")
+    assert small_out == "\n".join(expected) + "\n"
+    assert sum(w is not None and w.opening is not None for w in small_want) >= 5
 
 
 def test_chromaprint_compat_streaming_equals_oracle(lib3):
