@@ -345,9 +345,9 @@ def search_only(capi, synth, episodes, minutes, reps=10):
         pass
     pairs = episodes * (episodes - 1) // 2
     n_h = capi.lib().needle_hip_fingerprint_num_kept(int(round(half * RATE)), 2)
-    wall = sum(walls) / len(walls)
+    wall = sorted(walls)[len(walls) // 2]                         # the median call (the first timed one still warms caches)
     return {"episodes": episodes, "pairs": pairs, "hashes_per_episode": int(n_h),
-            "wall_ms": round(1e3 * wall, 3), "wall_ms_each": [round(1e3 * w, 3) for w in walls], "wall_ms_best": round(1e3 * min(walls), 3), "pairs_per_s": round(pairs / wall, 1),
+            "wall_ms": round(1e3 * wall, 3), "wall_ms_mean": round(1e3 * sum(walls) / len(walls), 3), "wall_ms_each": [round(1e3 * w, 3) for w in walls], "wall_ms_best": round(1e3 * min(walls), 3), "pairs_per_s": round(pairs / wall, 1),
             "scan_kernel_ms": round(sum(scan) / len(scan), 4), "simhash_kernel_ms": round(sum(simh) / len(simh), 4),
             "table_cells": float(pairs) * n_h * n_h, "prepare_s": round(prep_s, 2), "issued_evals": issued,
             "scan_form": scan_form, "matrix_instructions": scan_products,
@@ -397,7 +397,7 @@ def library_scale(capi, synth, episodes, minutes, jobs=3, check=4):
     flush()                                                      # first job: slabs grow, tables are built
     step()
     flush()
-    capi.set_kernel_timing("all")
+    capi.set_kernel_timing("all,sum")                            # a kernel's time = the SUM over the job's launches of it
     t0 = time.perf_counter()
     step()
     flush()                                                      # one job alone: its own kernels' events, and the latency
@@ -433,6 +433,11 @@ def library_scale(capi, synth, episodes, minutes, jobs=3, check=4):
                            "matrix_instructions_per_launch": int(products), "avg_launch_ms": kernel_ms["hamming_runs"],
                            "note": "v_mfma_f32_32x32x64_f8f6f4 (FP4 operands) instructions the launch issues x 131 072 operations / kernel time "
                                    "against the dense FP4 peak of MI355X_MICROARCH.md"}
+        try:                                                     # SQ_VALU_MFMA_BUSY_CYCLES of an earlier rocprofv3 --pmc run of this kernel
+            cj = json.load(open(os.path.join(ROOT, "profiles", "scan_mfma_counters.json")))
+            out["roofline"].update(pipe_busy=cj.get("pipe_busy"), pipe_busy_source=cj.get("source"))
+        except (OSError, ValueError):
+            pass
     return out
 
 
@@ -933,16 +938,16 @@ def main() -> None:
             elif "ceiling_cells_per_s" in vec:
                 so["roofline"] = search_roofline(vec["ceiling_cells_per_s"], issued, so["table_cells"], so["scan_kernel_ms"])
             out["search_only"] = so
-        if world == 1 and not args.no_extras and args.library_scale_episodes >= 2 and (n, args.minutes) == (28, 24.0):
-            try:
-                out["library_scale"] = library_scale(capi, synth, args.library_scale_episodes, 45.0)
-            except Exception as e:                               # (e.g. a device without 30 GB to spare)
-                out["library_scale"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             if eps is not None:
                 sample_ids, sample_pcm = list(range(n)), [e.pcm[: len(e.pcm) // 2] for e in eps]
             hashes = [lib.frame_hashes(v).opening_data()[0] for v in sample_ids]
             out["cpu_baseline"] = cpu_baseline(sample_pcm, n, state["results"], hashes, whole_job=len(sample_ids) == n)
+            try:                                                 # the checker's own pin (oracle/pin.py): costs nothing when absent
+                from oracle.pin import probe_report
+                out["oracle_pin"] = probe_report()
+            except Exception as e:                               # noqa: BLE001
+                out["oracle_pin"] = {"libchromaprint": "error", "error": f"{type(e).__name__}: {e}"}
         # one job at a time: resident (5 jobs after the timed region, wall clock around job_begin .. job_end) and from pinned
         # host PCM (end_to_end: upload + analyze + search + epilogue)
         out["latency_ms"] = {"resident": round(latency_resident_ms, 4),
@@ -960,6 +965,20 @@ def main() -> None:
             out["vs_baseline_what"] = ("end_to_end.pinned.pairs_per_s / cpu_baseline.value: both start from PCM in host memory, same "
                                        "machine, same job; the resident figure `value` over the same baseline is "
                                        f"{round(value / cpu, 1)}")
+        # LAST: 30 GB of PCM generated in HBM and several all-pairs jobs -- every other figure of the line has
+        # been measured by now, so a failure here (a device without 30 GB to spare) cannot colour them; its buffers are
+        # released whatever happens
+        if world == 1 and not args.no_extras and args.library_scale_episodes >= 2 and (n, args.minutes) == (28, 24.0):
+            try:
+                out["library_scale"] = library_scale(capi, synth, args.library_scale_episodes, 45.0)
+            except Exception as e:                               # noqa: BLE001
+                import gc
+                gc.collect()                                     # the leg's Library / DeviceLibrary objects free their HBM in __del__
+                try:
+                    capi.synchronize()
+                except Exception:                                # noqa: BLE001
+                    pass
+                out["library_scale"] = {"error": f"{type(e).__name__}: {e}"}
         if sup_dir:                                              # supervisor 0 prints it once the attempt has succeeded
             tmp = os.path.join(sup_dir, f".result.{attempt}.tmp")
             with open(tmp, "w") as f:

@@ -54,7 +54,10 @@ enum NeedleError needle_hip_host_alloc_free(void *host_ptr);
 double needle_hip_last_kernel_ms(const char *kernel);
 /* Selects the kernels that get those events: "all", a comma-separated list of names, or NULL / "" / "none".
  * Default: none (each event record is one more packet between dependent dispatches: timing all five kernels of
- * a 28 x 24 min job costs 3 % of its time), unless the environment variable NEEDLE_HIP_KERNEL_TIMING is set. */
+ * a 28 x 24 min job costs 3 % of its time), unless the environment variable NEEDLE_HIP_KERNEL_TIMING is set.
+ * With the extra item "sum" (e.g. "all,sum") every launch since this call keeps its own events and
+ * needle_hip_last_kernel_ms returns their SUM (it waits for them): a kernel that one job launches several times -- the
+ * first pass of a library-scale job -- then reads as the job's total, not as its last launch's. */
 void needle_hip_set_kernel_timing(const char *kernels);
 /* Diagnostic for the search roofline: table cells per second this device sustains on the scan's
  * per-cell instruction sequence (xor, popcount, compare, select) with operands in registers -- the integer-VALU
@@ -78,6 +81,11 @@ enum NeedleError needle_hip_scan_counts(uint64_t counts[2], bool reset);
  * -- and for form 4 the v_mfma_f32_32x32x64_f8f6f4 instructions (FP4 operands, two head rows each) that launch issued
  * (131 072 operations each): the numerator of ITS roofline.  Every form emits the same runs. */
 enum NeedleError needle_hip_scan_last_launch(int32_t *form, uint64_t *matrix_products);
+/* How many jobs of this process asked for the per-video epilogue (comparator.rs:405-515, 583-626) on the DEVICE and were
+ * handed back to the host form because one pair's bucket of runs exceeded what a single lane orders (256 runs: two
+ * stretches of silence or of one sustained tone).  Correct either way; this makes the performance cliff visible
+ * (also printed under NEEDLE_HIP_TRACE).  reset: start counting again. */
+enum NeedleError needle_hip_epilogue_host_fallbacks(uint64_t *jobs, bool reset);
 
 /* ---- fingerprint: the chromaprint Context replacement -------------------------------------------
  * Replaces chromaprint::Context::{start,feed,finish,get_fingerprint_raw,get_delay,get_item_duration,

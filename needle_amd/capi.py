@@ -95,7 +95,7 @@ NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_host_alloc_free", "needle_hip_int_valu_ceiling",
     "needle_hip_comparator_results_from_runs", "needle_hip_library_job_runs", "needle_hip_library_job_comm_bytes",
     "needle_hip_host_threads", "needle_hip_fingerprint_audit_device", "needle_hip_library_audit",
-    "needle_hip_scan_counts", "needle_hip_scan_last_launch"]
+    "needle_hip_scan_counts", "needle_hip_scan_last_launch", "needle_hip_epilogue_host_fallbacks"]
 
 _LIB = None
 
@@ -282,6 +282,14 @@ def scan_last_launch() -> Tuple[int, int]:
     lib().needle_hip_scan_last_launch.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     check(lib().needle_hip_scan_last_launch(C.byref(form), C.byref(products)))
     return int(form.value), int(products.value)
+
+
+def epilogue_host_fallbacks(reset: bool = False) -> int:
+    """Jobs whose device epilogue fell back to the host form (a pair's bucket of runs too large for one lane)."""
+    jobs = C.c_uint64(0)
+    lib().needle_hip_epilogue_host_fallbacks.argtypes = [C.POINTER(C.c_uint64), C.c_bool]
+    check(lib().needle_hip_epilogue_host_fallbacks(C.byref(jobs), reset))
+    return int(jobs.value)
 
 
 def host_threads() -> int:

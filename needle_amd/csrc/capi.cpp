@@ -15,6 +15,7 @@
 #include <fstream>
 #include <new>
 
+#include "epilogue.h"
 #include "hipctx.h"
 #include "needle_core.h"
 
@@ -449,6 +450,12 @@ enum NeedleError needle_hip_scan_counts(uint64_t counts[2], bool reset) {
 enum NeedleError needle_hip_scan_last_launch(int32_t *form, uint64_t *matrix_products) {
   if (!form || !matrix_products) return NeedleError_NullArgument;
   gpu_scan_last_launch(form, matrix_products);
+  return NeedleError_Ok;
+}
+
+enum NeedleError needle_hip_epilogue_host_fallbacks(uint64_t *jobs, bool reset) {
+  if (!jobs) return NeedleError_NullArgument;
+  *jobs = reset ? epilogue_host_fallbacks().exchange(0) : epilogue_host_fallbacks().load();
   return NeedleError_Ok;
 }
 

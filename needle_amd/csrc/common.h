@@ -164,7 +164,7 @@ Status gpu_fingerprint_streamed(const std::vector<size_t> &num_values, const Pcm
 Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
                                const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
                                NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync,
-                               bool count_is_zero = false, bool standalone = false);  // standalone: no other job's kernels run beside the scan
+                               bool count_is_zero = false);
 Status gpu_hamming_runs_host(const uint32_t *hashes, size_t num_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
                              const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
                              std::vector<NeedleHipRun> *runs);

@@ -668,6 +668,7 @@ Status Comparator::run_with_frame_hashes(const std::vector<const FrameHashesData
         trace.lap("display / skip files per video", n);
         return w;
       }
+      if (failed & kEpilogueBucketTooLarge) note_epilogue_host_fallback("Comparator::run_with_frame_hashes", runs.size(), n);
       return results_from_runs(fh, runs.data(), runs.size(), display, use_skip_files, write_skip_files, per_video);
     }
   }

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cstdint>
 #include <vector>
 
@@ -41,6 +42,11 @@ struct EpilogueJob {
 #endif
 constexpr uint32_t kEpilogueBucketLimit = NEEDLE_EPILOGUE_BUCKET_LIMIT;
 constexpr uint32_t kEpilogueBucketTooLarge = 0x80000000u;
+// Jobs whose device epilogue was handed back to the host because of that bit (needle_hip_epilogue_host_fallbacks): a
+// silent performance cliff otherwise -- one pair of silent stretches moves a whole library's epilogue to the host.
+std::atomic<uint64_t> &epilogue_host_fallbacks();
+// (host side of both callers: counts, and says so under NEEDLE_HIP_TRACE)
+void note_epilogue_host_fallback(const char *where, size_t runs, size_t videos);
 
 // Enqueues the epilogue kernels on `stream` behind whatever fills the segments, then the copies of results[n] and of the
 // failure count (videos whose padding / hash duration exceed the match end: the reference panics) into HOST memory

@@ -290,6 +290,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
   __shared__ __attribute__((aligned(16))) uint32_t image[kImageRows * kImagePitch];
   __shared__ uint32_t ntab[16];
   __shared__ BestKey best[2][256];
+  // a bucket too large for one lane (pair_entries_kernel): the whole job is the host form's, nothing here would be read
+  if (__builtin_nontemporal_load(failed) & kEpilogueBucketTooLarge) return;
   const uint32_t v = pr.v0 + blockIdx.x, t = threadIdx.x;
   const uint64_t n = pr.n;
   const uint32_t slots = pr.n - 1;  // the video's pairs in lexicographic order: (q, v) for q < v, then (v, q + 1)
@@ -509,6 +511,19 @@ Status upload_if_changed(DeviceBuffer<T> *dst, std::vector<T> *resident, const s
 }
 
 }  // namespace
+
+std::atomic<uint64_t> &epilogue_host_fallbacks() {
+  static std::atomic<uint64_t> count{0};
+  return count;
+}
+
+void note_epilogue_host_fallback(const char *where, size_t runs, size_t videos) {
+  epilogue_host_fallbacks().fetch_add(1);
+  if (getenv("NEEDLE_HIP_TRACE"))
+    std::fprintf(stderr, "[needle_hip] %s: a pair's bucket holds more than %u runs (silence / a sustained tone on both sides): the "
+                         "per-video epilogue of this job (%zu runs, %zu videos) falls back to the HOST form\n",
+                 where, kEpilogueBucketLimit, runs, videos);
+}
 
 Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHipSearchResult *host_results, uint32_t *host_failed) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());  // the per-device workspaces are shared, as everywhere else

@@ -122,6 +122,7 @@ struct KernelTimer {
   const char *name;
   hipStream_t stream;
   bool active = false;
+  int hist = -1;  // "sum" mode: this launch's own event pair
 };
 double kernel_ms(const std::string &name);
 // A launch that carries its own events (hipExtLaunchKernelGGL: the dispatch packet's completion signal IS the stop

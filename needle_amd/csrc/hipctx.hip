@@ -22,6 +22,11 @@ struct TimerEvents {  // two alternating event pairs, so the newest COMPLETED la
   hipEvent_t own_start[2] = {nullptr, nullptr}, own_stop[2] = {nullptr, nullptr};  // created by KernelTimer, recorded only by it
   bool recorded[2] = {false, false};
   int cur = 1;
+  // "sum" mode (set_kernel_timing("...,sum")): every launch since the selection was set keeps an event pair of its own and
+  // kernel_ms returns their SUM -- a kernel that a job launches several times (the first pass of a library-scale job runs
+  // in three workspace-sized launches) then reads as the job's, not as its last launch's
+  std::vector<hipEvent_t> hist_start, hist_stop;
+  size_t hist_n = 0;
 };
 std::map<std::string, TimerEvents> g_timers;  // keyed by "<device>:<kernel>"
 
@@ -88,19 +93,20 @@ namespace {
 // Which kernels get start/stop events.  Off unless asked for: every event record is one more packet between two
 // dependent dispatches, and timing all five kernels of a 28 x 24 min job costs 3 % of its step time.
 struct TimingSelection {
-  bool all = false;
+  bool all = false, sum = false;
   std::vector<std::string> names;
   TimingSelection() {
     if (const char *e = getenv("NEEDLE_HIP_KERNEL_TIMING")) set(e);
   }
   void set(const char *list) {
-    all = false;
+    all = sum = false;
     names.clear();
     if (!list) return;
     std::string item;
     for (const char *p = list;; p++) {
       if (*p == ',' || *p == '\0') {
         if (item == "all") all = true;
+        else if (item == "sum") sum = true;
         else if (!item.empty() && item != "none") names.push_back(item);
         item.clear();
         if (*p == '\0') break;
@@ -122,6 +128,7 @@ TimingSelection &timing_selection() {  // callers hold g_mu
 void set_kernel_timing(const char *kernels) {
   std::lock_guard<std::mutex> lock(g_mu);
   timing_selection().set(kernels);
+  for (auto &kv : g_timers) kv.second.hist_n = 0;  // a new selection starts a new sum (the events are kept for reuse)
 }
 
 // Downloads of results go here, behind an event of the library stream: a copy enqueued on the library stream itself
@@ -221,6 +228,18 @@ KernelTimer::KernelTimer(const char *n, hipStream_t on) : name(n), stream(on ? o
   active = timing_selection().on(name);
   if (!active) return;
   TimerEvents &t = g_timers[timer_key(name)];
+  if (timing_selection().sum && t.hist_n < 4096) {
+    if (t.hist_n == t.hist_start.size()) {
+      hipEvent_t a = nullptr, b = nullptr;
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      t.hist_start.push_back(a);
+      t.hist_stop.push_back(b);
+    }
+    hist = (int)t.hist_n++;
+    (void)hipEventRecord(t.hist_start[(size_t)hist], s);
+    return;
+  }
   t.cur ^= 1;
   if (!t.own_start[t.cur]) {
     (void)hipEventCreate(&t.own_start[t.cur]);
@@ -238,6 +257,10 @@ KernelTimer::~KernelTimer() {
   hipStream_t s = stream;
   std::lock_guard<std::mutex> lock(g_mu);
   TimerEvents &t = g_timers[timer_key(name)];
+  if (hist >= 0) {
+    (void)hipEventRecord(t.hist_stop[(size_t)hist], s);
+    return;
+  }
   (void)hipEventRecord(t.stop[t.cur], s);
   t.recorded[t.cur] = true;
 }
@@ -261,6 +284,19 @@ double kernel_ms(const std::string &name) {
   auto it = g_timers.find(timer_key(name.c_str()));
   if (it == g_timers.end()) return -1.0;
   TimerEvents &t = it->second;
+  if (timing_selection().sum) {  // every launch since the selection was set (waits for them)
+    if (t.hist_n == 0) return -1.0;
+    double total = 0.0;
+    for (size_t i = 0; i < t.hist_n; i++) {
+      float ms = 0.f;
+      if (hipEventSynchronize(t.hist_stop[i]) != hipSuccess || hipEventElapsedTime(&ms, t.hist_start[i], t.hist_stop[i]) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1.0;
+      }
+      total += (double)ms;
+    }
+    return total;
+  }
   // newest launch if it has finished, otherwise the one before it (never blocks behind queued work unless
   // nothing has completed yet)
   int idx = t.cur;

@@ -1022,8 +1022,10 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
     if (j.device_epilogue) {  // computed on the device behind the gather (epilogue.hip); j.done covers its copies
       device_results = static_cast<const NeedleHipSearchResult *>(j.host_results);
       const uint32_t fail = *reinterpret_cast<const uint32_t *>(device_results + lib->n);
-      if (fail & kEpilogueBucketTooLarge)
+      if (fail & kEpilogueBucketTooLarge) {
         device_results = nullptr;  // a pair with more runs than one lane should order: the host form below, same block of videos
+        note_epilogue_host_fallback("library job", total, vcount);
+      }
       else if (fail != 0)
         s = Status::Make(NeedleError_Unknown, "overflow when subtracting durations (time_padding / hash_duration exceed the match end)");
     }

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         const uint32_t kbase = (uint32_t)(32 * (rt0 + (s >> 1)) + 8 * g + 4 * h);
         const uint32_t j = (uint32_t)(j0 + 32 * (s & 1));
         const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
-        queue[qn + (int)before] = (j << 16) | kbase;
+        queue[qn + (int)before] = (j << 16) | kbase;  // j < m < 65536, kbase < the group's windows < 65536: search.hip build_plan (mfma_packable) stages nothing else
       }
       qn += (int)__popcll(ball);
       const int cnt = qn >= 64 ? 64 : (ball == 0ull && flush) ? qn : 0;

@@ -641,7 +641,10 @@ struct SearchPlan {
   std::vector<NeedleHipSeq> seqs;          // inputs ...
   std::vector<NeedleHipProblem> problems;
   int mode[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ... and the switches that steer the choice ([3]: threshold beyond the sampled kernel's bit trick,
-                                           // [4]: the sampled path's first stage on the matrix pipe, [5..7]: its form, waves per workgroup, chain)
+                                           // [4]: the sampled path's first stage on the matrix pipe, [5]: LDS limit of a staged pair in bytes
+                                           // (NEEDLE_HIP_SEARCH_LDS_LIMIT), [6]: the matrix-pipe form's waves per workgroup, [7]: its test
+                                           // switches -- bits 0..6 NEEDLE_HIP_MFMA_SPLITS, bit 8 _SINGLE, bit 9 _NO_IMAGES).  EVERY switch
+                                           // build_plan looks at is in here: the cached plan is keyed by it
   std::vector<SearchProblem> meta;         // derived: the pairs the chosen kernel can stage, then the oversize ones
   size_t staged = 0;                       // how many of meta go to the chosen kernel
   uint64_t oversize_blocks = 0;            // grid of the unstaged kernel over meta[staged..]
@@ -705,8 +708,7 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     // What a pair needs in LDS under the chosen kernel.  A pair beyond the CU's 160 KiB (a window of more than ~2.7 h
     // of audio at step 1) goes to the end of the table and is scanned from HBM by the unstaged kernel: one such
     // video must not fail the search of the whole library (the reference has no bound).
-    size_t lds_limit = 160 * 1024;
-    if (const char *e = getenv("NEEDLE_HIP_SEARCH_LDS_LIMIT")) lds_limit = (size_t)std::max(1, atoi(e));  // tests
+    const size_t lds_limit = (size_t)mode[5];  // 160 KiB, or NEEDLE_HIP_SEARCH_LDS_LIMIT (tests)
     // The matrix-pipe form of the sampled scan pays on large launches whose windows fill their row tiles of 32 (two sources
     // of one destination share a workgroup's tiles): measured against the vector form, scan kernel, 1.41 x at 39 060 pairs of
     // 24-minute windows (2 x 39 windows in 3 tiles), 1.66 x at 499 500 pairs of 45-minute ones (2 x 73 in 5); 0.97 x on the
@@ -754,15 +756,21 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
       if (mfma) return group_need(m, windows_of(m));
       return ((fast || sampled) ? (size_t)m.m + 2 * kBandB : (size_t)m.n + m.m) * sizeof(uint32_t);
     };
-    std::stable_partition(meta.begin(), meta.end(), [&](const SearchProblem &m) { return lds_need(m) <= lds_limit; });
+    // The matrix-pipe kernel packs its queue items as (j << 16) | kbase and a window / member word as w0 | member << 28
+    // (scan_mfma_kernel.h): a staged entry needs m < 65536, fewer than 65536 windows and n < 2^28.  The 160 KiB of LDS imply
+    // the first two (m <= ~40 900) only while the limit is the hardware's; checked here so that an overridden limit or a
+    // future layout cannot break the packing silently -- such an entry goes to the oversize partition.
+    auto mfma_packable = [&](const SearchProblem &m) { return m.m < 65536u && windows_of(m) < 65536u && m.n < (1u << 28); };
+    auto stageable = [&](const SearchProblem &m) { return lds_need(m) <= lds_limit && (!mfma || mfma_packable(m)); };
+    std::stable_partition(meta.begin(), meta.end(), stageable);
     size_t staged = 0;
-    while (staged < meta.size() && lds_need(meta[staged]) <= lds_limit) staged++;
+    while (staged < meta.size() && stageable(meta[staged])) staged++;
     size_t lds_bytes = 0;
     int bands_per_wave = 1;
     // pad of a group's first entry = how many followers; a follower (pad bit 31) owns no workgroups
     size_t groups = 0;
     if (mfma) {
-      const bool single = getenv("NEEDLE_HIP_MFMA_SINGLE") != nullptr;  // tests, measurements: one source per workgroup
+      const bool single = (mode[7] & 0x100) != 0;  // NEEDLE_HIP_MFMA_SINGLE (tests, measurements): one source per workgroup
       for (size_t i = 0; i < staged;) {
         SearchProblem &a = meta[i];
         a.pad = 0;
@@ -793,7 +801,7 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     if (mfma && groups > 0) {
       const uint64_t slots = (uint64_t)device_cus() * (uint64_t)(waves == 4 ? 3 : waves == 8 ? 2 : 1);
       splits = (int)std::min<uint64_t>(8, std::max<uint64_t>(1, (2 * slots + groups - 1) / groups));
-      if (const char *e = getenv("NEEDLE_HIP_MFMA_SPLITS")) splits = std::max(1, std::min(64, atoi(e)));  // tests, tuning
+      if (mode[7] & 0x7F) splits = mode[7] & 0x7F;  // NEEDLE_HIP_MFMA_SPLITS (tests, tuning), 1 .. 64
     }
     if (fast || sampled) {
       uint64_t fb = 0, total_bands = 0;
@@ -857,7 +865,7 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
     // build their own).  block_base of a staged entry -- not read by that kernel otherwise -- = first window of its source's image.
     plan->image_seqs.clear();
     plan->image_windows = plan->image_min_len = 0;
-    if (mfma && staged > 0 && !getenv("NEEDLE_HIP_MFMA_NO_IMAGES")) {
+    if (mfma && staged > 0 && !(mode[7] & 0x200)) {  // (bit 9: NEEDLE_HIP_MFMA_NO_IMAGES)
       bool one = true;
       for (size_t i = 1; i < staged && one; i++) one = meta[i].min_len == meta[0].min_len;
       if (one) {
@@ -962,8 +970,7 @@ void gpu_scan_last_launch(int32_t *form, uint64_t *matrix_products) {
 
 Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seqs, size_t num_seqs,
                                const NeedleHipProblem *problems, size_t num_problems, uint32_t threshold,
-                               NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync, bool count_is_zero,
-                               bool standalone) {
+                               NeedleHipRun *d_runs, uint32_t capacity, uint32_t *d_count, bool sync, bool count_is_zero) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());
   Status s = ensure_device();
   if (!s.ok()) return s;
@@ -972,7 +979,11 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
   const int mode[8] = {getenv("NEEDLE_HIP_GENERIC_SEARCH") != nullptr, getenv("NEEDLE_HIP_BAND_SEARCH") != nullptr,
                        getenv("NEEDLE_HIP_BANDS_PER_WAVE") ? std::max(1, atoi(getenv("NEEDLE_HIP_BANDS_PER_WAVE"))) : 0,
                        threshold > 31u,   // every cell matches at 32: the band / generic kernels take such a launch
-                       mfma_request(threshold), standalone || sync ? 1 : 0, mfma_waves(), 0};
+                       mfma_request(threshold),
+                       getenv("NEEDLE_HIP_SEARCH_LDS_LIMIT") ? std::max(1, atoi(getenv("NEEDLE_HIP_SEARCH_LDS_LIMIT"))) : 160 * 1024,
+                       mfma_waves(),
+                       (getenv("NEEDLE_HIP_MFMA_SPLITS") ? std::max(1, std::min(64, atoi(getenv("NEEDLE_HIP_MFMA_SPLITS")))) : 0) |
+                           (getenv("NEEDLE_HIP_MFMA_SINGLE") ? 0x100 : 0) | (getenv("NEEDLE_HIP_MFMA_NO_IMAGES") ? 0x200 : 0)};
   SearchWorkspace *ws = workspace();
   SearchPlan &plan = ws->plan;
   const bool reuse = plan.matches(seqs, num_seqs, problems, num_problems, mode);
@@ -1206,7 +1217,7 @@ Status gpu_search_results_host(const uint32_t *hashes, size_t num_hashes, const 
   for (int attempt = 0; attempt < 2; attempt++) {
     if (!(s = hb->d_runs.reserve(capacity)).ok()) return s;
     s = gpu_hamming_runs_device(hb->d_hashes.ptr, seqs, num_seqs, problems, num_problems, threshold, hb->d_runs.ptr, capacity,
-                                hb->d_count.ptr, false, false, true);
+                                hb->d_count.ptr, false, false);
     if (!s.ok()) return s;
     // the run count first (one small copy behind the scan): an attempt whose list overflowed is repeated without its
     // epilogue ever running, and the epilogue's workspaces (144 bytes per run, kept for the life of the process) are sized
@@ -1260,7 +1271,7 @@ Status gpu_hamming_runs_host(const uint32_t *hashes, size_t num_hashes, const Ne
   for (int attempt = 0; attempt < 2; attempt++) {
     if (!(s = d_runs.reserve(capacity)).ok()) return s;
     s = gpu_hamming_runs_device(d_hashes.ptr, seqs, num_seqs, problems, num_problems, threshold, d_runs.ptr,
-                                capacity, d_count.ptr, false, false, true);
+                                capacity, d_count.ptr, false, false);
     if (!s.ok()) return s;
     uint32_t found = 0;
     NEEDLE_HIP_TRY(hipMemcpyAsync(&found, d_count.ptr, sizeof(found), hipMemcpyDeviceToHost, stream));

@@ -136,6 +136,7 @@ extern "C" {
     /// Form of this process's last scan launch (3: aligned windows on the vector ALU, 4: head rows on the matrix pipe)
     /// and, for form 4, the matrix instructions it issued.
     pub fn needle_hip_scan_last_launch(form: *mut i32, matrix_products: *mut u64) -> NeedleError;
+    pub fn needle_hip_epilogue_host_fallbacks(jobs: *mut u64, reset: bool) -> NeedleError;
     /// The library's `hipStream_t` on the current device (NULL without one).
     pub fn needle_hip_stream() -> *mut c_void;
     pub fn needle_hip_analyzer_run_pcm(
