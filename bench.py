@@ -292,7 +292,7 @@ def search_roofline(ceiling_cells, issued_evals, covered_cells, scan_ms):
                     "not machine utilisation"}
 
 
-def search_only(capi, synth, episodes, minutes, reps=10):
+def search_only(capi, synth, episodes, minutes, reps=10, hostile=False):
     """BASELINE.json configs[2]: `episodes` x 24-min episodes as real .needle.dat files (written once by this
     analyzer from synthetic audio), then needle_audio_comparator_run(analyze=false) timed from disk: file reads,
     upload of the hashes, scan + simhash + epilogue kernels, download of the results."""
@@ -304,7 +304,7 @@ def search_only(capi, synth, episodes, minutes, reps=10):
     # fingerprinted there, and every video's FrameHashes is written with the product's own writer
     # (needle_hip_library_frame_hashes + needle_hip_frame_hashes_write -> <video>.needle.dat, data.rs layout).
     samples = int(round(half * RATE))
-    gen = synth.DeviceLibrary(episodes, samples, 90.0 if half > 400 else half / 4)
+    gen = synth.DeviceLibrary(episodes, samples, 90.0 if half > 400 else half / 4, hostile=hostile)
     src = capi.Library(episodes, opening_search_percentage=1.0)
     src.set_pcm_device(gen.pointers(), [samples] * episodes)
     gen.free()
@@ -315,6 +315,7 @@ def search_only(capi, synth, episodes, minutes, reps=10):
     prep_s = time.perf_counter() - t_prep
     cmp = capi.Comparator(paths)
     capi.set_kernel_timing("hamming_runs,simhash_runs")
+    capi.epilogue_host_fallbacks(reset=True)
     walls, scan, simh = [], [], []
     for rep in range(reps + 1):
         t0 = time.perf_counter()
@@ -351,6 +352,7 @@ def search_only(capi, synth, episodes, minutes, reps=10):
             "scan_kernel_ms": round(sum(scan) / len(scan), 4), "simhash_kernel_ms": round(sum(simh) / len(simh), 4),
             "table_cells": float(pairs) * n_h * n_h, "prepare_s": round(prep_s, 2), "issued_evals": issued,
             "scan_form": scan_form, "matrix_instructions": scan_products,
+            "corpus": "hostile" if hostile else "tonal", "epilogue_host_fallbacks": capi.epilogue_host_fallbacks(),
             "what": "needle_audio_comparator_run(analyze=false) over .needle.dat files in the page cache: read + parse, "
                     "H2D of hashes, scan, simhash, per-video epilogue on the device (from 16 384 sequence pairs up; the run "
                     "list stays in HBM), D2H of the results; wall clock per call"}
@@ -439,6 +441,96 @@ def library_scale(capi, synth, episodes, minutes, jobs=3, check=4):
         except (OSError, ValueError):
             pass
     return out
+
+
+def corpus_hostile(capi, synth, episodes, minutes, jobs=20, check=2):
+    """The headline job on the HOSTILE corpus (needle_amd/csrc/synth_hip.hip: broadband speech-like bodies, noise 20 dB under
+    the programme, 25 - 60 s of digital silence in every second episode and of one sustained chord in every third, a tonal
+    shared intro): the reference's cost does not depend on content (comparator.rs:176-187 visits every cell), this build's
+    does -- the first pass certifies fewer items, constant hashes defeat the scan's aligned-window filter and fill a pair's
+    bucket with hundreds of runs.  Same shape and call sequence as the headline (two jobs in flight); the GPU's hashes of
+    `check` episodes are compared with the oracle's outside the timed region (the whole job against the oracle:
+    tests/test_gpu_hostile.py and `bench.py --corpus hostile`)."""
+    from oracle import oracle as O
+    samples = int(round(minutes * 60.0 / 2 * RATE))
+    gen = synth.DeviceLibrary(episodes, samples, 90.0 if minutes >= 10 else minutes * 60.0 / 8, hostile=True)
+    ids = sorted({0, episodes // 2, episodes - 1})[:check]
+    sample_pcm = {k: gen.episode(k) for k in ids}
+    segments = gen.segments.tolist()
+    lib = capi.Library(episodes, opening_search_percentage=1.0)
+    lib.set_pcm_device(gen.pointers(), [samples] * episodes)
+    gen.free()
+    del gen
+    cmp = capi.Comparator([f"episode-{k:05d}.wav" for k in range(episodes)])
+    names = ["stft_chroma32", "features_cert", "stft_fallback", "fixup_items", "hamming_runs", "simhash_runs",
+             "epilogue_buckets", "epilogue_entries", "epilogue_best_match"]
+    state = {"res": None, "runs": 0}
+    pending, seq = [], [0]
+
+    def step():
+        slot = seq[0] & 1
+        seq[0] += 1
+        lib.job_begin(cmp, slot)
+        if pending:
+            state["res"], state["runs"] = lib.job_end(cmp, pending.pop())
+        pending.append(slot)
+
+    def flush():
+        while pending:
+            state["res"], state["runs"] = lib.job_end(cmp, pending.pop())
+        capi.synchronize()
+
+    for _ in range(3):
+        step()
+    flush()
+    capi.cert_stats(reset=True)
+    capi.epilogue_host_fallbacks(reset=True)
+    capi.set_kernel_timing("all,sum")
+    t0 = time.perf_counter()
+    step()
+    flush()
+    alone_ms = 1e3 * (time.perf_counter() - t0)
+    kernel_ms = {k: round(max(capi.last_kernel_ms(k), 0.0), 4) for k in names}
+    capi.set_kernel_timing(None)
+    cs = capi.cert_stats(reset=True)
+    for _ in range(10):                                          # back to the steady state of two jobs in flight
+        step()
+    flush()
+    t0 = time.perf_counter()
+    for _ in range(jobs):
+        step()
+    flush()
+    ms = 1e3 * (time.perf_counter() - t0) / jobs
+    form, products = capi.scan_last_launch()
+    os.environ["NEEDLE_HIP_SCAN_COUNT"] = "1"                   # what the vector form ISSUES on this content (untimed)
+    try:
+        step()
+        flush()
+        capi.scan_counts(reset=True)
+        step()
+        flush()
+        issued, survivors = capi.scan_counts(reset=True)
+    finally:
+        del os.environ["NEEDLE_HIP_SCAN_COUNT"]
+    pairs = episodes * (episodes - 1) // 2
+    n_h = int(capi.lib().needle_hip_fingerprint_num_kept(samples, 2))
+    hd = O.duration_from_secs_f32(0.3)
+    want = O.analyze_batch([sample_pcm[k] for k in ids], 1, hd, threads=usable_cpus())
+    hashes_ok = all(lib.frame_hashes(k).opening_data()[0].tolist() == [h for h, _ in w.opening] for k, w in zip(ids, want))
+    return {"episodes": episodes, "minutes": minutes, "pairs": pairs, "hashes_per_episode": n_h, "jobs_timed": jobs,
+            "ms_per_step": round(ms, 4), "pairs_per_s": round(pairs / (ms * 1e-3), 1), "latency_ms_one_job": round(alone_ms, 3),
+            "kernel_ms_one_job_alone": kernel_ms, "runs_per_step": int(state["runs"]),
+            "detected": sum(1 for r in state["res"] if r is not None and r.opening is not None),
+            "fallback_frac": {"items": round(cs["items_recomputed"] / max(cs["items"], 1), 6),
+                              "frame_pair_chunks": round(cs["chunks_recomputed"] / max(cs["chunks"], 1), 6)},
+            "scan_form": {1: "generic", 2: "band", 3: "aligned windows, vector ALU", 4: "aligned windows, matrix pipe"}.get(form, str(form)),
+            "scan_issued_evaluations": int(issued), "scan_head_survivors": int(survivors),
+            "scan_pruning_factor": round(float(pairs) * n_h * n_h / max(issued, 1), 2),
+            "epilogue_host_fallbacks": capi.epilogue_host_fallbacks(),
+            "episodes_with_silence": sum(1 for s in segments if s[1] > 0), "episodes_with_chord": sum(1 for s in segments if s[3] > 0),
+            "gpu_hashes_match_oracle": {"episodes_checked": ids, "ok": bool(hashes_ok)},
+            "what": "the headline job (28 x 24 min, analyze + search, two jobs in flight, PCM resident) on the hostile corpus; "
+                    "kernel times from one job run alone; results against the oracle: tests/test_gpu_hostile.py, bench.py --corpus hostile"}
 
 
 # ---- launching N ranks -----------------------------------------------------------------------------------------------
@@ -569,6 +661,9 @@ def main() -> None:
                     help="generate every rank's episodes in HBM (needle_amd.synth.DeviceLibrary) instead of on the host: what "
                          "makes BASELINE.json configs[4] (--episodes 2000 --minutes 45) fit a bench run; the opening half of "
                          "each episode is generated and is the whole search window")
+    ap.add_argument("--corpus", choices=["tonal", "hostile"], default="tonal",
+                    help="hostile: the whole run (value, roofline, cpu_baseline, parity check) on the hostile corpus of "
+                         "needle_amd/csrc/synth_hip.hip (generated in HBM: implies --device-synth)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / search_only / roofline_search")
     ap.add_argument("--search-only-episodes", type=int, default=280)
@@ -627,11 +722,13 @@ def main() -> None:
     # the episodes a rank's block meets
     t_setup = time.perf_counter()
     eps = None
+    if args.corpus == "hostile":
+        args.device_synth = True
     if args.device_synth:
         window_samples = int(round(args.minutes * 60.0 / 2 * RATE))
         lib = capi.Library(n, opening_search_percentage=1.0)
         first, count = lib.rank_videos([window_samples] * n, world, rank)
-        gen = synth.DeviceLibrary(count, window_samples, args.intro_seconds, first_episode=first)
+        gen = synth.DeviceLibrary(count, window_samples, args.intro_seconds, first_episode=first, hostile=args.corpus == "hostile")
         ptrs = gen.pointers()
         # a bounded sample for the CPU baseline / cross-check, read back before the generator's buffer goes
         sample_ids = list(range(min(n, 40))) if (world == 1 and not args.no_cpu_baseline) else []
@@ -852,7 +949,8 @@ def main() -> None:
                                        "included (a step is ~0.6 ms; the device needs ~30 ms under load before kernels run "
                                        "at their steady rate); `cold` is the figure without them.  Jobs longer than 20 ms "
                                        "get two untimed jobs and no cold figure",
-                       "setup_s": round(setup_s, 2), "synth": "device (HBM)" if args.device_synth else "host"},
+                       "setup_s": round(setup_s, 2), "synth": "device (HBM)" if args.device_synth else "host",
+                       "corpus": args.corpus},
             "cold": cold,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -938,6 +1036,17 @@ def main() -> None:
             elif "ceiling_cells_per_s" in vec:
                 so["roofline"] = search_roofline(vec["ceiling_cells_per_s"], issued, so["table_cells"], so["scan_kernel_ms"])
             out["search_only"] = so
+            if args.corpus == "tonal" and (n, args.minutes) == (28, 24.0):
+                try:                                             # the same two shapes on the hostile corpus
+                    out["corpus_hostile"] = corpus_hostile(capi, synth, 28, 24.0)
+                    soh = search_only(capi, synth, args.search_only_episodes, 24.0, reps=6, hostile=True)
+                    soh.pop("issued_evals", None)
+                    out["corpus_hostile"]["search_only"] = soh
+                    out["corpus_hostile"]["vs_tonal"] = {
+                        "ms_per_step": round(out["corpus_hostile"]["ms_per_step"] / ms_per_step, 3),
+                        "search_only_wall_ms": round(soh["wall_ms"] / so["wall_ms"], 3)}
+                except Exception as e:                           # noqa: BLE001
+                    out["corpus_hostile"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             if eps is not None:
                 sample_ids, sample_pcm = list(range(n)), [e.pcm[: len(e.pcm) // 2] for e in eps]

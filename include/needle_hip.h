@@ -82,9 +82,10 @@ enum NeedleError needle_hip_scan_counts(uint64_t counts[2], bool reset);
  * (131 072 operations each): the numerator of ITS roofline.  Every form emits the same runs. */
 enum NeedleError needle_hip_scan_last_launch(int32_t *form, uint64_t *matrix_products);
 /* How many jobs of this process asked for the per-video epilogue (comparator.rs:405-515, 583-626) on the DEVICE and were
- * handed back to the host form because one pair's bucket of runs exceeded what a single lane orders (256 runs: two
- * stretches of silence or of one sustained tone).  Correct either way; this makes the performance cliff visible
- * (also printed under NEEDLE_HIP_TRACE).  reset: start counting again. */
+ * handed back to the host form because one pair's bucket of runs exceeded what the device orders (since round 6 a
+ * bucket beyond a lane's 96 runs is a workgroup's, up to 8192 runs: two fully silent 24-minute windows are 5 800;
+ * beyond that, or with a row of 65 536 hashes or more).  Correct either way; this makes the performance cliff
+ * visible (also printed under NEEDLE_HIP_TRACE).  reset: start counting again. */
 enum NeedleError needle_hip_epilogue_host_fallbacks(uint64_t *jobs, bool reset);
 
 /* ---- fingerprint: the chromaprint Context replacement -------------------------------------------

@@ -34,13 +34,21 @@ struct EpilogueJob {
 };
 
 // The device form gives a pair's runs to ONE lane (insertion order + heap): a pair with more runs than this (silence against
-// silence, one sustained tone against itself) would keep that lane busy for seconds.  Then bit 31 of the failure word is
-// set and the caller computes the results with the host form (threaded, n log n) from the run list -- same results.
+// silence, one sustained tone against itself) would keep that lane busy for seconds; such a bucket is a workgroup's (below).
+// Bit 31 of the failure word: the caller computes the results with the host form (threaded, n log n) from the run list.
 // NEEDLE_HIP_EPILOGUE_BUCKET_LIMIT is not a switch: tests lower the constant by building with -D.
 #ifndef NEEDLE_EPILOGUE_BUCKET_LIMIT
-#define NEEDLE_EPILOGUE_BUCKET_LIMIT 256
+#define NEEDLE_EPILOGUE_BUCKET_LIMIT 96
 #endif
 constexpr uint32_t kEpilogueBucketLimit = NEEDLE_EPILOGUE_BUCKET_LIMIT;
+// Round 6: buckets beyond that limit (up to kEpilogueLargeLimit runs: two fully silent 24-minute windows are 5 800) go to a
+// WORKGROUP each (pair_entries_large_kernel: bitonic sort into the walk order and the heap's sift-ups on packed 64-bit keys in
+// LDS) instead of failing the job over to the host.  Only a bucket beyond kEpilogueLargeLimit, a row of 65 536 hashes or more, or
+// timestamps that do not strictly increase (the packed key stands for them) still set the bit.
+#ifndef NEEDLE_EPILOGUE_LARGE_LIMIT
+#define NEEDLE_EPILOGUE_LARGE_LIMIT 8192
+#endif
+constexpr uint32_t kEpilogueLargeLimit = NEEDLE_EPILOGUE_LARGE_LIMIT;
 constexpr uint32_t kEpilogueBucketTooLarge = 0x80000000u;
 // Jobs whose device epilogue was handed back to the host because of that bit (needle_hip_epilogue_host_fallbacks): a
 // silent performance cliff otherwise -- one pair of silent stretches moves a whole library's epilogue to the host.

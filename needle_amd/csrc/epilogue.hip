@@ -52,6 +52,7 @@ struct Candidate {  // :410-432
 
 struct EpilogueParams {
   uint32_t n, regions, buckets;          // videos, comparator regions, np * regions
+  uint32_t large_ok;                     // buckets beyond kEpilogueBucketLimit may go to pair_entries_large_kernel (see there)
   uint32_t rows_per_video;               // rows of the hash arena per video
   uint32_t v0, v1;                       // the videos whose results are wanted
   uint32_t bound;                        // threshold + threshold / 2 (:441)
@@ -194,16 +195,21 @@ __global__ __launch_bounds__(64) void pair_entries_kernel(EpilogueParams pr, con
                                                           NeedleHipRun *__restrict__ sorted, const uint32_t *__restrict__ row_len,
                                                           const uint32_t *__restrict__ row_ts, const uint64_t *__restrict__ row_seek,
                                                           const uint64_t *__restrict__ ts, DeviceEntry *__restrict__ entries,
-                                                          uint32_t *__restrict__ valid, uint32_t *__restrict__ failed) {
+                                                          uint32_t *__restrict__ valid, uint32_t *__restrict__ failed,
+                                                          uint32_t *__restrict__ large_count, uint32_t *__restrict__ large_list) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= pr.buckets) return;
   const uint32_t lo = start[b], hi = start[b + 1];
   uint32_t out = 0;
   if (hi - lo > kEpilogueBucketLimit) {
     // One lane orders a bucket by insertion (quadratic) and builds its heap alone: right for the handful of runs a pair of
-    // episodes has, not for the thousands two stretches of silence or of one sustained tone produce (an S x S block of equal
-    // hashes is ~2 S runs).  Such a library is handed back to the host form (threaded, n log n): bit 31 of `failed`.
-    atomicOr(failed, kEpilogueBucketTooLarge);
+    // episodes has, not for the hundreds two stretches of silence or of one sustained tone produce (an S x S block of equal
+    // hashes is ~2 S runs).  Such a bucket goes on the list of pair_entries_large_kernel (a workgroup each; the list cannot
+    // overflow: every entry stands for more than kEpilogueBucketLimit of the runs it was sized by); beyond what that kernel
+    // holds in LDS the library is handed back to the host form (threaded, n log n): bit 31 of `failed`.
+    if (pr.large_ok && hi - lo <= kEpilogueLargeLimit) large_list[atomicAdd(large_count, 1u)] = b;
+    else atomicOr(failed, kEpilogueBucketTooLarge);
+    return;  // (valid[b]: the large kernel's)
   } else if (hi > lo) {
     // the reference walks its table backwards: i = n-1..1 and, inside, j = m-1..1 (:191-192)
     for (uint32_t a = lo + 1; a < hi; a++) {
@@ -257,6 +263,117 @@ __global__ __launch_bounds__(64) void pair_entries_kernel(EpilogueParams pr, con
   valid[b] = out;
 }
 
+// One WORKGROUP per bucket of more than kEpilogueBucketLimit runs (round 6; the hostile corpus: silence against silence).
+// The same three steps as the lane above, on packed keys in LDS (8 bytes per run):
+//   1. walk order: bitonic sort by (src_end, dst_end) descending -- key (0xFFFF - src_end) << 16 | (0xFFFF - dst_end), the
+//      run's index in the low word;
+//   2. every thread turns its sorted elements into (rank << 16 | valid << 15 | index): rank = len << 32 | (src_end - len) << 16
+//      | dst_end IS the derived Ord of :22-35 inside one bucket -- score = len, and with timestamps that strictly increase along
+//      a row (checked on the host: large_ok) src_start / src_end / dst_start / dst_end order as src_end - len, src_end,
+//      dst_end - len, dst_end; two runs of a bucket never share (src_end, dst_end), so the hashes are never reached;
+//   3. ONE lane replays BinaryHeap::push over the valid elements in walk order, in place (the heap never holds more than the
+//      elements already consumed); then every thread builds the DeviceEntry of its heap slots.
+__global__ __launch_bounds__(256) void pair_entries_large_kernel(EpilogueParams pr, const uint32_t *__restrict__ start,
+                                                                 const NeedleHipRun *__restrict__ sorted, const uint32_t *__restrict__ row_len,
+                                                                 const uint32_t *__restrict__ row_ts, const uint64_t *__restrict__ row_seek,
+                                                                 const uint64_t *__restrict__ ts, DeviceEntry *__restrict__ entries,
+                                                                 uint32_t *__restrict__ valid, const uint32_t *__restrict__ large_count,
+                                                                 const uint32_t *__restrict__ large_list) {
+  extern __shared__ unsigned long long arr[];  // kEpilogueLargeLimit elements
+  __shared__ uint32_t heap_size;
+  const uint32_t t = threadIdx.x;
+  const uint32_t listed = *large_count;
+  for (uint32_t item = blockIdx.x; item < listed; item += gridDim.x) {
+    const uint32_t b = large_list[item];
+    const uint32_t lo = start[b], n = start[b + 1] - lo;
+    uint32_t p2 = 1;
+    while (p2 < n) p2 <<= 1;
+    for (uint32_t a = t; a < p2; a += 256) {
+      unsigned long long v = ~0ull;
+      if (a < n) {
+        const NeedleHipRun r = sorted[lo + a];
+        v = ((unsigned long long)(((0xFFFFu - (r.src_end & 0xFFFFu)) << 16) | (0xFFFFu - (r.dst_end & 0xFFFFu))) << 32) | a;
+      }
+      arr[a] = v;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= p2; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t a = t; a < p2; a += 256) {
+          const uint32_t partner = a ^ j;
+          if (partner > a) {
+            const unsigned long long x = arr[a], y = arr[partner];
+            const bool up = (a & k) == 0;
+            if ((x > y) == up) {
+              arr[a] = y;
+              arr[partner] = x;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    const uint32_t region = b % pr.regions;
+    uint32_t vi, vj;
+    pair_at_device(pr.n, b / pr.regions, &vi, &vj);
+    const uint32_t src_row = vi * pr.rows_per_video + region, dst_row = vj * pr.rows_per_video + region;
+    const uint32_t src_len = row_len[src_row], dst_len = row_len[dst_row];
+    const uint64_t *src_ts = ts + row_ts[src_row], *dst_ts = ts + row_ts[dst_row];
+    const uint64_t src_seek = row_seek[src_row], dst_seek = row_seek[dst_row];
+    const uint64_t min_duration = pr.min_duration[region];
+    auto entry_of = [&](const NeedleHipRun &r, DeviceEntry *e) {  // false: the reference skips the run (:212-223)
+      const uint32_t i = r.src_end, j = r.dst_end, len = r.len;
+      if (len == 0 || len > i || len > j || i >= src_len || j >= dst_len) return false;
+      e->src_start = src_ts[i - len] + src_seek;
+      e->src_end = src_ts[i] + src_seek;
+      e->dst_start = dst_ts[j - len] + dst_seek;
+      e->dst_end = dst_ts[j] + dst_seek;
+      if (e->src_end < e->src_start || e->dst_end < e->dst_start) return false;
+      if (e->src_end - e->src_start < min_duration || e->dst_end - e->dst_start < min_duration) return false;
+      e->score = len;
+      e->src_hash = r.src_match_hash;
+      e->dst_hash = r.dst_match_hash;
+      e->pad = 0;
+      return true;
+    };
+    for (uint32_t a = t; a < n; a += 256) {
+      const uint32_t idx = (uint32_t)arr[a];
+      const NeedleHipRun r = sorted[lo + idx];
+      DeviceEntry e;
+      const bool ok = entry_of(r, &e);
+      const unsigned long long rank = ((unsigned long long)r.len << 32) | ((unsigned long long)((r.src_end - r.len) & 0xFFFFu) << 16) | (r.dst_end & 0xFFFFu);
+      arr[a] = (rank << 16) | (ok ? 0x8000ull : 0ull) | idx;
+    }
+    __syncthreads();
+    if (t == 0) {
+      uint32_t out = 0;
+      for (uint32_t a = 0; a < n; a++) {
+        const unsigned long long e = arr[a];
+        if (!(e & 0x8000ull)) continue;
+        uint32_t pos = out++;
+        while (pos > 0) {  // BinaryHeap::push: append, sift up while greater than the parent
+          const uint32_t parent = (pos - 1) / 2;
+          const unsigned long long p = arr[parent];
+          if (!((e >> 16) > (p >> 16))) break;
+          arr[pos] = p;
+          pos = parent;
+        }
+        arr[pos] = e;
+      }
+      heap_size = out;
+      valid[b] = out;
+    }
+    __syncthreads();
+    const uint32_t out = heap_size;
+    for (uint32_t pos = t; pos < out; pos += 256) {
+      const NeedleHipRun r = sorted[lo + (uint32_t)(arr[pos] & 0x1FFFull)];
+      DeviceEntry e;
+      (void)entry_of(r, &e);
+      entries[lo + pos] = e;
+    }
+    __syncthreads();
+  }
+}
+
 struct BestKey {
   float score;
   uint32_t index;
@@ -289,6 +406,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
   __shared__ unsigned long long pool_base;
   __shared__ __attribute__((aligned(16))) uint32_t image[kImageRows * kImagePitch];
   __shared__ uint32_t ntab[16];
+  __shared__ uint32_t dlinks[2048];
+  __shared__ uint32_t distinct;
   __shared__ BestKey best[2][256];
   // a bucket too large for one lane (pair_entries_kernel): the whole job is the host form's, nothing here would be read
   if (__builtin_nontemporal_load(failed) & kEpilogueBucketTooLarge) return;
@@ -373,7 +492,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
   // staged through LDS as +-1 bytes, kImageRows candidates at a time, built by the workgroup and read by its four waves
   // as A fragments; a wave owns every fourth block of 32 k and keeps their sums in links[] between the stages.
   // (Rows beyond c are zero bytes: dot 0, "d = 16" -- counted as a match when bound > 16 and taken out again below.)
-  {
+  // Round 6: a video with thousands of candidates has them from stretches of ONE repeated hash (silence, a sustained chord: every
+  // diagonal of an S x S block is a run, and the simhash of a constant stretch is that constant) -- 33 000 candidates per video on
+  // the hostile corpus at 280 files, a handful of DISTINCT hashes among them.  Candidates of equal hash have equal link counts:
+  // links = sum over the distinct hashes within the bound of their multiplicities.  A 2048-slot table in LDS (the image's bytes,
+  // unused on this path) takes the hashes by 64-bit compare-and-swap; beyond 1536 distinct values the all-pairs products below run.
+  bool deduped = false;
+  if (c >= 4096) {
+    constexpr uint32_t kSlots = 2048, kMaxDistinct = 1536;
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(image);   // 1 << 32 | hash, 0 = empty
+    uint32_t *mult = image + 2 * kSlots;
+    for (uint32_t i = t; i < kSlots; i += 256) {
+      keys[i] = 0ull;
+      mult[i] = 0u;
+      dlinks[i] = 0u;
+    }
+    if (t == 0) distinct = 0;
+    __syncthreads();
+    auto slot_of = [](uint32_t hash) { return (hash * 0x9E3779B1u) >> 21; };
+    for (uint32_t k = t; k < c; k += 256) {
+      const uint32_t hash = cand[k].hash;
+      const unsigned long long want = (1ull << 32) | hash;
+      uint32_t sl = slot_of(hash);
+      for (uint32_t probe = 0; probe < kSlots; probe++, sl = (sl + 1) & (kSlots - 1)) {
+        if (*reinterpret_cast<volatile uint32_t *>(&distinct) > kMaxDistinct) break;  // (overflowing: the direct path will run)
+        const unsigned long long old = atomicCAS(&keys[sl], 0ull, want);
+        if (old == 0ull) atomicAdd(&distinct, 1u);
+        if (old == 0ull || old == want) {
+          atomicAdd(&mult[sl], 1u);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    deduped = distinct <= kMaxDistinct;
+    if (deduped) {
+      for (uint32_t a = t; a < kSlots; a += 256) {
+        const unsigned long long ka = keys[a];
+        if (ka == 0ull) continue;
+        uint32_t sum = 0;
+        for (uint32_t b = 0; b < kSlots; b++) {
+          const unsigned long long kb = keys[b];
+          if (kb != 0ull && (uint32_t)__popc((uint32_t)ka ^ (uint32_t)kb) < pr.bound) sum += mult[b];
+        }
+        dlinks[a] = sum;
+      }
+      __syncthreads();
+      for (uint32_t k = t; k < c; k += 256) {
+        const uint32_t hash = cand[k].hash;
+        const unsigned long long want = (1ull << 32) | hash;
+        uint32_t sl = slot_of(hash);
+        while (keys[sl] != want) sl = (sl + 1) & (kSlots - 1);                 // present by construction
+        links[k] = dlinks[sl];
+      }
+    }
+    __syncthreads();
+  }
+  if (!deduped) {
     const uint32_t lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
     if (t < 16) {
       uint32_t w = 0;
@@ -477,7 +652,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
 }
 
 struct EpilogueWorkspace {
-  DeviceBuffer<uint32_t> count, start, fill, sums, valid, links, ctl, row_len, row_ts;
+  DeviceBuffer<uint32_t> count, start, fill, sums, valid, links, ctl, row_len, row_ts, large_list;
+  bool large_checked = false;
+  bool large_ok = false, large_attr_set = false;  // of the resident row tables: every row under 65 536 hashes, timestamps strictly increasing
   DeviceBuffer<uint64_t> row_seek, ts;
   DeviceBuffer<NeedleHipRun> sorted;
   DeviceBuffer<DeviceEntry> entries;
@@ -520,9 +697,9 @@ std::atomic<uint64_t> &epilogue_host_fallbacks() {
 void note_epilogue_host_fallback(const char *where, size_t runs, size_t videos) {
   epilogue_host_fallbacks().fetch_add(1);
   if (getenv("NEEDLE_HIP_TRACE"))
-    std::fprintf(stderr, "[needle_hip] %s: a pair's bucket holds more than %u runs (silence / a sustained tone on both sides): the "
+    std::fprintf(stderr, "[needle_hip] %s: a pair's bucket holds more than %u runs (silence / a sustained tone on both sides) or the rows are too long for the packed keys: the "
                          "per-video epilogue of this job (%zu runs, %zu videos) falls back to the HOST form\n",
-                 where, kEpilogueBucketLimit, runs, videos);
+                 where, kEpilogueLargeLimit, runs, videos);
 }
 
 Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHipSearchResult *host_results, uint32_t *host_failed) {
@@ -535,6 +712,25 @@ Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHi
     return Status::Make(NeedleError_InvalidArgument, "device epilogue: library too large");
   EpilogueWorkspace *ws = workspace(job.slot);
   Status s;
+  // what pair_entries_large_kernel's packed keys stand on, recomputed when the tables change (before they are taken over below):
+  // every row under 65 536 hashes, every timestamp table strictly increasing (tables are shared by rows of equal length)
+  if (!ws->large_checked || ws->h_ts != *job.ts || ws->h_row_len != *job.row_len || ws->h_row_ts != *job.row_ts) {
+    static_assert(kEpilogueLargeLimit <= 8192, "13 bits of index in the packed key");
+    bool ok = true;
+    std::map<uint32_t, uint32_t> longest;  // table offset -> the longest row that reads it
+    for (size_t r = 0; r < job.row_len->size() && ok; r++) {
+      const uint32_t len = (*job.row_len)[r];
+      ok = len < 65536u;
+      uint32_t &m = longest[(*job.row_ts)[r]];
+      m = std::max(m, len);
+    }
+    for (const auto &kv : longest) {
+      const uint64_t *t = job.ts->data() + kv.first;
+      for (uint32_t k = 1; k < kv.second && ok; k++) ok = t[k] > t[k - 1];
+    }
+    ws->large_ok = ok;
+    ws->large_checked = true;
+  }
   // row tables: only re-uploaded when the geometry changes
   if (!(s = upload_if_changed(&ws->row_len, &ws->h_row_len, *job.row_len, stream)).ok() ||
       !(s = upload_if_changed(&ws->row_ts, &ws->h_row_ts, *job.row_ts, stream)).ok() ||
@@ -545,8 +741,14 @@ Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHi
   if (!(s = ws->count.reserve(buckets)).ok() || !(s = ws->fill.reserve(buckets)).ok() || !(s = ws->start.reserve(buckets + 1)).ok() ||
       !(s = ws->valid.reserve(buckets)).ok() || !(s = ws->sums.reserve((buckets + kScanBlock - 1) / kScanBlock + 1)).ok() ||
       !(s = ws->sorted.reserve(runs)).ok() || !(s = ws->entries.reserve(runs)).ok() || !(s = ws->cand.reserve(2 * runs)).ok() ||
-      !(s = ws->links.reserve(2 * runs)).ok() || !(s = ws->ctl.reserve(4)).ok() || !(s = ws->results.reserve(job.n)).ok())
+      !(s = ws->links.reserve(2 * runs)).ok() || !(s = ws->ctl.reserve(4)).ok() || !(s = ws->results.reserve(job.n)).ok() ||
+      !(s = ws->large_list.reserve(runs / (kEpilogueBucketLimit + 1) + 1)).ok())
     return s;
+  if (!ws->large_attr_set) {
+    NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pair_entries_large_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(kEpilogueLargeLimit * sizeof(unsigned long long))));
+    ws->large_attr_set = true;
+  }
   RunSegments segs;
   std::memset(&segs, 0, sizeof(segs));
   segs.count = job.num_segments;
@@ -569,6 +771,7 @@ Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHi
   pr.min_duration[1] = job.min_ending_duration;
   pr.time_padding = job.time_padding;
   pr.hash_duration = job.hash_duration;
+  pr.large_ok = ws->large_ok && getenv("NEEDLE_HIP_EPILOGUE_NO_LARGE") == nullptr ? 1u : 0u;  // (tests: the host fallback itself)
   NEEDLE_HIP_TRY(hipMemsetAsync(ws->count.ptr, 0, buckets * sizeof(uint32_t), stream));
   NEEDLE_HIP_TRY(hipMemsetAsync(ws->fill.ptr, 0, buckets * sizeof(uint32_t), stream));
   NEEDLE_HIP_TRY(hipMemsetAsync(ws->ctl.ptr, 0, 4 * sizeof(uint32_t), stream));
@@ -587,7 +790,12 @@ Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHi
   {
     KernelTimer timer("epilogue_entries", stream);
     hipLaunchKernelGGL(pair_entries_kernel, dim3((pr.buckets + 63) / 64), dim3(64), 0, stream, pr, ws->start.ptr, ws->sorted.ptr,
-                       ws->row_len.ptr, ws->row_ts.ptr, ws->row_seek.ptr, ws->ts.ptr, ws->entries.ptr, ws->valid.ptr, ws->ctl.ptr + 2);
+                       ws->row_len.ptr, ws->row_ts.ptr, ws->row_seek.ptr, ws->ts.ptr, ws->entries.ptr, ws->valid.ptr, ws->ctl.ptr + 2,
+                       ws->ctl.ptr + 3, ws->large_list.ptr);
+    // the buckets one lane should not order (a stride loop over a list that is empty on ordinary audio: ~2 us then)
+    hipLaunchKernelGGL(pair_entries_large_kernel, dim3(512), dim3(256), kEpilogueLargeLimit * sizeof(unsigned long long), stream, pr,
+                       ws->start.ptr, ws->sorted.ptr, ws->row_len.ptr, ws->row_ts.ptr, ws->row_seek.ptr, ws->ts.ptr, ws->entries.ptr,
+                       ws->valid.ptr, ws->ctl.ptr + 3, ws->large_list.ptr);
   }
   if (pr.v1 > pr.v0) {
     KernelTimer timer("epilogue_best_match", stream);

@@ -120,8 +120,29 @@ def _hip_lib():
                                                  ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64,
                                                  ctypes.c_uint64, ctypes.c_void_p]
         lib.needle_synth_hip_library.restype = ctypes.c_int
+        lib.needle_synth_hip_library_hostile.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                                         ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                                                         ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        lib.needle_synth_hip_library_hostile.restype = ctypes.c_int
         _HIP_LIB = lib
     return _HIP_LIB
+
+
+def hostile_segments(k: int, samples: int, intro_off: int, intro_len: int):
+    """Where episode k of the HOSTILE corpus has its stretch of digital silence and its sustained chord (samples within the
+    search window; length 0 = none): every second episode is silent for 25 - 60 s, every third holds the chord for 25 - 60 s,
+    both in the larger part of the window beside the shared intro, never overlapping it or each other."""
+    before, after = intro_off, samples - (intro_off + intro_len)
+    start, room = (0, before) if before >= after else (intro_off + intro_len, after)
+    sil_len = int((25.0 + 35.0 * ((k * 7) % 11) / 10.0) * RATE) if k % 2 == 0 else 0
+    chord_len = int((25.0 + 35.0 * ((k * 5) % 7) / 6.0) * RATE) if k % 3 == 0 else 0
+    if sil_len + chord_len + 2 * RATE > room:                    # short windows (tests): scale both down
+        scale = max(room - 2 * RATE, 0) / max(sil_len + chord_len, 1)
+        sil_len, chord_len = int(sil_len * scale), int(chord_len * scale)
+    slack = room - sil_len - chord_len - RATE
+    sil_off = start + (slack * ((k * 13) % 17)) // 17
+    chord_off = sil_off + sil_len + RATE
+    return sil_off, sil_len, chord_off, chord_len
 
 
 class DeviceLibrary:
@@ -130,7 +151,10 @@ class DeviceLibrary:
     opening search window: use with opening_search_percentage = 1.0).  Not the host generator's samples -- its own
     (csrc/synth_hip.hip); a checker reads the PCM it wants back with episode()."""
 
-    def __init__(self, n: int, samples: int, intro_s: float, first_episode: int = 0, seed_base: int = EPISODE_SEED):
+    def __init__(self, n: int, samples: int, intro_s: float, first_episode: int = 0, seed_base: int = EPISODE_SEED,
+                 hostile: bool = False):
+        """hostile: the round-6 corpus of csrc/synth_hip.hip -- broadband speech-like bodies, noise 20 dB under the programme,
+        stretches of digital silence and of one sustained chord (hostile_segments) -- instead of note sequences."""
         from . import capi
         self.n, self.samples = n, samples
         self.stride = (samples + 7) & ~7                       # every episode 16-byte aligned
@@ -142,8 +166,17 @@ class DeviceLibrary:
         self._buf = capi.DeviceBuffer(self.stride * 2 * n)
         off = capi.DeviceBuffer(4 * n)
         capi.check(capi.lib().needle_hip_memcpy_h2d(off.ptr, self.intro_off.ctypes.data, self.intro_off.nbytes))
-        rc = _hip_lib().needle_synth_hip_library(self._buf.ptr, self.stride, n, first_episode, samples, off.ptr,
-                                                 self.intro_len, seed_base, INTRO_SEED, capi.stream_ptr())
+        self.hostile = hostile
+        if hostile:
+            self.segments = np.array([hostile_segments(first_episode + k, samples, int(self.intro_off[k]), self.intro_len)
+                                      for k in range(n)], dtype=np.uint32)
+            seg = capi.DeviceBuffer(16 * n)
+            capi.check(capi.lib().needle_hip_memcpy_h2d(seg.ptr, self.segments.ctypes.data, self.segments.nbytes))
+            rc = _hip_lib().needle_synth_hip_library_hostile(self._buf.ptr, self.stride, n, first_episode, samples, off.ptr,
+                                                             self.intro_len, seg.ptr, seed_base, INTRO_SEED, capi.stream_ptr())
+        else:
+            rc = _hip_lib().needle_synth_hip_library(self._buf.ptr, self.stride, n, first_episode, samples, off.ptr,
+                                                     self.intro_len, seed_base, INTRO_SEED, capi.stream_ptr())
         if rc != 0:
             raise RuntimeError(f"needle_synth_hip_library: HIP error {rc}")
         capi.synchronize()

@@ -97,10 +97,11 @@ def test_device_epilogue_on_planted_hashes_equals_host_and_oracle(monkeypatch, n
     assert sum(1 for r in dev if r is not None and r[0] is not None) >= n // 2
 
 
-def test_pairs_with_hundreds_of_runs_go_back_to_the_host_form(monkeypatch):
-    """two stretches of one repeated hash (silence, a sustained tone) give a pair ~2 S runs -- every diagonal of an
-    S x S block is one.  The device form orders a pair's runs in ONE lane, quadratically; beyond 256 runs per pair it sets a
-    flag instead and the job's results come from the host form.  Same results either way, and equal to the oracle's."""
+def test_pairs_with_hundreds_of_runs_are_a_workgroups_or_the_hosts(monkeypatch):
+    """two stretches of one repeated hash (silence, a sustained tone) give a pair ~2 S runs -- every diagonal of
+    an S x S block is one.  The device form orders a pair's runs in ONE lane, quadratically; a bucket beyond a lane's 96 runs goes to a
+    WORKGROUP (round 6: pair_entries_large_kernel, sort + heap on packed keys in LDS), and with that kernel switched off the
+    job's results come from the host form, counted.  Same results every way, and equal to the oracle's."""
     rng = np.random.default_rng(77)
     n, S = 5, 230
     lens = [int(round(400.0 * synth.RATE))] * n                         # ~800 kept hashes in the opening half
@@ -120,9 +121,15 @@ def test_pairs_with_hundreds_of_runs_go_back_to_the_host_form(monkeypatch):
         capi.check(capi.lib().needle_hip_memcpy_h2d(d_arena + 4 * v * stride, h.ctypes.data, h.nbytes))
     cmp = capi.Comparator([f"v{v}.wav" for v in range(n)], min_opening_duration=15)
     host, runs_h = _job(lib, cmp, monkeypatch, device=False)
+    capi.epilogue_host_fallbacks(reset=True)
     dev, runs_d = _job(lib, cmp, monkeypatch, device=True)
+    assert capi.epilogue_host_fallbacks() == 0                              # the workgroup kernel took the silent pairs
     assert runs_h == runs_d > 3 * 2 * (S - 70)                              # the silent pairs alone: > 256 runs each
     assert dev == host
+    monkeypatch.setenv("NEEDLE_HIP_EPILOGUE_NO_LARGE", "1")                 # ... and without it: flagged, host form, counted
+    dev2, runs_d2 = _job(lib, cmp, monkeypatch, device=True)
+    monkeypatch.delenv("NEEDLE_HIP_EPILOGUE_NO_LARGE")
+    assert capi.epilogue_host_fallbacks(reset=True) >= 1 and dev2 == host and runs_d2 == runs_h
     hd = O.duration_from_secs_f32(0.3)
     ofh = []
     for v in range(n):
