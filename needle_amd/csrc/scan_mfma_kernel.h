@@ -56,6 +56,9 @@ constexpr int kM2Members = 8;                 // sources a workgroup takes at mo
 constexpr int kM2Pitch = kM2Heads * 4 + 4;    // words of a window's row in the A image: 4 x 32 FP4 nibbles of +-1, the window's member << 28 | w0, 3 spare
                                               // (20: sixteen lanes' 16-byte reads of one instruction fall into sixteen different groups of four banks)
 constexpr int kM2RunBuf = 64;                 // runs a workgroup collects in LDS before it asks for room in the run list (one atomic)
+constexpr int kM2Overflow = 32;               // ... and beyond those, runs a WAVE collects before it asks (round 6: stretches of one repeated hash --
+                                              // silence against silence -- give a workgroup thousands of runs; one returning atomic per run on the
+                                              // list's one counter was 46 of 52 ms at 39 060 pairs of the hostile corpus, 4.65 M runs)
 constexpr int kM2Table = 256;                 // a byte of hash bits -> its eight FP4 nibbles (bit set: +1 = 0x2, clear: -1 = 0xA)
 constexpr int kM2Probe = 4;                   // rows looked at on either side of a whole window
 constexpr int kM2Rows = kSampleW + 2 * kM2Probe;  // source hashes kept per window: rows w0 - 4 .. w0 + 11
@@ -70,7 +73,8 @@ static_assert(kSampleW + 2 * kM2Probe - 2 < 2 * kSampleW - 1 + 8, "a run that en
 // LDS words of a workgroup: staged destination (+ 64 zeros), tables, per-window source hashes, A image
 __host__ __device__ constexpr size_t m2_round4(size_t x) { return (x + 3) & ~(size_t)3; }
 __host__ __device__ constexpr size_t m2_lds_words(uint64_t m, uint64_t windows, int waves) {
-  return m2_round4(m + 64) + kM2CtlWords + kM2Table + 4 * kM2RunBuf + (size_t)waves * kM2Queue + (size_t)(windows + 1) * (kM2Pitch + kM2Rows);
+  return m2_round4(m + 64) + kM2CtlWords + kM2Table + 4 * kM2RunBuf + (size_t)waves * (kM2Queue + 4 * kM2Overflow) +
+         (size_t)(windows + 1) * (kM2Pitch + kM2Rows);
 }
 
 // A source sequence's windows as a workgroup wants them in LDS -- per window kM2Pitch words of the A image (its four head
@@ -160,7 +164,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   // source hashes.  36 = 4 x 9: sixteen lanes' 16-byte reads of sixteen different windows -- the A fragments of a tile, the
   // rows of the items' windows -- fall into sixteen different groups of four banks.  (Two arrays, the hashes at a pitch of
   // 16 words: lanes with different windows met in FOUR groups; SQ_LDS_BANK_CONFLICT was 61 % of SQ_LDS_IDX_ACTIVE.)
-  uint32_t *wimg = queues + WAVES * kM2Queue;    // 16-byte aligned: every size above is a multiple of 4 words
+  uint32_t *overflow = queues + WAVES * kM2Queue + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 4 * kM2Overflow;  // this wave's
+  int overflowed = 0;                            // runs in it (wave-uniform)
+  uint32_t *wimg = queues + WAVES * (kM2Queue + 4 * kM2Overflow);    // 16-byte aligned: every size above is a multiple of 4 words
 
   if (threadIdx.x == 0) {
     ctl[0] = 0u;
@@ -291,6 +297,21 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     return (mask & kWindow) == 0u && !((mask & kBelow) != 0u && (mask & kAbove) != 0u);
   };
 
+  // the wave's overflow buffer into the run list: one request for room, one run per lane
+  auto flush_overflow = [&]() __attribute__((always_inline)) {
+    if (overflowed == 0) return;
+    wave_lds_fence_search();
+    uint32_t base = 0u;
+    if (lane == 0) base = atomicAdd(count, (uint32_t)overflowed);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (lane < overflowed && base + (uint32_t)lane < capacity) {
+      const uint32_t *e = overflow + 4 * lane;
+      runs[base + (uint32_t)lane] = NeedleHipRun{e[0], e[1], e[2], e[3], 0u, 0u};
+    }
+    wave_lds_fence_search();
+    overflowed = 0;
+  };
+
   // Exact resolution, by the whole wave, of a CHAIN: consecutive aligned windows of one member, all whole on diagonal d.
   // Only the chain's LAST window (the one whose successor is not whole) comes here; the others do nothing -- they used to
   // spend a trip to global memory each on finding out that the run goes on into the next window, and with two runs of
@@ -322,17 +343,24 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     // A run goes to the workgroup's buffer in LDS; the buffer asks for its slots of the run list with ONE atomic at the end
     // (returning atomics on one address go one after the other: at 39 060 pairs the 79 027 of them WERE the resolution's
     // 0.43 ms, whatever the walk did).  A workgroup with more runs than the buffer holds emits the rest directly.
+    // (wave-uniform arguments.)  The workgroup's buffer first; when that is full, the wave's own, emptied into the run list
+    // kM2Overflow runs at a time with one atomic.
     auto emit = [&](const int a, const int b) {
-      if (b - a + 1 >= min_len && lane == 0) {
-        const uint32_t at = __hip_atomic_fetch_add(&ctl[34], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (at < (uint32_t)kM2RunBuf) {
+      if (b - a + 1 < min_len) return;
+      uint32_t at = 0u;
+      if (lane == 0) at = __hip_atomic_fetch_add(&ctl[34], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+      if (at < (uint32_t)kM2RunBuf) {
+        if (lane == 0)
           runbuf[4 * at] = (uint32_t)(lo + g), runbuf[4 * at + 1] = (uint32_t)b, runbuf[4 * at + 2] = (uint32_t)(b + d),
           runbuf[4 * at + 3] = (uint32_t)(b - a + 1);
-        } else {
-          const uint32_t slot = atomicAdd(count, 1u);
-          if (slot < capacity)
-            runs[slot] = NeedleHipRun{(uint32_t)(lo + g), (uint32_t)b, (uint32_t)(b + d), (uint32_t)(b - a + 1), 0u, 0u};
-        }
+        return;
+      }
+      if (lane == 0)
+        overflow[4 * overflowed] = (uint32_t)(lo + g), overflow[4 * overflowed + 1] = (uint32_t)b, overflow[4 * overflowed + 2] = (uint32_t)(b + d),
+        overflow[4 * overflowed + 3] = (uint32_t)(b - a + 1);
+      if (++overflowed == kM2Overflow) {
+        flush_overflow();
       }
     };
     constexpr int kBack = 8;                      // rows per lane of a backward trip
@@ -608,7 +636,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
       rt0 += kM2Batch;
     } while (!done && rt0 < row_tiles);
   }
-  // the workgroup's runs: one request for room, then the copy
+  // the workgroup's runs: one request for room, then the copy (every wave's own overflow first)
+  flush_overflow();
   __syncthreads();
   const uint32_t n_runs = min(ctl[34], (uint32_t)kM2RunBuf);
   if (n_runs == 0u) return;

@@ -321,6 +321,29 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
   // pair), so that every workgroup carries the same mix of short and long bands -- with consecutive bands per
   // workgroup the heavy middle workgroups of every pair land on the same CUs of a round-robin dispatch -- and the
   // slot a wave starts with rotates with the pair, so that no SIMD always gets the long ones.
+  // A wave's runs wait in REGISTERS -- run k in lane k of three registers (the values are wave-uniform) -- and go
+  // to the run list 64 at a time, or when the wave leaves, with ONE request for room.  (Round 6: one returning atomic per run
+  // on the list's single counter is ~11 ns, device-wide and one after the other; stretches of one repeated hash -- silence
+  // against silence: every diagonal of an S x S block is a run -- gave the 378 pairs of the hostile corpus 41 528 runs and
+  // the launch 0.46 ms of waiting for that counter.)
+  uint32_t held_b = 0u, held_e = 0u, held_len = 0u;
+  int held = 0;  // wave-uniform
+  auto flush_runs = [&]() {
+    if (held == 0) return;
+    uint32_t base = 0u;
+    if (lane == 0) base = atomicAdd(count, (uint32_t)held);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (lane < held && base + (uint32_t)lane < capacity)
+      runs[base + (uint32_t)lane] = NeedleHipRun{(uint32_t)lo, held_b, held_e, held_len, 0u, 0u};
+    held = 0;
+  };
+  auto emit_run = [&](const uint32_t b, const uint32_t e, const uint32_t len) {  // wave-uniform arguments
+    const bool mine = lane == held;               // (a select per field: cheaper to write than v_writelane_b32 through inline asm)
+    held_b = mine ? b : held_b;
+    held_e = mine ? e : held_e;
+    held_len = mine ? len : held_len;
+    if (++held == 64) flush_runs();
+  };
   const int slots = 4 * bands_per_wave;
   const int total_bands = (n + m - 3 + B - 1) / B;
   const int nb = (total_bands + slots - 1) / slots;
@@ -407,10 +430,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
         q -= 64;
       }
       const int len = b - a + 1;
-      if (len >= min_len && lane == 0) {
-        const uint32_t slot = atomicAdd(count, 1u);
-        if (slot < capacity) runs[slot] = NeedleHipRun{(uint32_t)lo, (uint32_t)b, (uint32_t)(b + d), (uint32_t)len, 0u, 0u};
-      }
+      if (len >= min_len) emit_run((uint32_t)b, (uint32_t)(b + d), (uint32_t)len);
     };
 
     // Survivors of the head rows.  On unrelated random hashes there are none and the window ends here; real audio
@@ -499,6 +519,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
     }
   }
   }  // bands of this wave
+  flush_runs();
   if (COUNT && lane == 0) {
     atomicAdd(eval_groups, groups);
     atomicAdd(eval_groups + 1, survived);  // diagonals that passed the head rows, over all windows
