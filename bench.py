@@ -1018,9 +1018,12 @@ def main() -> None:
             except capi.NeedleError as e:
                 out["roofline_search"] = {"error": str(e)}
         out["comm_bytes_per_job"] = dict(lib.job_comm_bytes(0), what="received per rank in one steady-state job: all-gather of "
-                                         "hash rows (the arena's equal blocks), all-gather of run-list heads (count + the last "
-                                         "job's largest list + margin, per rank), all-gather of per-video results when the "
-                                         "epilogue is sharded; scans_repeated = overflows met (0 in the steady state)")
+                                         "hash rows (the arena's equal blocks); run_heads = the run lists -- with the sharded device "
+                                         "epilogue (library scale) the OWNER-DIRECTED exchange: a count matrix + an all-to-all of blocks "
+                                         "sized by the last job's counts, a run of pair (i, j) going to the owners of videos i and j only; "
+                                         "otherwise the all-gather of every rank's head (count + the last job's largest list + margin) --; "
+                                         "all-gather of per-video results when the epilogue is sharded; scans_repeated = overflows met "
+                                         "(0 in the steady state)")
         out["host_threads_per_rank"] = capi.host_threads()
         if world == 1 and not args.no_extras and eps is not None:
             out["end_to_end"] = end_to_end(capi, eps, cmp, n_pairs)

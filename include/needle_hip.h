@@ -378,11 +378,16 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *library, const str
                                             int slot, NeedleHipSearchResult *results, size_t *num_runs);
 /* The complete run list (all pairs, all ranks' shares in rank order) the epilogue of the job that finished last in
  * `slot` worked from: host memory of the library, valid until the slot's next job_begin.  For checkers and callers
- * that want the segments themselves ("the final cross-shard pair list"), not only the per-video results. */
+ * that want the segments themselves ("the final cross-shard pair list"), not only the per-video results.
+ * With more than one rank and the sharded device epilogue (library scale) the runs travel OWNER-DIRECTED from the
+ * library's third job on -- a run of pair (i, j) to the ranks that own videos i and j (the epilogue of a video needs its
+ * own pairs and nothing else, comparator.rs:583-588), sizes from the previous job's count matrix -- and a rank then holds,
+ * and this call returns (downloaded on demand), the runs of ITS videos' pairs only; *num_runs of job_end stays the
+ * total over all ranks.  NEEDLE_HIP_DIRECTED_RUNS=0: every job gathers every rank's runs on every rank, as before. */
 enum NeedleError needle_hip_library_job_runs(const NeedleHipLibrary *library, int slot, const NeedleHipRun **runs,
                                              size_t *num_runs);
 /* What the collectives of that job moved, as received per rank: bytes[0] hash rows (all-gather of the arena's blocks),
- * bytes[1] run-list heads (every gather of the job, repeats included), bytes[2] per-video results of a sharded
+ * bytes[1] run lists (the gathered heads, or the owner-directed blocks + the count matrix; repeats included), bytes[2] per-video results of a sharded
  * epilogue; bytes[3] = scans repeated because a slab or a head overflowed (0 in the steady state). */
 enum NeedleError needle_hip_library_job_comm_bytes(const NeedleHipLibrary *library, int slot, uint64_t bytes[4]);
 /* Host threads this process uses for its parallel host phases (epilogue, file reads, upload staging): the CPUs usable

@@ -35,6 +35,11 @@ struct RcclApi {
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*GetVersion)(int *) = nullptr;
+  // optional (comm_all_to_all_v): absent -> the callers keep their all-gathers
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
 };
 
 Status load_rccl(RcclApi *api) {
@@ -58,6 +63,10 @@ Status load_rccl(RcclApi *api) {
     loaded.AllGather = reinterpret_cast<decltype(loaded.AllGather)>(sym("ncclAllGather"));
     loaded.GetErrorString = reinterpret_cast<decltype(loaded.GetErrorString)>(sym("ncclGetErrorString"));
     loaded.GetVersion = reinterpret_cast<decltype(loaded.GetVersion)>(sym("ncclGetVersion"));
+    loaded.Send = reinterpret_cast<decltype(loaded.Send)>(sym("ncclSend"));
+    loaded.Recv = reinterpret_cast<decltype(loaded.Recv)>(sym("ncclRecv"));
+    loaded.GroupStart = reinterpret_cast<decltype(loaded.GroupStart)>(sym("ncclGroupStart"));
+    loaded.GroupEnd = reinterpret_cast<decltype(loaded.GroupEnd)>(sym("ncclGroupEnd"));
     if (!loaded.GetUniqueId || !loaded.CommInitRank || !loaded.CommDestroy || !loaded.AllGather ||
         !loaded.GetErrorString) {
       dlclose(loaded.handle);
@@ -335,6 +344,55 @@ Status comm_all_gather(CommChannel ch, const void *d_send, void *d_recv, size_t 
         NEEDLE_HIP_TRY(hipMemcpyAsync(recv + (size_t)r * bytes + off, c->slot(r), len, hipMemcpyHostToDevice, stream));
     NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
     if (!(s = c->barrier_host()).ok()) return s;
+  }
+  return Status::Ok();
+}
+
+Status comm_all_to_all_v(CommChannel ch, const void *d_send, const size_t *send_off, const size_t *send_bytes, void *d_recv,
+                         const size_t *recv_off, const size_t *recv_bytes, size_t max_block_bytes, hipStream_t stream) {
+  Comm *c = g_comm;
+  const int world = comm_world(), rank = comm_rank();
+  const char *send = static_cast<const char *>(d_send);
+  char *recv = static_cast<char *>(d_recv);
+  for (int q = 0; q < world; q++)
+    if (send_bytes[q] % 4 || recv_bytes[q] % 4) return Status::Make(NeedleError_InvalidArgument, "all-to-all block sizes must be multiples of 4 bytes");
+  // this rank's own block never leaves the device
+  if (send_bytes[rank]) {
+    if (send_bytes[rank] != recv_bytes[rank]) return Status::Make(NeedleError_InvalidArgument, "all-to-all: a rank's block to itself has two sizes");
+    NEEDLE_HIP_TRY(hipMemcpyAsync(recv + recv_off[rank], send + send_off[rank], send_bytes[rank], hipMemcpyDeviceToDevice, stream));
+  }
+  if (!c || world == 1) return Status::Ok();
+  if (!c->host) {
+    if (!c->api.Send || !c->api.Recv || !c->api.GroupStart || !c->api.GroupEnd)
+      return Status::Make(NeedleError_InvalidArgument, "all-to-all unsupported: librccl has no ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+    Status s = nccl_status(c->api, c->api.GroupStart(), "ncclGroupStart");
+    for (int q = 0; q < world && s.ok(); q++) {
+      if (q == rank) continue;
+      if (send_bytes[q]) s = nccl_status(c->api, c->api.Send(send + send_off[q], send_bytes[q] / 4, ncclUint32, q, c->nccl[ch], stream), "ncclSend");
+      if (s.ok() && recv_bytes[q])
+        s = nccl_status(c->api, c->api.Recv(recv + recv_off[q], recv_bytes[q] / 4, ncclUint32, q, c->nccl[ch], stream), "ncclRecv");
+    }
+    Status e = nccl_status(c->api, c->api.GroupEnd(), "ncclGroupEnd");
+    return s.ok() ? e : s;
+  }
+  // host-staged: world - 1 rounds; in round k a rank sends to rank + k and receives from rank - k, a slot's worth at a time
+  // (every rank makes the same number of steps per round: the largest block of the call decides)
+  const size_t slot = c->header()->slot_bytes;
+  const size_t steps = (max_block_bytes + slot - 1) / slot;
+  for (int k = 1; k < world; k++) {
+    const int to = (rank + k) % world, from = (rank - k + world) % world;
+    for (size_t step = 0; step < steps; step++) {
+      const size_t off = step * slot;
+      const size_t out = off < send_bytes[to] ? std::min(slot, send_bytes[to] - off) : 0;
+      const size_t in = off < recv_bytes[from] ? std::min(slot, recv_bytes[from] - off) : 0;
+      if (out) NEEDLE_HIP_TRY(hipMemcpyAsync(c->slot(rank), send + send_off[to] + off, out, hipMemcpyDeviceToHost, stream));
+      NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+      Status s = c->barrier_host();
+      if (!s.ok()) return s;
+      if (in) NEEDLE_HIP_TRY(hipMemcpyAsync(recv + recv_off[from] + off, c->slot(from), in, hipMemcpyHostToDevice, stream));
+      NEEDLE_HIP_TRY(hipStreamSynchronize(stream));
+      if (!(s = c->barrier_host()).ok()) return s;
+    }
   }
   return Status::Ok();
 }

@@ -40,6 +40,14 @@ enum CommChannel { kData = 0, kSide = 1 };
 // All-gather of `bytes` per rank in stream order: rank r's block lands at d_recv + r * bytes on every rank.
 // In place when d_send == d_recv + rank * bytes.  `bytes` must be a multiple of 4.
 Status comm_all_gather(CommChannel ch, const void *d_send, void *d_recv, size_t bytes, hipStream_t stream);
+// All-to-all of blocks of DIFFERENT sizes in stream order (round 6: the owner-directed run exchange): bytes
+// send_bytes[q] at d_send + send_off[q] go to rank q, recv_bytes[r] arrive from rank r at d_recv + recv_off[r]; sizes are
+// multiples of 4 and known on the host of every rank (recv_bytes[r] here = send_bytes[me] on rank r); max_block_bytes =
+// the largest block any rank sends in this call (the same number on every rank: the host transport steps by it).
+// RCCL: one group of ncclSend / ncclRecv per peer; NeedleError_InvalidArgument with "unsupported" in the message when
+// the loaded librccl lacks them (the caller keeps its all-gather).
+Status comm_all_to_all_v(CommChannel ch, const void *d_send, const size_t *send_off, const size_t *send_bytes, void *d_recv,
+                         const size_t *recv_off, const size_t *recv_bytes, size_t max_block_bytes, hipStream_t stream);
 // Host buffers (staged through a small device buffer on the side channel); synchronous.
 Status comm_all_gather_host(const void *send, void *recv, size_t bytes);
 Status comm_barrier();

@@ -27,6 +27,7 @@ struct EpilogueJob {
   const NeedleHipRun *segment_runs[64] = {nullptr};
   int num_segments = 0;
   uint32_t segment_capacity = 0;
+  uint32_t segment_capacities[64] = {0};  // per segment where they differ (the owner-directed exchange's blocks); 0 = segment_capacity
   uint64_t max_runs = 0;             // upper bound of the runs in all segments (sizes the workspaces)
   // per arena row: hashes kept, offset of its (un-seeked) timestamps in `ts`, seek added to each of them
   const std::vector<uint32_t> *row_len = nullptr, *row_ts = nullptr;
@@ -55,6 +56,18 @@ constexpr uint32_t kEpilogueBucketTooLarge = 0x80000000u;
 std::atomic<uint64_t> &epilogue_host_fallbacks();
 // (host side of both callers: counts, and says so under NEEDLE_HIP_TRACE)
 void note_epilogue_host_fallback(const char *where, size_t runs, size_t videos);
+
+// The owner-directed exchange's send side (round 6, library.cpp): the runs of a rank's slab sorted into one block per
+// destination rank -- a run of pair (i, j) goes to the owners of video i and of video j (videos in blocks of `videos_per_rank`:
+// the sharded epilogue's blocks, comparator.rs:583-588 needs a video's pairs and nothing else).  A block = a slab: 32-byte
+// header (word 0: runs DIRECTED to it, which may exceed what it holds -- the caller's overflow test) + capacity[q] runs, at
+// send + offset[q] bytes.  Enqueued on `stream`; the headers are cleared first.
+struct DirectPlan {
+  uint32_t offset[64];    // bytes
+  uint32_t capacity[64];  // runs
+};
+Status gpu_direct_runs(const uint32_t *d_found, const NeedleHipRun *d_runs, uint32_t slab_capacity, uint32_t n, uint32_t regions,
+                       uint32_t videos_per_rank, int world, uint8_t *d_send, const DirectPlan &plan, hipStream_t stream);
 
 // Enqueues the epilogue kernels on `stream` behind whatever fills the segments, then the copies of results[n] and of the
 // failure count (videos whose padding / hash duration exceed the match end: the reference panics) into HOST memory

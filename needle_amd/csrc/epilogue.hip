@@ -177,6 +177,42 @@ __device__ __forceinline__ void pair_at_device(uint64_t n, uint64_t index, uint3
   *pj = (uint32_t)(i + 1 + (index - row_start(n, i)));
 }
 
+// A slab's runs into one block per destination rank (gpu_direct_runs).  A wave asks a block's counter once per destination
+// for all its lanes' runs (a returning atomic per run on `world` addresses would be the kernel).
+__global__ __launch_bounds__(256) void direct_runs_kernel(const uint32_t *__restrict__ found, const NeedleHipRun *__restrict__ runs,
+                                                          uint32_t slab_capacity, uint32_t n, uint32_t regions, uint32_t videos_per_rank,
+                                                          int world, uint8_t *__restrict__ send, DirectPlan plan) {
+  const uint32_t total = min(*found, slab_capacity);
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += stride) {  // (whole waves stay in the loop: ballots)
+    const uint32_t g = base + threadIdx.x;
+    NeedleHipRun r{};
+    uint32_t oi = 0xFFFFFFFFu, oj = 0xFFFFFFFFu;
+    if (g < total) {
+      r = runs[g];
+      uint32_t vi, vj;
+      pair_at_device(n, r.problem / regions, &vi, &vj);
+      oi = vi / videos_per_rank;
+      oj = vj / videos_per_rank;
+      if (oj == oi) oj = 0xFFFFFFFFu;
+    }
+    for (int q = 0; q < world; q++) {
+      const bool mine = oi == (uint32_t)q || oj == (uint32_t)q;
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(mine);
+      if (mask == 0ull) continue;  // wave-uniform
+      uint32_t *header = reinterpret_cast<uint32_t *>(send + plan.offset[q]);
+      uint32_t first = 0u;
+      if (lane == (uint32_t)(__ffsll((long long)mask) - 1)) first = atomicAdd(header, (uint32_t)__popcll(mask));
+      first = (uint32_t)__shfl((int)first, __ffsll((long long)mask) - 1);
+      if (mine) {
+        const uint32_t at = first + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (at < plan.capacity[q]) reinterpret_cast<NeedleHipRun *>(send + plan.offset[q] + 32)[at] = r;
+      }
+    }
+  }
+}
+
 // #[derive(Ord)] over (score, src_start, src_end, dst_start, dst_end, src_match_hash, dst_match_hash, ...): the rest of
 // the fields are equal for all entries of one bucket.  true: a > b.
 __device__ __forceinline__ bool entry_greater(const DeviceEntry &a, const DeviceEntry &b) {
@@ -702,6 +738,18 @@ void note_epilogue_host_fallback(const char *where, size_t runs, size_t videos) 
                  where, kEpilogueLargeLimit, runs, videos);
 }
 
+Status gpu_direct_runs(const uint32_t *d_found, const NeedleHipRun *d_runs, uint32_t slab_capacity, uint32_t n, uint32_t regions,
+                       uint32_t videos_per_rank, int world, uint8_t *d_send, const DirectPlan &plan, hipStream_t stream) {
+  if (world < 1 || world > 64 || n < 2 || regions < 1 || videos_per_rank < 1)
+    return Status::Make(NeedleError_InvalidArgument, "directed run exchange: invalid plan");
+  for (int q = 0; q < world; q++) NEEDLE_HIP_TRY(hipMemsetAsync(d_send + plan.offset[q], 0, 32, stream));
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(2048, ((uint64_t)slab_capacity + 255) / 256);
+  hipLaunchKernelGGL(direct_runs_kernel, dim3(std::max(grid, 1u)), dim3(256), 0, stream, d_found, d_runs, slab_capacity, n, regions,
+                     videos_per_rank, world, d_send, plan);
+  NEEDLE_HIP_TRY(hipGetLastError());
+  return Status::Ok();
+}
+
 Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHipSearchResult *host_results, uint32_t *host_failed) {
   std::lock_guard<std::recursive_mutex> gpu_lock(gpu_mutex());  // the per-device workspaces are shared, as everywhere else
   if (job.num_segments < 1 || job.num_segments > kMaxSegments)
@@ -755,7 +803,7 @@ Status gpu_epilogue_enqueue(const EpilogueJob &job, hipStream_t stream, NeedleHi
   for (int k = 0; k < job.num_segments; k++) {
     segs.found[k] = job.segment_count[k];
     segs.runs[k] = job.segment_runs[k];
-    segs.capacity[k] = job.segment_capacity;
+    segs.capacity[k] = job.segment_capacities[k] ? job.segment_capacities[k] : job.segment_capacity;
   }
   EpilogueParams pr;
   std::memset(&pr, 0, sizeof(pr));

@@ -101,6 +101,24 @@ struct NeedleHipLibrary {
                                // device form then failed on THIS rank alone -- the other ranks enter the collective that decision implies
     const NeedleHipRun *last_runs = nullptr;  // the complete run list of the job that finished last in this slot
     size_t last_total = 0;
+    // Owner-directed run exchange (round 6; world > 1 with the sharded device epilogue): a run of pair (i, j) travels to
+    // the owners of videos i and j only (comparator.rs:583-588: a video's epilogue needs its own pairs), not to every rank.
+    // d_dir_send = this rank's runs sorted into one block per destination (epilogue.h DirectPlan), d_dir_recv = the blocks
+    // received, in rank order, = the device epilogue's segments.  Block sizes are host values on every rank: cap[r * world + q]
+    // comes from the count matrix of the library's last finished job (every rank has all of it: d_dir_counts, one row of
+    // [slab count, runs directed to rank 0, 1, ...] per rank, all-gathered) plus a margin; a count beyond its block is the
+    // head overflow's case (job_end: sizes grow, the exchange is repeated).  A library's first job has no matrix yet: it
+    // counts, and travels as heads.
+    DeviceBuffer<uint8_t> d_dir_send, d_dir_recv;
+    DeviceBuffer<uint32_t> d_dir_counts;
+    void *host_counts = nullptr;
+    size_t host_counts_bytes = 0;
+    std::vector<uint32_t> cap;      // of this job's exchange (empty: this job travels as heads)
+    bool counted = false;           // host_counts holds this job's count matrix
+    bool directed = false;          // this job's runs travelled owner-directed
+    std::vector<NeedleHipRun> fetched;  // directed: the received runs, downloaded on demand (job_runs, a host fallback)
+    bool fetched_valid = false;
+    static size_t count_words(int world) { return ((size_t)world + 1 + 3) & ~(size_t)3; }
     uint64_t comm_bytes[4] = {0, 0, 0, 0};  // received per rank in this job: hash rows, run heads, results; scans repeated
     size_t slab_bytes() const { return kSlabHeader + (size_t)slab_runs * sizeof(NeedleHipRun); }
     size_t head_bytes() const { return kSlabHeader + (size_t)head_runs * sizeof(NeedleHipRun); }
@@ -108,6 +126,9 @@ struct NeedleHipLibrary {
   static constexpr size_t kSlabHeader = 32;
   uint32_t slab_runs = 0;      // per-rank run capacity of the next job (grows on overflow)
   uint32_t last_max_count = 0;  // largest per-rank run count of the last finished job: sizes the one-trip download
+  std::vector<uint32_t> dir_counts;  // [world][world]: runs rank r directed to rank q in the last finished job (Job::cap's source)
+  int dir_world = 0;
+  bool dir_unsupported = false;      // the communicator has no point-to-point transfers: every job travels as heads
   size_t arena_rows = 0;       // rows the arena was allocated with
   const uint32_t *count_zeroed = nullptr;  // a run counter the last kernel of this job's analyze has just cleared (job_begin)
   // what the device epilogue needs to know about the arena's rows (built once per geometry: plan_windows clears them)
@@ -140,6 +161,7 @@ struct NeedleHipLibrary {
     }
     for (Job &j : job) {
       if (j.host_results) (void)hipHostFree(j.host_results);
+      if (j.host_counts) (void)hipHostFree(j.host_counts);
       if (j.host) (void)hipHostFree(j.host);
       if (j.done) (void)hipEventDestroy(j.done);
       if (j.searched) (void)hipEventDestroy(j.searched);
@@ -704,6 +726,28 @@ bool device_epilogue_wanted(const NeedleHipLibrary *lib, size_t comparator_regio
   return (uint64_t)pair_count(lib->n) * comparator_regions >= kDeviceEpiloguePairs;
 }
 
+// Owner-directed job: the runs this rank received (its own videos' pairs), downloaded once, on demand.
+Status fetch_directed(NeedleHipLibrary::Job &j, int world, int rank) {
+  if (j.fetched_valid) return Status::Ok();
+  const size_t W = (size_t)world, cw = NeedleHipLibrary::Job::count_words(world);
+  const uint32_t *m = static_cast<const uint32_t *>(j.host_counts);
+  size_t total = 0, off = 0;
+  for (size_t r = 0; r < W; r++) total += std::min(m[r * cw + 1 + (size_t)rank], j.cap[r * W + (size_t)rank]);
+  j.fetched.resize(total);
+  size_t at = 0;
+  for (size_t r = 0; r < W; r++) {
+    const uint32_t cap = j.cap[r * W + (size_t)rank], have = std::min(m[r * cw + 1 + (size_t)rank], cap);
+    if (have)
+      NEEDLE_HIP_TRY(hipMemcpyAsync(j.fetched.data() + at, j.d_dir_recv.ptr + off + NeedleHipLibrary::kSlabHeader,
+                                    (size_t)have * sizeof(NeedleHipRun), hipMemcpyDeviceToHost, download_stream()));
+    at += have;
+    off += NeedleHipLibrary::kSlabHeader + (size_t)cap * sizeof(NeedleHipRun);
+  }
+  NEEDLE_HIP_TRY(hipStreamSynchronize(download_stream()));
+  j.fetched_valid = true;
+  return Status::Ok();
+}
+
 // scan of this rank's pair range into its slab, gather of the slabs, download of their heads: all asynchronous
 NeedleError job_search_and_gather(NeedleHipLibrary *lib, const NeedleAudioComparator *comparator, NeedleHipLibrary::Job &j) {
   const int world = comm_world(), rank = comm_rank();
@@ -717,31 +761,114 @@ NeedleError job_search_and_gather(NeedleHipLibrary *lib, const NeedleAudioCompar
   hipStream_t stream = library_stream(), down = download_stream();
   if (hipEventRecord(j.searched, stream) != hipSuccess || hipStreamWaitEvent(down, j.searched, 0) != hipSuccess)
     return report(Status::Make(NeedleError_Unknown, "stream ordering failed"));
-  // What travels is the HEAD of every rank's slab -- its count and as many runs as the last job needed plus a margin
-  // (job_buffers) -- not the slab's capacity: at BASELINE.json configs[4] on 8 GPUs a slab is 24 MB per rank and the
-  // runs found 13 MB.  The heads land side by side in d_heads and come down in ONE copy; a rank whose count exceeds the
-  // head is handled like a slab overflow in job_end (every rank sees every count): the head grows, the job's scan
-  // and gather are repeated, the size sticks.  One rank: the head is copied straight out of the slab.
-  const uint8_t *src = mine;
-  if (world > 1) {
-    Status s = comm_all_gather(kSide, mine, j.d_heads.ptr, j.head_bytes(), down);
-    if (!s.ok()) return report(s);
-    src = j.d_heads.ptr;
-    j.comm_bytes[1] += j.head_bytes() * (uint64_t)world;
-  }
-  if (hipMemcpyAsync(j.host, src, j.head_bytes() * (size_t)world, hipMemcpyDeviceToHost, down) != hipSuccess)
-    return report(Status::Make(NeedleError_Unknown, "asynchronous run download failed"));
+  // The epilogue's form first (the exchange depends on it): on the device or on host threads, every rank for all videos
+  // or -- more than one rank and a library large enough to pay for one more collective -- each for its own block (the
+  // decision cannot wait for the run count: the pairs stand in for it).
   const Comparator &cmp = comparator_of(comparator);
   const size_t Rc = cmp.include_endings() ? 2 : 1;
   j.device_epilogue = device_epilogue_wanted(lib, Rc) && lib->n >= 2;
   j.shape_fixed = j.device_epilogue;
   if (j.device_epilogue) {
-    // every rank for all videos, or -- more than one rank and a library large enough to pay for one more collective -- each
-    // for its own block of videos (the decision cannot wait for the run count: the pairs stand in for it)
     uint64_t shard_from = 1u << 16;
     if (const char *e = getenv("NEEDLE_HIP_SHARD_EPILOGUE_PAIRS")) shard_from = (uint64_t)std::max(1, atoi(e));  // tests
     j.sharded = world > 1 && (getenv("NEEDLE_HIP_SHARD_EPILOGUE") ? atoi(getenv("NEEDLE_HIP_SHARD_EPILOGUE")) != 0
                                                                    : (uint64_t)pair_count(lib->n) * Rc >= shard_from);
+  }
+  // Owner-directed exchange (Job): with the sharded device epilogue a rank needs the runs of its own videos' pairs only.
+  j.counted = j.directed = false;
+  j.cap.clear();
+  j.fetched_valid = false;
+  const char *dir_env = getenv("NEEDLE_HIP_DIRECTED_RUNS");  // 0: every job travels as heads (measurements, tests)
+  const bool want_directed = world > 1 && world <= 64 && j.device_epilogue && j.sharded && !lib->dir_unsupported &&
+                             !(dir_env && atoi(dir_env) == 0);
+  std::vector<size_t> recv_off((size_t)world, 0), recv_bytes((size_t)world, 0);
+  if (want_directed) {
+    const size_t W = (size_t)world;
+    const bool have = lib->dir_world == world && lib->dir_counts.size() == W * W;
+    std::vector<uint32_t> cap(W * W, 0u);
+    if (have)
+      for (size_t k = 0; k < W * W; k++) cap[k] = round_up4((uint64_t)lib->dir_counts[k] + lib->dir_counts[k] / 8 + 64);
+    DirectPlan plan;
+    std::memset(&plan, 0, sizeof(plan));
+    std::vector<size_t> send_off(W), send_bytes(W);
+    size_t off = 0, largest = 0;
+    for (size_t q = 0; q < W; q++) {
+      plan.offset[q] = (uint32_t)off;
+      plan.capacity[q] = cap[(size_t)rank * W + q];
+      send_off[q] = off;
+      send_bytes[q] = NeedleHipLibrary::kSlabHeader + (size_t)plan.capacity[q] * sizeof(NeedleHipRun);
+      off += send_bytes[q];
+    }
+    for (size_t k = 0; k < W * W; k++) largest = std::max(largest, NeedleHipLibrary::kSlabHeader + (size_t)cap[k] * sizeof(NeedleHipRun));
+    if (off >= 0xFFFFFFF0ull) return report(Status::Make(NeedleError_InvalidArgument, "directed run exchange: blocks beyond 4 GiB"));
+    const size_t cw = NeedleHipLibrary::Job::count_words(world);
+    Status s = j.d_dir_send.reserve(off);
+    if (s.ok()) s = j.d_dir_counts.reserve(cw * W);
+    if (s.ok() && cw * W * sizeof(uint32_t) > j.host_counts_bytes) {
+      if (j.host_counts) (void)hipHostFree(j.host_counts);
+      j.host_counts = nullptr;
+      j.host_counts_bytes = 0;
+      if (hipHostMalloc(&j.host_counts, cw * W * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+        s = Status::Make(NeedleError_Unknown, "pinned allocation failed");
+      else
+        j.host_counts_bytes = cw * W * sizeof(uint32_t);
+    }
+    if (s.ok())
+      s = gpu_direct_runs(reinterpret_cast<const uint32_t *>(mine), reinterpret_cast<const NeedleHipRun *>(mine + NeedleHipLibrary::kSlabHeader),
+                          j.slab_runs, (uint32_t)lib->n, (uint32_t)Rc, (uint32_t)shard_block(lib->n, world), world, j.d_dir_send.ptr, plan, down);
+    if (!s.ok()) return report(s);
+    // this rank's row of the count matrix: [runs in its slab, runs directed to rank 0, 1, ...]; every rank gets every row
+    uint32_t *row = j.d_dir_counts.ptr + (size_t)rank * cw;
+    bool ok = hipMemsetAsync(row, 0, cw * sizeof(uint32_t), down) == hipSuccess &&
+              hipMemcpyAsync(row, mine, sizeof(uint32_t), hipMemcpyDeviceToDevice, down) == hipSuccess;
+    for (size_t q = 0; q < W && ok; q++)
+      ok = hipMemcpyAsync(row + 1 + q, j.d_dir_send.ptr + send_off[q], sizeof(uint32_t), hipMemcpyDeviceToDevice, down) == hipSuccess;
+    if (!ok) return report(Status::Make(NeedleError_Unknown, "directed run exchange: count row failed"));
+    s = comm_all_gather(kSide, row, j.d_dir_counts.ptr, cw * sizeof(uint32_t), down);
+    if (!s.ok()) return report(s);
+    if (hipMemcpyAsync(j.host_counts, j.d_dir_counts.ptr, cw * W * sizeof(uint32_t), hipMemcpyDeviceToHost, down) != hipSuccess)
+      return report(Status::Make(NeedleError_Unknown, "directed run exchange: count download failed"));
+    j.counted = true;
+    j.comm_bytes[1] += cw * W * sizeof(uint32_t);
+    if (have) {
+      size_t roff = 0;
+      for (size_t r = 0; r < W; r++) {
+        recv_off[r] = roff;
+        recv_bytes[r] = NeedleHipLibrary::kSlabHeader + (size_t)cap[r * W + (size_t)rank] * sizeof(NeedleHipRun);
+        roff += recv_bytes[r];
+      }
+      if (!(s = j.d_dir_recv.reserve(roff)).ok()) return report(s);
+      s = comm_all_to_all_v(kSide, j.d_dir_send.ptr, send_off.data(), send_bytes.data(), j.d_dir_recv.ptr, recv_off.data(), recv_bytes.data(),
+                            largest, down);
+      if (s.ok()) {
+        j.directed = true;
+        j.cap = cap;
+        j.comm_bytes[1] += roff;
+      } else if (s.message.find("unsupported") != std::string::npos) {
+        lib->dir_unsupported = true;  // (every rank loads the same librccl: every rank lands here, before any transfer)
+        (void)hipGetLastError();
+      } else {
+        return report(s);
+      }
+    }
+  }
+  // What travels otherwise is the HEAD of every rank's slab -- its count and as many runs as the last job needed plus a margin
+  // (job_buffers) -- not the slab's capacity: at BASELINE.json configs[4] on 8 GPUs a slab is 24 MB per rank and the
+  // runs found 13 MB.  The heads land side by side in d_heads and come down in ONE copy; a rank whose count exceeds the
+  // head is handled like a slab overflow in job_end (every rank sees every count): the head grows, the job's scan
+  // and gather are repeated, the size sticks.  One rank: the head is copied straight out of the slab.
+  const uint8_t *src = mine;
+  if (!j.directed) {
+    if (world > 1) {
+      Status s = comm_all_gather(kSide, mine, j.d_heads.ptr, j.head_bytes(), down);
+      if (!s.ok()) return report(s);
+      src = j.d_heads.ptr;
+      j.comm_bytes[1] += j.head_bytes() * (uint64_t)world;
+    }
+    if (hipMemcpyAsync(j.host, src, j.head_bytes() * (size_t)world, hipMemcpyDeviceToHost, down) != hipSuccess)
+      return report(Status::Make(NeedleError_Unknown, "asynchronous run download failed"));
+  }
+  if (j.device_epilogue) {
     const size_t want = (lib->n + 1) * sizeof(NeedleHipSearchResult);
     if (want > j.host_results_bytes) {
       if (j.host_results) (void)hipHostFree(j.host_results);
@@ -772,14 +899,23 @@ NeedleError job_search_and_gather(NeedleHipLibrary *lib, const NeedleAudioCompar
       ej.segment_count[k] = reinterpret_cast<const uint32_t *>(slab);
       ej.segment_runs[k] = reinterpret_cast<const NeedleHipRun *>(slab + NeedleHipLibrary::kSlabHeader);
     };
-    if (world > 1) {
+    if (j.directed) {  // the blocks received: one segment per source rank, each of its own capacity
+      ej.max_runs = 0;
+      for (int r = 0; r < world; r++) {
+        segment(r, j.d_dir_recv.ptr + recv_off[(size_t)r]);
+        ej.segment_capacities[r] = j.cap[(size_t)r * (size_t)world + (size_t)rank];
+        ej.max_runs += ej.segment_capacities[r];
+      }
+      ej.segment_capacity = 0;
+    } else if (world > 1) {
       for (int r = 0; r < world && r < 64; r++) segment(r, j.d_heads.ptr + (size_t)r * j.head_bytes());
       ej.segment_capacity = j.head_runs;
+      ej.max_runs = (uint64_t)ej.segment_capacity * (uint64_t)world;
     } else {
       segment(0, mine);
       ej.segment_capacity = j.slab_runs;
+      ej.max_runs = (uint64_t)ej.segment_capacity * (uint64_t)world;
     }
-    ej.max_runs = (uint64_t)ej.segment_capacity * (uint64_t)world;
     ej.row_len = &lib->row_len;
     ej.row_ts = &lib->row_ts;
     ej.row_seek = &lib->row_seek;
@@ -948,31 +1084,62 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
     const int world = comm_world(), rank = comm_rank();
     const Comparator &cmp = comparator_of(comparator);
     std::vector<uint32_t> counts((size_t)world);
+    const size_t W = (size_t)world, cw = NeedleHipLibrary::Job::count_words(world);
+    auto take_matrix = [&]() {  // the job's count matrix becomes the next job's block sizes (every rank holds the same one)
+      const uint32_t *m = static_cast<const uint32_t *>(j.host_counts);
+      lib->dir_counts.assign(W * W, 0u);
+      for (size_t r = 0; r < W; r++)
+        for (size_t q = 0; q < W; q++) lib->dir_counts[r * W + q] = m[r * cw + 1 + q];
+      lib->dir_world = world;
+    };
     for (;;) {
       if (hipEventSynchronize(j.done) != hipSuccess) return report(Status::Make(NeedleError_Unknown, "run download failed"));
       uint32_t most = 0;
-      for (int r = 0; r < world; r++) {
-        counts[r] = *reinterpret_cast<const uint32_t *>(static_cast<const char *>(j.host) + (size_t)r * j.head_bytes());
-        most = std::max(most, counts[r]);
-      }
-      if (most <= j.slab_runs && (world == 1 || most <= j.head_runs)) {
-        lib->last_max_count = most;
-        break;
-      }
-      if (most <= j.slab_runs) {  // world > 1 and some rank's list is longer than the head that was gathered
-        lib->last_max_count = most;
-        Status s = job_buffers(lib, j, world);  // head_runs from last_max_count
-        if (!s.ok()) return report(s);
-        NeedleError e = job_search_and_gather(lib, comparator, j);
-        if (e != NeedleError_Ok) return e;
-        j.comm_bytes[3]++;
-        continue;
+      if (j.directed) {  // nothing but the counts came down
+        const uint32_t *m = static_cast<const uint32_t *>(j.host_counts);
+        for (size_t r = 0; r < W; r++) {
+          counts[r] = m[r * cw];
+          most = std::max(most, counts[r]);
+        }
+        if (most <= j.slab_runs) {
+          bool fits = true;
+          for (size_t r = 0; r < W && fits; r++)
+            for (size_t q = 0; q < W && fits; q++) fits = m[r * cw + 1 + q] <= j.cap[r * W + q];
+          take_matrix();
+          lib->last_max_count = most;
+          if (fits) break;
+          // a block overflowed (every rank sees it): the sizes follow the matrix just taken, scan and exchange are repeated
+          NeedleError e = job_search_and_gather(lib, comparator, j);
+          if (e != NeedleError_Ok) return e;
+          j.comm_bytes[3]++;
+          continue;
+        }
+      } else {
+        for (int r = 0; r < world; r++) {
+          counts[r] = *reinterpret_cast<const uint32_t *>(static_cast<const char *>(j.host) + (size_t)r * j.head_bytes());
+          most = std::max(most, counts[r]);
+        }
+        if (most <= j.slab_runs && (world == 1 || most <= j.head_runs)) {
+          lib->last_max_count = most;
+          if (j.counted) take_matrix();  // (a job that travelled as heads and counted: the next one can be directed)
+          break;
+        }
+        if (most <= j.slab_runs) {  // world > 1 and some rank's list is longer than the head that was gathered
+          lib->last_max_count = most;
+          Status s = job_buffers(lib, j, world);  // head_runs from last_max_count
+          if (!s.ok()) return report(s);
+          NeedleError e = job_search_and_gather(lib, comparator, j);
+          if (e != NeedleError_Ok) return e;
+          j.comm_bytes[3]++;
+          continue;
+        }
       }
       // Some rank found more runs than a slab holds (every rank sees the same counts, so every rank takes this
       // branch): grow and repeat the scan of this job -- the scan is deterministic and the arena still holds the
       // hashes, whether or not the next job's analyze has run in between (same PCM, same rows).
       lib->slab_runs = round_up4((uint64_t)most + most / 4 + 64);
       lib->last_max_count = most;
+      lib->dir_counts.clear();  // (counted over a clamped slab)
       Status s = job_buffers(lib, j, world);
       if (!s.ok()) return report(s);
       NeedleError e = job_search_and_gather(lib, comparator, j);
@@ -984,13 +1151,15 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
     size_t total = 0;
     for (int r = 0; r < world; r++) total += counts[r];
     const NeedleHipRun *run_list = nullptr;
-    if (world == 1 && counts[0] <= j.head_runs)  // one rank, everything in the pinned head: no copy of ~100 MB at library scale
+    if (j.directed)  // the runs stayed on the devices: each rank holds its own videos' (fetch_directed, on demand)
+      j.merged.clear();
+    else if (world == 1 && counts[0] <= j.head_runs)  // one rank, everything in the pinned head: no copy of ~100 MB at library scale
       run_list = reinterpret_cast<const NeedleHipRun *>(static_cast<const char *>(j.host) + NeedleHipLibrary::kSlabHeader);
     else
       j.merged.resize(total);
     size_t at = 0;
     bool tails = false;
-    for (int r = 0; r < world && !run_list; r++) {  // (tails beyond the head: one rank only, out of its own slab)
+    for (int r = 0; r < world && !run_list && !j.directed; r++) {  // (tails beyond the head: one rank only, out of its own slab)
       const uint32_t head = std::min(counts[r], j.head_runs);
       std::memcpy(j.merged.data() + at, static_cast<const char *>(j.host) + (size_t)r * j.head_bytes() + NeedleHipLibrary::kSlabHeader,
                   (size_t)head * sizeof(NeedleHipRun));
@@ -1014,7 +1183,7 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
     size_t v0 = 0, vcount = lib->n;
     if (sharded) shard_range(lib->n, world, rank, &v0, &vcount);
     const auto t0 = std::chrono::steady_clock::now();
-    if (!run_list) run_list = j.merged.data();
+    if (!run_list && !j.directed) run_list = j.merged.data();
     j.last_runs = run_list;
     j.last_total = total;
     Status s;
@@ -1031,7 +1200,13 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
     }
     if (!device_results) {
       const std::vector<const FrameHashesData *> fh = lib->shell_pointers();
-      s = cmp.results_from_runs(fh, run_list, total, false, false, false, &res, v0, v0 + vcount);
+      if (j.directed) {  // this rank's videos' runs are what it received: down they come, once
+        Status f = fetch_directed(j, world, rank);
+        if (!f.ok()) return report(f);
+        s = cmp.results_from_runs(fh, j.fetched.data(), j.fetched.size(), false, false, false, &res, v0, v0 + vcount);
+      } else {
+        s = cmp.results_from_runs(fh, run_list, total, false, false, false, &res, v0, v0 + vcount);
+      }
     }
     if (getenv("NEEDLE_HIP_TRACE"))
       std::fprintf(stderr, "[needle_hip] rank %d epilogue %zu runs, videos [%zu, %zu): %.1f us\n", rank, total, v0, v0 + vcount,
@@ -1075,8 +1250,16 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
 
 enum NeedleError needle_hip_library_job_runs(const NeedleHipLibrary *lib, int slot, const NeedleHipRun **runs, size_t *num_runs) {
   if (!lib || !runs || !num_runs) return NeedleError_NullArgument;
-  if (slot < 0 || slot > 1 || lib->job[slot].pending || (!lib->job[slot].last_runs && lib->job[slot].last_total))
-    return NeedleError_InvalidArgument;
+  if (slot < 0 || slot > 1 || lib->job[slot].pending) return NeedleError_InvalidArgument;
+  if (lib->job[slot].directed) {  // owner-directed exchange: a rank holds the runs of its own videos' pairs, nothing else
+    NeedleHipLibrary::Job &j = const_cast<NeedleHipLibrary *>(lib)->job[slot];
+    Status s = fetch_directed(j, comm_world(), comm_rank());
+    if (!s.ok()) return report(s);
+    *runs = j.fetched.data();
+    *num_runs = j.fetched.size();
+    return NeedleError_Ok;
+  }
+  if (!lib->job[slot].last_runs && lib->job[slot].last_total) return NeedleError_InvalidArgument;
   *runs = lib->job[slot].last_runs;
   *num_runs = lib->job[slot].last_total;
   return NeedleError_Ok;

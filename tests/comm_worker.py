@@ -47,17 +47,23 @@ def gpu_main(out, n, seconds):
     capi.set_kernel_timing("stft_chroma32,stft_chroma")
     lib.job_begin(cmp, 0)
     lib.job_begin(cmp, 1)
-    jobs.append(lib.job_end(cmp, 0))
+    comm = []
+
+    def end(slot):
+        jobs.append(lib.job_end(cmp, slot))
+        comm.append(dict(lib.job_comm_bytes(slot), held=int(len(lib.job_runs(slot)))))
+
+    end(0)
     lib.job_begin(cmp, 0)
-    jobs.append(lib.job_end(cmp, 1))
-    jobs.append(lib.job_end(cmp, 0))
+    end(1)
+    end(0)
     hashes = [lib.frame_hashes(v).opening_data()[0].tolist() for v in range(n)]
     stft_ms = max(capi.last_kernel_ms("stft_chroma32"), capi.last_kernel_ms("stft_chroma"))
     capi.set_kernel_timing(None)
     with open(f"{out}.{rank}", "w") as f:
         json.dump({"rank": rank, "backend": capi.comm_backend(), "world": capi.comm_world_size(),
                    "videos_held": [first, count], "stft_ms": stft_ms,
-                   "jobs": [{"results": _res(r), "runs": k} for r, k in jobs], "hashes": hashes}, f)
+                   "jobs": [{"results": _res(r), "runs": k, "comm": c} for (r, k), c in zip(jobs, comm)], "hashes": hashes}, f)
     capi.comm_barrier()
     capi.comm_finalize()
     rdzv.close()
@@ -91,7 +97,8 @@ def lib_main(out, n, minutes):
         t0 = time.perf_counter()
         res, found = lib.job_end(cmp, slot)
         wait_ms = 1e3 * (time.perf_counter() - t0)
-        jobs.append({"results": _res(res), "runs": found, "digest": run_digest(lib.job_runs(slot)),
+        held = lib.job_runs(slot)      # the complete list, or -- owner-directed exchange -- the runs of this rank's own videos' pairs
+        jobs.append({"results": _res(res), "runs": found, "held": int(len(held)), "digest": run_digest(held),
                      "comm": lib.job_comm_bytes(slot), "end_ms": wait_ms})
 
     lib.job_begin(cmp, 0)

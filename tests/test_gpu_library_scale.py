@@ -219,7 +219,16 @@ def test_config4_shape_between_ranks_on_one_gpu(tmp_path, monkeypatch, world, en
     lib.job_begin(cmp, 0)
     res, found = lib.job_end(cmp, 0)
     want_results = [None if r is None else [None if x is None else list(x) for x in (r.opening, r.ending)] for r in res]
-    want_digest = run_digest(lib.job_runs(0))
+    want_runs = lib.job_runs(0).copy()
+    want_digest = run_digest(want_runs)
+    # what a rank holds after an OWNER-DIRECTED exchange (round 6): the runs of the pairs with a video of its block
+    pi, pj = np.triu_indices(n, 1)                                # pair p = (pi[p], pj[p]), i-major (comparator.rs:534-545)
+    held_digest, held_count = {}, {}
+    for r in range(world):
+        f, c = capi.comm_shard(n, world, r)
+        i, j = pi[want_runs["problem"]], pj[want_runs["problem"]]
+        mine = ((i >= f) & (i < f + c)) | ((j >= f) & (j < f + c))
+        held_digest[r], held_count[r] = run_digest(want_runs[mine]), int(mine.sum())
     assert lib.job_comm_bytes(0) == {"hash_rows": 0, "run_heads": 0, "results": 0, "scans_repeated": 0}
     # 79 800 pairs: the job above ran the per-video epilogue on the device (epilogue.hip); the host form must agree
     monkeypatch.setenv("NEEDLE_HIP_DEVICE_EPILOGUE", "0")
@@ -245,17 +254,27 @@ def test_config4_shape_between_ranks_on_one_gpu(tmp_path, monkeypatch, world, en
         assert g["backend"] == "host" and g["world"] == world and g["videos_held"][1] >= n // world
         assert g["host_threads"] == max(1, usable // world)       # the node's CPUs are divided between the ranks
         assert g["arena_digest"] == want_arena, g["rank"]         # rows computed by other ranks included
+        sharded = env.get("NEEDLE_HIP_SHARD_EPILOGUE") != "0" and found >= (1 << 17)
         for k, job in enumerate(g["jobs"]):
-            assert job["runs"] == found and job["digest"] == want_digest, (g["rank"], k)
-            assert job["results"] == want_results, (g["rank"], k)
+            assert job["runs"] == found and job["results"] == want_results, (g["rank"], k)
             c = job["comm"]
             assert c["hash_rows"] == n * g["stride"] * 4          # one all-gather of the arena's equal blocks
-            assert c["run_heads"] >= 24 * found                   # every rank receives every run once (+ margins)
-            sharded = env.get("NEEDLE_HIP_SHARD_EPILOGUE") != "0" and found >= (1 << 17)
             assert (c["results"] > 0) == sharded
+            # the first two jobs are in flight before any count matrix exists and travel as heads; with the sharded device
+            # epilogue the third goes owner-directed: a rank receives the runs of its own videos' pairs and nothing else
+            directed = sharded and k == 2
+            if directed:
+                assert job["held"] == held_count[g["rank"]] < found and job["digest"] == held_digest[g["rank"]], (g["rank"], k)
+                assert c["run_heads"] <= 0.6 * 24 * found         # (every run to every rank: >= 24 * found)
+            else:
+                assert job["held"] == found and job["digest"] == want_digest, (g["rank"], k)
+                assert c["run_heads"] >= 24 * found               # every rank receives every run once (+ margins)
         # the first job met the overflow that was forced and repeated its scan; the steady state repeats nothing
         assert g["jobs"][0]["comm"]["scans_repeated"] >= 1 and g["jobs"][2]["comm"]["scans_repeated"] == 0
         assert g["jobs"][2]["comm"]["run_heads"] < 3 * 24 * found + world * 4096
+    if env.get("NEEDLE_HIP_SHARD_EPILOGUE") != "0" and found >= (1 << 17):
+        print("run bytes received per rank, job 2 (owner-directed):", [g["jobs"][2]["comm"]["run_heads"] for g in got],
+              "as heads (job 1):", [g["jobs"][1]["comm"]["run_heads"] for g in got], "24 x runs:", 24 * found)
         a = g["audit"]                                            # this rank's block of hashes, f32 first pass vs f64 kernel
         assert a["mismatches"] == 0 and a["accepted_mismatches"] == 0 and a["max_error_over_s"] <= 8.0
     assert sum(g["host_threads"] for g in got) <= max(usable, world)

@@ -143,7 +143,7 @@ def _check_ranks(got, lib, want, ref, world, backend):
 
 
 @pytest.mark.parametrize("world,shard_epilogue,slab_runs", [(2, "0", None), (2, "1", None), (3, "1", 4), (2, "0", 4),
-                                                            (5, "1", None)])
+                                                            (5, "1", None), (3, "directed", None), (4, "directed", 4)])
 def test_ranks_over_host_transport_on_one_gpu(lib7, tmp_path, world, shard_epilogue, slab_runs):
     """The complete N-rank path of the library -- own-block analyze, all-gather of rows, own pair range, all-gather of
     run slabs, (sharded) epilogue, all-gather of results, two jobs in flight -- between real processes that share
@@ -151,10 +151,20 @@ def test_ranks_over_host_transport_on_one_gpu(lib7, tmp_path, world, shard_epilo
     are 1.4 episodes' worth of frames each (whole videos would be 2, 2, 2, 1, 0), and every rank's STFT kernel runs."""
     ref, want = _oracle(lib7)
     env = {"NEEDLE_HIP_COMM": "host", "NEEDLE_HIP_SHARD_EPILOGUE": shard_epilogue}
+    if shard_epilogue == "directed":   # sharded DEVICE epilogue at this small size: the third job's runs travel owner-directed
+        env.update(NEEDLE_HIP_SHARD_EPILOGUE="1", NEEDLE_HIP_DEVICE_EPILOGUE="1")
     if slab_runs:
         env["NEEDLE_HIP_SLAB_RUNS"] = str(slab_runs)
     got = launch("gpu", world, str(tmp_path / "r"), [len(lib7), 90.0], extra_env=env, local_ranks=[0] * world)
     _check_ranks(got, lib7, want, ref, world, "host")
+    if shard_epilogue == "directed":
+        # jobs 0 and 1 were in flight before any count matrix existed (heads: a rank holds every run); job 2 went
+        # owner-directed: a rank holds the runs of its own videos' pairs -- all ranks together every run at least once
+        for g in got:
+            assert g["jobs"][0]["comm"]["held"] == g["jobs"][0]["runs"] == g["jobs"][1]["comm"]["held"]
+            assert 0 < g["jobs"][2]["comm"]["held"] <= g["jobs"][2]["runs"]
+        assert sum(g["jobs"][2]["comm"]["held"] for g in got) >= got[0]["jobs"][2]["runs"]
+        assert any(g["jobs"][2]["comm"]["held"] < g["jobs"][2]["runs"] for g in got)
 
 
 def test_device_epilogue_failing_on_one_rank_keeps_the_collective_shape(lib7, tmp_path):
