@@ -526,7 +526,7 @@ def corpus_hostile(capi, synth, episodes, minutes, jobs=20, check=2):
             "scan_form": {1: "generic", 2: "band", 3: "aligned windows, vector ALU", 4: "aligned windows, matrix pipe"}.get(form, str(form)),
             "scan_issued_evaluations": int(issued), "scan_head_survivors": int(survivors),
             "scan_pruning_factor": round(float(pairs) * n_h * n_h / max(issued, 1), 2),
-            "epilogue_host_fallbacks": capi.epilogue_host_fallbacks(),
+            "epilogue_host_fallbacks": capi.epilogue_host_fallbacks(), "job_form": lib.job_form(0),
             "episodes_with_silence": sum(1 for s in segments if s[1] > 0), "episodes_with_chord": sum(1 for s in segments if s[3] > 0),
             "gpu_hashes_match_oracle": {"episodes_checked": ids, "ok": bool(hashes_ok)},
             "what": "the headline job (28 x 24 min, analyze + search, two jobs in flight, PCM resident) on the hostile corpus; "
@@ -1025,6 +1025,7 @@ def main() -> None:
                                          "all-gather of per-video results when the epilogue is sharded; scans_repeated = overflows met "
                                          "(0 in the steady state)")
         out["host_threads_per_rank"] = capi.host_threads()
+        out["job_form"] = lib.job_form(0)
         if world == 1 and not args.no_extras and eps is not None:
             out["end_to_end"] = end_to_end(capi, eps, cmp, n_pairs)
         if world == 1 and not args.no_extras:

@@ -83,7 +83,7 @@ enum NeedleError needle_hip_scan_counts(uint64_t counts[2], bool reset);
 enum NeedleError needle_hip_scan_last_launch(int32_t *form, uint64_t *matrix_products);
 /* How many jobs of this process asked for the per-video epilogue (comparator.rs:405-515, 583-626) on the DEVICE and were
  * handed back to the host form because one pair's bucket of runs exceeded what the device orders (since round 6 a
- * bucket beyond a lane's 96 runs is a workgroup's, up to 8192 runs: two fully silent 24-minute windows are 5 800;
+ * bucket beyond a lane's 24 runs is a workgroup's, up to 8192 runs: two fully silent 24-minute windows are 5 800;
  * beyond that, or with a row of 65 536 hashes or more).  Correct either way; this makes the performance cliff
  * visible (also printed under NEEDLE_HIP_TRACE).  reset: start counting again. */
 enum NeedleError needle_hip_epilogue_host_fallbacks(uint64_t *jobs, bool reset);
@@ -390,6 +390,13 @@ enum NeedleError needle_hip_library_job_runs(const NeedleHipLibrary *library, in
  * bytes[1] run lists (the gathered heads, or the owner-directed blocks + the count matrix; repeats included), bytes[2] per-video results of a sharded
  * epilogue; bytes[3] = scans repeated because a slab or a head overflowed (0 in the steady state). */
 enum NeedleError needle_hip_library_job_comm_bytes(const NeedleHipLibrary *library, int slot, uint64_t bytes[4]);
+/* Which forms the job that finished last in `slot` took: form[0] 1 = per-video epilogue on the device (0: host threads;
+ * a device epilogue handed back to the host counts in needle_hip_epilogue_host_fallbacks), form[1] 1 = epilogue sharded by
+ * video across ranks, form[2] 1 = runs exchanged owner-directed, form[3] the scan's form (needle_hip_scan_last_launch).
+ * The epilogue goes to the device from 16 384 sequence pairs -- or, whatever the pair count, once the library's last
+ * finished job found 16 384 runs or more per rank (stretches of silence, sustained chords: the run list, not the pair
+ * count, is what the host form pays for; NEEDLE_HIP_DEVICE_EPILOGUE=0 / 1 forces either). */
+enum NeedleError needle_hip_library_job_form(const NeedleHipLibrary *library, int slot, uint32_t form[4]);
 /* Host threads this process uses for its parallel host phases (epilogue, file reads, upload staging): the CPUs usable
  * by the process (affinity, cgroup quota) divided by the rank processes of the node once a communicator is up
  * (LOCAL_WORLD_SIZE if the launcher exports it, else the world size); NEEDLE_HOST_THREADS overrides. */

@@ -94,6 +94,7 @@ NEEDLE_HIP_H_SYMBOLS = [
     "needle_hip_library_job_end", "needle_hip_library_stream_pcm", "needle_hip_host_alloc",
     "needle_hip_host_alloc_free", "needle_hip_int_valu_ceiling",
     "needle_hip_comparator_results_from_runs", "needle_hip_library_job_runs", "needle_hip_library_job_comm_bytes",
+    "needle_hip_library_job_form",
     "needle_hip_host_threads", "needle_hip_fingerprint_audit_device", "needle_hip_library_audit",
     "needle_hip_scan_counts", "needle_hip_scan_last_launch", "needle_hip_epilogue_host_fallbacks"]
 
@@ -811,6 +812,13 @@ class Library:
         if total.value:
             C.memmove(out.ctypes.data, ptr.value, out.nbytes)
         return out
+
+    def job_form(self, slot: int = 0) -> dict:
+        """Which forms the slot's last finished job took (needle_hip_library_job_form)."""
+        f = (C.c_uint32 * 4)()
+        lib().needle_hip_library_job_form.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]
+        check(lib().needle_hip_library_job_form(self._h, slot, f))
+        return {"device_epilogue": bool(f[0]), "sharded_epilogue": bool(f[1]), "directed_runs": bool(f[2]), "scan_form": int(f[3])}
 
     def job_comm_bytes(self, slot: int = 0) -> dict:
         b = (C.c_uint64 * 4)()

@@ -177,6 +177,7 @@ void gpu_prefetch_hashes(const uint32_t *hashes, size_t num_hashes);
 // Sequence pairs from which the per-video epilogue runs on the device (epilogue.hip) instead of on host threads
 // (NEEDLE_HIP_DEVICE_EPILOGUE=1 / 0 forces either): the library job and Comparator::run_with_frame_hashes alike.
 constexpr uint64_t kDeviceEpiloguePairs = 1u << 14;
+constexpr uint32_t kDeviceEpilogueRuns = 1u << 14;  // ... or from this many runs per rank in the library's last finished job
 
 // Diagnostic (search.hip): cells/s of the band scan's 4-instruction cell on registers only, measured on this device.
 Status gpu_int_valu_ceiling(double *cells_per_second);

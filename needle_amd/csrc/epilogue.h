@@ -39,7 +39,7 @@ struct EpilogueJob {
 // Bit 31 of the failure word: the caller computes the results with the host form (threaded, n log n) from the run list.
 // NEEDLE_HIP_EPILOGUE_BUCKET_LIMIT is not a switch: tests lower the constant by building with -D.
 #ifndef NEEDLE_EPILOGUE_BUCKET_LIMIT
-#define NEEDLE_EPILOGUE_BUCKET_LIMIT 96
+#define NEEDLE_EPILOGUE_BUCKET_LIMIT 24
 #endif
 constexpr uint32_t kEpilogueBucketLimit = NEEDLE_EPILOGUE_BUCKET_LIMIT;
 // Round 6: buckets beyond that limit (up to kEpilogueLargeLimit runs: two fully silent 24-minute windows are 5 800) go to a

@@ -444,6 +444,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
   __shared__ uint32_t ntab[16];
   __shared__ uint32_t dlinks[2048];
   __shared__ uint32_t distinct;
+  __shared__ uint32_t slot_cnt[256], slot_at[256];
+  __shared__ uint16_t occupied[1536 + 256];
   __shared__ BestKey best[2][256];
   // a bucket too large for one lane (pair_entries_kernel): the whole job is the host form's, nothing here would be read
   if (__builtin_nontemporal_load(failed) & kEpilogueBucketTooLarge) return;
@@ -498,20 +500,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
       __syncthreads();
     }
     uint32_t at = carry + scan[t] - cnt;
-    if (cnt) {
-      const bool as_source = q >= v;
+    // a slot's entries -> candidates: by its own thread while they are few; a slot with many (a pair of silent stretches: hundreds)
+    // by the whole workgroup -- one thread copying 400 entries while 255 wait was most of this kernel on the hostile corpus
+    auto copy_entries = [&](const uint64_t bb, const bool as_source, uint32_t first, const uint32_t k0, const uint32_t kstep) {
       for (uint32_t r = 0; r < pr.regions; r++) {  // openings first, then endings (:414-431)
-        const DeviceEntry *e = entries + start[b + r];
-        const uint32_t k1 = valid[b + r];
-        for (uint32_t k = 0; k < k1; k++) {
+        const DeviceEntry *e = entries + start[bb + r];
+        const uint32_t k1 = valid[bb + r];
+        for (uint32_t k = k0; k < k1; k += kstep) {
           Candidate cd;
           cd.start = as_source ? e[k].src_start : e[k].dst_start;
           cd.end = as_source ? e[k].src_end : e[k].dst_end;
           cd.hash = as_source ? e[k].src_hash : e[k].dst_hash;
           cd.is_opening = r == 0 ? 1u : 0u;
-          cand[at++] = cd;
+          cand[first + k] = cd;
         }
+        first += k1;
       }
+    };
+    constexpr uint32_t kOwnCopy = 16;
+    slot_cnt[t] = cnt;
+    slot_at[t] = at;
+    if (cnt && cnt <= kOwnCopy) copy_entries(b, q >= v, at, 0u, 1u);
+    __syncthreads();
+    for (uint32_t qq = 0; qq < 256; qq++) {
+      if (slot_cnt[qq] <= kOwnCopy) continue;  // (uniform)
+      const uint32_t q2 = base + qq;
+      copy_entries(bucket_of(q2), q2 >= v, slot_at[qq], t, 256u);
     }
     __syncthreads();
     if (t == 255) carry += scan[255];
@@ -534,7 +548,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
   // links = sum over the distinct hashes within the bound of their multiplicities.  A 2048-slot table in LDS (the image's bytes,
   // unused on this path) takes the hashes by 64-bit compare-and-swap; beyond 1536 distinct values the all-pairs products below run.
   bool deduped = false;
-  if (c >= 4096) {
+  if (c >= 512) {
     constexpr uint32_t kSlots = 2048, kMaxDistinct = 1536;
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(image);   // 1 << 32 | hash, 0 = empty
     uint32_t *mult = image + 2 * kSlots;
@@ -552,8 +566,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
       uint32_t sl = slot_of(hash);
       for (uint32_t probe = 0; probe < kSlots; probe++, sl = (sl + 1) & (kSlots - 1)) {
         if (*reinterpret_cast<volatile uint32_t *>(&distinct) > kMaxDistinct) break;  // (overflowing: the direct path will run)
-        const unsigned long long old = atomicCAS(&keys[sl], 0ull, want);
-        if (old == 0ull) atomicAdd(&distinct, 1u);
+        unsigned long long old = *reinterpret_cast<volatile unsigned long long *>(&keys[sl]);  // (mostly there already: no atomic)
+        if (old == 0ull) {
+          old = atomicCAS(&keys[sl], 0ull, want);
+          if (old == 0ull) atomicAdd(&distinct, 1u);
+        }
         if (old == 0ull || old == want) {
           atomicAdd(&mult[sl], 1u);
           break;
@@ -563,13 +580,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
     __syncthreads();
     deduped = distinct <= kMaxDistinct;
     if (deduped) {
-      for (uint32_t a = t; a < kSlots; a += 256) {
-        const unsigned long long ka = keys[a];
-        if (ka == 0ull) continue;
+      if (t == 0) distinct = 0;  // now: the occupied slots, listed
+      __syncthreads();
+      for (uint32_t a = t; a < kSlots; a += 256)
+        if (keys[a] != 0ull) occupied[atomicAdd(&distinct, 1u)] = (uint16_t)a;
+      __syncthreads();
+      const uint32_t u = distinct;
+      for (uint32_t ia = t; ia < u; ia += 256) {
+        const uint32_t a = occupied[ia];
+        const uint32_t ha = (uint32_t)keys[a];
         uint32_t sum = 0;
-        for (uint32_t b = 0; b < kSlots; b++) {
-          const unsigned long long kb = keys[b];
-          if (kb != 0ull && (uint32_t)__popc((uint32_t)ka ^ (uint32_t)kb) < pr.bound) sum += mult[b];
+        for (uint32_t ib = 0; ib < u; ib++) {
+          const uint32_t b2 = occupied[ib];
+          if ((uint32_t)__popc(ha ^ (uint32_t)keys[b2]) < pr.bound) sum += mult[b2];
         }
         dlinks[a] = sum;
       }

@@ -114,6 +114,8 @@ struct NeedleHipLibrary {
     void *host_counts = nullptr;
     size_t host_counts_bytes = 0;
     std::vector<uint32_t> cap;      // of this job's exchange (empty: this job travels as heads)
+    bool ran_device_epilogue = false, ran_sharded = false;  // what job_end found (needle_hip_library_job_form)
+    uint32_t scan_form = 0;
     bool counted = false;           // host_counts holds this job's count matrix
     bool directed = false;          // this job's runs travelled owner-directed
     std::vector<NeedleHipRun> fetched;  // directed: the received runs, downloaded on demand (job_runs, a host fallback)
@@ -723,7 +725,10 @@ Status job_buffers(NeedleHipLibrary *lib, NeedleHipLibrary::Job &j, int world) {
 // (the run count is not known yet): by the number of sequence pairs, or NEEDLE_HIP_DEVICE_EPILOGUE=1 / 0.
 bool device_epilogue_wanted(const NeedleHipLibrary *lib, size_t comparator_regions) {
   if (const char *e = getenv("NEEDLE_HIP_DEVICE_EPILOGUE")) return atoi(e) != 0;
-  return (uint64_t)pair_count(lib->n) * comparator_regions >= kDeviceEpiloguePairs;
+  // ... or by what the library's last finished job found (round 6): content decides the run count -- 28 episodes with
+  // stretches of silence give their 378 pairs 41 528 runs instead of 852, and the host form 2.5 ms of a 0.5 ms job.
+  // (Every rank sees every rank's count: the same decision everywhere.)
+  return (uint64_t)pair_count(lib->n) * comparator_regions >= kDeviceEpiloguePairs || lib->last_max_count >= kDeviceEpilogueRuns;
 }
 
 // Owner-directed job: the runs this rank received (its own videos' pairs), downloaded once, on demand.
@@ -1198,6 +1203,14 @@ enum NeedleError needle_hip_library_job_end(NeedleHipLibrary *lib, const struct 
       else if (fail != 0)
         s = Status::Make(NeedleError_Unknown, "overflow when subtracting durations (time_padding / hash_duration exceed the match end)");
     }
+    j.ran_device_epilogue = device_results != nullptr;
+    j.ran_sharded = sharded;
+    {
+      int32_t form = 0;
+      uint64_t products = 0;
+      gpu_scan_last_launch(&form, &products);  // (of this process's last scan launch: this job's, or the next one's -- the same shape)
+      j.scan_form = (uint32_t)form;
+    }
     if (!device_results) {
       const std::vector<const FrameHashesData *> fh = lib->shell_pointers();
       if (j.directed) {  // this rank's videos' runs are what it received: down they come, once
@@ -1262,6 +1275,17 @@ enum NeedleError needle_hip_library_job_runs(const NeedleHipLibrary *lib, int sl
   if (!lib->job[slot].last_runs && lib->job[slot].last_total) return NeedleError_InvalidArgument;
   *runs = lib->job[slot].last_runs;
   *num_runs = lib->job[slot].last_total;
+  return NeedleError_Ok;
+}
+
+enum NeedleError needle_hip_library_job_form(const NeedleHipLibrary *lib, int slot, uint32_t form[4]) {
+  if (!lib || !form) return NeedleError_NullArgument;
+  if (slot < 0 || slot > 1 || lib->job[slot].pending) return NeedleError_InvalidArgument;
+  const NeedleHipLibrary::Job &j = lib->job[slot];
+  form[0] = j.ran_device_epilogue ? 1u : 0u;
+  form[1] = j.ran_sharded ? 1u : 0u;
+  form[2] = j.directed ? 1u : 0u;
+  form[3] = j.scan_form;
   return NeedleError_Ok;
 }
 

@@ -253,6 +253,7 @@ extern "C" {
     ) -> NeedleError;
     /// `{hash rows, run heads, results}` bytes received in the job's all-gathers, `[3]` = scans repeated.
     pub fn needle_hip_library_job_comm_bytes(library: *const NeedleHipLibrary, slot: c_int, bytes: *mut u64) -> NeedleError;
+    pub fn needle_hip_library_job_form(library: *const NeedleHipLibrary, slot: c_int, form: *mut u32) -> NeedleError;
     pub fn needle_hip_library_audit(library: *mut NeedleHipLibrary, audit: *mut NeedleHipCertAudit) -> NeedleError;
     pub fn needle_hip_host_threads() -> c_int;
     pub fn needle_hip_host_alloc(host_ptr: *mut *mut c_void, bytes: usize) -> NeedleError;

@@ -99,7 +99,7 @@ def test_device_epilogue_on_planted_hashes_equals_host_and_oracle(monkeypatch, n
 
 def test_pairs_with_hundreds_of_runs_are_a_workgroups_or_the_hosts(monkeypatch):
     """two stretches of one repeated hash (silence, a sustained tone) give a pair ~2 S runs -- every diagonal of
-    an S x S block is one.  The device form orders a pair's runs in ONE lane, quadratically; a bucket beyond a lane's 96 runs goes to a
+    an S x S block is one.  The device form orders a pair's runs in ONE lane, quadratically; a bucket beyond a lane's 24 runs goes to a
     WORKGROUP (round 6: pair_entries_large_kernel, sort + heap on packed keys in LDS), and with that kernel switched off the
     job's results come from the host form, counted.  Same results every way, and equal to the oracle's."""
     rng = np.random.default_rng(77)

@@ -54,9 +54,11 @@ def test_hostile_corpus_hashes_runs_and_results_match_oracle():
     capi.epilogue_host_fallbacks(reset=True)
     lib.job_begin(cmp, 0)
     res, found = lib.job_end(cmp, 0)
+    assert not lib.job_form(0)["device_epilogue"]                 # 66 pairs: the host form ... until the run count is known:
     lib.job_begin(cmp, 1)
     res2, found2 = lib.job_end(cmp, 1)
     assert found == found2 and _pairs(res) == _pairs(res2)
+    assert lib.job_form(1)["device_epilogue"] == (found >= 16384)  # (the switch on a measured density, needle_hip.h)
     cs = capi.cert_stats()
     gen.free()
 
@@ -119,3 +121,38 @@ def test_hostile_corpus_on_the_device_epilogue(monkeypatch):
     assert found == found_host == found_flagged
     assert _pairs(res) == _pairs(res_host) == _pairs(res_flagged)
     assert sum(1 for r in res if r is not None and r.opening is not None) >= n // 2
+
+
+def test_run_density_moves_a_small_librarys_epilogue_to_the_device(monkeypatch):
+    """The headline shape on the hostile corpus: 378 pairs -- far below the 16 384 from which the epilogue goes to the device by
+    itself -- with 41 000 runs (852 on the tonal corpus).  A job enqueued knowing that the library's last scan found 16 384
+    runs or more takes the device form (needle_hip_library_job_form) -- the first job already when its slab overflowed and the
+    scan was repeated --; the results are the same as with the device form switched off; the tonal library of the same
+    shape stays with the host form."""
+    assert capi.device_count() > 0
+    n, samples = 28, int(12 * 60 * 11025)
+    gen, _, lib = _library(n, samples, 90.0)
+    gen.free()
+    cmp = capi.Comparator([f"hostile-{k:02d}.wav" for k in range(n)])
+    capi.epilogue_host_fallbacks(reset=True)
+    lib.job_begin(cmp, 0)
+    res0, found0 = lib.job_end(cmp, 0)
+    assert found0 >= 16384
+    lib.job_begin(cmp, 1)
+    res1, found1 = lib.job_end(cmp, 1)
+    assert found1 == found0 and lib.job_form(1)["device_epilogue"] and capi.epilogue_host_fallbacks() == 0
+    assert _pairs(res1) == _pairs(res0)
+    monkeypatch.setenv("NEEDLE_HIP_DEVICE_EPILOGUE", "0")
+    lib.job_begin(cmp, 0)
+    res2, _ = lib.job_end(cmp, 0)
+    assert not lib.job_form(0)["device_epilogue"] and _pairs(res2) == _pairs(res0)
+    assert sum(1 for r in res0 if r is not None and r.opening is not None) == n
+    monkeypatch.delenv("NEEDLE_HIP_DEVICE_EPILOGUE")
+    tonal = synth.DeviceLibrary(n, samples, 90.0)
+    lib_t = capi.Library(n, opening_search_percentage=1.0)
+    lib_t.set_pcm_device(tonal.pointers(), [samples] * n)
+    tonal.free()
+    for slot in (0, 1, 0):
+        lib_t.job_begin(cmp, slot)
+        _, found_t = lib_t.job_end(cmp, slot)
+        assert found_t < 16384 and not lib_t.job_form(slot)["device_epilogue"]
