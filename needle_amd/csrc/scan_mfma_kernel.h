@@ -56,9 +56,14 @@ constexpr int kM2Members = 8;                 // sources a workgroup takes at mo
 constexpr int kM2Pitch = kM2Heads * 4 + 4;    // words of a window's row in the A image: 4 x 32 FP4 nibbles of +-1, the window's member << 28 | w0, 3 spare
                                               // (20: sixteen lanes' 16-byte reads of one instruction fall into sixteen different groups of four banks)
 constexpr int kM2RunBuf = 64;                 // runs a workgroup collects in LDS before it asks for room in the run list (one atomic)
-constexpr int kM2Overflow = 32;               // ... and beyond those, runs a WAVE collects before it asks (round 6: stretches of one repeated hash --
+#ifndef NEEDLE_M2_OVERFLOW
+#define NEEDLE_M2_OVERFLOW 16                  // (0: measurements -- one atomic per run beyond the workgroup's buffer, as before round 6)
+#endif
+constexpr int kM2Overflow = NEEDLE_M2_OVERFLOW;  // ... and beyond those, runs a WAVE collects before it asks (round 6: stretches of one repeated hash --
                                               // silence against silence -- give a workgroup thousands of runs; one returning atomic per run on the
-                                              // list's one counter was 46 of 52 ms at 39 060 pairs of the hostile corpus, 4.65 M runs)
+                                              // list's one counter was 46 of 52 ms at 39 060 pairs of the hostile corpus, 4.65 M runs).  They lie in the
+                                              // 64 words of the wave's item queue whose items process() has just taken: no LDS of their own (a buffer of
+                                              // 4 KB per workgroup cost 45-minute windows a source per workgroup and the scan 6 %)
 constexpr int kM2Table = 256;                 // a byte of hash bits -> its eight FP4 nibbles (bit set: +1 = 0x2, clear: -1 = 0xA)
 constexpr int kM2Probe = 4;                   // rows looked at on either side of a whole window
 constexpr int kM2Rows = kSampleW + 2 * kM2Probe;  // source hashes kept per window: rows w0 - 4 .. w0 + 11
@@ -73,8 +78,7 @@ static_assert(kSampleW + 2 * kM2Probe - 2 < 2 * kSampleW - 1 + 8, "a run that en
 // LDS words of a workgroup: staged destination (+ 64 zeros), tables, per-window source hashes, A image
 __host__ __device__ constexpr size_t m2_round4(size_t x) { return (x + 3) & ~(size_t)3; }
 __host__ __device__ constexpr size_t m2_lds_words(uint64_t m, uint64_t windows, int waves) {
-  return m2_round4(m + 64) + kM2CtlWords + kM2Table + 4 * kM2RunBuf + (size_t)waves * (kM2Queue + 4 * kM2Overflow) +
-         (size_t)(windows + 1) * (kM2Pitch + kM2Rows);
+  return m2_round4(m + 64) + kM2CtlWords + kM2Table + 4 * kM2RunBuf + (size_t)waves * kM2Queue + (size_t)(windows + 1) * (kM2Pitch + kM2Rows);
 }
 
 // A source sequence's windows as a workgroup wants them in LDS -- per window kM2Pitch words of the A image (its four head
@@ -164,9 +168,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   // source hashes.  36 = 4 x 9: sixteen lanes' 16-byte reads of sixteen different windows -- the A fragments of a tile, the
   // rows of the items' windows -- fall into sixteen different groups of four banks.  (Two arrays, the hashes at a pitch of
   // 16 words: lanes with different windows met in FOUR groups; SQ_LDS_BANK_CONFLICT was 61 % of SQ_LDS_IDX_ACTIVE.)
-  uint32_t *overflow = queues + WAVES * kM2Queue + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 4 * kM2Overflow;  // this wave's
+  uint32_t *wimg = queues + WAVES * kM2Queue;    // 16-byte aligned: every size above is a multiple of 4 words
+  static_assert(4 * kM2Overflow <= 64 && kM2Queue >= 128, "the overflow runs lie in the queue words of the 64 items a process() call has taken");
+  uint32_t *overflow = nullptr;                  // this wave's overflow runs: set by process() (below)
   int overflowed = 0;                            // runs in it (wave-uniform)
-  uint32_t *wimg = queues + WAVES * (kM2Queue + 4 * kM2Overflow);    // 16-byte aligned: every size above is a multiple of 4 words
 
   if (threadIdx.x == 0) {
     ctl[0] = 0u;
@@ -356,6 +361,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
           runbuf[4 * at + 3] = (uint32_t)(b - a + 1);
         return;
       }
+      if (kM2Overflow == 0) {
+        if (lane == 0) {
+          const uint32_t slot = atomicAdd(count, 1u);
+          if (slot < capacity) runs[slot] = NeedleHipRun{(uint32_t)(lo + g), (uint32_t)b, (uint32_t)(b + d), (uint32_t)(b - a + 1), 0u, 0u};
+        }
+        return;
+      }
       if (lane == 0)
         overflow[4 * overflowed] = (uint32_t)(lo + g), overflow[4 * overflowed + 1] = (uint32_t)b, overflow[4 * overflowed + 2] = (uint32_t)(b + d),
         overflow[4 * overflowed + 3] = (uint32_t)(b - a + 1);
@@ -487,6 +499,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     M2_COUNT_LANES(6, lane < cnt ? 1 : 0);
     M2_COUNT_LANES(7, __popc(passm));
     if (__builtin_amdgcn_ballot_w64(passm != 0u) == 0ull) return;
+    wave_lds_fence_search();
+    overflow = queue + first;                     // the items are in registers: their (and the following, unused) 64 words hold overflow runs
+    overflowed = 0;
     // What passes is rare (a window in three thousand of the items') and is looked at by the WAVE, window by window:
     // whole?  the last of its chain -- no successor (the member's last window), or one that is not whole on this diagonal?
     // Then the chain is resolved.
@@ -507,6 +522,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         resolve(w0, cj - w0, g);
       }
     }
+    flush_overflow();                             // (the words are the queue's again when this call returns)
   };
   // A batch's flags become items.  flags: bit 4 n - 1 - (4 s + g) set <=> tile slot s (s = 2 (row tile - rt0) + column block,
   // n slots in all), group g.  One item per lane and turn (turns = the most set bits any lane holds), 64 are processed
@@ -636,8 +652,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
       rt0 += kM2Batch;
     } while (!done && rt0 < row_tiles);
   }
-  // the workgroup's runs: one request for room, then the copy (every wave's own overflow first)
-  flush_overflow();
+  // the workgroup's runs: one request for room, then the copy
   __syncthreads();
   const uint32_t n_runs = min(ctl[34], (uint32_t)kM2RunBuf);
   if (n_runs == 0u) return;
