@@ -131,6 +131,7 @@ struct NeedleHipLibrary {
   std::vector<uint32_t> dir_counts;  // [world][world]: runs rank r directed to rank q in the last finished job (Job::cap's source)
   int dir_world = 0;
   bool dir_unsupported = false;      // the communicator has no point-to-point transfers: every job travels as heads
+  bool dir_cap_forced = false;       // (tests: NEEDLE_HIP_TEST_DIRECTED_CAP applied once)
   size_t arena_rows = 0;       // rows the arena was allocated with
   const uint32_t *count_zeroed = nullptr;  // a run counter the last kernel of this job's analyze has just cleared (job_begin)
   // what the device epilogue needs to know about the arena's rows (built once per geometry: plan_windows clears them)
@@ -793,6 +794,11 @@ NeedleError job_search_and_gather(NeedleHipLibrary *lib, const NeedleAudioCompar
     std::vector<uint32_t> cap(W * W, 0u);
     if (have)
       for (size_t k = 0; k < W * W; k++) cap[k] = round_up4((uint64_t)lib->dir_counts[k] + lib->dir_counts[k] / 8 + 64);
+    if (const char *e = getenv("NEEDLE_HIP_TEST_DIRECTED_CAP"))  // tests: the library's first directed job gets blocks that overflow
+      if (have && !lib->dir_cap_forced) {
+        std::fill(cap.begin(), cap.end(), round_up4((uint64_t)std::max(4, atoi(e))));
+        lib->dir_cap_forced = true;
+      }
     DirectPlan plan;
     std::memset(&plan, 0, sizeof(plan));
     std::vector<size_t> send_off(W), send_bytes(W);

@@ -143,7 +143,8 @@ def _check_ranks(got, lib, want, ref, world, backend):
 
 
 @pytest.mark.parametrize("world,shard_epilogue,slab_runs", [(2, "0", None), (2, "1", None), (3, "1", 4), (2, "0", 4),
-                                                            (5, "1", None), (3, "directed", None), (4, "directed", 4)])
+                                                            (5, "1", None), (3, "directed", None), (4, "directed", 4),
+                                                            (3, "directed-overflow", None)])
 def test_ranks_over_host_transport_on_one_gpu(lib7, tmp_path, world, shard_epilogue, slab_runs):
     """The complete N-rank path of the library -- own-block analyze, all-gather of rows, own pair range, all-gather of
     run slabs, (sharded) epilogue, all-gather of results, two jobs in flight -- between real processes that share
@@ -151,13 +152,15 @@ def test_ranks_over_host_transport_on_one_gpu(lib7, tmp_path, world, shard_epilo
     are 1.4 episodes' worth of frames each (whole videos would be 2, 2, 2, 1, 0), and every rank's STFT kernel runs."""
     ref, want = _oracle(lib7)
     env = {"NEEDLE_HIP_COMM": "host", "NEEDLE_HIP_SHARD_EPILOGUE": shard_epilogue}
-    if shard_epilogue == "directed":   # sharded DEVICE epilogue at this small size: the third job's runs travel owner-directed
+    if shard_epilogue.startswith("directed"):   # sharded DEVICE epilogue at this small size: the third job's runs travel owner-directed
         env.update(NEEDLE_HIP_SHARD_EPILOGUE="1", NEEDLE_HIP_DEVICE_EPILOGUE="1")
+    if shard_epilogue == "directed-overflow":   # ... into blocks of 4 runs the first time: every rank sees the counts, sizes grow, once more
+        env.update(NEEDLE_HIP_TEST_DIRECTED_CAP="4")
     if slab_runs:
         env["NEEDLE_HIP_SLAB_RUNS"] = str(slab_runs)
     got = launch("gpu", world, str(tmp_path / "r"), [len(lib7), 90.0], extra_env=env, local_ranks=[0] * world)
     _check_ranks(got, lib7, want, ref, world, "host")
-    if shard_epilogue == "directed":
+    if shard_epilogue.startswith("directed"):
         # jobs 0 and 1 were in flight before any count matrix existed (heads: a rank holds every run); job 2 went
         # owner-directed: a rank holds the runs of its own videos' pairs -- all ranks together every run at least once
         for g in got:
@@ -165,6 +168,8 @@ def test_ranks_over_host_transport_on_one_gpu(lib7, tmp_path, world, shard_epilo
             assert 0 < g["jobs"][2]["comm"]["held"] <= g["jobs"][2]["runs"]
         assert sum(g["jobs"][2]["comm"]["held"] for g in got) >= got[0]["jobs"][2]["runs"]
         assert any(g["jobs"][2]["comm"]["held"] < g["jobs"][2]["runs"] for g in got)
+        repeated = [g["jobs"][2]["comm"]["scans_repeated"] for g in got]
+        assert repeated == [1 if shard_epilogue == "directed-overflow" else 0] * world
 
 
 def test_device_epilogue_failing_on_one_rank_keeps_the_collective_shape(lib7, tmp_path):
@@ -186,6 +191,14 @@ def test_ranks_with_endings_over_host_transport(tmp_path):
     for g in got:
         for job in g["jobs"]:
             assert job["results"] == want
+    # the same with the device epilogue: two comparator regions per pair, the third job's runs owner-directed
+    got = launch("gpu", 2, str(tmp_path / "d"), [5, 90.0], local_ranks=[0, 0],
+                 extra_env={"NEEDLE_HIP_COMM": "host", "NEEDLE_HIP_SHARD_EPILOGUE": "1", "NEEDLE_TEST_ENDINGS": "1",
+                            "NEEDLE_HIP_DEVICE_EPILOGUE": "1"})
+    for g in got:
+        for job in g["jobs"]:
+            assert job["results"] == want
+        assert g["jobs"][2]["comm"]["held"] <= g["jobs"][2]["runs"] == g["jobs"][0]["comm"]["held"]
 
 
 @pytest.mark.parametrize("world,hash_duration,step", [(3, 0.3, 2), (4, 0.15, 1), (3, 0.4, 3)])
