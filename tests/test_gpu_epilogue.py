@@ -139,6 +139,30 @@ def test_pairs_with_hundreds_of_runs_are_a_workgroups_or_the_hosts(monkeypatch):
     assert dev == _as(want)
 
 
+def test_a_bucket_beyond_the_workgroup_kernels_limit_is_still_the_hosts(monkeypatch):
+    """Two windows that are silent for 17 minutes each: ~8 250 runs in one pair's bucket, more than pair_entries_large_kernel holds
+    in LDS (8192).  The job is handed to the host form and counted (needle_hip_epilogue_host_fallbacks); same results."""
+    rng = np.random.default_rng(78)
+    n, S = 3, 4210
+    lens = [int(round(2230.0 * synth.RATE))] * n                        # ~4 500 kept hashes in the opening half
+    lib = capi.Library(n)
+    lib.stream_pcm([np.zeros(v, dtype=np.int16) for v in lens], lens)
+    kept = len(lib.frame_hashes(0).opening_data()[0])
+    assert kept > S + 100
+    d_arena, stride = lib.hash_arena()
+    for v in range(n):
+        h = rng.integers(0, 2 ** 32, kept, dtype=np.uint64).astype(np.uint32)
+        if v < 2:
+            h[30 + 7 * v: 30 + 7 * v + S] = np.uint32(0x0F1E2D3C)
+        capi.check(capi.lib().needle_hip_memcpy_h2d(d_arena + 4 * v * stride, h.ctypes.data, h.nbytes))
+    cmp = capi.Comparator([f"v{v}.wav" for v in range(n)])
+    host, runs_h = _job(lib, cmp, monkeypatch, device=False)
+    capi.epilogue_host_fallbacks(reset=True)
+    dev, runs_d = _job(lib, cmp, monkeypatch, device=True)
+    assert runs_h == runs_d > 8192 and capi.epilogue_host_fallbacks(reset=True) >= 1
+    assert dev == host and dev[0] is not None and dev[0][0] is not None
+
+
 def test_device_epilogue_on_audio_with_two_jobs_in_flight(monkeypatch):
     eps = [synth.make_episode(k, 100.0 + 7.0 * k, 22.0, 21.0) for k in range(6)]
     lens = [len(e.pcm) for e in eps]
