@@ -70,7 +70,23 @@ constexpr int kM2Rows = kSampleW + 2 * kM2Probe;  // source hashes kept per wind
 constexpr int kM2ColBlocks = 2;               // column blocks of 32 positions a wave takes per unit
 constexpr int kM2Batch = 4;                   // row tiles (x 2 column blocks = 8 tiles = 32 flag bits) between two looks at the flags
 constexpr int kM2Queue = 128;                 // items a wave can hold: < 64 waiting + the <= 64 one turn adds
-constexpr int kM2CtlWords = 36;               // [0] unit counter, [1 + g] first row of member g (g = members: all rows), [10 + g] source offset, [18 + g] source length, [26 + g] first window of its image, [34] runs collected, [35] their first slot in the run list
+constexpr int kM2CtlWords = 40;               // [0] unit counter, [1 + g] first row of member g (g = members: all rows), [10 + g] source offset, [18 + g] source length, [26 + g] first window of its image, [34] runs collected, [35] their first slot in the run list, [36] chains pushed, [37] chains taken
+// The workgroup's CHAIN QUEUE (round 6).  The chains of a destination's intro against its up to eight sources end within one
+// or two column units: ONE wave found them all and resolved them one after the other, a trip to global memory each.  While the
+// workgroup has units to hand out that costs nothing (the other waves take them); near its end the other seven ran out of
+// units and waited -- a third of the resolution's 0.24 of 0.74 ms at 39 060 pairs of 24-minute windows.  So a chain found
+// within the last kM2LateUnits units per wave goes to a queue in LDS, which every wave empties at its end (drain()); one
+// found earlier, or finding the queue full, is resolved by its finder as before.  0.738 -> 0.648 ms there; 79 800 pairs of
+// 45-minute windows 2.67 -> 2.71 (+1.3 %: the same with the queue drained between units, with every chain queued, with 64
+// entries).
+#ifndef NEEDLE_M2_LATE_UNITS
+#define NEEDLE_M2_LATE_UNITS 2
+#endif
+constexpr int kM2LateUnits = NEEDLE_M2_LATE_UNITS;
+#ifndef NEEDLE_M2_CHAINS
+#define NEEDLE_M2_CHAINS 32
+#endif
+constexpr int kM2Chains = NEEDLE_M2_CHAINS;   // entries, filled once per workgroup (no wrap)
 static_assert((kM2Batch & (kM2Batch - 1)) == 0 && 8 * kM2Batch <= 32, "a batch's flags fill at most one word");
 static_assert(kM2Probe == 4 && kM2Rows == 16, "a window's sixteen source hashes are read as 16-byte words");
 static_assert(kSampleW + 2 * kM2Probe - 2 < 2 * kSampleW - 1 + 8, "a run that ends inside the probed rows must be shorter than any min_len the sampled path takes");
@@ -78,7 +94,7 @@ static_assert(kSampleW + 2 * kM2Probe - 2 < 2 * kSampleW - 1 + 8, "a run that en
 // LDS words of a workgroup: staged destination (+ 64 zeros), tables, per-window source hashes, A image
 __host__ __device__ constexpr size_t m2_round4(size_t x) { return (x + 3) & ~(size_t)3; }
 __host__ __device__ constexpr size_t m2_lds_words(uint64_t m, uint64_t windows, int waves) {
-  return m2_round4(m + 64) + kM2CtlWords + kM2Table + 4 * kM2RunBuf + (size_t)waves * kM2Queue + (size_t)(windows + 1) * (kM2Pitch + kM2Rows);
+  return m2_round4(m + 64) + kM2CtlWords + kM2Table + 4 * kM2RunBuf + 2 * kM2Chains + (size_t)waves * kM2Queue + (size_t)(windows + 1) * (kM2Pitch + kM2Rows);
 }
 
 // A source sequence's windows as a workgroup wants them in LDS -- per window kM2Pitch words of the A image (its four head
@@ -162,7 +178,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   uint32_t *ctl = lds + dst_words;
   uint32_t *ntab = ctl + kM2CtlWords;            // 8 bits -> 8 nibbles of +-1
   uint32_t *runbuf = ntab + kM2Table;            // the workgroup's runs: (pair, last row, last column, length)
-  uint32_t *queues = runbuf + 4 * kM2RunBuf;     // per wave: items waiting for their exact test
+  uint32_t *chains = runbuf + 4 * kM2RunBuf;     // the workgroup's chains waiting for a wave: (member << 28 | w0, diagonal); word 0 == 0: not written yet
+  uint32_t *queues = chains + 2 * kM2Chains;     // per wave: items waiting for their exact test
   // per window the source hashes of rows w0 - E .. w0 + W + E - 1 (zero where there is none)
   // Per window ONE row of kM2ImageWords = 36 words: its A image row (the head hashes' nibbles, then w0), then its sixteen
   // source hashes.  36 = 4 x 9: sixteen lanes' 16-byte reads of sixteen different windows -- the A fragments of a tile, the
@@ -176,6 +193,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   if (threadIdx.x == 0) {
     ctl[0] = 0u;
     ctl[34] = 0u;
+    ctl[36] = 0u;
+    ctl[37] = 0u;
     int rows = 0;
     for (int g = 0; g < members; g++) {
       ctl[1 + g] = (uint32_t)rows;
@@ -188,6 +207,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   }
   static_assert(64 * WAVES >= kM2Table, "");
   if (threadIdx.x < kM2Table) ntab[threadIdx.x] = m2_nibbles(threadIdx.x);
+  static_assert(64 * WAVES >= 2 * kM2Chains, "");
+  if (threadIdx.x < 2 * kM2Chains) chains[threadIdx.x] = 0u;
   {
     constexpr int kU = 4;
     const int nt = 64 * WAVES;
@@ -462,6 +483,37 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     }
   };
 
+  // The workgroup's chain queue (kM2Chains entries, filled once: no wrap).  All wave-uniform; lane 0 does the work.
+  auto push_chain = [&](const uint32_t wm, const int d) __attribute__((always_inline)) {   // false: the queue is full
+    uint32_t at = (uint32_t)kM2Chains;
+    if (lane == 0) {
+      at = __hip_atomic_fetch_add(&ctl[36], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (at < (uint32_t)kM2Chains) {
+        chains[2 * at + 1] = (uint32_t)d;
+        __hip_atomic_store(&chains[2 * at], wm, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (w0 >= 1: never 0)
+      }
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)at) < (uint32_t)kM2Chains;
+  };
+  auto pop_chain = [&](uint32_t &wm, uint32_t &d) __attribute__((always_inline)) {
+    uint32_t e0 = 0u, e1 = 0u;
+    if (lane == 0) {
+      uint32_t h = __hip_atomic_load(&ctl[37], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (h < min(__hip_atomic_load(&ctl[36], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), (uint32_t)kM2Chains)) {
+        if (__hip_atomic_compare_exchange_strong(&ctl[37], &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+          do {                                    // (its finder has counted it and writes it next)
+            e0 = __hip_atomic_load(&chains[2 * h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } while (e0 == 0u);
+          e1 = __hip_atomic_load(&chains[2 * h + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          break;
+        }
+      }
+    }
+    wm = (uint32_t)__builtin_amdgcn_readfirstlane((int)e0);
+    d = (uint32_t)__builtin_amdgcn_readfirstlane((int)e1);
+    return wm != 0u;
+  };
+
   // What the flags point at.  An ITEM = (group of four windows, destination position) that may hold a survivor.  Items
   // are handed out one per lane, 64 at a time, whatever lane flagged them (a destination position that looks like many
   // windows -- a sustained sound -- flags the same lane again and again: left to that lane, the wave would wait for it).
@@ -504,7 +556,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     overflowed = 0;
     // What passes is rare (a window in three thousand of the items') and is looked at by the WAVE, window by window:
     // whole?  the last of its chain -- no successor (the member's last window), or one that is not whole on this diagonal?
-    // Then the chain is resolved.
+    // Then the chain goes to the WORKGROUP's queue (drain(), below), and when that is full it is resolved here.
 #pragma unroll 1
     for (int i = 0; i < 4; i++) {
       const bool tails = ((passm >> i) & 1u) != 0u;
@@ -519,10 +571,22 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         const int g = (int)(wm >> 28), w0 = (int)(wm & 0x0FFFFFFFu);
         if (!window_whole_wave(ck, g, w0, cj)) continue;
         if (ck + 1 < (int)__builtin_amdgcn_readfirstlane(ctl[2 + g]) && window_whole_wave(ck + 1, g, w0 + P, cj + P)) continue;
-        resolve(w0, cj - w0, g);
+        // Found while the workgroup still has plenty of units to hand out: resolved here, beside the other waves' tiles.  Found
+        // LATE -- the units left are fewer than the waves would take during a cluster's eight resolutions -- it waits for drain().
+        const bool late = (int)__builtin_amdgcn_readfirstlane(ctl[0]) + kM2LateUnits * WAVES >= units;
+        if (!late || !push_chain(wm, cj - w0)) resolve(w0, cj - w0, g);
       }
     }
     flush_overflow();                             // (the words are the queue's again when this call returns)
+  };
+  // Chains from the workgroup's queue, whoever found them, until it is empty: between two units and at the wave's end
+  // (fewer than 64 items wait in the wave's queue there: its upper 64 words hold the overflow runs).
+  auto drain = [&]() __attribute__((always_inline)) {
+    overflow = queue + 64;
+    overflowed = 0;
+    uint32_t wm = 0u, dd = 0u;
+    while (pop_chain(wm, dd)) resolve((int)(wm & 0x0FFFFFFFu), (int)dd, (int)(wm >> 28));
+    flush_overflow();
   };
   // A batch's flags become items.  flags: bit 4 n - 1 - (4 s + g) set <=> tile slot s (s = 2 (row tile - rt0) + column block,
   // n slots in all), group g.  One item per lane and turn (turns = the most set bits any lane holds), 64 are processed
@@ -555,6 +619,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
 
   const uint32_t *arow = wimg + r * STRIDE + 4 * h;                                         // rows of a full tile: + rt 32 STRIDE
   const uint32_t *arow_last = wimg + min(32 * (row_tiles - 1) + r, nW) * STRIDE + 4 * h;  // the last tile's may lie beyond the last window
+  // (Measured and dropped, round 6: the last tile = the LAST 32 windows, overlapping its neighbour instead of reaching beyond the
+  // last window -- a tile's address is then one per-lane base plus a scalar, 41 instead of 43 vector instructions per two tiles --
+  // with the overlap's second flags dropped in enqueue(): 2.81 against 2.66 ms at 79 800 pairs of 45-minute windows, 0.665
+  // against 0.650 at 39 060 pairs: the overlap's flags and the second ballot per turn cost more than the two instructions.)
   auto load_a = [&](const int rt, mfma_v4i (&fa)[HP]) {
     const uint32_t *ap = rt == row_tiles - 1 ? arow_last : arow + rt * 32 * STRIDE;
 #pragma unroll
@@ -601,6 +669,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     c = __builtin_amdgcn_readfirstlane(c);
     const int unit = b_in_group + splits * c;     // (every wave sees the counter pass `units`: the loop ends for all)
     done = unit >= units;                         // then one more turn with nothing in it: the queue's last items
+
     // B fragments: lane (r, h) holds dst[j + s] for the head rows s = (0 | 2), (4 | 7) of its half h as 32 nibbles of +-1,
     // eight bits at a time through a table of 256 words
     mfma_v4i fb[CB][HP], fa[HP];
@@ -633,6 +702,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     do {
       uint32_t flags = 0u;                        // sign bits of the groups' words: set = look here
       const int nb = done ? 0 : min(kM2Batch, row_tiles - rt0);
+
       mfma_v16f a0, b0;
 #pragma unroll 1
       for (int rt = rt0; rt < rt0 + nb; rt++) {
@@ -651,6 +721,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
 #endif
       rt0 += kM2Batch;
     } while (!done && rt0 < row_tiles);
+    if (done) drain();                            // the workgroup's chains, by all its waves
   }
   // the workgroup's runs: one request for room, then the copy
   __syncthreads();
