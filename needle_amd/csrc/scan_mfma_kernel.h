@@ -573,7 +573,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         if (ck + 1 < (int)__builtin_amdgcn_readfirstlane(ctl[2 + g]) && window_whole_wave(ck + 1, g, w0 + P, cj + P)) continue;
         // Found while the workgroup still has plenty of units to hand out: resolved here, beside the other waves' tiles.  Found
         // LATE -- the units left are fewer than the waves would take during a cluster's eight resolutions -- it waits for drain().
-        const bool late = (int)__builtin_amdgcn_readfirstlane(ctl[0]) + kM2LateUnits * WAVES >= units;
+        const bool late = ((int)__builtin_amdgcn_readfirstlane(ctl[0]) + kM2LateUnits * WAVES) * splits >= units;   // (ctl[0]: this workgroup's share)
         if (!late || !push_chain(wm, cj - w0)) resolve(w0, cj - w0, g);
       }
     }

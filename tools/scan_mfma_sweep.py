@@ -20,6 +20,9 @@ VARIANTS = {
     "w8": {"NEEDLE_HIP_MFMA_WAVES": "8"},
     "w16": {"NEEDLE_HIP_MFMA_WAVES": "16"},
     "w8forced": {"NEEDLE_HIP_MFMA_WAVES": "8", "NEEDLE_HIP_SCAN_MFMA": "1"},    # below the size the automatic choice takes it from
+    "w8s2": {"NEEDLE_HIP_MFMA_WAVES": "8", "NEEDLE_HIP_SCAN_MFMA": "1", "NEEDLE_HIP_MFMA_SPLITS": "2"},   # workgroups per group
+    "w8s3": {"NEEDLE_HIP_MFMA_WAVES": "8", "NEEDLE_HIP_SCAN_MFMA": "1", "NEEDLE_HIP_MFMA_SPLITS": "3"},
+    "w8s4": {"NEEDLE_HIP_MFMA_WAVES": "8", "NEEDLE_HIP_SCAN_MFMA": "1", "NEEDLE_HIP_MFMA_SPLITS": "4"},
 }
 # laboratory builds (tools/build_variant.sh, wrong results, timing only): <lab>@<variant>, e.g. m2lab1@w12c2
 LAB_DIR = os.path.join(ROOT, "needle_amd", "lib", "ab")
