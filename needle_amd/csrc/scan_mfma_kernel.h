@@ -524,9 +524,15 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     uint32_t passm = 0u;                          // windows of the group (bit i) whose W cells all match
     int kbase = 0, j = 0;
     if (lane < cnt) {
-      const uint32_t item = queue[first + lane];
-      kbase = (int)(item & 0xFFFFu);
-      j = (int)(item >> 16);
+      // the item's token (enqueue(), below): flag bit | finder's lane << 5 | batch << 11 | unit << 17.  Decoded HERE, 64 items per
+      // instruction; in enqueue() the same arithmetic served the five or so lanes of a turn that held a flag.
+      const uint32_t token = queue[first + lane];
+      const int f = (int)(token & 31u), fr = (int)((token >> 5) & 31u), fh = (int)((token >> 10) & 1u);
+      const int brt0 = (int)((token >> 11) & 63u) * kM2Batch, bunit = (int)(token >> 17);
+      const int idx = 8 * min(kM2Batch, row_tiles - brt0) - 1 - f;   // flag bit -> tile slot s = 2 (row tile - rt0) + column block, group g
+      const int s = idx >> 2, g = idx & 3;
+      kbase = 32 * (brt0 + (s >> 1)) + 8 * g + 4 * fh;
+      j = 32 * CB * bunit + fr + 32 * (s & 1);
       // All eight rows at once: the window's rows come as two 16-byte reads anyway, the destination's eight serve the four
       // windows.  (Head rows first and the tail rows of the survivors in a loop of their own -- one turn per window with
       // four lanes in a hundred busy -- was a quarter more instructions.)
@@ -590,22 +596,23 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   };
   // A batch's flags become items.  flags: bit 4 n - 1 - (4 s + g) set <=> tile slot s (s = 2 (row tile - rt0) + column block,
   // n slots in all), group g.  One item per lane and turn (turns = the most set bits any lane holds), 64 are processed
-  // as soon as they are there.
+  // as soon as they are there.  An item goes into the queue as a TOKEN that names its flag bit (round 6): a turn serves the few
+  // lanes that hold a flag, and the arithmetic from bit to (windows, position) -- 9 of a turn's 17 vector instructions, 2.6 per
+  // tile beside the fold's 20 -- is done by process() for 64 items at a time instead.
   int qn = 0;                                     // wave-uniform: items waiting in this wave's queue (< 64 between turns)
   // (ONE call site, and one of process() inside: the rare paths' code, inlined at three sites each, had grown to where the
   // waves waited for instructions -- the same head tests took 0.12 instead of 0.08 ms.  flush: the wave's last call.)
-  auto enqueue = [&](uint32_t flags, const int rt0, const int n_slots, const int j0, const bool flush) __attribute__((always_inline)) {
+  auto enqueue = [&](uint32_t flags, const int rt0, const int unit, const bool flush) __attribute__((always_inline)) {
+    // (unit < 32768 and rt0 / kM2Batch < 64: m < 65536 and fewer than 8192 windows per group -- search.hip build_plan stages nothing else)
+    const uint32_t mine = ((uint32_t)unit << 17) | ((uint32_t)(rt0 / kM2Batch) << 11) | ((uint32_t)lane << 5);
     for (;;) {
       const bool act = flags != 0u;
       const unsigned long long ball = __builtin_amdgcn_ballot_w64(act);
       if (act) {
-        const int idx = 4 * n_slots - 1 - (__ffs((int)flags) - 1);
+        const uint32_t f = (uint32_t)(__ffs((int)flags) - 1);
         flags &= flags - 1u;
-        const int s = idx >> 2, g = idx & 3;
-        const uint32_t kbase = (uint32_t)(32 * (rt0 + (s >> 1)) + 8 * g + 4 * h);
-        const uint32_t j = (uint32_t)(j0 + 32 * (s & 1));
         const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(ball >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ball, 0u));
-        queue[qn + (int)before] = (j << 16) | kbase;  // j < m < 65536, kbase < the group's windows < 65536: search.hip build_plan (mfma_packable) stages nothing else
+        queue[qn + (int)before] = mine | f;
       }
       qn += (int)__popcll(ball);
       const int cnt = qn >= 64 ? 64 : (ball == 0ull && flush) ? qn : 0;
@@ -715,7 +722,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         __builtin_amdgcn_sched_barrier(0);
       }
 #if !(NEEDLE_M2_LAB & 1)   // laboratory: flags ignored -- the tile loop alone
-      enqueue(flags, rt0, 2 * nb, j0, done);
+      enqueue(flags, rt0, unit, done);
 #else
       if (flags == 0x12345u + threshold) atomicAdd(count, 1u);
 #endif

@@ -777,11 +777,11 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
       if (mfma) return group_need(m, windows_of(m));
       return ((fast || sampled) ? (size_t)m.m + 2 * kBandB : (size_t)m.n + m.m) * sizeof(uint32_t);
     };
-    // The matrix-pipe kernel packs its queue items as (j << 16) | kbase and a window / member word as w0 | member << 28
-    // (scan_mfma_kernel.h): a staged entry needs m < 65536, fewer than 65536 windows and n < 2^28.  The 160 KiB of LDS imply
+    // The matrix-pipe kernel packs its queue items as unit << 17 | batch of row tiles << 11 | lane << 5 | flag bit and a window /
+    // member word as w0 | member << 28 (scan_mfma_kernel.h): a staged entry needs m < 65536, fewer than 8192 windows (per group) and n < 2^28.  The 160 KiB of LDS imply
     // the first two (m <= ~40 900) only while the limit is the hardware's; checked here so that an overridden limit or a
     // future layout cannot break the packing silently -- such an entry goes to the oversize partition.
-    auto mfma_packable = [&](const SearchProblem &m) { return m.m < 65536u && windows_of(m) < 65536u && m.n < (1u << 28); };
+    auto mfma_packable = [&](const SearchProblem &m) { return m.m < 65536u && windows_of(m) < 8192u && m.n < (1u << 28); };
     auto stageable = [&](const SearchProblem &m) { return lds_need(m) <= lds_limit && (!mfma || mfma_packable(m)); };
     std::stable_partition(meta.begin(), meta.end(), stageable);
     size_t staged = 0;
@@ -798,7 +798,7 @@ Status build_plan(const NeedleHipSeq *seqs, size_t num_seqs, const NeedleHipProb
         uint64_t windows = windows_of(a);
         size_t k = 1;
         while (!single && k < max_members && i + k < staged && same_group(a, meta[i + k]) &&
-               windows + windows_of(meta[i + k]) < 65536 &&
+               windows + windows_of(meta[i + k]) < 8192 &&
                group_need(a, windows + windows_of(meta[i + k])) <= group_budget) {
           windows += windows_of(meta[i + k]);
           meta[i + k].pad = 0x80000000u;
