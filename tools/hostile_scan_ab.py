@@ -1,5 +1,5 @@
 # The hostile corpus's headline job (28 x 24 min) under whichever library NEEDLE_CAPI_LIB names: the scan kernel alone, the
-# job alone and the steady rate with two jobs in flight -- for A/B builds of search.hip (e.g. -DNEEDLE_LANE_RESOLVE_FROM=65).
+# job alone and the steady rate with two jobs in flight -- for A/B builds of search.hip (tools/build_variant.sh).
 # usage: NEEDLE_CAPI_LIB=<path> python tools/hostile_scan_ab.py [tonal]
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
