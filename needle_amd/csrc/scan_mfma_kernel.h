@@ -70,15 +70,17 @@ constexpr int kM2Rows = kSampleW + 2 * kM2Probe;  // source hashes kept per wind
 constexpr int kM2ColBlocks = 2;               // column blocks of 32 positions a wave takes per unit
 constexpr int kM2Batch = 4;                   // row tiles (x 2 column blocks = 8 tiles = 32 flag bits) between two looks at the flags
 constexpr int kM2Queue = 128;                 // items a wave can hold: < 64 waiting + the <= 64 one turn adds
-constexpr int kM2CtlWords = 40;               // [0] unit counter, [1 + g] first row of member g (g = members: all rows), [10 + g] source offset, [18 + g] source length, [26 + g] first window of its image, [34] runs collected, [35] their first slot in the run list, [36] chains pushed, [37] chains taken
+constexpr int kM2CtlWords = 40;               // [0] unit counter, [1 + g] first row of member g (g = members: all rows), [10 + g] source offset, [18 + g] source length, [26 + g] first window of its image, [34] runs collected, [35] their first slot in the run list, [36] chains taken, [37] chains pushed, [38] the chain queue's lock, [39] waves that have flushed their items
 // The workgroup's CHAIN QUEUE (round 6).  The chains of a destination's intro against its up to eight sources end within one
 // or two column units: ONE wave found them all and resolved them one after the other, a trip to global memory each.  While the
 // workgroup has units to hand out that costs nothing (the other waves take them); near its end the other seven ran out of
 // units and waited -- a third of the resolution's 0.24 of 0.74 ms at 39 060 pairs of 24-minute windows.  So a chain found
-// within the last kM2LateUnits units per wave goes to a queue in LDS, which every wave empties at its end (drain()); one
-// found earlier, or finding the queue full, is resolved by its finder as before.  0.738 -> 0.648 ms there; 79 800 pairs of
-// 45-minute windows 2.67 -> 2.71 (+1.3 %: the same with the queue drained between units, with every chain queued, with 64
-// entries).
+// within the last kM2LateUnits units per wave goes to a queue in LDS (a ring behind a lock), which every wave empties at its
+// end (drain()); one found earlier, or finding the queue full, is resolved by its finder as before.  0.738 -> 0.648 ms there;
+// 79 800 pairs of 45-minute windows unchanged inside +-1 % (the same with the queue drained between units, with every chain
+// queued, with 64 entries).  And a wave in a CROWD of chains (a block of equal hashes: silence against silence) hands them
+// over too, once it has resolved kM2Crowd of a process() call itself: the waves whose units were cheap are through by then and
+// stay in drain() until every wave has flushed its items.
 #ifndef NEEDLE_M2_LATE_UNITS
 #define NEEDLE_M2_LATE_UNITS 2
 #endif
@@ -86,7 +88,12 @@ constexpr int kM2LateUnits = NEEDLE_M2_LATE_UNITS;
 #ifndef NEEDLE_M2_CHAINS
 #define NEEDLE_M2_CHAINS 32
 #endif
-constexpr int kM2Chains = NEEDLE_M2_CHAINS;   // entries, filled once per workgroup (no wrap)
+constexpr int kM2Chains = NEEDLE_M2_CHAINS;   // entries of the ring
+static_assert((kM2Chains & (kM2Chains - 1)) == 0, "");
+#ifndef NEEDLE_M2_CROWD
+#define NEEDLE_M2_CROWD 4
+#endif
+constexpr int kM2Crowd = NEEDLE_M2_CROWD;     // chains one process() call resolves itself before it hands the rest to the queue
 static_assert((kM2Batch & (kM2Batch - 1)) == 0 && 8 * kM2Batch <= 32, "a batch's flags fill at most one word");
 static_assert(kM2Probe == 4 && kM2Rows == 16, "a window's sixteen source hashes are read as 16-byte words");
 static_assert(kSampleW + 2 * kM2Probe - 2 < 2 * kSampleW - 1 + 8, "a run that ends inside the probed rows must be shorter than any min_len the sampled path takes");
@@ -195,6 +202,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     ctl[34] = 0u;
     ctl[36] = 0u;
     ctl[37] = 0u;
+    ctl[38] = 0u;
+    ctl[39] = 0u;
     int rows = 0;
     for (int g = 0; g < members; g++) {
       ctl[1 + g] = (uint32_t)rows;
@@ -207,8 +216,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   }
   static_assert(64 * WAVES >= kM2Table, "");
   if (threadIdx.x < kM2Table) ntab[threadIdx.x] = m2_nibbles(threadIdx.x);
-  static_assert(64 * WAVES >= 2 * kM2Chains, "");
-  if (threadIdx.x < 2 * kM2Chains) chains[threadIdx.x] = 0u;
   {
     constexpr int kU = 4;
     const int nt = 64 * WAVES;
@@ -483,31 +490,44 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     }
   };
 
-  // The workgroup's chain queue (kM2Chains entries, filled once: no wrap).  All wave-uniform; lane 0 does the work.
+  // The workgroup's chain queue: a ring of kM2Chains entries behind a lock (ctl[38]); ctl[36] counts the chains taken, ctl[37]
+  // the chains pushed.  All wave-uniform; lane 0 does the work, a handful of LDS operations under the lock.
+  auto chain_lock = [&]() __attribute__((always_inline)) {
+    while (__hip_atomic_exchange(&ctl[38], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
+  };
+  auto chain_unlock = [&]() __attribute__((always_inline)) {
+    __hip_atomic_store(&ctl[38], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
   auto push_chain = [&](const uint32_t wm, const int d) __attribute__((always_inline)) {   // false: the queue is full
-    uint32_t at = (uint32_t)kM2Chains;
+    uint32_t ok = 0u;
     if (lane == 0) {
-      at = __hip_atomic_fetch_add(&ctl[36], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (at < (uint32_t)kM2Chains) {
-        chains[2 * at + 1] = (uint32_t)d;
-        __hip_atomic_store(&chains[2 * at], wm, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (w0 >= 1: never 0)
+      chain_lock();
+      const uint32_t taken = __hip_atomic_load(&ctl[36], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t pushed = __hip_atomic_load(&ctl[37], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (pushed - taken < (uint32_t)kM2Chains) {
+        const uint32_t at = pushed & (uint32_t)(kM2Chains - 1);
+        __hip_atomic_store(&chains[2 * at], wm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&chains[2 * at + 1], (uint32_t)d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&ctl[37], pushed + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ok = 1u;
       }
+      chain_unlock();
     }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)at) < (uint32_t)kM2Chains;
+    return __builtin_amdgcn_readfirstlane((int)ok) != 0;
   };
   auto pop_chain = [&](uint32_t &wm, uint32_t &d) __attribute__((always_inline)) {
-    uint32_t e0 = 0u, e1 = 0u;
-    if (lane == 0) {
-      uint32_t h = __hip_atomic_load(&ctl[37], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      while (h < min(__hip_atomic_load(&ctl[36], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), (uint32_t)kM2Chains)) {
-        if (__hip_atomic_compare_exchange_strong(&ctl[37], &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-          do {                                    // (its finder has counted it and writes it next)
-            e0 = __hip_atomic_load(&chains[2 * h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          } while (e0 == 0u);
-          e1 = __hip_atomic_load(&chains[2 * h + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          break;
-        }
+    uint32_t e0 = 0u, e1 = 0u;                    // (w0 >= 1: a chain's first word is never 0)
+    if (lane == 0 && __hip_atomic_load(&ctl[37], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) !=
+                         __hip_atomic_load(&ctl[36], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+      chain_lock();
+      const uint32_t taken = __hip_atomic_load(&ctl[36], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (taken != __hip_atomic_load(&ctl[37], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        const uint32_t at = taken & (uint32_t)(kM2Chains - 1);
+        e0 = __hip_atomic_load(&chains[2 * at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        e1 = __hip_atomic_load(&chains[2 * at + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&ctl[36], taken + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+      chain_unlock();
     }
     wm = (uint32_t)__builtin_amdgcn_readfirstlane((int)e0);
     d = (uint32_t)__builtin_amdgcn_readfirstlane((int)e1);
@@ -560,9 +580,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     wave_lds_fence_search();
     overflow = queue + first;                     // the items are in registers: their (and the following, unused) 64 words hold overflow runs
     overflowed = 0;
+    int resolved_here = 0;                        // by this call (wave-uniform)
     // What passes is rare (a window in three thousand of the items') and is looked at by the WAVE, window by window:
     // whole?  the last of its chain -- no successor (the member's last window), or one that is not whole on this diagonal?
-    // Then the chain goes to the WORKGROUP's queue (drain(), below), and when that is full it is resolved here.
+    // Then the chain is resolved here, or goes to the WORKGROUP's queue (drain(), below).
 #pragma unroll 1
     for (int i = 0; i < 4; i++) {
       const bool tails = ((passm >> i) & 1u) != 0u;
@@ -578,20 +599,32 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         if (!window_whole_wave(ck, g, w0, cj)) continue;
         if (ck + 1 < (int)__builtin_amdgcn_readfirstlane(ctl[2 + g]) && window_whole_wave(ck + 1, g, w0 + P, cj + P)) continue;
         // Found while the workgroup still has plenty of units to hand out: resolved here, beside the other waves' tiles.  Found
-        // LATE -- the units left are fewer than the waves would take during a cluster's eight resolutions -- it waits for drain().
+        // LATE -- the units left are fewer than the waves would take during a cluster's eight resolutions -- or in a CROWD (this
+        // call has resolved kM2Crowd already: a block of equal hashes, every diagonal through it a chain) it goes to the queue,
+        // which the waves that have run out of units empty (drain()); resolved here after all when the queue is full.
         const bool late = ((int)__builtin_amdgcn_readfirstlane(ctl[0]) + kM2LateUnits * WAVES) * splits >= units;   // (ctl[0]: this workgroup's share)
-        if (!late || !push_chain(wm, cj - w0)) resolve(w0, cj - w0, g);
+        if ((late || resolved_here >= kM2Crowd) && push_chain(wm, cj - w0)) continue;
+        resolve(w0, cj - w0, g);
+        resolved_here++;
       }
     }
     flush_overflow();                             // (the words are the queue's again when this call returns)
   };
-  // Chains from the workgroup's queue, whoever found them, until it is empty: between two units and at the wave's end
-  // (fewer than 64 items wait in the wave's queue there: its upper 64 words hold the overflow runs).
+  // Chains from the workgroup's queue, whoever found them -- behind a wave's last unit, when it has flushed its items and will
+  // push nothing any more.  It says so (ctl[39]) and STAYS until every wave has: the waves of a workgroup whose units are cheap
+  // finish first and then take what the waves in a block of equal hashes keep pushing (the hostile corpus, 280 files: scan
+  // 15.3 -> 8.5 ms; the tonal figures unchanged).  (No items wait in the wave's queue here: its upper 64 words hold the overflow runs.)
   auto drain = [&]() __attribute__((always_inline)) {
     overflow = queue + 64;
     overflowed = 0;
-    uint32_t wm = 0u, dd = 0u;
-    while (pop_chain(wm, dd)) resolve((int)(wm & 0x0FFFFFFFu), (int)dd, (int)(wm >> 28));
+    if (lane == 0) __hip_atomic_fetch_add(&ctl[39], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+      const bool all = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ctl[39], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == WAVES;
+      uint32_t wm = 0u, dd = 0u;
+      while (pop_chain(wm, dd)) resolve((int)(wm & 0x0FFFFFFFu), (int)dd, (int)(wm >> 28));
+      if (all) break;                             // (read BEFORE the queue was found empty: nothing can have come since)
+      __builtin_amdgcn_s_sleep(8);
+    }
     flush_overflow();
   };
   // A batch's flags become items.  flags: bit 4 n - 1 - (4 s + g) set <=> tile slot s (s = 2 (row tile - rt0) + column block,
