@@ -265,7 +265,10 @@ __device__ __forceinline__ void wave_lds_fence_search() {  // (stft_kernel.h wav
 // cell lies inside the table, on the padding or repeats another lane's) and adds the total to *eval_groups when it
 // leaves -- the numerator of an honest roofline: issued cell evaluations per second against the measured
 // integer-VALU ceiling, <= 1 by construction, unlike the cells of the reference's table the scan merely COVERS.
-template <int R, int W, bool COUNT = false, int H = kSampleHead>
+// LEGACY: with the two older ways of finishing the head rows' survivors compiled in (sparse_max >= 0: NEEDLE_HIP_SPARSE_MAX, tests and
+// tuning).  The kernel every job runs has the default way only (round 6: a third fewer instructions; the scan runs beside the next
+// job's first pass, and the size of this kernel shows in that job's time -- profiles/NOTES.md).
+template <int R, int W, bool COUNT = false, int H = kSampleHead, bool LEGACY = false>
 __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_t *__restrict__ hashes,
                                                                    const SearchProblem *__restrict__ problems,
                                                                    int num_problems, uint32_t threshold,
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
     }
     if (COUNT) survived += (unsigned long long)survivors;
     if (survivors == 0) continue;
-    if (sparse_max < 0) {
+    if (!LEGACY || sparse_max < 0) {
       // Default.  Every cell of the window on this lane's R diagonals is already in E: a diagonal that survived the head
       // rows in ANY lane has its remaining rows tested by all lanes straight from registers -- W - H cells per lane, no LDS
       // round trip, no lane shuffling, nothing the next window waits for but arithmetic.  (The sparse form below re-reads
@@ -473,6 +476,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
       }
       continue;
     }
+    if constexpr (LEGACY) {
     if (survivors <= sparse_max) {
       // lane k (k < W - H) takes the k-th remaining row; lanes beyond repeat the last of them
       constexpr int kTail = W - H;
@@ -517,6 +521,7 @@ __global__ __launch_bounds__(256) void hamming_runs_sampled_kernel(const uint32_
         resolve(D0 + src_lane * R + r);
       }
     }
+    }  // LEGACY
   }
   }  // bands of this wave
   flush_runs();
@@ -650,12 +655,13 @@ ScanShape scan_shape() {
 using SampledKernel = void (*)(const uint32_t *, const SearchProblem *, int, uint32_t, NeedleHipRun *, uint32_t, uint32_t *, int, int,
                                unsigned long long *);
 template <bool COUNT>
-SampledKernel sampled_kernel(ScanShape sh) {
+SampledKernel sampled_kernel(ScanShape sh, bool legacy) {
 #define NEEDLE_SHAPE(W_, H_) \
-  if (sh.w == W_ && sh.h == H_) return hamming_runs_sampled_kernel<kBandR, W_, COUNT, H_>;
+  if (sh.w == W_ && sh.h == H_) return hamming_runs_sampled_kernel<kBandR, W_, COUNT, H_, true>;
   NEEDLE_SHAPE(4, 2) NEEDLE_SHAPE(4, 3) NEEDLE_SHAPE(8, 2) NEEDLE_SHAPE(8, 4) NEEDLE_SHAPE(16, 2) NEEDLE_SHAPE(16, 3) NEEDLE_SHAPE(16, 4)
 #undef NEEDLE_SHAPE
-  return hamming_runs_sampled_kernel<kBandR, kSampleW, COUNT, kSampleHead>;
+  if (legacy) return hamming_runs_sampled_kernel<kBandR, kSampleW, COUNT, kSampleHead, true>;
+  return hamming_runs_sampled_kernel<kBandR, kSampleW, COUNT, kSampleHead, false>;   // (the other shapes are tuning runs: LEGACY form)
 }
 
 struct SearchPlan {
@@ -1030,10 +1036,12 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
       for (int w : {4, 8, 16})
         for (int h : {2, 3, 4}) {
           if (h >= w) continue;
-          NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sampled_kernel<false>(ScanShape{w, h})),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sampled_kernel<true>(ScanShape{w, h})),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          for (bool legacy : {false, true}) {
+            NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sampled_kernel<false>(ScanShape{w, h}, legacy)),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            NEEDLE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(sampled_kernel<true>(ScanShape{w, h}, legacy)),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          }
         }
       ws->lds_attr_set = true;
     }
@@ -1050,7 +1058,7 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
             NEEDLE_HIP_TRY(hipMalloc((void **)&ws->eval_groups, 2 * sizeof(unsigned long long)));
             NEEDLE_HIP_TRY(hipMemsetAsync(ws->eval_groups, 0, 2 * sizeof(unsigned long long), stream));
           }
-          hipLaunchKernelGGL(sampled_kernel<true>(scan_shape()), dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
+          hipLaunchKernelGGL(sampled_kernel<true>(scan_shape(), sparse_max >= 0), dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
                              ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,
                              ws->eval_groups);
         } else if (plan.mfma) {
@@ -1078,7 +1086,7 @@ Status gpu_hamming_runs_device(const uint32_t *d_hashes, const NeedleHipSeq *seq
           }
 #endif
         } else {
-          hipLaunchKernelGGL(sampled_kernel<false>(scan_shape()), dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
+          hipLaunchKernelGGL(sampled_kernel<false>(scan_shape(), sparse_max >= 0), dim3((uint32_t)blocks), dim3(256), lds_bytes, stream, d_hashes,
                              ws->problems.ptr, staged, threshold, d_runs, capacity, d_count, bands_per_wave, sparse_max,
                              (unsigned long long *)nullptr);
         }
