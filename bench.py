@@ -437,7 +437,8 @@ def library_scale(capi, synth, episodes, minutes, jobs=3, check=4):
                                    "against the dense FP4 peak of MI355X_MICROARCH.md"}
         try:                                                     # SQ_VALU_MFMA_BUSY_CYCLES of an earlier rocprofv3 --pmc run of this kernel
             cj = json.load(open(os.path.join(ROOT, "profiles", "scan_mfma_counters.json")))
-            out["roofline"].update(pipe_busy=cj.get("pipe_busy"), pipe_busy_source=cj.get("source"))
+            out["roofline"].update(pipe_busy=cj.get("pipe_busy"), valu_issue_frac=cj.get("valu_issue_frac"),
+                                   vector_per_matrix_instruction=cj.get("vector_per_matrix_instruction"), pipe_busy_source=cj.get("source"))
         except (OSError, ValueError):
             pass
     return out
@@ -906,12 +907,13 @@ def main() -> None:
         cs = capi.cert_stats()
         certified = cs["items"] > 0
         achieved = abytes / (avg[dominant] * 1e-3) / 1e9 if avg[dominant] > 0 else 0.0
-        traffic = traffic_source = None
+        traffic = traffic_source = valu_issue = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes/launch from rocprofv3 PMC passes (N = 1 launch shape)
         if os.path.exists(tpath) and world == 1 and n == 28 and args.minutes == 24.0:
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(dominant)
+                valu_issue = (tj.get("valu_issue_frac") or {}).get(dominant)
                 if traffic is not None:
                     traffic_source = (f"{tj.get('source', 'profiles/traffic.json')}: rocprofv3 --pmc pass of an earlier run of "
                                       "this command, NOT measured in this run (counters cannot be read from inside it)")
@@ -923,7 +925,11 @@ def main() -> None:
             tf = fl / (avg[dominant] * 1e-3) / 1e12
             peak = F64_VALU_PEAK_TFLOPS if dominant == "stft_chroma" else F32_VALU_PEAK_TFLOPS
             compute = {"bound": "f64 valu" if dominant == "stft_chroma" else "f32 valu", "achieved": round(tf, 2), "peak": peak,
-                       "unit": "TFLOP/s", "frac": round(tf / peak, 4), "flops_per_launch": int(fl)}
+                       "unit": "TFLOP/s", "frac": round(tf / peak, 4), "flops_per_launch": int(fl),
+                       "valu_issue_frac": valu_issue,
+                       "valu_issue_note": "share of the SIMDs' cycles in which a vector instruction issues (SQ_ACTIVE_INST_VALU x 4 / SIMD "
+                                          "cycles, profiles/traffic.json: the same earlier counter pass as `traffic`): the kernel's real bound -- "
+                                          "of ~716 vector instructions per frame pair 432 are the butterflies' arithmetic"}
         out = {
             "metric": "episode-pairs/sec (analyze+search)", "value": round(value, 2), "unit": "episode-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),

@@ -31,6 +31,10 @@ m = summary.get("mfma_scan", {})
 if m.get("SQ_VALU_MFMA_BUSY_CYCLES") and m.get("GRBM_GUI_ACTIVE"):
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES is cycles summed over the 1024 SIMDs
     summary["pipe_busy"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * m["GRBM_GUI_ACTIVE"] / 8.0), 4)
+    if m.get("SQ_ACTIVE_INST_VALU"):   # a vector wave-instruction holds its SIMD's vector ALU for 4 cycles
+        summary["valu_issue_frac"] = round(4.0 * m["SQ_ACTIVE_INST_VALU"] / (1024.0 * m["GRBM_GUI_ACTIVE"] / 8.0), 4)
+    if m.get("SQ_INSTS_VALU") and m.get("SQ_INSTS_MFMA"):
+        summary["vector_per_matrix_instruction"] = round(m["SQ_INSTS_VALU"] / m["SQ_INSTS_MFMA"], 2)
     if m.get("SQ_LDS_IDX_ACTIVE"):
         summary["lds_bank_conflict_share"] = round(m.get("SQ_LDS_BANK_CONFLICT", 0) / m["SQ_LDS_IDX_ACTIVE"], 4)
     summary["source"] = "tools/scan_mfma_counters.sh %s: rocprofv3 --pmc, two passes, per launch" % (sys.argv[2] if len(sys.argv) > 2 else "")

@@ -49,7 +49,7 @@ def main():
             if k:
                 pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("\n## PMC per launch (separate passes)\n")
-    traffic = {}
+    traffic, issue = {}, {}
     for k, counters in pmc.items():
         line = [f"**{k}**"]
         for c, vals in sorted(counters.items()):
@@ -62,7 +62,15 @@ def main():
             wb = 1024.0 * sum(write) / len(write)
             traffic[k] = int(fb + wb)
             line.append(f"HBM bytes/launch (2*FETCH+WRITE) = {fb + wb:.4g} (fetch {fb:.4g}, write {wb:.4g})")
+        act, gui = counters.get("SQ_ACTIVE_INST_VALU"), counters.get("GRBM_GUI_ACTIVE")
+        if act and gui:
+            # share of the SIMDs' issue cycles a vector instruction occupies: a wave-instruction holds its SIMD's vector ALU for 4
+            # cycles; SQ_ACTIVE_INST_VALU is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
+            issue[k] = round(4.0 * (sum(act) / len(act)) / (1024.0 * (sum(gui) / len(gui)) / 8.0), 4)
+            line.append(f"vector-instruction issue = {100 * issue[k]:.1f} % of the SIMDs' cycles")
         print("- " + ", ".join(line))
+    if issue:
+        traffic["valu_issue_frac"] = issue
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"))
     for name in ("stats.log", "plain.json"):
         p = os.path.join(out, name)
