@@ -694,7 +694,10 @@ Status gpu_fingerprint_device(const int16_t *d_pcm, const std::vector<StreamSpan
       if (certified) {
         float cert_k = 64.0f;  // 35 x the worst |log v32 - log v64| / S observed (profiles/r03_f32_gate.log)
         if (const char *e = getenv("NEEDLE_HIP_CERT_K")) cert_k = std::max(0.0f, (float)atof(e));  // tests: 0 = accept everything
-        constexpr uint32_t kChunkPairs = 2;  // 634 four-pair chunks per 28 x 24 min job are two rounds of the 512 workgroup slots; two-pair chunks fit one
+#ifndef NEEDLE_CHUNK_PAIRS
+#define NEEDLE_CHUNK_PAIRS 2
+#endif
+        constexpr uint32_t kChunkPairs = NEEDLE_CHUNK_PAIRS;  // 634 four-pair chunks per 28 x 24 min job are two rounds of the 512 workgroup slots; two-pair chunks fit one
         const uint64_t nchunks = (pairs + kChunkPairs - 1) / kChunkPairs;
         const size_t ctl_words = sizeof(CertWork) / 4 + (size_t)((nchunks + 31) / 32);
         DeviceBuffer<float> &energy_buf = pp ? pp->energy : ws->energy;
