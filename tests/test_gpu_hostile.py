@@ -36,7 +36,7 @@ def _pairs(res):
     return [None if r is None else (r.opening, r.ending) for r in res]
 
 
-def test_hostile_corpus_hashes_runs_and_results_match_oracle():
+def test_hostile_corpus_hashes_runs_and_results_match_oracle(monkeypatch):
     assert capi.device_count() > 0
     n, samples, threads = 12, int(8 * 60 * 11025), _cpus()       # 12 windows of 8 minutes: 1937 hashes each, 66 pairs
     gen, pcm, lib = _library(n, samples, 45.0)
@@ -86,6 +86,17 @@ def test_hostile_corpus_hashes_runs_and_results_match_oracle():
     assert np.array_equal(got[np.lexsort((got[:, 2], got[:, 1], got[:, 0]))], want[np.lexsort((want[:, 2], want[:, 1], want[:, 0]))])
     per_pair = np.bincount(runs["problem"].astype(np.int64), minlength=lib.num_pairs())
     assert per_pair.max() > 256, "no pair of silent stretches filled a bucket beyond the device epilogue's limit: not hostile enough"
+    # ... and the same list from the MATRIX-PIPE form of the scan (taken by itself from 2048 pairs up; forced here): blocks of equal
+    # hashes are where its workgroups hand chains round (a crowd: scan_mfma_kernel.h drain()) and its waves' run buffers overflow
+    monkeypatch.setenv("NEEDLE_HIP_SCAN_MFMA", "1")
+    lib.search(cmp, 0, lib.num_pairs(), d_runs.ptr, cap, d_count.ptr, sync=True)
+    assert capi.scan_last_launch()[0] == 4
+    k2 = int(d_count.to_host(np.uint32, 1)[0])
+    assert k2 == k
+    runs2 = d_runs.to_host(capi.RUN_DTYPE, k2)
+    got2 = np.stack([runs2["problem"], runs2["src_end"], runs2["dst_end"], runs2["len"]], axis=1).astype(np.uint32)
+    assert np.array_equal(got2[np.lexsort((got2[:, 2], got2[:, 1], got2[:, 0]))], want[np.lexsort((want[:, 2], want[:, 1], want[:, 0]))])
+    monkeypatch.delenv("NEEDLE_HIP_SCAN_MFMA")
 
     # (3) final results == comparator.rs:524-629 on the oracle (full tables, heap order, clustering), through both entry points
     want_res = O.run_with_frame_hashes(O.Comparator(), ref, threads=threads)
