@@ -243,6 +243,38 @@ def test_fast_kernels_all_cells_match_and_many_problems(search_mode):
         assert got.get(p, []) == _oracle_runs(seqs[a], seqs[b], 9, ml), (p, a, b)
 
 
+@pytest.mark.parametrize("waves,splits", [(4, 1), (8, 3), (16, 2), (12, 1), (8, 1)])
+def test_matrix_pipe_form_in_its_shapes_with_crowds_of_chains(waves, splits, monkeypatch):
+    """The matrix-pipe form's workgroup shapes (NEEDLE_HIP_MFMA_WAVES) and workgroups per group (NEEDLE_HIP_MFMA_SPLITS) on content
+    that fills its queues: a ragged shared intro (chains of whole windows) and stretches of ONE repeated hash in three sequences --
+    every diagonal of a block a chain: the workgroup's chain ring wraps, a wave in a crowd hands chains over, the waves that are
+    through stay and take them, run buffers overflow (scan_mfma_kernel.h, round 6).  Complete run lists against the DP."""
+    monkeypatch.setenv("NEEDLE_HIP_SCAN_MFMA", "1")
+    monkeypatch.setenv("NEEDLE_HIP_MFMA_WAVES", str(waves))
+    monkeypatch.setenv("NEEDLE_HIP_MFMA_SPLITS", str(splits))
+    rng = np.random.default_rng(4242)
+    lens = [1400, 1250, 1500, 1100, 1333]
+    seqs = [_rand_hashes(rng, n) for n in lens]
+    intro = _rand_hashes(rng, 260)
+    for k, at in zip(range(4), (50, 400, 900, 17)):                # the intro, a bit of noise in every copy, a break in two of them
+        noise = (np.uint32(1) << rng.integers(0, 32, 260).astype(np.uint32)) * (rng.random(260) < 0.4)
+        seqs[k][at:at + 260] = intro ^ noise
+    seqs[1][400 + 131] ^= np.uint32(0xFFFFF000)
+    seqs[3][17 + 77] ^= np.uint32(0xFFFFF000)
+    for k, at, length in ((1, 800, 150), (2, 200, 120), (4, 600, 170)):   # digital silence: one constant hash
+        seqs[k][at:at + length] = np.uint32(0x1F07C1F0)
+    seqs[4][900:1010] = np.uint32(0x1F07C1F1)                     # ... and a second constant one bit away (a sustained chord)
+    problems = [(a, b, 40) for a in range(5) for b in range(a + 1, 5)]
+    got = _gpu_runs(seqs, problems, 10)
+    assert capi.scan_last_launch()[0] == 4
+    most = 0
+    for p, (a, b, ml) in enumerate(problems):
+        want = _oracle_runs(seqs[a], seqs[b], 10, ml)
+        assert got.get(p, []) == want, (p, a, b, waves, splits)
+        most = max(most, len(want))
+    assert most > 200, most                                       # a pair of silent stretches: hundreds of runs
+
+
 def test_hamming_runs_thresholds_and_min_len():
     rng = np.random.default_rng(9)
     src, dst = _rand_hashes(rng, 120), _rand_hashes(rng, 140)
