@@ -28,6 +28,10 @@
 //    windows on a diagonal form a CHAIN; only its last window resolves it -- one trip to global memory fetches 512 rows
 //    backward and 128 forward, every stretch of >= min_len matching rows in it is a run (resolve()).
 //  * Runs go to a buffer in LDS; the workgroup asks for their slots in the run list with one atomic at its end.
+//  * (Round 6.)  The kernel is bound by vector-instruction issue (80 % of the SIMDs' cycles, the matrix pipe 34 %): an item
+//    enters the queue as a TOKEN naming its flag bit, decoded 64 at a time by process(); and a workgroup's END is shared work:
+//    chains found late, and chains found in a crowd (a block of equal hashes), go to a ring in LDS that the waves which are through
+//    with their units empty (kM2Chains, drain()).
 //  * One workgroup = one destination x up to EIGHT sources (as many as its share of the CU's LDS holds); the sources'
 //    windows (A image rows + sixteen hashes each) are built once per launch (m2_window_images_kernel) and copied in; an A
 //    fragment read serves both column blocks of a unit; waves take units from a counter in LDS, so none idles while another
