@@ -276,6 +276,7 @@ def test_adversarial_corpus_stays_inside_the_radius(monkeypatch):
     spec.loader.exec_module(fz)
     corpus = json.load(open(os.path.join(root, "tests", "golden", "cert_adversarial.json")))
     thetas = [corpus["before_pair_energy"]["theta"]] + [v["theta"] for v in corpus["after_pair_energy"]["families"].values()]
+    thetas += [v["theta"] for v in corpus.get("round6", {}).get("families", {}).values()]   # (the best of round 6's seeds 6 and 7)
     pcms = [fz.synth(np.array(th)) for th in thetas]
     aud = fz.Auditor(len(pcms))
     first = aud.audit(pcms[:1])
