@@ -32,7 +32,7 @@
 //    enters the queue as a TOKEN naming its flag bit, decoded 64 at a time by process(); and a workgroup's END is shared work:
 //    chains found late, and chains found in a crowd (a block of equal hashes), go to a ring in LDS that the waves which are through
 //    with their units empty (kM2Chains, drain()).
-//  * One workgroup = one destination x up to EIGHT sources (as many as its share of the CU's LDS holds); the sources'
+//  * One workgroup = one destination x up to kM2Members sources (as many as its share of the CU's LDS holds); the sources'
 //    windows (A image rows + sixteen hashes each) are built once per launch (m2_window_images_kernel) and copied in; an A
 //    fragment read serves both column blocks of a unit; waves take units from a counter in LDS, so none idles while another
 //    still has units; a workgroup finds its group with one load (round 4: a binary search of the table, 17 dependent loads).
@@ -56,10 +56,19 @@ __device__ unsigned long long m2_dbg[8];
 #define M2_COUNT_LANES(i, n) do { } while (0)
 #endif
 constexpr int kM2Heads = 4;
-constexpr int kM2Members = 8;                 // sources a workgroup takes at most (of one destination)
+#ifndef NEEDLE_M2_MEMBERS
+#define NEEDLE_M2_MEMBERS 12
+#endif
+constexpr int kM2Members = NEEDLE_M2_MEMBERS; // sources a workgroup takes at most (of one destination; its share of the CU's LDS decides: nine 24-minute
+                                              // windows, four 45-minute ones); < 16: a window's member rides in 4 bits.  (8 until round 6: the ninth -- room
+                                              // made by a run buffer of 32 instead of 64 -- is 2.2 % at 39 060 pairs of 24-minute windows: one more pair per setup,
+                                              // 98 instead of 94 % of the row tiles' rows in use)
 constexpr int kM2Pitch = kM2Heads * 4 + 4;    // words of a window's row in the A image: 4 x 32 FP4 nibbles of +-1, the window's member << 28 | w0, 3 spare
                                               // (20: sixteen lanes' 16-byte reads of one instruction fall into sixteen different groups of four banks)
-constexpr int kM2RunBuf = 64;                 // runs a workgroup collects in LDS before it asks for room in the run list (one atomic)
+#ifndef NEEDLE_M2_RUNBUF
+#define NEEDLE_M2_RUNBUF 32
+#endif
+constexpr int kM2RunBuf = NEEDLE_M2_RUNBUF;   // runs a workgroup collects in LDS before it asks for room in the run list (one atomic)
 #ifndef NEEDLE_M2_OVERFLOW
 #define NEEDLE_M2_OVERFLOW 16                  // (0: measurements -- one atomic per run beyond the workgroup's buffer, as before round 6)
 #endif
@@ -74,8 +83,20 @@ constexpr int kM2Rows = kSampleW + 2 * kM2Probe;  // source hashes kept per wind
 constexpr int kM2ColBlocks = 2;               // column blocks of 32 positions a wave takes per unit
 constexpr int kM2Batch = 4;                   // row tiles (x 2 column blocks = 8 tiles = 32 flag bits) between two looks at the flags
 constexpr int kM2Queue = 128;                 // items a wave can hold: < 64 waiting + the <= 64 one turn adds
-constexpr int kM2CtlWords = 40;               // [0] unit counter, [1 + g] first row of member g (g = members: all rows), [10 + g] source offset, [18 + g] source length, [26 + g] first window of its image, [34] runs collected, [35] their first slot in the run list, [36] chains taken, [37] chains pushed, [38] the chain queue's lock, [39] waves that have flushed their items
-// The workgroup's CHAIN QUEUE (round 6).  The chains of a destination's intro against its up to eight sources end within one
+// The workgroup's control words (one table in LDS)
+constexpr int kCtlUnits = 0;                              // units handed out
+constexpr int kCtlRows = 1;                               // [+ g] first row (window) of member g; [+ members]: all rows
+constexpr int kCtlSrc = kCtlRows + kM2Members + 1;        // [+ g] member g's source offset in the hash arena
+constexpr int kCtlLen = kCtlSrc + kM2Members;             // [+ g] its length
+constexpr int kCtlImage = kCtlLen + kM2Members;           // [+ g] first window of its image
+constexpr int kCtlRuns = kCtlImage + kM2Members;          // runs collected in the workgroup's buffer
+constexpr int kCtlSlot = kCtlRuns + 1;                    // their first slot in the run list
+constexpr int kCtlTaken = kCtlSlot + 1;                   // chain queue: chains taken,
+constexpr int kCtlPushed = kCtlTaken + 1;                 // chains pushed,
+constexpr int kCtlLock = kCtlPushed + 1;                  // its lock
+constexpr int kCtlThrough = kCtlLock + 1;                 // waves that have flushed their items
+constexpr int kM2CtlWords = (kCtlThrough + 1 + 3) & ~3;   // (a multiple of 4: what follows stays 16-byte aligned)
+// The workgroup's CHAIN QUEUE (round 6).  The chains of a destination's intro against its eight or nine sources end within one
 // or two column units: ONE wave found them all and resolved them one after the other, a trip to global memory each.  While the
 // workgroup has units to hand out that costs nothing (the other waves take them); near its end the other seven ran out of
 // units and waited -- a third of the resolution's 0.24 of 0.74 ms at 39 060 pairs of 24-minute windows.  So a chain found
@@ -99,6 +120,7 @@ static_assert((kM2Chains & (kM2Chains - 1)) == 0, "");
 #endif
 constexpr int kM2Crowd = NEEDLE_M2_CROWD;     // chains one process() call resolves itself before it hands the rest to the queue
 static_assert((kM2Batch & (kM2Batch - 1)) == 0 && 8 * kM2Batch <= 32, "a batch's flags fill at most one word");
+static_assert(kM2Members >= 1 && kM2Members <= 15, "");
 static_assert(kM2Probe == 4 && kM2Rows == 16, "a window's sixteen source hashes are read as 16-byte words");
 static_assert(kSampleW + 2 * kM2Probe - 2 < 2 * kSampleW - 1 + 8, "a run that ends inside the probed rows must be shorter than any min_len the sampled path takes");
 
@@ -202,21 +224,21 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   int overflowed = 0;                            // runs in it (wave-uniform)
 
   if (threadIdx.x == 0) {
-    ctl[0] = 0u;
-    ctl[34] = 0u;
-    ctl[36] = 0u;
-    ctl[37] = 0u;
-    ctl[38] = 0u;
-    ctl[39] = 0u;
+    ctl[kCtlUnits] = 0u;
+    ctl[kCtlRuns] = 0u;
+    ctl[kCtlTaken] = 0u;
+    ctl[kCtlPushed] = 0u;
+    ctl[kCtlLock] = 0u;
+    ctl[kCtlThrough] = 0u;
     int rows = 0;
     for (int g = 0; g < members; g++) {
-      ctl[1 + g] = (uint32_t)rows;
-      ctl[10 + g] = problems[lo + g].src_off;
-      ctl[18 + g] = problems[lo + g].n;
-      ctl[26 + g] = problems[lo + g].block_base;
+      ctl[kCtlRows + g] = (uint32_t)rows;
+      ctl[kCtlSrc + g] = problems[lo + g].src_off;
+      ctl[kCtlLen + g] = problems[lo + g].n;
+      ctl[kCtlImage + g] = problems[lo + g].block_base;
       rows += mfma_windows((int)problems[lo + g].n, min_len, W);
     }
-    ctl[1 + members] = (uint32_t)rows;
+    ctl[kCtlRows + members] = (uint32_t)rows;
   }
   static_assert(64 * WAVES >= kM2Table, "");
   if (threadIdx.x < kM2Table) ntab[threadIdx.x] = m2_nibbles(threadIdx.x);
@@ -248,8 +270,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         const int idx = min(base + u * 64 * WAVES, nW * kPieces - 1);
         const int k = idx / kPieces, piece = idx % kPieces;
         int g = 0;
-        for (int i = 1; i < members; i++) g += (uint32_t)k >= ctl[1 + i] ? 1 : 0;
-        const uint32_t from = ctl[26 + g] + ((uint32_t)k - ctl[1 + g]);
+        for (int i = 1; i < members; i++) g += (uint32_t)k >= ctl[kCtlRows + i] ? 1 : 0;
+        const uint32_t from = ctl[kCtlImage + g] + ((uint32_t)k - ctl[kCtlRows + g]);
         v[u] = *reinterpret_cast<const mfma_v4i *>(images + (size_t)from * kM2ImageWords + 4 * piece);
         if (piece == PITCH / 4 - 1) v[u][0] |= (int)((uint32_t)g << 28);   // w0 -> member << 28 | w0
         to[u] = wimg + k * STRIDE + 4 * piece;
@@ -272,11 +294,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
       for (int u = 0; u < kU; u++) {
         const int k = min(k0 + u * kStep, nW - 1);
         int g = 0;
-        for (int i = 1; i < members; i++) g += (uint32_t)k >= ctl[1 + i] ? 1 : 0;
-        const int w0 = 1 + (k - (int)ctl[1 + g]) * P;
+        for (int i = 1; i < members; i++) g += (uint32_t)k >= ctl[kCtlRows + i] ? 1 : 0;
+        const int w0 = 1 + (k - (int)ctl[kCtlRows + g]) * P;
         const int row = w0 + s;
         wm[u] = ((uint32_t)g << 28) | (uint32_t)w0;
-        hv[u] = row >= 0 && row < (int)ctl[18 + g] ? hashes[ctl[10 + g] + (uint32_t)row] : 0u;
+        hv[u] = row >= 0 && row < (int)ctl[kCtlLen + g] ? hashes[ctl[kCtlSrc + g] + (uint32_t)row] : 0u;
       }
 #pragma unroll
       for (int u = 0; u < kU; u++) {
@@ -323,7 +345,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   // 1.0 ms at 39 060 pairs.)
   auto window_whole_wave = [&](const int k, const int g, const int w0, const int j) __attribute__((always_inline)) {
     const int d = j - w0;
-    const int ns = (int)__builtin_amdgcn_readfirstlane(ctl[18 + g]);
+    const int ns = (int)__builtin_amdgcn_readfirstlane(ctl[kCtlLen + g]);
     const int ilo = d < 0 ? 1 - d : 1;
     const int ihi = min(ns - 1, m - 1 - d);
     const int row = w0 - E + (lane & (NR - 1));
@@ -360,9 +382,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   // window: the window is not whole, so the one below it is the last of a chain of its own.)
   // A trip fetches eight rows per lane backward (and the first one two forward): a 90-second run is two trips.
   auto resolve = [&](const int w0, const int d, const int g) __attribute__((always_inline)) {  // (wave-uniform arguments)
-    const uint32_t *__restrict__ sp = hashes + __builtin_amdgcn_readfirstlane(ctl[10 + g]);
-    const int ns = (int)__builtin_amdgcn_readfirstlane(ctl[18 + g]);
-    const int kg = (int)__builtin_amdgcn_readfirstlane(ctl[1 + g]);   // the member's first window
+    const uint32_t *__restrict__ sp = hashes + __builtin_amdgcn_readfirstlane(ctl[kCtlSrc + g]);
+    const int ns = (int)__builtin_amdgcn_readfirstlane(ctl[kCtlLen + g]);
+    const int kg = (int)__builtin_amdgcn_readfirstlane(ctl[kCtlRows + g]);   // the member's first window
     const int ilo = d < 0 ? 1 - d : 1;
     const int ihi = min(ns - 1, m - 1 - d);
     if (w0 < ilo || w0 + W - 1 > ihi) return;
@@ -385,7 +407,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     auto emit = [&](const int a, const int b) {
       if (b - a + 1 < min_len) return;
       uint32_t at = 0u;
-      if (lane == 0) at = __hip_atomic_fetch_add(&ctl[34], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) at = __hip_atomic_fetch_add(&ctl[kCtlRuns], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
       if (at < (uint32_t)kM2RunBuf) {
         if (lane == 0)
@@ -494,25 +516,25 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     }
   };
 
-  // The workgroup's chain queue: a ring of kM2Chains entries behind a lock (ctl[38]); ctl[36] counts the chains taken, ctl[37]
+  // The workgroup's chain queue: a ring of kM2Chains entries behind a lock (ctl[kCtlLock]); ctl[kCtlTaken] counts the chains taken, ctl[kCtlPushed]
   // the chains pushed.  All wave-uniform; lane 0 does the work, a handful of LDS operations under the lock.
   auto chain_lock = [&]() __attribute__((always_inline)) {
-    while (__hip_atomic_exchange(&ctl[38], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
+    while (__hip_atomic_exchange(&ctl[kCtlLock], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
   };
   auto chain_unlock = [&]() __attribute__((always_inline)) {
-    __hip_atomic_store(&ctl[38], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&ctl[kCtlLock], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   auto push_chain = [&](const uint32_t wm, const int d) __attribute__((always_inline)) {   // false: the queue is full
     uint32_t ok = 0u;
     if (lane == 0) {
       chain_lock();
-      const uint32_t taken = __hip_atomic_load(&ctl[36], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const uint32_t pushed = __hip_atomic_load(&ctl[37], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t taken = __hip_atomic_load(&ctl[kCtlTaken], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t pushed = __hip_atomic_load(&ctl[kCtlPushed], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (pushed - taken < (uint32_t)kM2Chains) {
         const uint32_t at = pushed & (uint32_t)(kM2Chains - 1);
         __hip_atomic_store(&chains[2 * at], wm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_store(&chains[2 * at + 1], (uint32_t)d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_store(&ctl[37], pushed + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&ctl[kCtlPushed], pushed + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         ok = 1u;
       }
       chain_unlock();
@@ -521,15 +543,15 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   };
   auto pop_chain = [&](uint32_t &wm, uint32_t &d) __attribute__((always_inline)) {
     uint32_t e0 = 0u, e1 = 0u;                    // (w0 >= 1: a chain's first word is never 0)
-    if (lane == 0 && __hip_atomic_load(&ctl[37], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) !=
-                         __hip_atomic_load(&ctl[36], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+    if (lane == 0 && __hip_atomic_load(&ctl[kCtlPushed], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) !=
+                         __hip_atomic_load(&ctl[kCtlTaken], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
       chain_lock();
-      const uint32_t taken = __hip_atomic_load(&ctl[36], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (taken != __hip_atomic_load(&ctl[37], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+      const uint32_t taken = __hip_atomic_load(&ctl[kCtlTaken], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (taken != __hip_atomic_load(&ctl[kCtlPushed], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
         const uint32_t at = taken & (uint32_t)(kM2Chains - 1);
         e0 = __hip_atomic_load(&chains[2 * at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         e1 = __hip_atomic_load(&chains[2 * at + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_store(&ctl[36], taken + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&ctl[kCtlTaken], taken + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       chain_unlock();
     }
@@ -601,12 +623,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         const uint32_t wm = __builtin_amdgcn_readfirstlane(wimg[ck * STRIDE + 4 * H]);
         const int g = (int)(wm >> 28), w0 = (int)(wm & 0x0FFFFFFFu);
         if (!window_whole_wave(ck, g, w0, cj)) continue;
-        if (ck + 1 < (int)__builtin_amdgcn_readfirstlane(ctl[2 + g]) && window_whole_wave(ck + 1, g, w0 + P, cj + P)) continue;
+        if (ck + 1 < (int)__builtin_amdgcn_readfirstlane(ctl[kCtlRows + 1 + g]) && window_whole_wave(ck + 1, g, w0 + P, cj + P)) continue;
         // Found while the workgroup still has plenty of units to hand out: resolved here, beside the other waves' tiles.  Found
         // LATE -- the units left are fewer than the waves would take during a cluster's eight resolutions -- or in a CROWD (this
         // call has resolved kM2Crowd already: a block of equal hashes, every diagonal through it a chain) it goes to the queue,
         // which the waves that have run out of units empty (drain()); resolved here after all when the queue is full.
-        const bool late = ((int)__builtin_amdgcn_readfirstlane(ctl[0]) + kM2LateUnits * WAVES) * splits >= units;   // (ctl[0]: this workgroup's share)
+        const bool late = ((int)__builtin_amdgcn_readfirstlane(ctl[kCtlUnits]) + kM2LateUnits * WAVES) * splits >= units;   // (ctl[kCtlUnits]: this workgroup's share)
         if ((late || resolved_here >= kM2Crowd) && push_chain(wm, cj - w0)) continue;
         resolve(w0, cj - w0, g);
         resolved_here++;
@@ -615,15 +637,15 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
     flush_overflow();                             // (the words are the queue's again when this call returns)
   };
   // Chains from the workgroup's queue, whoever found them -- behind a wave's last unit, when it has flushed its items and will
-  // push nothing any more.  It says so (ctl[39]) and STAYS until every wave has: the waves of a workgroup whose units are cheap
+  // push nothing any more.  It says so (ctl[kCtlThrough]) and STAYS until every wave has: the waves of a workgroup whose units are cheap
   // finish first and then take what the waves in a block of equal hashes keep pushing (the hostile corpus, 280 files: scan
   // 15.3 -> 8.5 ms; the tonal figures unchanged).  (No items wait in the wave's queue here: its upper 64 words hold the overflow runs.)
   auto drain = [&]() __attribute__((always_inline)) {
     overflow = queue + 64;
     overflowed = 0;
-    if (lane == 0) __hip_atomic_fetch_add(&ctl[39], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_fetch_add(&ctl[kCtlThrough], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (;;) {
-      const bool all = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ctl[39], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == WAVES;
+      const bool all = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ctl[kCtlThrough], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == WAVES;
       uint32_t wm = 0u, dd = 0u;
       while (pop_chain(wm, dd)) resolve((int)(wm & 0x0FFFFFFFu), (int)dd, (int)(wm >> 28));
       if (all) break;                             // (read BEFORE the queue was found empty: nothing can have come since)
@@ -709,7 +731,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   bool done = false;
   while (!done) {
     int c = 0;
-    if (lane == 0) c = (int)__hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) c = (int)__hip_atomic_fetch_add(&ctl[kCtlUnits], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     c = __builtin_amdgcn_readfirstlane(c);
     const int unit = b_in_group + splits * c;     // (every wave sees the counter pass `units`: the loop ends for all)
     done = unit >= units;                         // then one more turn with nothing in it: the queue's last items
@@ -769,12 +791,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   }
   // the workgroup's runs: one request for room, then the copy
   __syncthreads();
-  const uint32_t n_runs = min(ctl[34], (uint32_t)kM2RunBuf);
+  const uint32_t n_runs = min(ctl[kCtlRuns], (uint32_t)kM2RunBuf);
   if (n_runs == 0u) return;
-  if (threadIdx.x == 0) ctl[35] = atomicAdd(count, n_runs);
+  if (threadIdx.x == 0) ctl[kCtlSlot] = atomicAdd(count, n_runs);
   __syncthreads();
   if (threadIdx.x < n_runs) {
-    const uint32_t slot = ctl[35] + threadIdx.x;
+    const uint32_t slot = ctl[kCtlSlot] + threadIdx.x;
     const uint32_t *e = runbuf + 4 * threadIdx.x;
     if (slot < capacity) runs[slot] = NeedleHipRun{e[0], e[1], e[2], e[3], 0u, 0u};
   }
