@@ -24,7 +24,7 @@
 //    flags the same lane again and again: left to that lane, the wave waits for it).  A lane tests its item's four
 //    windows on all eight rows with popcounts out of LDS.
 //  * What passes (a window in thousands) is looked at by the WAVE, window by window, sixteen lanes reading its sixteen
-//    rows in LDS (window_whole_wave): whole, and not a run that ends within kM2Probe rows on both sides?  Consecutive whole
+//    rows in LDS (window_whole_wave): whole, and the probes of one side (rows up to half a minimum run away) all matching?  Consecutive whole
 //    windows on a diagonal form a CHAIN; only its last window resolves it -- one trip to global memory fetches 512 rows
 //    backward and 128 forward, every stretch of >= min_len matching rows in it is a run (resolve()).
 //  * Runs go to a buffer in LDS; the workgroup asks for their slots in the run list with one atomic at its end.
@@ -79,7 +79,7 @@ constexpr int kM2Overflow = NEEDLE_M2_OVERFLOW;  // ... and beyond those, runs a
                                               // 4 KB per workgroup cost 45-minute windows a source per workgroup and the scan 6 %)
 constexpr int kM2Table = 256;                 // a byte of hash bits -> its eight FP4 nibbles (bit set: +1 = 0x2, clear: -1 = 0xA)
 constexpr int kM2Probe = 4;                   // rows looked at on either side of a whole window
-constexpr int kM2Rows = kSampleW + 2 * kM2Probe;  // source hashes kept per window: rows w0 - 4 .. w0 + 11
+constexpr int kM2Rows = kSampleW + 2 * kM2Probe;  // source hashes kept per window: its W rows and four probes on either side (m2_probe_offset)
 constexpr int kM2ColBlocks = 2;               // column blocks of 32 positions a wave takes per unit
 constexpr int kM2Batch = 4;                   // row tiles (x 2 column blocks = 8 tiles = 32 flag bits) between two looks at the flags
 constexpr int kM2Queue = 128;                 // items a wave can hold: < 64 waiting + the <= 64 one turn adds
@@ -122,7 +122,20 @@ constexpr int kM2Crowd = NEEDLE_M2_CROWD;     // chains one process() call resol
 static_assert((kM2Batch & (kM2Batch - 1)) == 0 && 8 * kM2Batch <= 32, "a batch's flags fill at most one word");
 static_assert(kM2Members >= 1 && kM2Members <= 15, "");
 static_assert(kM2Probe == 4 && kM2Rows == 16, "a window's sixteen source hashes are read as 16-byte words");
-static_assert(kSampleW + 2 * kM2Probe - 2 < 2 * kSampleW - 1 + 8, "a run that ends inside the probed rows must be shorter than any min_len the sampled path takes");
+// Which rows the PROBES of a window are (round 6): slot s = -kM2Probe .. -1 below the window, kSampleW .. kSampleW + kM2Probe - 1 above it,
+// as an offset from the window's first row.  A run of min_len rows or more that holds the window's W rows has min_len - W others, so at
+// least REACH = ceil((min_len - W) / 2) of them on one side: the probes of a side lie at distances 1 .. REACH from the window, evenly,
+// and "all probes of one side match" stays a NECESSARY condition of such a run -- but one that a run of a dozen rows no longer meets
+// (the four rows next to the window, as until now, match or fail together on audio; a window with a run of 9 - 14 rows around it cost a
+// trip to global memory to find that out: a quarter of all resolutions at 39 060 pairs).
+__host__ __device__ constexpr int m2_probe_offset(int s, int min_len) {
+  const int reach = (min_len - kSampleW + 1) / 2;
+  const int i = s < 0 ? -1 - s : s - kSampleW;                    // 0 .. kM2Probe - 1, the nearest first
+  const int dist = 1 + i * (reach - 1) / (kM2Probe - 1);
+  return s < 0 ? -dist : kSampleW - 1 + dist;
+}
+__host__ __device__ constexpr int m2_row_offset(int s, int min_len) { return s >= 0 && s < kSampleW ? s : m2_probe_offset(s, min_len); }
+static_assert(m2_probe_offset(-1, 23) == -1 && m2_probe_offset(-4, 23) == -8 && m2_probe_offset(8, 67) == 8 && m2_probe_offset(11, 67) == 37, "");
 
 // LDS words of a workgroup: staged destination (+ 64 zeros), tables, per-window source hashes, A image
 __host__ __device__ constexpr size_t m2_round4(size_t x) { return (x + 3) & ~(size_t)3; }
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(256) void m2_window_images_kernel(const uint32_t *_
     }
     const M2ImageSeq q = seqs[lo];
     const uint32_t w0 = 1u + (k - q.first_window) * P;
-    const int row = (int)w0 + s;
+    const int row = (int)w0 + m2_row_offset(s, (int)min_len);
     const uint32_t hsh = row >= 0 && row < (int)q.n ? hashes[q.src_off + (uint32_t)row] : 0u;
     uint32_t *img = images + (size_t)k * kM2ImageWords;
     img[PITCH + s + E] = hsh;
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   uint32_t *runbuf = ntab + kM2Table;            // the workgroup's runs: (pair, last row, last column, length)
   uint32_t *chains = runbuf + 4 * kM2RunBuf;     // the workgroup's chains waiting for a wave: (member << 28 | w0, diagonal); word 0 == 0: not written yet
   uint32_t *queues = chains + 2 * kM2Chains;     // per wave: items waiting for their exact test
-  // per window the source hashes of rows w0 - E .. w0 + W + E - 1 (zero where there is none)
+  // per window the source hashes of its W rows and of its 2 E probe rows (m2_row_offset; zero where there is none)
   // Per window ONE row of kM2ImageWords = 36 words: its A image row (the head hashes' nibbles, then w0), then its sixteen
   // source hashes.  36 = 4 x 9: sixteen lanes' 16-byte reads of sixteen different windows -- the A fragments of a tile, the
   // rows of the items' windows -- fall into sixteen different groups of four banks.  (Two arrays, the hashes at a pitch of
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
         int g = 0;
         for (int i = 1; i < members; i++) g += (uint32_t)k >= ctl[kCtlRows + i] ? 1 : 0;
         const int w0 = 1 + (k - (int)ctl[kCtlRows + g]) * P;
-        const int row = w0 + s;
+        const int row = w0 + m2_row_offset(s, min_len);
         wm[u] = ((uint32_t)g << 28) | (uint32_t)w0;
         hv[u] = row >= 0 && row < (int)ctl[kCtlLen + g] ? hashes[ctl[kCtlSrc + g] + (uint32_t)row] : 0u;
       }
@@ -338,17 +351,18 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(PER_
   const uint32_t p_magic = (uint32_t)(0xFFFFFFFFull / (uint32_t)P);   // ~ 2^32 / P from below (P >= W: the host takes this path from min_len >= 2 W - 1)
   const uint32_t bias = 31u - (uint32_t)t;        // popcount + bias has bit 5 set exactly when the cell does NOT match
   // Is window k (member g, first row w0) WHOLE at destination position j: inside the table on its diagonal, its W cells all
-  // match, and its run does not end inside the kM2Probe rows on BOTH sides (such a run has at most W + 2 E - 2 rows, below
-  // every min_len this path takes)?  All from LDS, asked by the whole wave about ONE window (wave-uniform arguments): lane
-  // s < 16 looks at row w0 - E + s.  One predicate for three askers who must agree: a window about itself, about its
-  // successor, and the walk below about the windows it passes.  (Run per lane by 64 lanes in step it was 0.33 of the scan's
+  // match, and the probes of at least ONE side all match (m2_probe_offset: a run of min_len rows that holds the window reaches
+  // the farthest probe of one side; any deterministic predicate with that property serves the chain rule)?  All from LDS, asked by
+  // the whole wave about ONE window (wave-uniform arguments): lane s < 16 looks at the image row's s-th hash.  One predicate for
+  // three askers who must agree: a window about itself, about its successor, and the walk below about the windows it passes.  (Run per lane by 64 lanes in step it was 0.33 of the scan's
   // 1.0 ms at 39 060 pairs.)
+  const int whole_row_off = m2_row_offset((lane & (NR - 1)) - E, min_len);
   auto window_whole_wave = [&](const int k, const int g, const int w0, const int j) __attribute__((always_inline)) {
     const int d = j - w0;
     const int ns = (int)__builtin_amdgcn_readfirstlane(ctl[kCtlLen + g]);
     const int ilo = d < 0 ? 1 - d : 1;
     const int ihi = min(ns - 1, m - 1 - d);
-    const int row = w0 - E + (lane & (NR - 1));
+    const int row = w0 + whole_row_off;        // lane s < 16: the window's rows, and its probes (m2_probe_offset)
     const bool in = row >= ilo && row <= ihi;
     const bool is_bad = !in || (uint32_t)__popc(wimg[k * STRIDE + PITCH + (lane & (NR - 1))] ^ ldst[min(max(row, ilo), ihi) + d]) > threshold;
     const uint32_t mask = (uint32_t)__builtin_amdgcn_ballot_w64(is_bad) & 0xFFFFu;
